@@ -1,0 +1,165 @@
+"""CPU tests (-m "not gpu"): pin the oracle.
+
+1. the CPU restatement (oracle/xlating_oracle.c) reproduces every golden vector the reference's own tests hold
+   for this path, under the reference's own assertion semantics;
+2. it is bit-identical to the committed outputs of the UNMODIFIED reference (tests/golden/live_*.npz) on all
+   scenarios, including streaming state, ragged blocks, the even-tap quirk and the shared-history quirk;
+3. when oracle/_ref is present (build container, and on the GPU box as a shipped .so) the same holds live.
+"""
+import numpy as np
+import pytest
+
+import scenarios
+from conftest import assert_ref_cf32, bits_equal, load_live, trunc1e4
+from pyoracle import Oracle, RefLib
+
+
+def olpf(*a):
+    code, t = Oracle.lpf(*a)
+    assert code == 0
+    return t
+
+
+def run_oracle(sc, sum_mode=0):
+    taps = scenarios.make_taps(sc, lpf=olpf)
+    o = Oracle(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"], sum_mode=sum_mode)
+    outs = []
+    for call in sc["calls"]:
+        x = scenarios.to_path_input(sc, scenarios.make_input(sc, call))
+        outs.append(o.process(sc["fmt"], x, call["out"]))
+    return taps, outs, o
+
+
+# ---------------------------------------------------------------- reference test arrays (G1-G7)
+
+
+def test_lpf_golden_test_lpf_c(ref_vectors):
+    """test/test_lpf.c:25-39"""
+    exp = ref_vectors["test_lpf.c"]["test_lowpassTaps"]["expected_taps"]
+    code, taps = Oracle.lpf(1.0, 8000, 1750, 500)
+    assert code == 0 and taps.size == 39
+    assert np.array_equal(trunc1e4(exp), trunc1e4(taps))
+
+
+@pytest.mark.parametrize("args", [(0, 1750, 500), (8000, 5000, 500), (8000, 1750, 0)])
+def test_lpf_bounds_test_lpf_c(args):
+    """test/test_lpf.c:7-23: invalid arguments return -1"""
+    code, taps = Oracle.lpf(1.0, *args)
+    assert code == -1 and taps is None
+
+
+def test_ntaps_table():
+    """SURVEY A.6 tap-count table (lpf.c:31-38)"""
+    L = Oracle.lib()
+    assert L.orc_lpf_ntaps(2016000, 48000) == 101
+    assert L.orc_lpf_ntaps(2016000, 9600) == 505
+    assert L.orc_lpf_ntaps(2016000, 19200) == 253
+    assert L.orc_lpf_ntaps(2016000, 2000) == 2429
+    assert L.orc_lpf_ntaps(48000, 2000) == 57
+    assert L.orc_lpf_ntaps(48000, 1920) == 61
+    assert L.orc_lpf_ntaps(8000, 500) == 39
+
+
+def test_g1_max_input_buffer_size(ref_vectors):
+    """test/test_xlating.c:24-37"""
+    v = ref_vectors["test_xlating.c"]["test_max_input_buffer_size"]
+    _, outs, _ = run_oracle(scenarios.BY_NAME["g1_full"])
+    assert_ref_cf32(v["expected_cf32"], outs[0])
+    assert np.array_equal(np.asarray(v["expected_cs16"], np.int16), outs[1].reshape(-1))
+
+
+def test_g2_partial_input_buffer_size(ref_vectors):
+    """test/test_xlating.c:39-61"""
+    v = ref_vectors["test_xlating.c"]["test_partial_input_buffer_size"]
+    _, outs, _ = run_oracle(scenarios.BY_NAME["g2_partial"])
+    assert_ref_cf32(v["expected_cf32"], outs[0])
+    assert np.array_equal(np.asarray(v["expected_cs16"], np.int16), outs[1].reshape(-1))
+    assert_ref_cf32(v["expected_next_cf32"], outs[2])
+    assert np.array_equal(np.asarray(v["expected_next_cs16"], np.int16), outs[3].reshape(-1))
+
+
+def test_g3_small_input_data():
+    """test/test_xlating.c:63-81: one extra complex sample must not produce output"""
+    _, outs, _ = run_oracle(scenarios.BY_NAME["g3_small"])
+    assert len(outs[0]) == 20 and len(outs[1]) == 20
+    assert len(outs[2]) == 0 and len(outs[3]) == 0
+
+
+@pytest.mark.parametrize("name,fn", [("g4_rtl", "test_rtlsdr"), ("g5_airspy", "test_airspy"), ("g6_hackrf", "test_hackrf")])
+def test_g4_g6_tcp_server_vectors(ref_vectors, name, fn):
+    """test/test_tcp_server.c:154-248 end-to-end vectors, reproduced by calling lpf+xlating directly"""
+    exp = ref_vectors["test_tcp_server.c"][fn]["expected"]
+    _, outs, _ = run_oracle(scenarios.BY_NAME[name])
+    assert_ref_cf32(exp, outs[0])
+
+
+# ---------------------------------------------------------------- committed outputs of the unmodified reference
+
+
+@pytest.mark.parametrize("sc", scenarios.SCENARIOS, ids=lambda s: s["name"])
+def test_restatement_bit_exact_vs_committed_reference_outputs(sc):
+    live = load_live(sc["name"])
+    taps, outs, o = run_oracle(sc)
+    assert bits_equal(taps, live["taps"])
+    for ci, call in enumerate(sc["calls"]):
+        assert len(outs[ci]) == int(live[f"n{ci}"]), (ci, len(outs[ci]), int(live[f"n{ci}"]))
+        if call.get("keep", True):
+            y = outs[ci] if call.get("keep_n") is None else outs[ci][: call["keep_n"]]
+            assert bits_equal(y, live[f"y{ci}"]), f"{sc['name']} call {ci}"
+    o.close()
+
+
+@pytest.mark.parametrize("name", ["g9_default", "g11_t101", "g13_cf32_257"])
+def test_f64_yardstick_close_to_canonical(name):
+    """Accuracy yardstick: double-accumulated FIR vs canonical float32 order, max|d|/max|y| << 1e-5"""
+    sc = scenarios.BY_NAME[name]
+    _, a, _ = run_oracle(sc, sum_mode=0)
+    _, b, _ = run_oracle(sc, sum_mode=1)
+    for ci, call in enumerate(sc["calls"]):
+        if call["out"] != "cf32" or len(a[ci]) == 0:
+            continue
+        err = np.abs(a[ci] - b[ci]).max() / np.abs(b[ci]).max()
+        assert err < 2e-6, (name, ci, err)
+
+
+def test_hypotf_double_form_matches_libm():
+    """The NCO renormalisation kernel evaluates hypotf as (float)sqrt((double)x*x + (double)y*y); glibc's
+    hypotf must agree on this box (xlating.c:73)."""
+    import ctypes as C
+
+    libm = C.CDLL("libm.so.6")
+    libm.hypotf.argtypes = [C.c_float, C.c_float]
+    libm.hypotf.restype = C.c_float
+    L = Oracle.lib()
+    rng = np.random.default_rng(7)
+    th = rng.uniform(0, 2 * np.pi, 20000)
+    r = 1 + rng.uniform(-1e-5, 1e-5, th.size)
+    xs = (r * np.cos(th)).astype(np.float32)
+    ys = (r * np.sin(th)).astype(np.float32)
+    for x, y in zip(xs, ys):
+        assert libm.hypotf(x, y) == L.orc_hypotf_via_double(x, y)
+
+
+# ---------------------------------------------------------------- live reference (when oracle/_ref is present)
+
+
+@pytest.mark.skipif(not RefLib.available("canon"), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("name", ["g1_full", "g3_small", "g9_default", "g12_even256"])
+def test_restatement_bit_exact_vs_live_reference(name):
+    sc = scenarios.BY_NAME[name]
+    taps = scenarios.make_taps(sc, lpf=lambda *a: RefLib.lpf(*a)[1])
+    ref = RefLib(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"])
+    _, outs, _ = run_oracle(sc)
+    for ci, call in enumerate(sc["calls"]):
+        x = scenarios.make_input(sc, call)
+        y = ref.process(sc.get("ref_fmt", sc["fmt"]), x, call["out"])
+        assert bits_equal(y, outs[ci])
+
+
+@pytest.mark.skipif(not RefLib.available("canon"), reason="oracle/_ref not built")
+def test_lpf_bit_exact_vs_live_reference():
+    for fs, cut, tw in [(2016000, 24000, 9600), (2016000, 24000, 48000), (2016000, 24000, 2000), (48000, 4800, 2000),
+                        (8000, 1750, 500), (10000000, 50000, 20000), (2016000, 48000, 19200)]:
+        a = Oracle.lpf(1.0, fs, cut, tw)[1]
+        b = RefLib.lpf(1.0, fs, cut, tw)[1]
+        assert bits_equal(a, b)
