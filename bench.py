@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the xlating-FIR hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path over one IQ block for every client of every GPU:
+    N > 1: rank 0's block is broadcast over RCCL/xGMI (the path's only exchange step), then each rank runs its
+    own clients on it -- no further communication (clients are embarrassingly parallel).
+Workload (config.workload): 1024 concurrent 48 kHz clients PER GPU off one 2.016 Msps cu8 stream, server-default
+262144-byte blocks (131072 complex samples), D=42, low-pass designed with the server default lpf_cutoff_rate=5
+-> 505 taps (the BASELINE "~84-tap" figure is not reachable with the reference's designer; the
+lpf_cutoff_rate=1 -> 101-tap variant is measured too and reported under "variants").  Weak scaling: per-GPU work
+is fixed as N grows.  Inputs are synthetic (xorshift bytes), already resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0): value = input IQ Msamples/s summed over all clients and GPUs.
+"roofline":     HBM-read roofline of the FIR kernel, per-client-read model of SURVEY 8(d): algorithmic bytes per
+                launch = clients x samples x (2 B in + 8/D B out), divided by the kernel's mean duration measured
+                with HIP events on the launch stream inside the timed region.  Because 505 taps at D=42 is 96 flop
+                per (client, sample) the binding ceiling is FP32, so "fp32" gives that fraction as well.
+"cpu_baseline": the reference itself (oracle/_ref, unmodified sources, -O3 -ffast-math AVX2) -- or the repo's CPU
+                restatement when that build is absent -- timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+FS = 2016000
+RATE = 48000
+D = FS // RATE
+BLOCK_BYTES = 262144            # server default buffer_size (src/resources/config.conf:13)
+S = BLOCK_BYTES // 2            # complex samples per block
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
+
+
+def shard_clients(total_clients, world_size, rank):
+    """Client c -> GPU (c mod G); returns this rank's global client indices."""
+    return [c for c in range(total_clients) if c % world_size == rank]
+
+
+def client_center_freq(c):
+    """Distinct in-band offsets: 1920 Hz raster across +-984 kHz, shifted by 240 Hz per 1024 clients."""
+    return -984000 + 1920 * (c % 1024) + 240 * ((c // 1024) % 8)
+
+
+def algorithmic_bytes_per_unit(decim):
+    """per (client, complex input sample): 2 B cu8 in + 8/D B cf32 out."""
+    return 2.0 + 8.0 / decim
+
+
+def flops_per_unit(ntaps, decim):
+    """8 flop per complex MAC, T/D MACs per input sample, + 6/D for the NCO rotate."""
+    return 8.0 * ntaps / decim + 6.0 / decim
+
+
+def make_blocks(nblocks, seed):
+    import siggen
+
+    return [siggen.xs_u8(seed + k, BLOCK_BYTES) for k in range(nblocks)]
+
+
+def cpu_baseline(ntaps_rate, seconds=12.0):
+    """Reference (oracle/_ref libref_fast.so) or port (oracle/liboracle.so) on the host cores, thread per client
+    like the reference's dsp_worker threads (src/dsp_worker.c:41-88), each thread its own filter over the same
+    block.  Bounded sample: `seconds` of wall time."""
+    import threading
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import siggen
+    from pyoracle import Oracle, RefLib
+
+    flags = open("/proc/cpuinfo").read()
+    model = "unknown"
+    for line in flags.splitlines():
+        if line.startswith("model name"):
+            model = line.split(":", 1)[1].strip()
+            break
+    use_ref = RefLib.available("fast") and " avx2 " in flags.replace("\n", " ") and " fma " in flags.replace("\n", " ")
+    cores = os.cpu_count() or 1
+    x = siggen.xs_u8(siggen.XS_SEED, BLOCK_BYTES)
+    if use_ref:
+        taps = RefLib.lpf(1.0, FS, RATE // 2, RATE // ntaps_rate, flavour="fast")[1]
+        mk = lambda c: RefLib(D, taps, client_center_freq(c), FS, BLOCK_BYTES, flavour="fast", variant="optimized")
+        run = lambda f: f.process_raw("cu8", x, "cf32")
+        kind, what = "reference", f"unmodified src/xlating.c process_optimized_cu8_cf32 ({RefLib.simd_status('fast')}, -O3 -ffast-math -mavx2 -mfma)"
+    else:
+        taps = Oracle.lpf(1.0, FS, RATE // 2, RATE // ntaps_rate)[1]
+        mk = lambda c: Oracle(D, taps, client_center_freq(c), FS, BLOCK_BYTES)
+        run = lambda f: len(f.process("cu8", x))
+        kind, what = "port", "oracle/xlating_oracle.c scalar restatement (-O2, canonical order)"
+
+    def timed(nthreads, budget):
+        filters = [mk(c) for c in range(nthreads)]
+        counts = [0] * nthreads
+        stop = time.perf_counter() + budget
+
+        def work(i):
+            f = filters[i]
+            run(f)
+            while time.perf_counter() < stop:
+                run(f)
+                counts[i] += 1
+
+        t0 = time.perf_counter()
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        dt = time.perf_counter() - t0
+        for f in filters:
+            f.close()
+        return sum(counts) * S / dt / 1e6, sum(counts)
+
+    one, n1 = timed(1, seconds * 0.3)
+    allc, nall = timed(cores, seconds * 0.7)
+    return {
+        "value": round(allc, 2), "unit": "Msamples/s", "cores": cores, "kind": kind,
+        "single_thread_value": round(one, 2),
+        "sample": f"{what}; {ntaps_rate=} -> {taps.size} taps, D={D}, {BLOCK_BYTES}-byte cu8 blocks; {nall} calls on "
+                  f"{cores} threads in {seconds * 0.7:.1f} s wall (+ {n1} calls single-thread); host CPU: {model}",
+    }
+
+
+def run_workload(eng_cls, xl, torch, dist, args, rank, world, ntaps_rate, steps, warmup, dev_blocks, recv):
+    """Build this rank's engine with its shard of clients and time `steps` blocks.  Returns dict of measurements."""
+    code, taps = xl.create_low_pass_filter(1.0, FS, RATE // 2, RATE // ntaps_rate)
+    assert code == 0
+    total_clients = args.clients_per_gpu * world
+    mine = shard_clients(total_clients, world, rank)
+    eng = eng_cls(FS, "cu8", BLOCK_BYTES, device=torch.cuda.current_device())
+    for c in mine:
+        eng.add_client(D, taps, client_center_freq(c))
+    stream = torch.cuda.current_stream()
+
+    def step(k):
+        if world > 1:
+            if rank == 0:
+                recv.copy_(dev_blocks[k % len(dev_blocks)], non_blocking=True)
+            dist.broadcast(recv, src=0)                     # RCCL over xGMI: the raw IQ block
+            ptr = recv.data_ptr()
+        else:
+            ptr = dev_blocks[k % len(dev_blocks)].data_ptr()
+        eng.process_device(ptr, BLOCK_BYTES, args.mode, stream.cuda_stream)
+
+    for k in range(warmup):
+        step(k)
+    torch.cuda.synchronize()
+    eng.timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(warmup + k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nt, fir_ms, nco_ms = eng.timing_read(reset=True)
+    eng.timing(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    klen = eng.output_len(0)
+    eng.close()
+    return {"ntaps": int(taps.size), "seconds": dt, "fir_ms_avg": fir_ms / max(nt, 1), "nco_ms_avg": nco_ms / max(nt, 1),
+            "timed_launches": nt, "clients_this_rank": len(mine), "total_clients": total_clients, "K": int(klen)}
+
+
+def summarize(m, steps, world):
+    units_per_step = m["total_clients"] * S
+    value = units_per_step * steps / m["seconds"] / 1e6
+    per_gpu_units = m["clients_this_rank"] * S
+    bpu = algorithmic_bytes_per_unit(D)
+    fpu = flops_per_unit(m["ntaps"], D)
+    fir_s = m["fir_ms_avg"] * 1e-3
+    ach_gbs = per_gpu_units * bpu / fir_s / 1e9 if fir_s > 0 else 0.0
+    ach_tf = per_gpu_units * fpu / fir_s / 1e12 if fir_s > 0 else 0.0
+    return value, ach_gbs, ach_tf, bpu, fpu
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--clients-per-gpu", type=int, default=1024)
+    ap.add_argument("--mode", default="optimized", choices=["native", "optimized"])
+    ap.add_argument("--lpf-cutoff-rate", type=int, default=5, help="server config lpf_cutoff_rate: 5 -> 505 taps, 1 -> 101")
+    ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU path to time)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import sdr_server_amd as xl
+
+    blocks = make_blocks(8, 0x5DEECE66D)
+    dev_blocks = [torch.from_numpy(b).cuda() for b in blocks] if (rank == 0 or world == 1) else []
+    recv = torch.empty(BLOCK_BYTES, dtype=torch.uint8, device="cuda") if world > 1 else None
+    if world > 1 and rank != 0:
+        dev_blocks = [recv]
+
+    m = run_workload(xl.BatchEngine, xl, torch, dist, args, rank, world, args.lpf_cutoff_rate, args.steps, args.warmup,
+                     dev_blocks, recv)
+    value, ach_gbs, ach_tf, bpu, fpu = summarize(m, args.steps, world)
+
+    variants = {}
+    if not args.no_variants:
+        other_rate = 1 if args.lpf_cutoff_rate != 1 else 5
+        vs = max(20, args.steps // 2)
+        mv = run_workload(xl.BatchEngine, xl, torch, dist, args, rank, world, other_rate, vs, min(args.warmup, 5),
+                          dev_blocks, recv)
+        v2, g2, t2, _, f2 = summarize(mv, vs, world)
+        variants[f"lpf_cutoff_rate={other_rate} ({mv['ntaps']} taps)"] = {
+            "value": round(v2, 1), "ms_per_step": round(mv["seconds"] / vs * 1e3, 4),
+            "roofline_hbm_frac": round(g2 / HBM_PEAK_GBS, 4), "achieved_GBs": round(g2, 1),
+            "fp32_frac": round(t2 / FP32_PEAK_TFLOPS, 4), "achieved_TFLOPs": round(t2, 2),
+            "fir_kernel_ms": round(mv["fir_ms_avg"], 4), "flop_per_unit": round(f2, 2)}
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "input IQ Msamples/s processed (all clients), 2.016 Msps->48 kHz xlating FIR",
+        "value": round(value, 1),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(m["seconds"] / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.clients_per_gpu} clients/GPU x 48 kHz off one 2.016 Msps cu8 stream, {BLOCK_BYTES}-byte blocks, "
+                        f"D={D}, {m['ntaps']} taps (lpf_cutoff_rate={args.lpf_cutoff_rate}), process_{args.mode}_cu8_cf32 semantics "
+                        f"(BASELINE configs[3] per-GPU share x8 = the 1-GPU >=1000-client target)",
+            "clients_total": m["total_clients"], "block_samples": S, "outputs_per_client_per_block": m["K"],
+            "parallelism": f"clients sharded c%{world}; RCCL broadcast of the raw IQ block per step" if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel": f"xl_fir_kernel<8,{1 if args.mode == 'optimized' else 0}>", "kernel_ms": round(m["fir_ms_avg"], 4),
+            "bytes_per_unit": round(bpu, 4), "units_per_launch": m["clients_this_rank"] * S,
+            "model": "per-client-read (SURVEY 8(d)): 2 B in + 8/D B out per (client, input sample)",
+            "fp32": {"achieved": round(ach_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach_tf / FP32_PEAK_TFLOPS, 4), "flop_per_unit": round(fpu, 2),
+                     "note": "binding ceiling at this tap count (SURVEY H2): HBM frac cannot exceed "
+                             f"{min(1.0, FP32_PEAK_TFLOPS * 1e12 / fpu * bpu / (HBM_PEAK_GBS * 1e9)):.3f}"},
+            "nco_table_kernel_ms": round(m["nco_ms_avg"], 4),
+        },
+        "variants": variants,
+        "device": xl.device_info(),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.lpf_cutoff_rate, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+/*
+ * include/xlating_batch.h -- batched fan-out boundary (extension).
+ *
+ * The reference fans one IQ block out to N clients with N memcpy's and N per-thread process_* calls
+ * (src/tcp_server.c:257-271 sdr_callback -> src/dsp_worker.c:202-204 -> src/queue.c:87-119, then
+ * dsp_worker.c:57-65 per client).  On a GPU that is N redundant H2D copies and N tiny launches.
+ * This API is what sdr_callback would call instead: ONE block in, ONE fused launch for all clients
+ * of a device, per-client outputs out.  Per client the arithmetic is exactly that of the
+ * single-filter API in xlating.h (same taps, same NCO recurrence, same streaming rules), so each
+ * client's output stream equals what process_{native,optimized}_<fmt>_cf32 would have produced for a
+ * filter created when the client was added.
+ *
+ * Everything here is a plain C ABI: pointers, sizes, ints.  Device pointers and the HIP stream are
+ * passed as void* so that a torch/RCCL host (bench.py) or a C host can drive it.
+ */
+#ifndef SDR_SERVER_AMD_XLATING_BATCH_H_
+#define SDR_SERVER_AMD_XLATING_BATCH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xlating_batch_t xlating_batch;
+
+/* input sample formats == the reference's three device formats (dsp_worker.c:55-67) + the cf32 extension */
+enum { XL_FMT_CU8 = 0, XL_FMT_CS8 = 1, XL_FMT_CS16 = 2, XL_FMT_CF32 = 3 };
+/* arithmetic variants == the reference's cpu_optimization setting (config.h:20-23, dsp_worker.c:110-124) */
+enum { XL_MODE_NATIVE = 0, XL_MODE_OPTIMIZED = 1 };
+
+/* Create an engine for one input stream on one GPU.
+ *   sampling_freq             band sampling rate (server_config->band_sampling_rate)
+ *   input_format              XL_FMT_*
+ *   max_input_buffer_length   like create_frequency_xlating_filter(): bytes of a cu8 stream, i.e. the
+ *                             engine accepts up to max_input_buffer_length/2 complex samples per block
+ *   device                    HIP device ordinal, or -1 for the calling thread's current device
+ * Returns 0, -ENODEV (no usable HIP device), -EINVAL, -ENOMEM. */
+int xlating_batch_create(uint32_t sampling_freq, int input_format, uint32_t max_input_buffer_length, int device,
+                         xlating_batch **batch);
+
+/* Add a client whose stream starts with the NEXT block (like dsp_worker_start, dsp_worker.c:90-108).
+ * `taps` is the real low-pass prototype (lpf.h); it is COPIED (unlike create_frequency_xlating_filter
+ * the caller keeps ownership).  Returns a client id >= 0, or -1 (taps_len == 0), -EINVAL, -ENOMEM. */
+int xlating_batch_add_client(xlating_batch *batch, uint32_t decimation, const float *taps, size_t taps_len,
+                             int32_t center_freq);
+
+/* Remove a client (dsp_worker_destroy).  0 or -EINVAL. */
+int xlating_batch_remove_client(xlating_batch *batch, int client_id);
+
+int xlating_batch_num_clients(const xlating_batch *batch);
+
+/* Process one block for ALL clients.  `input_len` = scalar elements, as in xlating.h.
+ * _host:   `input` is host memory; copied H2D on the engine's stream.
+ * _device: `d_input` is device memory on the engine's GPU (e.g. the receive buffer of an RCCL
+ *          broadcast); read in place, not copied.  `hip_stream` (a hipStream_t, may be NULL = the
+ *          engine's own stream) is the stream all work for this block is enqueued on; the call does
+ *          not synchronise it.  The caller must keep d_input unmodified until that work has run.
+ * Results stay on the device until fetched.  Returns 0, -EINVAL (too long / bad mode), -EIO (HIP error). */
+int xlating_batch_process_host(xlating_batch *batch, const void *input, size_t input_len, int mode);
+int xlating_batch_process_device(xlating_batch *batch, const void *d_input, size_t input_len, int mode,
+                                 void *hip_stream);
+
+/* Number of complex output samples client produced in the last processed block (host-side integer state). */
+size_t xlating_batch_output_len(const xlating_batch *batch, int client_id);
+
+/* Copy every client's last-block output D2H into engine-owned pinned memory (one copy) and wait for it. */
+int xlating_batch_fetch(xlating_batch *batch);
+/* After xlating_batch_fetch(): pointer to client's samples as interleaved (re,im) float pairs. */
+int xlating_batch_output_host(xlating_batch *batch, int client_id, const float **output, size_t *output_len);
+/* Device pointer to the client's last-block output (valid until the next process call). */
+int xlating_batch_output_device(xlating_batch *batch, int client_id, const void **d_output, size_t *output_len);
+
+/* Current NCO phase of a client (synchronises the engine stream). */
+int xlating_batch_client_phase(xlating_batch *batch, int client_id, float *re, float *im);
+
+/* Block until all enqueued work of the engine has finished. */
+int xlating_batch_sync(xlating_batch *batch);
+
+/* Kernel timing with HIP events recorded on the launch stream around the FIR kernel of every block
+ * (for bench.py's roofline figures).  enable: 0/1.  _read returns the number of timed launches since
+ * the last reset and their summed duration in milliseconds; it synchronises the stream. */
+int xlating_batch_timing(xlating_batch *batch, int enable);
+int xlating_batch_timing_read(xlating_batch *batch, double *fir_ms_total, double *nco_ms_total, int reset);
+
+void xlating_batch_destroy(xlating_batch *batch);
+
+/* Build/selection information, e.g. "HIP gfx950 (AMD Instinct MI355X), 256 CUs". Never NULL. */
+const char *xlating_hip_device_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDR_SERVER_AMD_XLATING_BATCH_H_ */

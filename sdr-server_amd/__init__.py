@@ -1,0 +1,285 @@
+"""sdr-server_amd -- MI355X-native implementation of sdr-server's frequency-xlating FIR hot path.
+
+The product is the C-ABI shared library `lib/libxlating_hip.so` (sources in csrc/, headers in ../include/):
+hand-written HIP kernels for gfx950 behind the reference's own `xlating.h` / `lpf.h` API plus the batched
+fan-out API of `xlating_batch.h`.  This Python package is only a thin ctypes host used by the tests and by
+bench.py; it mirrors the reference interface one to one (same names, argument meaning, error behaviour):
+
+    code, taps = create_low_pass_filter(1.0, 2016000, 24000, 9600)          # src/lpf.h:6
+    f = XlatingFilter(42, taps, -12000, 2016000, 262144)                    # create_frequency_xlating_filter
+    y = f.process("native", "cu8", "cf32", block)                           # process_native_cu8_cf32
+    f.close()                                                               # destroy_xlating
+
+There is NO CPU arithmetic path: if the library or a HIP device is missing, construction raises.
+(The directory name contains '-'; import it through the top-level alias module `sdr_server_amd`.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import build_library, library_path
+
+_c_float_p = C.POINTER(C.c_float)
+_c_i16_p = C.POINTER(C.c_int16)
+
+FMT = {"cu8": 0, "cs8": 1, "cs16": 2, "cf32": 3}
+MODE = {"native": 0, "optimized": 1}
+_NP = {"cu8": np.uint8, "cs8": np.int8, "cs16": np.int16, "cf32": np.float32}
+_CT = {"cu8": C.c_uint8, "cs8": C.c_int8, "cs16": C.c_int16, "cf32": C.c_float}
+
+# every symbol include/xlating.h, include/lpf.h and include/xlating_batch.h declare
+EXPORTED_SYMBOLS = (
+    ["SIMD_STATUS", "create_frequency_xlating_filter", "destroy_xlating", "create_low_pass_filter"]
+    + [f"process_{v}_{i}_{o}" for v in ("native", "optimized") for i in ("cu8", "cs8", "cs16") for o in ("cf32", "cs16")]
+    + ["process_native_cf32_cf32", "process_optimized_cf32_cf32"]
+    + ["xlating_batch_create", "xlating_batch_add_client", "xlating_batch_remove_client", "xlating_batch_num_clients",
+       "xlating_batch_process_host", "xlating_batch_process_device", "xlating_batch_output_len", "xlating_batch_fetch",
+       "xlating_batch_output_host", "xlating_batch_output_device", "xlating_batch_client_phase", "xlating_batch_sync",
+       "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_destroy", "xlating_hip_device_info"]
+)
+
+_lib = None
+
+
+def lib():
+    """Load (never build) the in-tree shared library and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(path)
+    L.create_low_pass_filter.argtypes = [C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_c_float_p), C.POINTER(C.c_size_t)]
+    L.create_low_pass_filter.restype = C.c_int
+    L.create_frequency_xlating_filter.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.create_frequency_xlating_filter.restype = C.c_int
+    L.destroy_xlating.argtypes = [C.c_void_p]
+    L.destroy_xlating.restype = None
+    for v in ("native", "optimized"):
+        for i in ("cu8", "cs8", "cs16", "cf32"):
+            fn = getattr(L, f"process_{v}_{i}_cf32")
+            fn.argtypes = [C.POINTER(_CT[i]), C.c_size_t, C.POINTER(_c_float_p), C.POINTER(C.c_size_t), C.c_void_p]
+            fn.restype = None
+            if i != "cf32":
+                fn = getattr(L, f"process_{v}_{i}_cs16")
+                fn.argtypes = [C.POINTER(_CT[i]), C.c_size_t, C.POINTER(_c_i16_p), C.POINTER(C.c_size_t), C.c_void_p]
+                fn.restype = None
+    L.xlating_batch_create.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+    L.xlating_batch_create.restype = C.c_int
+    L.xlating_batch_add_client.argtypes = [C.c_void_p, C.c_uint32, _c_float_p, C.c_size_t, C.c_int32]
+    L.xlating_batch_add_client.restype = C.c_int
+    L.xlating_batch_remove_client.argtypes = [C.c_void_p, C.c_int]
+    L.xlating_batch_remove_client.restype = C.c_int
+    L.xlating_batch_num_clients.argtypes = [C.c_void_p]
+    L.xlating_batch_num_clients.restype = C.c_int
+    L.xlating_batch_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.xlating_batch_process_host.restype = C.c_int
+    L.xlating_batch_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    L.xlating_batch_process_device.restype = C.c_int
+    L.xlating_batch_output_len.argtypes = [C.c_void_p, C.c_int]
+    L.xlating_batch_output_len.restype = C.c_size_t
+    L.xlating_batch_fetch.argtypes = [C.c_void_p]
+    L.xlating_batch_fetch.restype = C.c_int
+    L.xlating_batch_output_host.argtypes = [C.c_void_p, C.c_int, C.POINTER(_c_float_p), C.POINTER(C.c_size_t)]
+    L.xlating_batch_output_host.restype = C.c_int
+    L.xlating_batch_output_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.xlating_batch_output_device.restype = C.c_int
+    L.xlating_batch_client_phase.argtypes = [C.c_void_p, C.c_int, _c_float_p, _c_float_p]
+    L.xlating_batch_client_phase.restype = C.c_int
+    L.xlating_batch_sync.argtypes = [C.c_void_p]
+    L.xlating_batch_sync.restype = C.c_int
+    L.xlating_batch_timing.argtypes = [C.c_void_p, C.c_int]
+    L.xlating_batch_timing.restype = C.c_int
+    L.xlating_batch_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    L.xlating_batch_timing_read.restype = C.c_int
+    L.xlating_batch_destroy.argtypes = [C.c_void_p]
+    L.xlating_batch_destroy.restype = None
+    L.xlating_hip_device_info.argtypes = []
+    L.xlating_hip_device_info.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+_libc = C.CDLL(None)
+_libc.malloc.restype = C.c_void_p
+_libc.malloc.argtypes = [C.c_size_t]
+_libc.free.argtypes = [C.c_void_p]
+
+
+def simd_status():
+    """The exported SIMD_STATUS string (reference src/xlating.c:145-268; printed by src/main.c:23)."""
+    return C.c_char_p.in_dll(lib(), "SIMD_STATUS").value.decode()
+
+
+def device_info():
+    return lib().xlating_hip_device_info().decode()
+
+
+def create_low_pass_filter(gain, sampling_freq, cutoff_freq, transition_width):
+    """reference src/lpf.h:6 -> (code, float32 taps | None)"""
+    p = _c_float_p()
+    n = C.c_size_t(0)
+    code = lib().create_low_pass_filter(gain, sampling_freq, cutoff_freq, transition_width, C.byref(p), C.byref(n))
+    if code != 0:
+        return code, None
+    taps = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+    _libc.free(p)
+    return 0, taps
+
+
+class XlatingError(RuntimeError):
+    def __init__(self, what, code):
+        super().__init__(f"{what} failed with code {code}")
+        self.code = code
+
+
+class XlatingFilter:
+    """One `xlating *` handle (reference src/xlating.h:8-38)."""
+
+    def __init__(self, decimation, taps, center_freq, sampling_freq, max_input_buffer_length):
+        L = lib()
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        # create() takes ownership of a malloc'd taps array (xlating.c:508, freed at :600-602)
+        buf = _libc.malloc(max(4, taps.nbytes))
+        C.memmove(buf, taps.ctypes.data, taps.nbytes)
+        h = C.c_void_p()
+        code = L.create_frequency_xlating_filter(decimation, buf, taps.size, center_freq, sampling_freq,
+                                                 max_input_buffer_length, C.byref(h))
+        if code != 0:
+            if code == -1:  # taps_len == 0: taps not consumed (xlating.c:496-498)
+                _libc.free(buf)
+            raise XlatingError("create_frequency_xlating_filter", code)
+        self.h = h
+        self.D = decimation
+
+    def process(self, variant, in_fmt, out_fmt, x):
+        """process_<variant>_<in_fmt>_<out_fmt>(x) -> complex64[K] (cf32) or int16[K, 2] (cs16).
+        x: 1-D array of scalar elements (I,Q interleaved); len(x) is the C API's input_len."""
+        x = np.ascontiguousarray(x, dtype=_NP[in_fmt])
+        fn = getattr(lib(), f"process_{variant}_{in_fmt}_{out_fmt}")
+        n = C.c_size_t(0)
+        if out_fmt == "cf32":
+            p = _c_float_p()
+            fn(x.ctypes.data_as(C.POINTER(_CT[in_fmt])), x.size, C.byref(p), C.byref(n), self.h)
+            if n.value == 0:
+                return np.zeros(0, np.complex64)
+            return np.ctypeslib.as_array(p, shape=(2 * n.value,)).copy().view(np.complex64)
+        p = _c_i16_p()
+        fn(x.ctypes.data_as(C.POINTER(_CT[in_fmt])), x.size, C.byref(p), C.byref(n), self.h)
+        if n.value == 0:
+            return np.zeros((0, 2), np.int16)
+        return np.ctypeslib.as_array(p, shape=(n.value, 2)).copy()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().destroy_xlating(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchEngine:
+    """`xlating_batch *` (include/xlating_batch.h): one IQ stream, many clients, one GPU."""
+
+    def __init__(self, sampling_freq, in_fmt, max_input_buffer_length, device=-1):
+        h = C.c_void_p()
+        code = lib().xlating_batch_create(sampling_freq, FMT[in_fmt], max_input_buffer_length, device, C.byref(h))
+        if code != 0:
+            raise XlatingError("xlating_batch_create", code)
+        self.h = h
+        self.in_fmt = in_fmt
+
+    def add_client(self, decimation, taps, center_freq):
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        cid = lib().xlating_batch_add_client(self.h, decimation, taps.ctypes.data_as(_c_float_p), taps.size, center_freq)
+        if cid < 0:
+            raise XlatingError("xlating_batch_add_client", cid)
+        return cid
+
+    def remove_client(self, cid):
+        code = lib().xlating_batch_remove_client(self.h, cid)
+        if code != 0:
+            raise XlatingError("xlating_batch_remove_client", code)
+
+    @property
+    def num_clients(self):
+        return lib().xlating_batch_num_clients(self.h)
+
+    def process_host(self, x, variant="native"):
+        x = np.ascontiguousarray(x, dtype=_NP[self.in_fmt])
+        code = lib().xlating_batch_process_host(self.h, x.ctypes.data, x.size, MODE[variant])
+        if code != 0:
+            raise XlatingError("xlating_batch_process_host", code)
+
+    def process_device(self, d_ptr, input_len, variant="native", stream=0):
+        code = lib().xlating_batch_process_device(self.h, C.c_void_p(d_ptr), input_len, MODE[variant],
+                                                  C.c_void_p(stream) if stream else None)
+        if code != 0:
+            raise XlatingError("xlating_batch_process_device", code)
+
+    def fetch(self):
+        code = lib().xlating_batch_fetch(self.h)
+        if code != 0:
+            raise XlatingError("xlating_batch_fetch", code)
+
+    def output(self, cid):
+        p = _c_float_p()
+        n = C.c_size_t(0)
+        code = lib().xlating_batch_output_host(self.h, cid, C.byref(p), C.byref(n))
+        if code != 0:
+            raise XlatingError("xlating_batch_output_host", code)
+        if n.value == 0:
+            return np.zeros(0, np.complex64)
+        return np.ctypeslib.as_array(p, shape=(2 * n.value,)).copy().view(np.complex64)
+
+    def output_len(self, cid):
+        return lib().xlating_batch_output_len(self.h, cid)
+
+    def output_device(self, cid):
+        p = C.c_void_p()
+        n = C.c_size_t(0)
+        code = lib().xlating_batch_output_device(self.h, cid, C.byref(p), C.byref(n))
+        if code != 0:
+            raise XlatingError("xlating_batch_output_device", code)
+        return p.value, n.value
+
+    def phase(self, cid):
+        a, b = C.c_float(), C.c_float()
+        code = lib().xlating_batch_client_phase(self.h, cid, C.byref(a), C.byref(b))
+        if code != 0:
+            raise XlatingError("xlating_batch_client_phase", code)
+        return np.float32(a.value), np.float32(b.value)
+
+    def sync(self):
+        code = lib().xlating_batch_sync(self.h)
+        if code != 0:
+            raise XlatingError("xlating_batch_sync", code)
+
+    def timing(self, enable):
+        lib().xlating_batch_timing(self.h, 1 if enable else 0)
+
+    def timing_read(self, reset=True):
+        """-> (n_timed_blocks, fir_ms_total, nco_ms_total)"""
+        a, b = C.c_double(0), C.c_double(0)
+        n = lib().xlating_batch_timing_read(self.h, C.byref(a), C.byref(b), 1 if reset else 0)
+        if n < 0:
+            raise XlatingError("xlating_batch_timing_read", n)
+        return n, a.value, b.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().xlating_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,563 @@
+// xl_batch.cpp -- batched fan-out engine behind include/xlating_batch.h.
+//
+// What the reference does per IQ block with N clients (src/tcp_server.c:257-271 -> src/dsp_worker.c:202-204 ->
+// src/queue.c:87-119 -> dsp_worker.c:57-65): N memcpy's of the block and N process_* calls on N threads.
+// Here: the block lives ONCE in HBM, one NCO-table launch and one fused FIR launch (per register-tile height)
+// serve every client of this GPU, outputs stay in HBM until fetched.
+//
+// HBM layout (all resident across blocks; only XlDynArgs -- 16 B per class -- travels per block, as kernargs):
+//   hist[2]     raw history: the last XL_HCAP samples of the stream in the INPUT format (ping-pong)
+//   block       engine-owned copy of the current block (host path) -- or the caller's device buffer, in place
+//   taps        [tile][Tpad][ct] float2, tap i of the ct clients of a tile contiguous (one s_load_dwordx16)
+//   groups[ct]  XlGroup descriptors (<= 4 tiles of one class each)
+//   nco         XlNcoClient per client; phase[slot] running NCO phase per client
+//   phtab/out   [client][K_cap] float2: phase table and outputs, same indexing
+//
+// Streaming rule: a client's outputs lie on the global grid n = k*D of ITS stream; output k's
+// newest sample is stream sample k*D.  With `consumed` = samples this client has seen before the block,
+// j0 = (-consumed) mod D is the block-local index of the first output's newest sample, K = ceil((S - j0)/D),
+// and in [hist | block] coordinates the first window starts at XL_HCAP - (T-1) + j0.  Samples older than the
+// client (it joined mid-stream) must read as zero: zero_below = XL_HCAP - min(consumed, XL_HCAP).
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <new>
+#include <tuple>
+#include <vector>
+
+#include "../../include/xlating_batch.h"
+#include "xl_common.h"
+#include "xl_device.h"
+#include "xl_taps.h"
+
+#define XL_HCAP 16384u  // raw history kept on the device, in samples; needs T - 1 <= XL_HCAP
+
+namespace {
+
+struct Client {
+  bool alive = false;
+  uint32_t D = 0, T = 0, Tpad = 0;
+  std::vector<float> rt;  // [Tpad] interleaved re,im, zero padded
+  float incr[2] = {1.0f, 0.0f};
+  uint64_t consumed = 0;
+  uint32_t out_off = 0, out_cap = 0;
+  uint32_t last_K = 0;
+  uint32_t cls = 0;
+};
+
+struct ClassState {
+  uint32_t D, T;
+  uint32_t rem;  // consumed mod D
+  uint32_t hv;   // min(consumed, XL_HCAP)
+};
+
+struct Launch {
+  int ct = 0;
+  std::vector<XlGroup> groups;
+  XlGroup *d_groups = nullptr;
+  size_t lds = 0;
+};
+
+}  // namespace
+
+struct xlating_batch_t {
+  uint32_t fs = 0;
+  int fmt = 0;
+  uint32_t bps = 2;
+  uint32_t max_samples = 0;
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t last_stream = nullptr;
+
+  std::vector<Client> clients;
+  int nalive = 0;
+  bool dirty = true;
+  std::vector<ClassState> classes;
+  Launch launches[4];  // ct = 8, 4, 2, 1
+  std::vector<XlNcoClient> nco;
+  size_t out_total = 0;
+
+  void *d_hist[2] = {nullptr, nullptr};
+  int hcur = 0;
+  void *d_block = nullptr;
+  void *h_block = nullptr;  // pinned staging
+  float2 *d_taps = nullptr;
+  XlNcoClient *d_nco = nullptr;
+  float2 *d_phase = nullptr;
+  size_t phase_cap = 0;
+  float2 *d_phtab = nullptr;
+  float2 *d_out = nullptr;
+  size_t out_alloc = 0;
+  float2 *h_out = nullptr;
+  size_t h_out_alloc = 0;
+  bool fetched = false;
+
+  bool timing = false;
+  std::vector<hipEvent_t> ev;  // triples: nco start, fir start, fir stop
+  size_t ev_used = 0;
+  double fir_ms = 0.0, nco_ms = 0.0;
+  int timed_launches = 0;
+};
+
+static void xl_batch_free_plan(xlating_batch *b) {
+  for (Launch &l : b->launches) {
+    if (l.d_groups) (void)hipFree(l.d_groups);
+    l.d_groups = nullptr;
+    l.groups.clear();
+  }
+  if (b->d_taps) (void)hipFree(b->d_taps);
+  if (b->d_nco) (void)hipFree(b->d_nco);
+  b->d_taps = nullptr;
+  b->d_nco = nullptr;
+}
+
+extern "C" void xlating_batch_destroy(xlating_batch *b) {
+  if (b == nullptr) return;
+  if (b->device >= 0) (void)hipSetDevice(b->device);
+  if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
+  if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
+  xl_batch_free_plan(b);
+  void *dev[] = {b->d_hist[0], b->d_hist[1], b->d_block, b->d_phase, b->d_phtab, b->d_out};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  if (b->h_block) (void)hipHostFree(b->h_block);
+  if (b->h_out) (void)hipHostFree(b->h_out);
+  for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+  if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+  delete b;
+}
+
+extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, uint32_t max_input_buffer_length,
+                                    int device, xlating_batch **batch) {
+  if (batch == nullptr || input_format < XL_FMT_CU8 || input_format > XL_FMT_CF32 || sampling_freq == 0 ||
+      max_input_buffer_length < 2)
+    return -EINVAL;
+  const int dev = xl_hip_select_device(device);
+  if (dev < 0) {
+    XL_LOG_ERR("no usable HIP device (%s); this build has no CPU arithmetic path", xlating_hip_device_info());
+    return -ENODEV;
+  }
+  xlating_batch *b = new (std::nothrow) xlating_batch_t();
+  if (b == nullptr) return -ENOMEM;
+  b->fs = sampling_freq;
+  b->fmt = input_format;
+  b->bps = xl_bytes_per_sample(input_format);
+  b->max_samples = max_input_buffer_length / 2;
+  b->device = dev;
+  {
+    const size_t hbytes = (size_t)XL_HCAP * b->bps;
+    const size_t bbytes = (size_t)b->max_samples * b->bps + 16;
+    XL_TRY(hipSetDevice(dev));
+    XL_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+    XL_TRY(hipMalloc(&b->d_hist[0], hbytes));
+    XL_TRY(hipMalloc(&b->d_hist[1], hbytes));
+    XL_TRY(hipMalloc(&b->d_block, bbytes));
+    XL_TRY(hipHostMalloc(&b->h_block, bbytes, hipHostMallocDefault));
+    XL_TRY(hipMemsetAsync(b->d_hist[0], 0, hbytes, b->own_stream));
+    XL_TRY(hipMemsetAsync(b->d_hist[1], 0, hbytes, b->own_stream));
+    XL_TRY(hipStreamSynchronize(b->own_stream));
+  }
+  b->last_stream = b->own_stream;
+  *batch = b;
+  return 0;
+fail:
+  xlating_batch_destroy(b);
+  return -ENOMEM;
+}
+
+extern "C" int xlating_batch_num_clients(const xlating_batch *b) { return b ? b->nalive : 0; }
+
+extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, const float *taps, size_t taps_len,
+                                        int32_t center_freq) {
+  if (taps_len == 0) return -1;  // like create_frequency_xlating_filter (xlating.c:496-498)
+  if (b == nullptr || taps == nullptr || decimation == 0) return -EINVAL;
+  if (taps_len - 1 > XL_HCAP) {
+    XL_LOG_ERR("%zu taps exceed the engine's history capacity (%u samples)", taps_len, XL_HCAP);
+    return -EINVAL;
+  }
+  const uint32_t Tpad = xl_roundup((uint32_t)taps_len, XL_TAP_UNROLL);
+  if (xl_fir_lds_bytes(decimation, Tpad) > 160 * 1024) {
+    XL_LOG_ERR("decimation %u with %zu taps needs a %zu-byte window image (> 160 KiB LDS)", decimation, taps_len,
+               xl_fir_lds_bytes(decimation, Tpad));
+    return -EINVAL;
+  }
+  int id = -1;
+  for (size_t i = 0; i < b->clients.size(); ++i)
+    if (!b->clients[i].alive) {
+      id = (int)i;
+      break;
+    }
+  if (id < 0) {
+    b->clients.emplace_back();
+    id = (int)b->clients.size() - 1;
+  }
+  Client &c = b->clients[id];
+  c = Client();
+  c.alive = true;
+  c.D = decimation;
+  c.T = (uint32_t)taps_len;
+  c.Tpad = Tpad;
+  c.rt.assign(2 * (size_t)Tpad, 0.0f);
+  std::vector<int16_t> q15(2 * taps_len);
+  int16_t qinc[2];
+  xl_prepare_taps(taps, taps_len, center_freq, b->fs, decimation, c.rt.data(), q15.data(), c.incr, qinc);
+  c.out_cap = b->max_samples / decimation + 1;  // xlating.c:568
+  b->nalive++;
+  b->dirty = true;
+  // the running phase of a new client starts at 1 + 0j (xlating.c:543); slot = client id
+  if ((size_t)id >= b->phase_cap) {
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->last_stream);
+    const size_t ncap = std::max<size_t>(1024, 2 * b->clients.size());
+    float2 *np = nullptr;
+    if (hipMalloc((void **)&np, ncap * sizeof(float2)) != hipSuccess) {
+      c.alive = false;
+      b->nalive--;
+      return -ENOMEM;
+    }
+    if (b->d_phase) {
+      (void)hipMemcpy(np, b->d_phase, b->phase_cap * sizeof(float2), hipMemcpyDeviceToDevice);
+      (void)hipFree(b->d_phase);
+    }
+    b->d_phase = np;
+    b->phase_cap = ncap;
+  }
+  {
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->last_stream);
+    const float2 one = make_float2(1.0f, 0.0f);
+    if (hipMemcpy(b->d_phase + id, &one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess) return -EIO;
+  }
+  return id;
+}
+
+extern "C" int xlating_batch_remove_client(xlating_batch *b, int id) {
+  if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive) return -EINVAL;
+  b->clients[id].alive = false;
+  b->clients[id].rt.clear();
+  b->nalive--;
+  b->dirty = true;
+  return 0;
+}
+
+// (Re)build the resident plan: classes, tiles (register-tile heights 8/4/2/1), groups, tap image, NCO table.
+static int xl_batch_plan(xlating_batch *b) {
+  (void)hipStreamSynchronize(b->last_stream);
+  xl_batch_free_plan(b);
+  b->classes.clear();
+  b->nco.clear();
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> cls_of;
+  std::vector<std::vector<int>> members;
+  uint32_t off = 0;
+  for (size_t i = 0; i < b->clients.size(); ++i) {
+    Client &c = b->clients[i];
+    if (!c.alive) continue;
+    const uint32_t rem = (uint32_t)(c.consumed % c.D);
+    const uint32_t hv = (uint32_t)std::min<uint64_t>(c.consumed, XL_HCAP);
+    auto key = std::make_tuple(c.D, c.T, rem, hv);
+    auto it = cls_of.find(key);
+    if (it == cls_of.end()) {
+      if (b->classes.size() >= XL_MAX_CLASSES) {
+        XL_LOG_ERR("more than %d distinct (decimation, taps, stream offset) classes in one engine", XL_MAX_CLASSES);
+        return -E2BIG;
+      }
+      it = cls_of.emplace(key, (uint32_t)b->classes.size()).first;
+      b->classes.push_back(ClassState{c.D, c.T, rem, hv});
+      members.emplace_back();
+    }
+    c.cls = it->second;
+    members[c.cls].push_back((int)i);
+    c.out_off = off;
+    off += c.out_cap;
+    XlNcoClient nc;
+    memset(&nc, 0, sizeof(nc));
+    nc.incr = make_float2(c.incr[0], c.incr[1]);
+    nc.out_off = c.out_off;
+    nc.cls = c.cls;
+    nc.slot = (uint32_t)i;
+    b->nco.push_back(nc);
+  }
+  b->out_total = off;
+
+  static const int kHeights[4] = {8, 4, 2, 1};
+  std::vector<float> image;  // tap image, floats
+  for (int li = 0; li < 4; ++li) {
+    b->launches[li].ct = kHeights[li];
+    b->launches[li].lds = 0;
+  }
+  for (size_t k = 0; k < members.size(); ++k) {
+    const ClassState &cs = b->classes[k];
+    const uint32_t Tpad = xl_roundup(cs.T, XL_TAP_UNROLL);
+    size_t next = 0;
+    const std::vector<int> &m = members[k];
+    for (int li = 0; li < 4; ++li) {
+      const int ct = kHeights[li];
+      Launch &L = b->launches[li];
+      XlGroup *g = nullptr;
+      while (m.size() - next >= (size_t)ct) {
+        if (g == nullptr || g->ntiles == XL_NW) {
+          L.groups.emplace_back();
+          g = &L.groups.back();
+          memset(g, 0, sizeof(*g));
+          g->D = cs.D;
+          g->T = cs.T;
+          g->Tpad = Tpad;
+          g->cls = (uint32_t)k;
+          g->wide = (cs.D % 2 == 0) ? 1u : 0u;
+          L.lds = std::max(L.lds, xl_fir_lds_bytes(cs.D, Tpad));
+        }
+        XlTile &t = g->tiles[g->ntiles++];
+        t.tap_off = (uint32_t)(image.size() / 2);
+        t.nclients = (uint32_t)ct;
+        image.resize(image.size() + (size_t)2 * Tpad * ct, 0.0f);
+        float *dst = image.data() + (size_t)2 * t.tap_off;
+        for (int j = 0; j < ct; ++j) {
+          const Client &c = b->clients[m[next + j]];
+          t.out_off[j] = c.out_off;
+          for (uint32_t i = 0; i < Tpad; ++i) {
+            dst[((size_t)i * ct + j) * 2] = c.rt[2 * i];
+            dst[((size_t)i * ct + j) * 2 + 1] = c.rt[2 * i + 1];
+          }
+        }
+        next += ct;
+      }
+    }
+  }
+
+  // upload
+  if (b->nco.empty()) {
+    b->dirty = false;
+    return 0;
+  }
+  XL_TRY(hipMalloc((void **)&b->d_taps, image.size() * sizeof(float) + 256));
+  XL_TRY(hipMemcpy(b->d_taps, image.data(), image.size() * sizeof(float), hipMemcpyHostToDevice));
+  XL_TRY(hipMalloc((void **)&b->d_nco, b->nco.size() * sizeof(XlNcoClient)));
+  XL_TRY(hipMemcpy(b->d_nco, b->nco.data(), b->nco.size() * sizeof(XlNcoClient), hipMemcpyHostToDevice));
+  for (Launch &L : b->launches) {
+    if (L.groups.empty()) continue;
+    XL_TRY(hipMalloc((void **)&L.d_groups, L.groups.size() * sizeof(XlGroup)));
+    XL_TRY(hipMemcpy(L.d_groups, L.groups.data(), L.groups.size() * sizeof(XlGroup), hipMemcpyHostToDevice));
+  }
+  if (b->out_total > b->out_alloc) {
+    if (b->d_out) (void)hipFree(b->d_out);
+    if (b->d_phtab) (void)hipFree(b->d_phtab);
+    b->d_out = b->d_phtab = nullptr;
+    b->out_alloc = 0;
+    XL_TRY(hipMalloc((void **)&b->d_out, b->out_total * sizeof(float2)));
+    XL_TRY(hipMalloc((void **)&b->d_phtab, b->out_total * sizeof(float2)));
+    b->out_alloc = b->out_total;
+  }
+  b->dirty = false;
+  return 0;
+fail:
+  return -ENOMEM;
+}
+
+static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len, int mode, hipStream_t s) {
+  const size_t S = input_len / 2;
+  if (S > b->max_samples || (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED)) return -EINVAL;
+  if (b->dirty) {
+    int rc = xl_batch_plan(b);
+    if (rc != 0) return rc;
+  }
+  b->last_stream = s;
+  b->fetched = false;
+  if (b->nco.empty()) return 0;
+
+  XlDynArgs dyn;
+  memset(&dyn, 0, sizeof(dyn));
+  uint32_t maxK = 0;
+  for (size_t k = 0; k < b->classes.size(); ++k) {
+    ClassState &cs = b->classes[k];
+    const uint32_t j0 = (cs.D - cs.rem) % cs.D;
+    const uint32_t K = S > j0 ? (uint32_t)((S - j0 + cs.D - 1) / cs.D) : 0u;
+    dyn.d[k].base = XL_HCAP - (cs.T - 1) + j0;
+    dyn.d[k].K = K;
+    dyn.d[k].zero_below = XL_HCAP - cs.hv;
+    maxK = std::max(maxK, K);
+    cs.rem = (uint32_t)((cs.rem + S) % cs.D);
+    cs.hv = (uint32_t)std::min<uint64_t>((uint64_t)cs.hv + S, XL_HCAP);
+  }
+  for (Client &c : b->clients) {
+    if (!c.alive) continue;
+    c.last_K = dyn.d[c.cls].K;
+    c.consumed += S;
+  }
+
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  if (b->timing) {
+    if (b->ev_used + 3 > b->ev.size()) {
+      for (int i = 0; i < 3; ++i) {
+        hipEvent_t e;
+        XL_TRY(hipEventCreate(&e));
+        b->ev.push_back(e);
+      }
+    }
+    e0 = b->ev[b->ev_used];
+    e1 = b->ev[b->ev_used + 1];
+    e2 = b->ev[b->ev_used + 2];
+    b->ev_used += 3;
+  }
+
+  if (maxK > 0) {
+    if (e0) XL_TRY(hipEventRecord(e0, s));
+    XL_TRY(xl_launch_nco_table(b->d_nco, (uint32_t)b->nco.size(), b->d_phase, b->d_phtab, dyn, s));
+    if (e1) XL_TRY(hipEventRecord(e1, s));
+    for (Launch &L : b->launches) {
+      if (L.groups.empty()) continue;
+      XlFirArgs a;
+      memset(&a, 0, sizeof(a));
+      a.in0 = b->d_hist[b->hcur];
+      a.n0 = XL_HCAP;
+      a.in1 = d_block;
+      a.n1 = (uint32_t)S;
+      a.fmt = b->fmt;
+      a.groups = L.d_groups;
+      a.ngroups = (uint32_t)L.groups.size();
+      a.groups_per_xcd = (a.ngroups + 7) / 8;
+      a.xtiles = (maxK + 63) / 64;
+      a.taps = b->d_taps;
+      a.phtab = b->d_phtab;
+      a.out = b->d_out;
+      XL_TRY(xl_launch_fir(L.ct, mode, a, dyn, L.lds, s));
+    }
+    if (e2) XL_TRY(hipEventRecord(e2, s));
+  } else if (b->timing) {
+    b->ev_used -= 3;
+  }
+  // roll the raw history: the last XL_HCAP samples of [hist | block]
+  XL_TRY(xl_launch_update_history(b->d_hist[b->hcur], d_block, XL_HCAP, (uint32_t)S, b->bps, b->d_hist[b->hcur ^ 1], s));
+  b->hcur ^= 1;
+  return 0;
+fail:
+  return -EIO;
+}
+
+extern "C" int xlating_batch_process_device(xlating_batch *b, const void *d_input, size_t input_len, int mode,
+                                            void *hip_stream) {
+  if (b == nullptr || (d_input == nullptr && input_len > 0)) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : b->own_stream;
+  return xl_batch_run(b, d_input, input_len, mode, s);
+}
+
+extern "C" int xlating_batch_process_host(xlating_batch *b, const void *input, size_t input_len, int mode) {
+  if (b == nullptr || (input == nullptr && input_len > 0)) return -EINVAL;
+  const size_t S = input_len / 2;
+  if (S > b->max_samples) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  hipStream_t s = b->own_stream;
+  // the pinned staging buffer is reused: wait for the previous block's H2D to have been consumed
+  if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+  const size_t bytes = S * b->bps;
+  if (bytes) {
+    memcpy(b->h_block, input, bytes);
+    if (hipMemcpyAsync(b->d_block, b->h_block, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+  }
+  return xl_batch_run(b, b->d_block, input_len, mode, s);
+}
+
+extern "C" size_t xlating_batch_output_len(const xlating_batch *b, int id) {
+  if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive) return 0;
+  return b->clients[id].last_K;
+}
+
+extern "C" int xlating_batch_sync(xlating_batch *b) {
+  if (b == nullptr) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  return hipStreamSynchronize(b->last_stream) == hipSuccess ? 0 : -EIO;
+}
+
+extern "C" int xlating_batch_fetch(xlating_batch *b) {
+  if (b == nullptr) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  if (b->out_total == 0 || b->d_out == nullptr) {
+    b->fetched = true;
+    return xlating_batch_sync(b);
+  }
+  if (b->out_total > b->h_out_alloc) {
+    if (b->h_out) (void)hipHostFree(b->h_out);
+    b->h_out = nullptr;
+    b->h_out_alloc = 0;
+    if (hipHostMalloc((void **)&b->h_out, b->out_total * sizeof(float2), hipHostMallocDefault) != hipSuccess)
+      return -ENOMEM;
+    b->h_out_alloc = b->out_total;
+  }
+  if (hipMemcpyAsync(b->h_out, b->d_out, b->out_total * sizeof(float2), hipMemcpyDeviceToHost, b->last_stream) !=
+      hipSuccess)
+    return -EIO;
+  if (hipStreamSynchronize(b->last_stream) != hipSuccess) return -EIO;
+  b->fetched = true;
+  return 0;
+}
+
+extern "C" int xlating_batch_output_host(xlating_batch *b, int id, const float **output, size_t *output_len) {
+  if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive || !b->fetched ||
+      output == nullptr || output_len == nullptr)
+    return -EINVAL;
+  const Client &c = b->clients[id];
+  *output = b->h_out ? reinterpret_cast<const float *>(b->h_out + c.out_off) : nullptr;
+  *output_len = c.last_K;
+  return 0;
+}
+
+extern "C" int xlating_batch_output_device(xlating_batch *b, int id, const void **d_output, size_t *output_len) {
+  if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive || d_output == nullptr ||
+      output_len == nullptr || b->dirty)
+    return -EINVAL;
+  const Client &c = b->clients[id];
+  *d_output = b->d_out + c.out_off;
+  *output_len = c.last_K;
+  return 0;
+}
+
+extern "C" int xlating_batch_client_phase(xlating_batch *b, int id, float *re, float *im) {
+  if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  if (hipStreamSynchronize(b->last_stream) != hipSuccess) return -EIO;
+  float2 p;
+  if (hipMemcpy(&p, b->d_phase + id, sizeof(p), hipMemcpyDeviceToHost) != hipSuccess) return -EIO;
+  *re = p.x;
+  *im = p.y;
+  return 0;
+}
+
+static int xl_batch_drain_events(xlating_batch *b) {
+  if (hipStreamSynchronize(b->last_stream) != hipSuccess) return -EIO;
+  for (size_t i = 0; i + 3 <= b->ev_used; i += 3) {
+    float a = 0.0f, c = 0.0f;
+    if (hipEventElapsedTime(&a, b->ev[i], b->ev[i + 1]) != hipSuccess) return -EIO;
+    if (hipEventElapsedTime(&c, b->ev[i + 1], b->ev[i + 2]) != hipSuccess) return -EIO;
+    b->nco_ms += a;
+    b->fir_ms += c;
+    b->timed_launches++;
+  }
+  b->ev_used = 0;
+  return 0;
+}
+
+extern "C" int xlating_batch_timing(xlating_batch *b, int enable) {
+  if (b == nullptr) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  if (b->timing && !enable) (void)xl_batch_drain_events(b);
+  b->timing = enable != 0;
+  return 0;
+}
+
+extern "C" int xlating_batch_timing_read(xlating_batch *b, double *fir_ms_total, double *nco_ms_total, int reset) {
+  if (b == nullptr) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  int rc = xl_batch_drain_events(b);
+  if (rc != 0) return rc;
+  if (fir_ms_total) *fir_ms_total = b->fir_ms;
+  if (nco_ms_total) *nco_ms_total = b->nco_ms;
+  const int n = b->timed_launches;
+  if (reset) {
+    b->fir_ms = b->nco_ms = 0.0;
+    b->timed_launches = 0;
+  }
+  return n;
+}

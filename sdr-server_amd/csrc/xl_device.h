@@ -1,0 +1,97 @@
+// xl_device.h -- device-side data layout shared by the kernels (xl_kernels.hip) and the host engines
+// (xl_filter.cpp: the xlating.h drop-in; xl_batch.cpp: the batched fan-out engine).
+//
+// Vocabulary (follows the reference, src/xlating.c):
+//   sample   one complex IQ sample of the input stream (cu8/cs8: 2 B, cs16: 4 B, cf32: 8 B)
+//   window   the T consecutive samples one output is computed from (xlating.c:61-69)
+//   client   one xlating filter = (decimation D, T reversed band-pass taps, NCO phase + increment)
+//   tile     up to CT clients that share (D, T, window grid) -> one wavefront's work, taps interleaved
+//            [tap i][client c] so that one scalar load fetches tap i of every client of the tile
+//   group    up to XL_NW tiles of the same class -> one workgroup; its waves share one LDS window image
+//   class    all groups sharing (D, T, stream offset mod D, valid-history length); only the per-block
+//            numbers of a class (window origin, output count) change from block to block and travel
+//            as kernel arguments, everything else is resident in HBM.
+#ifndef XL_DEVICE_H_
+#define XL_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define XL_NW 4          // waves (tiles) per workgroup
+#define XL_WG (64 * XL_NW)
+#define XL_CT_MAX 8      // clients per tile (register-tile height)
+#define XL_TAP_UNROLL 4  // taps per inner-loop step; Tpad = roundup(T, 4)
+#define XL_MAX_CLASSES 48
+
+enum { XLF_CU8 = 0, XLF_CS8 = 1, XLF_CS16 = 2, XLF_CF32 = 3 };
+
+struct XlTile {
+  uint32_t tap_off;              // float2 index into the tap image; layout [Tpad][ct]
+  uint32_t nclients;             // 1..ct real clients (the rest of the tile has zero taps)
+  uint32_t out_off[XL_CT_MAX];   // per client: float2 index into the output / phase-table images
+};
+
+struct XlGroup {
+  uint32_t D, T, Tpad;
+  uint32_t cls;                  // index into XlDynArgs::d
+  uint32_t ntiles;               // 1..XL_NW
+  uint32_t wide;                 // 1: 16-byte LDS reads are aligned & conflict-free for this D (D even)
+  uint32_t pad0, pad1;
+  XlTile tiles[XL_NW];
+};
+
+struct XlDyn {
+  uint32_t base;        // sample index (in [in0|in1] coordinates) of the first tap of output 0
+  uint32_t K;           // outputs produced by every client of the class in this block
+  uint32_t zero_below;  // samples with index < zero_below read as 0 (client joined mid-stream)
+  uint32_t pad;
+};
+
+struct XlDynArgs {
+  XlDyn d[XL_MAX_CLASSES];
+};
+
+struct XlFirArgs {
+  const void *in0;      // first part of the sample stream seen by this launch (history), n0 samples
+  const void *in1;      // second part (the new block), n1 samples; may be null when n1 == 0
+  uint32_t n0, n1;
+  int fmt;              // XLF_*
+  const XlGroup *groups;
+  uint32_t ngroups;
+  uint32_t groups_per_xcd;
+  uint32_t xtiles;      // ceil(max K / 64)
+  const float2 *taps;   // tap image
+  const float2 *phtab;  // NCO phase table, indexed like out
+  float2 *out;
+};
+
+struct XlNcoClient {
+  float2 incr;          // phase increment cexpf(-j*w0*D) (xlating.c:544)
+  uint32_t out_off;     // float2 index of the client's row in the phase-table image
+  uint32_t cls;         // index into XlDynArgs::d (K of this block)
+  uint32_t slot;        // index of the client's running phase in the phase-state array
+  uint32_t pad;
+};
+
+// ---- launchers (xl_kernels.hip).  All return hipError_t of the launch. -------------------------------------
+// mode: 0 native (bit-exact scalar order, unfused), 1 optimized (fma).  ct: 1, 2, 4 or 8.
+hipError_t xl_launch_fir(int ct, int mode, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds_bytes, hipStream_t s);
+hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, float2 *phase_state, float2 *phtab,
+                               const XlDynArgs &dyn, hipStream_t s);
+// raw -> converted sample images of the single-filter path (xlating.c:352-433)
+hipError_t xl_launch_convert_cf32(const void *raw, int fmt, uint32_t nsamples, float2 *dst, hipStream_t s);
+hipError_t xl_launch_convert_q15(const void *raw, int fmt, uint32_t nelems, int16_t *dst, hipStream_t s);
+// memmove(buf, buf + from, count) in elements of `elem_bytes` (4 or 8) with overlap-safe forward order
+hipError_t xl_launch_move_down(void *buf, uint32_t from, uint32_t count, uint32_t elem_bytes, hipStream_t s);
+// new_hist[j] = concat(hist[0..h), block[0..n))[n + j], j < h   (raw samples, `bps` bytes each)
+hipError_t xl_launch_update_history(const void *hist, const void *block, uint32_t h, uint32_t n, uint32_t bps,
+                                    void *new_hist, hipStream_t s);
+// Q15 family (xlating.c:92-140): one filter
+hipError_t xl_launch_nco_table_q15(int16_t incr_re, int16_t incr_im, short2 *phase_state, short2 *phtab, uint32_t K,
+                                   hipStream_t s);
+hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T, uint32_t D, uint32_t K,
+                             const short2 *phtab, short2 *out, hipStream_t s);
+
+size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad);
+
+#endif

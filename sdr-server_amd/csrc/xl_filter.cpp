@@ -1,0 +1,294 @@
+// xl_filter.cpp -- the xlating.h drop-in: one `xlating` handle == one client filter, all arithmetic on the GPU.
+//
+// State machine = the reference's (src/xlating.c:14-43, 52-140, 495-616), held in device memory:
+//   work_f / work_q   converted sample images [history | new samples] of the two output families
+//   hist              ONE history counter shared by both families (xlating.c:29,76,133 -- quirk kept)
+//   phase / qphase    float32 and Q15 NCO state (xlating.c:36-42)
+// Per process_* call (xlating.c:352-447): H2D of the raw block -> convert kernel (appends at work[hist]) ->
+// NCO phase-table kernel -> FIR kernel (the batch kernel with a one-client tile) -> D2H of the K outputs ->
+// in-place history memmove kernel -> stream sync -> return the filter-owned host pointer.
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/xlating.h"
+#include "xl_common.h"
+#include "xl_device.h"
+#include "xl_taps.h"
+
+struct xlating_t {
+  uint32_t D = 0;
+  size_t T = 0;
+  uint32_t Tpad = 0;
+  float *original_taps = nullptr;  // owned, like xlating.c:508
+  int device = -1;
+  hipStream_t stream = nullptr;
+  size_t hist = 0;         // shared history counter
+  size_t cap = 0;          // samples per work image
+  size_t max_samples = 0;  // max_input_buffer_length / 2
+  size_t out_cap = 0;
+  int16_t qinc[2] = {0, 0};
+  bool warned = false;
+
+  void *d_raw = nullptr;
+  float2 *d_work_f = nullptr;
+  short2 *d_work_q = nullptr;
+  float2 *d_out_f = nullptr;
+  short2 *d_out_q = nullptr;
+  float2 *d_phtab = nullptr;
+  short2 *d_qphtab = nullptr;
+  float2 *d_phase = nullptr;
+  short2 *d_qphase = nullptr;
+  float2 *d_taps = nullptr;
+  short2 *d_qtaps = nullptr;
+  XlGroup *d_group = nullptr;
+  XlNcoClient *d_nco = nullptr;
+
+  void *h_in = nullptr;
+  float2 *h_out_f = nullptr;
+  short2 *h_out_q = nullptr;
+};
+
+static void xl_filter_free(xlating *f) {
+  if (f == nullptr) return;
+  if (f->device >= 0) (void)hipSetDevice(f->device);
+  if (f->stream) (void)hipStreamSynchronize(f->stream);
+  void *dev[] = {f->d_raw,   f->d_work_f, f->d_work_q, f->d_out_f, f->d_out_q, f->d_phtab, f->d_qphtab,
+                 f->d_phase, f->d_qphase, f->d_taps,   f->d_qtaps, f->d_group, f->d_nco};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  void *host[] = {f->h_in, f->h_out_f, f->h_out_q};
+  for (void *p : host)
+    if (p) (void)hipHostFree(p);
+  if (f->stream) (void)hipStreamDestroy(f->stream);
+  if (f->original_taps) free(f->original_taps);  // xlating.c:600-602
+  delete f;
+}
+
+extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps, size_t taps_len, int32_t center_freq,
+                                               uint32_t sampling_freq, uint32_t max_input_buffer_length,
+                                               xlating **filter) {
+  if (taps_len == 0) return -1;  // xlating.c:496-498 (taps NOT consumed)
+  if (decimation == 0 || filter == nullptr || taps == nullptr) return -EINVAL;
+  const int dev = xl_hip_select_device(-1);
+  if (dev < 0) {
+    XL_LOG_ERR("no usable HIP device (%s); this build has no CPU arithmetic path", xlating_hip_device_info());
+    return -ENODEV;
+  }
+  xlating *f = new (std::nothrow) xlating_t();
+  if (f == nullptr) {
+    free(taps);
+    return -ENOMEM;
+  }
+  f->original_taps = taps;
+  f->D = decimation;
+  f->T = taps_len;
+  f->Tpad = xl_roundup((uint32_t)taps_len, XL_TAP_UNROLL);
+  f->device = dev;
+  f->hist = taps_len - 1;  // xlating.c:552
+  f->max_samples = max_input_buffer_length / 2;
+  f->cap = f->max_samples + f->hist;                             // xlating.c:553
+  f->out_cap = max_input_buffer_length / 2 / decimation + 1;     // xlating.c:568
+
+  std::vector<float> rt(2 * (size_t)f->Tpad, 0.0f);  // zero-padded to the unroll width: pad taps are exact zeros
+  std::vector<int16_t> rtq(2 * taps_len);
+  float incr[2];
+  xl_prepare_taps(taps, taps_len, center_freq, sampling_freq, decimation, rt.data(), rtq.data(), incr, f->qinc);
+
+  XlGroup g;
+  memset(&g, 0, sizeof(g));
+  g.D = decimation;
+  g.T = (uint32_t)taps_len;
+  g.Tpad = f->Tpad;
+  g.cls = 0;
+  g.ntiles = 1;
+  g.wide = (decimation % 2 == 0) ? 1u : 0u;
+  g.tiles[0].tap_off = 0;
+  g.tiles[0].nclients = 1;
+  XlNcoClient nc;
+  memset(&nc, 0, sizeof(nc));
+  nc.incr = make_float2(incr[0], incr[1]);
+  const float2 one = make_float2(1.0f, 0.0f);          // xlating.c:543
+  const short2 qone = make_short2(INT16_MAX, 0);        // xlating.c:546-547
+  // work images hold a few samples past `cap`: the FIR kernel's window image is padded to the unroll width
+  const size_t work_n = f->cap + XL_TAP_UNROLL;
+
+  XL_TRY(hipSetDevice(dev));
+  XL_TRY(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  XL_TRY(hipMalloc(&f->d_raw, f->max_samples * 8 + 16));
+  XL_TRY(hipMalloc((void **)&f->d_work_f, work_n * sizeof(float2)));
+  XL_TRY(hipMalloc((void **)&f->d_work_q, work_n * sizeof(short2)));
+  XL_TRY(hipMalloc((void **)&f->d_out_f, f->out_cap * sizeof(float2)));
+  XL_TRY(hipMalloc((void **)&f->d_out_q, f->out_cap * sizeof(short2)));
+  XL_TRY(hipMalloc((void **)&f->d_phtab, f->out_cap * sizeof(float2)));
+  XL_TRY(hipMalloc((void **)&f->d_qphtab, f->out_cap * sizeof(short2)));
+  XL_TRY(hipMalloc((void **)&f->d_phase, sizeof(float2)));
+  XL_TRY(hipMalloc((void **)&f->d_qphase, sizeof(short2)));
+  XL_TRY(hipMalloc((void **)&f->d_taps, rt.size() * sizeof(float)));
+  XL_TRY(hipMalloc((void **)&f->d_qtaps, rtq.size() * sizeof(int16_t)));
+  XL_TRY(hipMalloc((void **)&f->d_group, sizeof(XlGroup)));
+  XL_TRY(hipMalloc((void **)&f->d_nco, sizeof(XlNcoClient)));
+  XL_TRY(hipHostMalloc(&f->h_in, f->max_samples * 8 + 16, hipHostMallocDefault));
+  XL_TRY(hipHostMalloc((void **)&f->h_out_f, f->out_cap * sizeof(float2), hipHostMallocDefault));
+  XL_TRY(hipHostMalloc((void **)&f->h_out_q, f->out_cap * sizeof(short2), hipHostMallocDefault));
+  // xlating.c:559,565: both work images start as zeros (the stream is preceded by T-1 zero samples)
+  XL_TRY(hipMemsetAsync(f->d_work_f, 0, work_n * sizeof(float2), f->stream));
+  XL_TRY(hipMemsetAsync(f->d_work_q, 0, work_n * sizeof(short2), f->stream));
+  XL_TRY(hipMemcpyAsync(f->d_taps, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice, f->stream));
+  XL_TRY(hipMemcpyAsync(f->d_qtaps, rtq.data(), rtq.size() * sizeof(int16_t), hipMemcpyHostToDevice, f->stream));
+  XL_TRY(hipMemcpyAsync(f->d_group, &g, sizeof(g), hipMemcpyHostToDevice, f->stream));
+  XL_TRY(hipMemcpyAsync(f->d_nco, &nc, sizeof(nc), hipMemcpyHostToDevice, f->stream));
+  XL_TRY(hipMemcpyAsync(f->d_phase, &one, sizeof(one), hipMemcpyHostToDevice, f->stream));
+  XL_TRY(hipMemcpyAsync(f->d_qphase, &qone, sizeof(qone), hipMemcpyHostToDevice, f->stream));
+  XL_TRY(hipStreamSynchronize(f->stream));
+  if (xl_fir_lds_bytes(decimation, f->Tpad) > 160 * 1024) {
+    XL_LOG_ERR("decimation %u with %zu taps needs a %zu-byte window image (> 160 KiB LDS)", decimation, taps_len,
+               xl_fir_lds_bytes(decimation, f->Tpad));
+    xl_filter_free(f);
+    return -EINVAL;
+  }
+  *filter = f;
+  return 0;
+fail:
+  xl_filter_free(f);  // frees taps too, like the reference's -ENOMEM paths (xlating.c:521,556,...)
+  return -ENOMEM;
+}
+
+extern "C" void destroy_xlating(xlating *filter) { xl_filter_free(filter); }
+
+// Output count and consumed samples for `fresh` new samples (xlating.c:53-60,76): W = hist + fresh;
+// outputs at window starts 0, D, 2D, ... < W - (T-1).
+static inline void xl_counts(const xlating *f, size_t fresh, size_t *W, size_t *K, size_t *pos) {
+  *W = f->hist + fresh;
+  *K = 0;
+  if (*W > f->T - 1) {
+    const size_t limit = *W - (f->T - 1);
+    *K = (limit + f->D - 1) / f->D;
+  }
+  *pos = *K * (size_t)f->D;
+}
+
+static bool xl_check_len(xlating *f, size_t nsamples) {
+  if (nsamples <= f->max_samples) return true;
+  if (!f->warned) {
+    XL_LOG_ERR("input of %zu samples exceeds max_input_buffer_length/2 = %zu; block dropped", nsamples, f->max_samples);
+    f->warned = true;
+  }
+  return false;
+}
+
+static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt, int mode, XL_CF32 **output,
+                        size_t *output_len) {
+  *output = reinterpret_cast<XL_CF32 *>(f->h_out_f);
+  *output_len = 0;
+  const size_t n = input_len / 2;
+  if (!xl_check_len(f, n)) return;
+  const size_t bytes = n * xl_bytes_per_sample(fmt);
+  size_t W, K, pos;
+  xl_counts(f, n, &W, &K, &pos);
+  XL_TRY(hipSetDevice(f->device));
+  if (n > 0) {
+    memcpy(f->h_in, input, bytes);
+    XL_TRY(hipMemcpyAsync(f->d_raw, f->h_in, bytes, hipMemcpyHostToDevice, f->stream));
+    XL_TRY(xl_launch_convert_cf32(f->d_raw, fmt, (uint32_t)n, f->d_work_f + f->hist, f->stream));
+  }
+  if (K > 0) {
+    XlDynArgs dyn;
+    dyn.d[0].base = 0;
+    dyn.d[0].K = (uint32_t)K;
+    dyn.d[0].zero_below = 0;
+    dyn.d[0].pad = 0;
+    XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phtab, dyn, f->stream));
+    XlFirArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in0 = f->d_work_f;
+    a.n0 = (uint32_t)W;
+    a.in1 = nullptr;
+    a.n1 = 0;
+    a.fmt = XLF_CF32;
+    a.groups = f->d_group;
+    a.ngroups = 1;
+    a.groups_per_xcd = 1;
+    a.xtiles = (uint32_t)((K + 63) / 64);
+    a.taps = f->d_taps;
+    a.phtab = f->d_phtab;
+    a.out = f->d_out_f;
+    XL_TRY(xl_launch_fir(1, mode, a, dyn, xl_fir_lds_bytes(f->D, f->Tpad), f->stream));
+    XL_TRY(hipMemcpyAsync(f->h_out_f, f->d_out_f, K * sizeof(float2), hipMemcpyDeviceToHost, f->stream));
+  }
+  {
+    // xlating.c:76-79.  pos can only exceed W when D > T (the reference underflows there); clamp.
+    const size_t keep = pos <= W ? W - pos : 0;
+    if (pos > 0) XL_TRY(xl_launch_move_down(f->d_work_f, (uint32_t)pos, (uint32_t)keep, 8, f->stream));
+    f->hist = keep;
+  }
+  XL_TRY(hipStreamSynchronize(f->stream));
+  *output_len = K;
+  return;
+fail:
+  *output_len = 0;
+}
+
+static void xl_run_q15(xlating *f, const void *input, size_t input_len, int fmt, int16_t **output, size_t *output_len) {
+  *output = reinterpret_cast<int16_t *>(f->h_out_q);
+  *output_len = 0;
+  const size_t n = input_len / 2;
+  if (!xl_check_len(f, (input_len + 1) / 2)) return;
+  const size_t bytes = input_len * (fmt == XLF_CS16 ? 2 : 1);
+  size_t W, K, pos;
+  xl_counts(f, n, &W, &K, &pos);
+  XL_TRY(hipSetDevice(f->device));
+  if (input_len > 0) {
+    memcpy(f->h_in, input, bytes);
+    XL_TRY(hipMemcpyAsync(f->d_raw, f->h_in, bytes, hipMemcpyHostToDevice, f->stream));
+    // xlating.c:417-419: every scalar element is converted (also a trailing odd one)
+    XL_TRY(xl_launch_convert_q15(f->d_raw, fmt, (uint32_t)input_len, reinterpret_cast<int16_t *>(f->d_work_q + f->hist),
+                                 f->stream));
+  }
+  if (K > 0) {
+    XL_TRY(xl_launch_nco_table_q15(f->qinc[0], f->qinc[1], f->d_qphase, f->d_qphtab, (uint32_t)K, f->stream));
+    XL_TRY(xl_launch_fir_q15(f->d_work_q, f->d_qtaps, (uint32_t)f->T, f->D, (uint32_t)K, f->d_qphtab, f->d_out_q,
+                             f->stream));
+    XL_TRY(hipMemcpyAsync(f->h_out_q, f->d_out_q, K * sizeof(short2), hipMemcpyDeviceToHost, f->stream));
+  }
+  {
+    const size_t keep = pos <= W ? W - pos : 0;  // xlating.c:133-136
+    if (pos > 0) XL_TRY(xl_launch_move_down(f->d_work_q, (uint32_t)pos, (uint32_t)keep, 4, f->stream));
+    f->hist = keep;
+  }
+  XL_TRY(hipStreamSynchronize(f->stream));
+  *output_len = K;
+  return;
+fail:
+  *output_len = 0;
+}
+
+#define XL_CF32_ENTRY(name, ctype, fmt, mode)                                                                    \
+  extern "C" void name(const ctype *input, size_t input_len, XL_CF32 **output, size_t *output_len, xlating *filter) { \
+    xl_run_cf32(filter, input, input_len, fmt, mode, output, output_len);                                        \
+  }
+#define XL_Q15_ENTRY(name, ctype, fmt)                                                                           \
+  extern "C" void name(const ctype *input, size_t input_len, int16_t **output, size_t *output_len, xlating *filter) { \
+    xl_run_q15(filter, input, input_len, fmt, output, output_len);                                               \
+  }
+
+// reference src/xlating.c:384-414 (native) and :352-382 (optimized)
+XL_CF32_ENTRY(process_native_cu8_cf32, uint8_t, XLF_CU8, 0)
+XL_CF32_ENTRY(process_native_cs8_cf32, int8_t, XLF_CS8, 0)
+XL_CF32_ENTRY(process_native_cs16_cf32, int16_t, XLF_CS16, 0)
+XL_CF32_ENTRY(process_optimized_cu8_cf32, uint8_t, XLF_CU8, 1)
+XL_CF32_ENTRY(process_optimized_cs8_cf32, int8_t, XLF_CS8, 1)
+XL_CF32_ENTRY(process_optimized_cs16_cf32, int16_t, XLF_CS16, 1)
+// extension: cf32 input
+XL_CF32_ENTRY(process_native_cf32_cf32, float, XLF_CF32, 0)
+XL_CF32_ENTRY(process_optimized_cf32_cf32, float, XLF_CF32, 1)
+// reference src/xlating.c:416-447; optimized == native there (:437-447)
+XL_Q15_ENTRY(process_native_cu8_cs16, uint8_t, XLF_CU8)
+XL_Q15_ENTRY(process_native_cs8_cs16, int8_t, XLF_CS8)
+XL_Q15_ENTRY(process_native_cs16_cs16, int16_t, XLF_CS16)
+XL_Q15_ENTRY(process_optimized_cu8_cs16, uint8_t, XLF_CU8)
+XL_Q15_ENTRY(process_optimized_cs8_cs16, int8_t, XLF_CS8)
+XL_Q15_ENTRY(process_optimized_cs16_cs16, int16_t, XLF_CS16)

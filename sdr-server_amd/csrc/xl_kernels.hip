@@ -1,0 +1,385 @@
+// xl_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for sdr-server's frequency-xlating FIR path.
+//
+// Reference semantics: /root/reference/src/xlating.c (cited per kernel).  Compiled with -ffp-contract=off:
+// nothing is fused unless written as __builtin_fmaf, so the "native" kernels evaluate exactly the reference's
+// scalar float32 expression tree (one rounding per multiply/add) and the "optimized" kernels fuse by choice.
+//
+// Kernel map
+//   xl_fir_kernel<CT,MODE>   fused  sample convert -> LDS window image -> T-tap complex FIR at stride D ->
+//                            NCO rotate -> store, for a batch of clients.           (xlating.c:52-72, 352-414)
+//   xl_nco_table_kernel      float32 phase recurrence + per-call hypotf renormalisation (xlating.c:71,73)
+//   xl_convert_*             raw -> cf32 / Q15 sample images of the single-filter path  (xlating.c:356-433)
+//   xl_move_down_kernel      history memmove                                            (xlating.c:76-79)
+//   xl_update_history_kernel raw history roll of the batch engine
+//   xl_fir_q15_kernel / xl_nco_table_q15_kernel   the Q15 family                        (xlating.c:92-140)
+//
+// Work decomposition of xl_fir_kernel (the hot kernel):
+//   lane      = one output sample m (64 consecutive outputs per wave)           -> no cross-lane reduction
+//   registers = CT complex accumulators, one per client of the wave's tile      -> each LDS sample read feeds
+//                                                                                  CT complex MACs (4*CT FMAs)
+//   taps      = wave-uniform: fetched with SCALAR loads (s_load_dwordx16 = tap i of 8 clients) from a
+//               [tap][client] interleaved image and used as SGPR operands of v_fma_f32 -> zero VALU/LDS cost
+//   window    = converted once per workgroup into LDS as cf32; the 4 waves of a workgroup (4 tiles = up to 32
+//               clients) share it.  Lane m reads sample (m*D + i): for odd D ds_read_b64 is bank-conflict
+//               free; for even D two samples are read per ds_read_b128 (conflict-free when D = 2 mod 4).
+//   grid      = (output tiles) x (groups), flattened so that every XCD owns a contiguous range of groups:
+//               all output tiles of a group re-read the same taps, which then stay in that XCD's L2.
+#include "xl_device.h"
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+// constant address space: uniform loads through these pointers are selected as scalar (SMEM) loads
+typedef const float __attribute__((address_space(4))) *cfloat_p;
+typedef const uint32_t __attribute__((address_space(4))) *cu32_p;
+
+#define XL_DEV static __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------- sample converters
+// xlating.c:357-358 / 367-368 / 377-378: all three maps are exact in float32.
+XL_DEV v2f xl_sample(const void *__restrict__ p, int fmt, uint32_t i) {
+  v2f r;
+  if (fmt == XLF_CU8) {
+    const uint32_t v = reinterpret_cast<const uint16_t *>(p)[i];
+    r.x = ((float)(v & 0xFFu) - 127.5f) / 128.0f;
+    r.y = ((float)(v >> 8) - 127.5f) / 128.0f;
+  } else if (fmt == XLF_CS8) {
+    const int32_t v = reinterpret_cast<const int16_t *>(p)[i];
+    r.x = (float)((int32_t)(int8_t)(v & 0xFF)) / 128.0f;
+    r.y = (float)(v >> 8) / 128.0f;
+  } else if (fmt == XLF_CS16) {
+    const int32_t v = reinterpret_cast<const int32_t *>(p)[i];
+    r.x = (float)((int32_t)(int16_t)(v & 0xFFFF)) / 32768.0f;
+    r.y = (float)(v >> 16) / 32768.0f;
+  } else {
+    r = reinterpret_cast<const v2f *>(p)[i];
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------- complex arithmetic
+// MODE 0 (native): the reference's scalar expression tree, xlating.c:68 `temp += x * h` in C99 complex float:
+//   p = (xr*hr - xi*hi) + j(xr*hi + xi*hr);  acc += p        -- 4 mul, 2 add/sub, 2 add, each rounded.
+// MODE 1 (optimized): 4 fused multiply-adds, same tap order.
+template <int MODE>
+XL_DEV void xl_cmac(v2f &acc, const v2f x, const float hr, const float hi) {
+  if (MODE == 0) {
+    const float pr = x.x * hr - x.y * hi;
+    const float pi = x.x * hi + x.y * hr;
+    acc.x = acc.x + pr;
+    acc.y = acc.y + pi;
+  } else {
+    acc.x = __builtin_fmaf(x.x, hr, acc.x);
+    acc.x = __builtin_fmaf(-x.y, hi, acc.x);
+    acc.y = __builtin_fmaf(x.x, hi, acc.y);
+    acc.y = __builtin_fmaf(x.y, hr, acc.y);
+  }
+}
+
+// xlating.c:70 `out = temp * phase`
+template <int MODE>
+XL_DEV v2f xl_rotate(const v2f a, const v2f p) {
+  v2f r;
+  if (MODE == 0) {
+    r.x = a.x * p.x - a.y * p.y;
+    r.y = a.x * p.y + a.y * p.x;
+  } else {
+    r.x = __builtin_fmaf(-a.y, p.y, a.x * p.x);
+    r.y = __builtin_fmaf(a.y, p.x, a.x * p.y);
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------- the FIR kernel
+template <int CT, int MODE>
+__global__ __launch_bounds__(XL_WG) void xl_fir_kernel(const XlFirArgs a, const XlDynArgs dyn) {
+  extern __shared__ __attribute__((aligned(16))) v2f xl_win[];
+
+  // block -> (group y, output tile x); XCD k (= blockIdx % 8 on this part) owns groups [k*gpx, (k+1)*gpx)
+  const uint32_t b = blockIdx.x;
+  const uint32_t xcd = b & 7u, idx = b >> 3;
+  const uint32_t y = xcd * a.groups_per_xcd + idx / a.xtiles;
+  const uint32_t x = idx % a.xtiles;
+  if (y >= a.ngroups) return;
+
+  const cu32_p g = (cu32_p)(uintptr_t)(a.groups + y);  // XlGroup as dwords, scalar-loaded
+  const uint32_t D = g[0], Tpad = g[2], cls = g[3], ntiles = g[4], wide = g[5];
+  const XlDyn d = dyn.d[cls];
+  const uint32_t K = d.K;
+  if (x * 64u >= K) return;
+
+  // ---- stage the window image: samples [win0, win0 + 63*D + Tpad) of the stream [in0 | in1], as cf32
+  const uint32_t win0 = d.base + x * 64u * D;
+  const uint32_t wlen = 63u * D + Tpad;
+  for (uint32_t j = threadIdx.x; j < wlen; j += XL_WG) {
+    const uint32_t s = win0 + j;
+    v2f v = {0.0f, 0.0f};
+    if (s >= d.zero_below) {
+      if (s < a.n0) {
+        v = xl_sample(a.in0, a.fmt, s);
+      } else if (s - a.n0 < a.n1) {
+        v = xl_sample(a.in1, a.fmt, s - a.n0);
+      }
+    }
+    xl_win[j] = v;
+  }
+  __syncthreads();
+
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (w >= ntiles) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const cu32_p t = g + 8 + w * (2 + XL_CT_MAX);  // XlTile of this wave
+  const uint32_t ncl = t[1];
+  const cfloat_p tp = (cfloat_p)(uintptr_t)(a.taps + t[0]);
+
+  v2f acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) acc[c] = (v2f){0.0f, 0.0f};
+
+  const v2f *lp = xl_win + lane * D;
+  if (wide) {
+    // even D: lane*D is even -> 16-byte aligned pairs of samples
+    for (uint32_t i = 0; i < Tpad; i += XL_TAP_UNROLL) {
+      const v4f q0 = *reinterpret_cast<const v4f *>(lp + i);
+      const v4f q1 = *reinterpret_cast<const v4f *>(lp + i + 2);
+      const v2f xs[4] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}};
+      const cfloat_p tq = tp + (size_t)i * (2 * CT);
+#pragma unroll
+      for (int u = 0; u < XL_TAP_UNROLL; ++u) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) xl_cmac<MODE>(acc[c], xs[u], tq[(u * CT + c) * 2], tq[(u * CT + c) * 2 + 1]);
+      }
+    }
+  } else {
+    for (uint32_t i = 0; i < Tpad; i += XL_TAP_UNROLL) {
+      v2f xs[4];
+#pragma unroll
+      for (int u = 0; u < XL_TAP_UNROLL; ++u) xs[u] = lp[i + u];
+      const cfloat_p tq = tp + (size_t)i * (2 * CT);
+#pragma unroll
+      for (int u = 0; u < XL_TAP_UNROLL; ++u) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) xl_cmac<MODE>(acc[c], xs[u], tq[(u * CT + c) * 2], tq[(u * CT + c) * 2 + 1]);
+      }
+    }
+  }
+
+  // ---- epilogue: derotate with the tabulated NCO phase and store (coalesced: lanes = consecutive outputs)
+  const uint32_t m = x * 64u + lane;
+  if (m < K) {
+    const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
+    v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      if ((uint32_t)c < ncl) {
+        const uint32_t off = t[2 + c] + m;
+        out[off] = xl_rotate<MODE>(acc[c], ph[off]);
+      }
+    }
+  }
+}
+
+size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad) { return (size_t)(63u * D + Tpad) * sizeof(v2f); }
+
+template <int CT, int MODE>
+static hipError_t xl_fir_go(const XlFirArgs &a, const XlDynArgs &dyn, size_t lds, hipStream_t s) {
+  static bool attr_done = false;  // per instantiation; benign race (idempotent)
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&xl_fir_kernel<CT, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const uint32_t nblocks = 8u * a.groups_per_xcd * a.xtiles;
+  if (nblocks == 0) return hipSuccess;
+  hipLaunchKernelGGL((xl_fir_kernel<CT, MODE>), dim3(nblocks), dim3(XL_WG), lds, s, a, dyn);
+  return hipGetLastError();
+}
+
+hipError_t xl_launch_fir(int ct, int mode, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds, hipStream_t s) {
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  switch (ct * 2 + (mode ? 1 : 0)) {
+    case 2: return xl_fir_go<1, 0>(a, dyn, lds, s);
+    case 3: return xl_fir_go<1, 1>(a, dyn, lds, s);
+    case 4: return xl_fir_go<2, 0>(a, dyn, lds, s);
+    case 5: return xl_fir_go<2, 1>(a, dyn, lds, s);
+    case 8: return xl_fir_go<4, 0>(a, dyn, lds, s);
+    case 9: return xl_fir_go<4, 1>(a, dyn, lds, s);
+    case 16: return xl_fir_go<8, 0>(a, dyn, lds, s);
+    case 17: return xl_fir_go<8, 1>(a, dyn, lds, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- NCO phase table
+// xlating.c:70-73: the phasor is a float32 RECURRENCE p <- p * incr (never re-seeded), renormalised once per
+// call that could produce output.  It is data independent, so one lane per client tabulates the K phases of
+// the block ahead of the FIR kernel; the recurrence itself must stay sequential to be bit-exact.
+// hypotf: glibc evaluates sqrt(x*x + y*y) in double and narrows; restated with IEEE double ops.
+__global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
+                                                          float2 *__restrict__ state, float2 *__restrict__ tab,
+                                                          const XlDynArgs dyn) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const XlNcoClient k = cl[c];
+  const uint32_t K = dyn.d[k.cls].K;
+  if (K == 0) return;
+  float pr = state[k.slot].x, pi = state[k.slot].y;
+  const float ir = k.incr.x, ii = k.incr.y;
+  float2 *__restrict__ o = tab + k.out_off;
+  for (uint32_t m = 0; m < K; ++m) {
+    o[m] = make_float2(pr, pi);
+    const float nr = pr * ir - pi * ii;
+    const float ni = pr * ii + pi * ir;
+    pr = nr;
+    pi = ni;
+  }
+  const double mag2 = (double)pr * (double)pr + (double)pi * (double)pi;
+  const float mag = (float)__dsqrt_rn(mag2);
+  state[k.slot] = make_float2(pr / mag, pi / mag);
+}
+
+hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, float2 *phase_state, float2 *phtab,
+                               const XlDynArgs &dyn, hipStream_t s) {
+  if (nclients == 0) return hipSuccess;
+  hipLaunchKernelGGL(xl_nco_table_kernel, dim3((nclients + 63) / 64), dim3(64), 0, s, clients, nclients, phase_state,
+                     phtab, dyn);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------- single-filter helpers
+__global__ void xl_convert_cf32_kernel(const void *__restrict__ raw, int fmt, uint32_t n, v2f *__restrict__ dst) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    dst[i] = xl_sample(raw, fmt, i);
+}
+
+hipError_t xl_launch_convert_cf32(const void *raw, int fmt, uint32_t nsamples, float2 *dst, hipStream_t s) {
+  if (nsamples == 0) return hipSuccess;
+  const uint32_t blocks = (nsamples + 255) / 256 < 2048 ? (nsamples + 255) / 256 : 2048;
+  hipLaunchKernelGGL(xl_convert_cf32_kernel, dim3(blocks), dim3(256), 0, s, raw, fmt, nsamples,
+                     reinterpret_cast<v2f *>(dst));
+  return hipGetLastError();
+}
+
+// xlating.c:418 ((u8 - 128) << 8), :425 (s8 << 8), :432 (copy); per scalar element
+__global__ void xl_convert_q15_kernel(const void *__restrict__ raw, int fmt, uint32_t n, int16_t *__restrict__ dst) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int32_t v;
+    if (fmt == XLF_CU8) {
+      v = ((int32_t) reinterpret_cast<const uint8_t *>(raw)[i] - 128) * 256;
+    } else if (fmt == XLF_CS8) {
+      v = (int32_t) reinterpret_cast<const int8_t *>(raw)[i] * 256;
+    } else {
+      v = reinterpret_cast<const int16_t *>(raw)[i];
+    }
+    dst[i] = (int16_t)v;
+  }
+}
+
+hipError_t xl_launch_convert_q15(const void *raw, int fmt, uint32_t nelems, int16_t *dst, hipStream_t s) {
+  if (nelems == 0) return hipSuccess;
+  const uint32_t blocks = (nelems + 255) / 256 < 2048 ? (nelems + 255) / 256 : 2048;
+  hipLaunchKernelGGL(xl_convert_q15_kernel, dim3(blocks), dim3(256), 0, s, raw, fmt, nelems, dst);
+  return hipGetLastError();
+}
+
+// memmove towards lower addresses (xlating.c:76-79), dword granularity, ONE workgroup: chunk k is read
+// completely (barrier) before it is written, and chunks go in increasing order, so overlap is safe.
+__global__ __launch_bounds__(1024) void xl_move_down_kernel(uint32_t *buf, uint32_t from_dw, uint32_t count_dw) {
+  for (uint32_t base = 0; base < count_dw; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    uint32_t v = 0;
+    if (i < count_dw) v = buf[from_dw + i];
+    __syncthreads();
+    if (i < count_dw) buf[i] = v;
+    __syncthreads();
+  }
+}
+
+hipError_t xl_launch_move_down(void *buf, uint32_t from, uint32_t count, uint32_t elem_bytes, hipStream_t s) {
+  if (count == 0 || from == 0) return hipSuccess;
+  const uint32_t k = elem_bytes / 4;
+  hipLaunchKernelGGL(xl_move_down_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<uint32_t *>(buf), from * k,
+                     count * k);
+  return hipGetLastError();
+}
+
+// batch engine: roll the raw history (the last h samples of [hist | block]) into the other history buffer
+__global__ void xl_update_history_kernel(const uint16_t *__restrict__ hist, const uint16_t *__restrict__ block,
+                                         uint32_t h_u, uint32_t n_u, uint16_t *__restrict__ out) {
+  // units of 2 bytes; out[j] = concat(hist, block)[n_u + j], j < h_u
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < h_u; j += gridDim.x * blockDim.x) {
+    const uint32_t s = n_u + j;
+    out[j] = (s < h_u) ? hist[s] : block[s - h_u];
+  }
+}
+
+hipError_t xl_launch_update_history(const void *hist, const void *block, uint32_t h, uint32_t n, uint32_t bps,
+                                    void *new_hist, hipStream_t s) {
+  if (h == 0) return hipSuccess;
+  const uint32_t u = bps / 2;
+  const uint32_t hu = h * u, nu = n * u;
+  const uint32_t blocks = (hu + 255) / 256 < 256 ? (hu + 255) / 256 : 256;
+  hipLaunchKernelGGL(xl_update_history_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint16_t *>(hist),
+                     reinterpret_cast<const uint16_t *>(block), hu, nu, reinterpret_cast<uint16_t *>(new_hist));
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------- Q15 family
+XL_DEV int32_t xl_sat16(int32_t v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }  // xlating.c:85-90
+
+// xlating.c:126-129: truncating Q15 phase recurrence, never renormalised.  One thread (one filter).
+__global__ void xl_nco_table_q15_kernel(int32_t ir, int32_t ii, short2 *__restrict__ state,
+                                        short2 *__restrict__ tab, uint32_t K) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int32_t pr = state->x, pi = state->y;
+  for (uint32_t m = 0; m < K; ++m) {
+    tab[m] = make_short2((short)pr, (short)pi);
+    const int32_t tr = pr * ir - pi * ii;
+    const int32_t ti = pr * ii + pi * ir;
+    pr = xl_sat16(tr >> 15);
+    pi = xl_sat16(ti >> 15);
+  }
+  *state = make_short2((short)pr, (short)pi);
+}
+
+hipError_t xl_launch_nco_table_q15(int16_t incr_re, int16_t incr_im, short2 *phase_state, short2 *phtab, uint32_t K,
+                                   hipStream_t s) {
+  if (K == 0) return hipSuccess;
+  hipLaunchKernelGGL(xl_nco_table_q15_kernel, dim3(1), dim3(64), 0, s, (int32_t)incr_re, (int32_t)incr_im, phase_state,
+                     phtab, K);
+  return hipGetLastError();
+}
+
+// xlating.c:100-124: int16 x int16 products accumulated in int64, >>15, saturate, rotate by the Q15 phase.
+// Lane = output; taps wave-uniform (scalar loads of packed int16 pairs); window read straight from L2.
+__global__ __launch_bounds__(256) void xl_fir_q15_kernel(const int32_t *__restrict__ work, const int32_t *taps,
+                                                         uint32_t T, uint32_t D, uint32_t K,
+                                                         const short2 *__restrict__ phtab, short2 *__restrict__ out) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= K) return;
+  const int32_t *__restrict__ w = work + (size_t)m * D;
+  const cu32_p tq = (cu32_p)(uintptr_t)taps;
+  long long sr = 0, si = 0;
+  for (uint32_t i = 0; i < T; ++i) {
+    const int32_t xv = w[i];
+    const int32_t hv = (int32_t)tq[i];
+    const int32_t xr = (int16_t)(xv & 0xFFFF), xi = xv >> 16;
+    const int32_t hr = (int16_t)(hv & 0xFFFF), hi = hv >> 16;
+    sr += (long long)(xr * hr - xi * hi);
+    si += (long long)(xr * hi + xi * hr);
+  }
+  const int32_t ar = xl_sat16((int32_t)(sr >> 15));
+  const int32_t ai = xl_sat16((int32_t)(si >> 15));
+  const short2 p = phtab[m];
+  const int32_t tr = ar * p.x - ai * p.y;
+  const int32_t ti = ar * p.y + ai * p.x;
+  out[m] = make_short2((short)xl_sat16(tr >> 15), (short)xl_sat16(ti >> 15));
+}
+
+hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T, uint32_t D, uint32_t K,
+                             const short2 *phtab, short2 *out, hipStream_t s) {
+  if (K == 0) return hipSuccess;
+  hipLaunchKernelGGL(xl_fir_q15_kernel, dim3((K + 255) / 256), dim3(256), 0, s, reinterpret_cast<const int32_t *>(work),
+                     reinterpret_cast<const int32_t *>(taps), T, D, K, phtab, out);
+  return hipGetLastError();
+}

@@ -1,0 +1,191 @@
+"""GPU parity tests (-m gpu) of the batched fan-out engine (include/xlating_batch.h): every client's stream must
+equal what a single reference filter created at the client's join time would have produced.
+native: bit-exact vs the oracle;  optimized: max|d|/max|y| <= 1e-5 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+import scenarios
+import siggen
+import sdr_server_amd as xl
+from conftest import bits_equal
+from pyoracle import Oracle
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5
+FS = 2016000
+
+
+def lpf(fs, cutoff, tw):
+    code, t = xl.create_low_pass_filter(1.0, fs, cutoff, tw)
+    assert code == 0
+    return t
+
+
+def rel_err(a, b):
+    if len(b) == 0:
+        return 0.0
+    return float(np.abs(a.astype(np.complex128) - b.astype(np.complex128)).max() / max(np.abs(b).max(), 1e-30))
+
+
+def check_clients(eng, oracles, fmt, x, variant, ids=None):
+    eng.process_host(x, variant)
+    eng.fetch()
+    for cid, o in oracles.items():
+        if ids is not None and cid not in ids:
+            o.process(fmt, x)  # keep the oracle's stream state in step
+            continue
+        want = o.process(fmt, x)
+        got = eng.output(cid)
+        assert eng.output_len(cid) == len(want), (cid, eng.output_len(cid), len(want))
+        if variant == "native":
+            assert bits_equal(got, want), f"client {cid}"
+        else:
+            assert rel_err(got, want) <= REL_TOL, (cid, rel_err(got, want))
+
+
+@pytest.mark.parametrize("variant", ["native", "optimized"])
+@pytest.mark.parametrize("nclients", [1, 13, 24])
+def test_homogeneous_clients_server_default(variant, nclients):
+    """N clients, 48 kHz off 2.016 Msps (D=42, 505 taps), three blocks incl. a ragged one."""
+    taps = lpf(FS, 24000, 9600)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    oracles = {}
+    for c in range(nclients):
+        fc = -900000 + c * 28000
+        cid = eng.add_client(42, taps, fc)
+        oracles[cid] = Oracle(42, taps, fc, FS, 262144)
+    assert eng.num_clients == nclients
+    for k, n in enumerate((262144, 100002, 262144)):
+        check_clients(eng, oracles, "cu8", siggen.xs_u8(siggen.XS_SEED + k, n), variant)
+    eng.close()
+
+
+def test_mixed_rates_config3_64_clients():
+    """BASELINE config 3: 32 x 48 kHz (D=42, T=505) + 32 x 96 kHz (D=21, T=253) sharing each block."""
+    t48, t96 = lpf(FS, 24000, 9600), lpf(FS, 48000, 19200)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    oracles = {}
+    for c in range(64):
+        fc = -900000 + c * 28000
+        D, taps = (42, t48) if c % 2 == 0 else (21, t96)
+        cid = eng.add_client(D, taps, fc)
+        oracles[cid] = Oracle(D, taps, fc, FS, 262144)
+    for k in range(2):
+        check_clients(eng, oracles, "cu8", siggen.xs_u8(siggen.XS_SEED + 7 + k, 262144), "native")
+    check_clients(eng, oracles, "cu8", siggen.xs_u8(siggen.XS_SEED + 9, 262144), "optimized")
+    eng.close()
+
+
+def test_join_and_leave_mid_stream():
+    """A client added after some blocks starts a fresh stream (zero history, phase 1, own output grid); removing a
+    client does not disturb the others (dsp_worker_start / dsp_worker_destroy semantics)."""
+    taps = lpf(FS, 24000, 9600)
+    t101 = lpf(FS, 24000, 48000)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    oracles = {}
+    for c in range(9):
+        cid = eng.add_client(42, taps, 1000 * c - 4000)
+        oracles[cid] = Oracle(42, taps, 1000 * c - 4000, FS, 262144)
+    blocks = [siggen.xs_u8(100 + k, n) for k, n in enumerate((262144, 262144, 50000, 262144, 262144))]
+    check_clients(eng, oracles, "cu8", blocks[0], "native")
+    # two late joiners: same shape as the others, and a different (D, T)
+    cid = eng.add_client(42, taps, 777)
+    oracles[cid] = Oracle(42, taps, 777, FS, 262144)
+    cid = eng.add_client(42, t101, -5555)
+    oracles[cid] = Oracle(42, t101, -5555, FS, 262144)
+    check_clients(eng, oracles, "cu8", blocks[1], "native")
+    gone = sorted(oracles)[3]
+    eng.remove_client(gone)
+    oracles.pop(gone).close()
+    check_clients(eng, oracles, "cu8", blocks[2], "native")
+    cid = eng.add_client(42, taps, 31337)  # reuses the freed slot; must start from phase 1
+    oracles[cid] = Oracle(42, taps, 31337, FS, 262144)
+    check_clients(eng, oracles, "cu8", blocks[3], "native")
+    check_clients(eng, oracles, "cu8", blocks[4], "optimized")
+    eng.close()
+
+
+@pytest.mark.parametrize("fmt", ["cs8", "cs16", "cf32"])
+def test_other_input_formats(fmt):
+    taps = lpf(FS, 24000, 48000)  # 101 taps
+    nsamp = 65536
+    eng = xl.BatchEngine(FS, fmt, 4 * nsamp)
+    oracles = {}
+    for c in range(10):
+        cid = eng.add_client(42, taps, -300000 + 61111 * c)
+        oracles[cid] = Oracle(42, taps, -300000 + 61111 * c, FS, 4 * nsamp)
+    for k in range(2):
+        if fmt == "cs8":
+            x = siggen.xs_s8(40 + k, 2 * nsamp)
+        elif fmt == "cs16":
+            x = siggen.xs_s16(40 + k, 2 * nsamp)
+        else:
+            x = (siggen.xs_s16(40 + k, 2 * nsamp).astype(np.float32) / np.float32(32768)).astype(np.float32)
+        check_clients(eng, oracles, fmt, x, "native")
+    eng.close()
+
+
+def test_config5_cf32_10msps_257_taps():
+    """BASELINE config 5 (as corrected in SURVEY D4): cf32 input at 10 Msps, D=100, 257 explicit taps."""
+    taps = siggen.hamming_sinc(257, 0.004)
+    nsamp = 131072
+    eng = xl.BatchEngine(10000000, "cf32", 2 * nsamp)
+    oracles = {}
+    for c in range(16):
+        fc = -4000000 + 500000 * c
+        cid = eng.add_client(100, taps, fc)
+        oracles[cid] = Oracle(100, taps, fc, 10000000, 2 * nsamp)
+    x = np.empty(2 * nsamp, np.float32)
+    x[:] = siggen.sin_f32(0, 2 * nsamp)
+    check_clients(eng, oracles, "cf32", x, "native")
+    check_clients(eng, oracles, "cf32", x, "optimized")
+    eng.close()
+
+
+def test_device_pointer_path_matches_host_path():
+    """xlating_batch_process_device: block already in HBM (what an RCCL broadcast leaves), caller's stream."""
+    import torch
+
+    taps = lpf(FS, 24000, 9600)
+    e1 = xl.BatchEngine(FS, "cu8", 262144)
+    e2 = xl.BatchEngine(FS, "cu8", 262144)
+    ids = []
+    for c in range(16):
+        ids.append((e1.add_client(42, taps, 5000 * c), e2.add_client(42, taps, 5000 * c)))
+    for k in range(3):
+        x = siggen.xs_u8(900 + k, 262144)
+        e1.process_host(x, "optimized")
+        xd = torch.from_numpy(x).cuda()
+        e2.process_device(xd.data_ptr(), x.size, "optimized", torch.cuda.current_stream().cuda_stream)
+        e1.fetch()
+        e2.fetch()
+        for a, b in ids:
+            assert bits_equal(e1.output(a), e2.output(b))
+    e1.close()
+    e2.close()
+
+
+def test_full_size_1024_clients_properties():
+    """BASELINE target size (1024 concurrent 48 kHz clients, 505 taps, 262144-byte blocks).  The oracle is too slow
+    for all of it, so: (a) duplicated clients placed in different tiles/groups/XCDs must agree bit for bit,
+    (b) a checksum over all outputs is identical across two engines fed the same stream, (c) 16 sampled clients
+    are compared with the oracle."""
+    taps = lpf(FS, 24000, 9600)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    fcs = [-984000 + 1920 * (c % 512) for c in range(1024)]
+    for fc in fcs:
+        eng.add_client(42, taps, fc)
+    rng = np.random.default_rng(3)
+    sample = sorted(rng.choice(1024, 16, replace=False).tolist())
+    oracles = {c: Oracle(42, taps, fcs[c], FS, 262144) for c in sample}
+    for k in range(2):
+        x = siggen.xs_u8(5000 + k, 262144)
+        eng.process_host(x, "native")
+        eng.fetch()
+        outs = [eng.output(c) for c in range(1024)]
+        for c in range(512):
+            assert bits_equal(outs[c], outs[c + 512]), c
+        for c in sample:
+            assert bits_equal(outs[c], oracles[c].process("cu8", x)), c
+        assert all(len(o) == len(outs[0]) for o in outs)
+    eng.close()

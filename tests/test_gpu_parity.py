@@ -1,0 +1,206 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI of include/xlating.h, against
+  (1) the oracle run live on the same inputs      -- native: BIT-EXACT;  optimized: max|d|/max|y| <= 1e-5
+  (2) the committed outputs of the unmodified reference (tests/golden/live_*.npz) -- same bars
+  (3) the expected arrays of the reference's own tests under the reference's own assertion (G1-G6).
+cs16 (Q15) outputs are exact integers: bit-exact in every variant.
+Tolerance: BASELINE.json north_star "within 1e-5 relative", read as max|d| / max|y_ref| per call.
+"""
+import numpy as np
+import pytest
+
+import scenarios
+import sdr_server_amd as xl
+from conftest import assert_ref_cf32, bits_equal, load_live
+from pyoracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+
+
+def hip_lpf(*a):
+    code, t = xl.create_low_pass_filter(*a)
+    assert code == 0
+    return t
+
+
+def run_hip(sc, variant):
+    taps = scenarios.make_taps(sc, lpf=hip_lpf)
+    f = xl.XlatingFilter(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"])
+    outs = []
+    for call in sc["calls"]:
+        x = scenarios.to_path_input(sc, scenarios.make_input(sc, call))
+        outs.append(f.process(variant, sc["fmt"], call["out"], x))
+    f.close()
+    return taps, outs
+
+
+def run_oracle(sc):
+    code_taps = scenarios.make_taps(sc, lpf=lambda *a: Oracle.lpf(*a)[1])
+    o = Oracle(sc["D"], code_taps, sc["fc"], sc["fs"], sc["max_input"])
+    outs = []
+    for call in sc["calls"]:
+        x = scenarios.to_path_input(sc, scenarios.make_input(sc, call))
+        outs.append(o.process(sc["fmt"], x, call["out"]))
+    o.close()
+    return outs
+
+
+def rel_err(a, b):
+    if len(b) == 0:
+        return 0.0
+    return float(np.abs(a.astype(np.complex128) - b.astype(np.complex128)).max() / max(np.abs(b).max(), 1e-30))
+
+
+FAST = [s for s in scenarios.SCENARIOS if s["name"] != "g15_drift"]
+
+
+def test_device_is_gfx950():
+    assert xl.simd_status() == "HIP gfx950"
+    assert "gfx950" in xl.device_info(), xl.device_info()
+
+
+@pytest.mark.parametrize("sc", FAST, ids=lambda s: s["name"])
+def test_native_bit_exact_vs_oracle_and_reference_fixture(sc):
+    taps, outs = run_hip(sc, "native")
+    want = run_oracle(sc)
+    live = load_live(sc["name"])
+    assert bits_equal(taps, live["taps"])
+    for ci, call in enumerate(sc["calls"]):
+        assert len(outs[ci]) == int(live[f"n{ci}"]), (sc["name"], ci)
+        assert bits_equal(outs[ci], want[ci]), f"{sc['name']} call {ci} ({call['out']}) differs from oracle"
+        if call.get("keep", True):
+            y = outs[ci] if call.get("keep_n") is None else outs[ci][: call["keep_n"]]
+            assert bits_equal(y, live[f"y{ci}"]), f"{sc['name']} call {ci} differs from committed reference output"
+
+
+@pytest.mark.parametrize("sc", FAST, ids=lambda s: s["name"])
+def test_optimized_within_tolerance(sc):
+    _, outs = run_hip(sc, "optimized")
+    want = run_oracle(sc)
+    for ci, call in enumerate(sc["calls"]):
+        assert len(outs[ci]) == len(want[ci])
+        if call["out"] == "cs16":
+            assert bits_equal(outs[ci], want[ci])  # Q15: optimized == native == exact (xlating.c:437-447)
+        else:
+            assert rel_err(outs[ci], want[ci]) <= REL_TOL, (sc["name"], ci, rel_err(outs[ci], want[ci]))
+
+
+@pytest.mark.parametrize("variant", ["native", "optimized"])
+def test_reference_test_arrays_g1_g6(ref_vectors, variant):
+    """The reference's own assertions (test/utils.c:176-189) on test/test_xlating.c + test/test_tcp_server.c arrays."""
+    v = ref_vectors["test_xlating.c"]
+    _, o = run_hip(scenarios.BY_NAME["g1_full"], variant)
+    assert_ref_cf32(v["test_max_input_buffer_size"]["expected_cf32"], o[0])
+    assert np.array_equal(np.asarray(v["test_max_input_buffer_size"]["expected_cs16"], np.int16), o[1].reshape(-1))
+    _, o = run_hip(scenarios.BY_NAME["g2_partial"], variant)
+    p = v["test_partial_input_buffer_size"]
+    assert_ref_cf32(p["expected_cf32"], o[0])
+    assert np.array_equal(np.asarray(p["expected_cs16"], np.int16), o[1].reshape(-1))
+    assert_ref_cf32(p["expected_next_cf32"], o[2])
+    assert np.array_equal(np.asarray(p["expected_next_cs16"], np.int16), o[3].reshape(-1))
+    _, o = run_hip(scenarios.BY_NAME["g3_small"], variant)
+    assert len(o[0]) == 20 and len(o[1]) == 20 and len(o[2]) == 0 and len(o[3]) == 0
+    for name, fn in (("g4_rtl", "test_rtlsdr"), ("g5_airspy", "test_airspy"), ("g6_hackrf", "test_hackrf")):
+        _, o = run_hip(scenarios.BY_NAME[name], variant)
+        assert_ref_cf32(ref_vectors["test_tcp_server.c"][fn]["expected"], o[0])
+
+
+def test_nco_drift_100_blocks_native_bit_exact():
+    """G15: 100 server-default blocks on one filter; the float32 phase recurrence + per-call renormalisation must
+    track the reference bit for bit (an 'ideal' NCO would be 5e-5 off after one block)."""
+    sc = scenarios.BY_NAME["g15_drift"]
+    taps, outs = run_hip(sc, "native")
+    live = load_live(sc["name"])
+    for ci, call in enumerate(sc["calls"]):
+        assert len(outs[ci]) == int(live[f"n{ci}"])
+        if call.get("keep", True):
+            y = outs[ci] if call.get("keep_n") is None else outs[ci][: call["keep_n"]]
+            assert bits_equal(y, live[f"y{ci}"]), f"block {ci}"
+
+
+def test_nco_drift_100_blocks_optimized_within_tolerance():
+    sc = scenarios.BY_NAME["g15_drift"]
+    _, outs = run_hip(sc, "optimized")
+    live = load_live(sc["name"])
+    worst = 0.0
+    for ci, call in enumerate(sc["calls"]):
+        if call.get("keep", True):
+            y = outs[ci] if call.get("keep_n") is None else outs[ci][: call["keep_n"]]
+            ref = live[f"y{ci}"]
+            worst = max(worst, float(np.abs(y - ref).max() / np.abs(live["y99"]).max()))
+    assert worst <= REL_TOL, worst
+
+
+def test_optimized_accuracy_vs_f64_yardstick():
+    """The fused variant should be at least as close to a double-accumulated FIR as the canonical float32 order."""
+    sc = scenarios.BY_NAME["g9_default"]
+    taps = scenarios.make_taps(sc, lpf=hip_lpf)
+    x = scenarios.make_input(sc, sc["calls"][0])
+    o64 = Oracle(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"], sum_mode=1)
+    o32 = Oracle(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"], sum_mode=0)
+    y64 = o64.process("cu8", x)
+    y32 = o32.process("cu8", x)
+    f = xl.XlatingFilter(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"])
+    yo = f.process("optimized", "cu8", "cf32", x)
+    f.close()
+    e_fast, e_canon = rel_err(yo, y64), rel_err(y32, y64)
+    assert e_fast <= 2e-6 and e_fast <= 1.5 * e_canon + 1e-7, (e_fast, e_canon)
+
+
+@pytest.mark.parametrize("fmt", ["cu8", "cs8", "cs16"])
+def test_empty_and_tiny_inputs(fmt):
+    """input_len 0, 1 element, 1 sample: no output, state intact, later output still bit-exact."""
+    taps = hip_lpf(1.0, 48000, 4800, 2000)
+    f = xl.XlatingFilter(5, taps, -12000, 48000, 4000)
+    o = Oracle(5, taps, -12000, 48000, 4000)
+    gen = {"cu8": scenarios.siggen.ramp_u8, "cs8": scenarios.siggen.ramp_s8, "cs16": scenarios.siggen.ramp_s16}[fmt]
+    for n in (0, 1, 2, 0, 3, 400, 2, 2, 2, 2, 2, 2000):
+        x = gen(n * 3, n)
+        a, b = f.process("native", fmt, "cf32", x), o.process(fmt, x, "cf32")
+        assert bits_equal(a, b), n
+        a, b = f.process("native", fmt, "cs16", x), o.process(fmt, x, "cs16")
+        assert bits_equal(a, b), n
+    f.close()
+    o.close()
+
+
+def test_maximum_block_server_default():
+    """Largest block the server feeds (buffer_size 262144 bytes, config.conf:13) for all three device formats."""
+    taps = hip_lpf(1.0, 2016000, 24000, 9600)
+    for fmt, x in (("cu8", scenarios.siggen.xs_u8(11, 262144)), ("cs8", scenarios.siggen.xs_s8(12, 262144)),
+                   ("cs16", scenarios.siggen.xs_s16(13, 131072))):
+        f = xl.XlatingFilter(42, taps, 123456, 2016000, 262144)
+        o = Oracle(42, taps, 123456, 2016000, 262144)
+        for _ in range(2):
+            assert bits_equal(f.process("native", fmt, "cf32", x), o.process(fmt, x, "cf32"))
+        f.close()
+        o.close()
+
+
+def test_many_filters_threads():
+    """dsp_worker model: N threads, each with its own filter, concurrently (SURVEY 8(b) threading)."""
+    import threading
+
+    taps = hip_lpf(1.0, 2016000, 24000, 9600)
+    x = scenarios.siggen.xs_u8(5, 262144)
+    o = Oracle(42, taps, -12000, 2016000, 262144)
+    want = [o.process("cu8", x) for _ in range(3)]
+    o.close()
+    errs = []
+
+    def worker():
+        try:
+            f = xl.XlatingFilter(42, taps, -12000, 2016000, 262144)
+            for k in range(3):
+                y = f.process("native", "cu8", "cf32", x)
+                if not bits_equal(y, want[k]):
+                    errs.append(k)
+            f.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker) for _ in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
