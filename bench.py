@@ -62,6 +62,22 @@ def flops_per_unit(ntaps, decim):
     return 8.0 * ntaps / decim + 6.0 / decim
 
 
+def broadcast_block(dist, recv, src_block, rank):
+    """The path's only exchange step: rank 0's raw IQ block -> every rank (RCCL over xGMI on GPUs, gloo in the
+    CPU tests).  `recv` is each rank's receive buffer; returns the tensor holding the block on this rank."""
+    if rank == 0:
+        recv.copy_(src_block, non_blocking=True)
+    dist.broadcast(recv, src=0)
+    return recv
+
+
+def reduce_max_seconds(dist, torch, dt, device):
+    """bench contract: the step time is the MAX over ranks."""
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def make_blocks(nblocks, seed):
     import siggen
 
@@ -69,63 +85,41 @@ def make_blocks(nblocks, seed):
 
 
 def cpu_baseline(ntaps_rate, seconds=12.0):
-    """Reference (oracle/_ref libref_fast.so) or port (oracle/liboracle.so) on the host cores, thread per client
-    like the reference's dsp_worker threads (src/dsp_worker.c:41-88), each thread its own filter over the same
-    block.  Bounded sample: `seconds` of wall time."""
-    import threading
+    """Reference (oracle/_ref/libref_fast.so) -- or the repo's CPU restatement when that build is absent -- on the
+    host cores, via the native pthread driver oracle/cpu_bench: one thread per client, each with its own filter
+    over the same block (the reference's dsp_worker model, src/dsp_worker.c:41-88).  Bounded sample: `seconds` of
+    wall time split between a 1-thread and an all-cores run."""
+    import subprocess
 
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import siggen
-    from pyoracle import Oracle, RefLib
-
+    odir = os.path.join(ROOT, "oracle")
+    drv = os.path.join(odir, "cpu_bench")
     flags = open("/proc/cpuinfo").read()
-    model = "unknown"
-    for line in flags.splitlines():
-        if line.startswith("model name"):
-            model = line.split(":", 1)[1].strip()
-            break
-    use_ref = RefLib.available("fast") and " avx2 " in flags.replace("\n", " ") and " fma " in flags.replace("\n", " ")
-    cores = os.cpu_count() or 1
-    x = siggen.xs_u8(siggen.XS_SEED, BLOCK_BYTES)
-    if use_ref:
-        taps = RefLib.lpf(1.0, FS, RATE // 2, RATE // ntaps_rate, flavour="fast")[1]
-        mk = lambda c: RefLib(D, taps, client_center_freq(c), FS, BLOCK_BYTES, flavour="fast", variant="optimized")
-        run = lambda f: f.process_raw("cu8", x, "cf32")
-        kind, what = "reference", f"unmodified src/xlating.c process_optimized_cu8_cf32 ({RefLib.simd_status('fast')}, -O3 -ffast-math -mavx2 -mfma)"
+    model = next((l.split(":", 1)[1].strip() for l in flags.splitlines() if l.startswith("model name")), "unknown")
+    flat = " " + flags.replace("\n", " ") + " "
+    ref = os.path.join(odir, "_ref", "libref_fast.so")
+    if os.path.exists(ref) and " avx2 " in flat and " fma " in flat:
+        lib, api, variant, kind = ref, "ref", "optimized", "reference"
+        what = "unmodified src/xlating.c process_optimized_cu8_cf32 (hand-written AVX path; gcc -O3 -ffast-math -mavx2 -mfma)"
     else:
-        taps = Oracle.lpf(1.0, FS, RATE // 2, RATE // ntaps_rate)[1]
-        mk = lambda c: Oracle(D, taps, client_center_freq(c), FS, BLOCK_BYTES)
-        run = lambda f: len(f.process("cu8", x))
-        kind, what = "port", "oracle/xlating_oracle.c scalar restatement (-O2, canonical order)"
+        lib, api, variant, kind = os.path.join(odir, "liboracle.so"), "orc", "native", "port"
+        what = "oracle/xlating_oracle.c scalar restatement (gcc -O2, canonical order)"
+    cores = os.cpu_count() or 1
 
-    def timed(nthreads, budget):
-        filters = [mk(c) for c in range(nthreads)]
-        counts = [0] * nthreads
-        stop = time.perf_counter() + budget
+    def run(threads, secs):
+        r = subprocess.run([drv, lib, api, variant, str(threads), str(secs), str(FS), str(RATE), str(RATE // ntaps_rate),
+                            str(BLOCK_BYTES)], capture_output=True, text=True, timeout=secs * 3 + 60)
+        if r.returncode != 0:
+            raise RuntimeError(f"cpu_bench failed: {r.stderr[-500:]}")
+        return json.loads(r.stdout.strip().splitlines()[-1])
 
-        def work(i):
-            f = filters[i]
-            run(f)
-            while time.perf_counter() < stop:
-                run(f)
-                counts[i] += 1
-
-        t0 = time.perf_counter()
-        ts = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
-        [t.start() for t in ts]
-        [t.join() for t in ts]
-        dt = time.perf_counter() - t0
-        for f in filters:
-            f.close()
-        return sum(counts) * S / dt / 1e6, sum(counts)
-
-    one, n1 = timed(1, seconds * 0.3)
-    allc, nall = timed(cores, seconds * 0.7)
+    one = run(1, max(2.0, seconds * 0.3))
+    allc = run(cores, max(3.0, seconds * 0.7))
     return {
-        "value": round(allc, 2), "unit": "Msamples/s", "cores": cores, "kind": kind,
-        "single_thread_value": round(one, 2),
-        "sample": f"{what}; {ntaps_rate=} -> {taps.size} taps, D={D}, {BLOCK_BYTES}-byte cu8 blocks; {nall} calls on "
-                  f"{cores} threads in {seconds * 0.7:.1f} s wall (+ {n1} calls single-thread); host CPU: {model}",
+        "value": round(allc["msps"], 1), "unit": "Msamples/s", "cores": cores, "kind": kind,
+        "single_thread_value": round(one["msps"], 1),
+        "sample": f"{what}; lpf_cutoff_rate={ntaps_rate} -> {allc['ntaps']} taps, D={D}, {BLOCK_BYTES}-byte cu8 blocks, one "
+                  f"filter per thread over a shared block; {allc['calls']} calls on {cores} threads in {allc['seconds']:.1f} s "
+                  f"wall (+ {one['calls']} calls on 1 thread in {one['seconds']:.1f} s); host CPU: {model}",
     }
 
 
@@ -142,10 +136,7 @@ def run_workload(eng_cls, xl, torch, dist, args, rank, world, ntaps_rate, steps,
 
     def step(k):
         if world > 1:
-            if rank == 0:
-                recv.copy_(dev_blocks[k % len(dev_blocks)], non_blocking=True)
-            dist.broadcast(recv, src=0)                     # RCCL over xGMI: the raw IQ block
-            ptr = recv.data_ptr()
+            ptr = broadcast_block(dist, recv, dev_blocks[k % len(dev_blocks)], rank).data_ptr()  # RCCL over xGMI
         else:
             ptr = dev_blocks[k % len(dev_blocks)].data_ptr()
         eng.process_device(ptr, BLOCK_BYTES, args.mode, stream.cuda_stream)
@@ -168,9 +159,7 @@ def run_workload(eng_cls, xl, torch, dist, args, rank, world, ntaps_rate, steps,
     nt, fir_ms, nco_ms = eng.timing_read(reset=True)
     eng.timing(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = reduce_max_seconds(dist, torch, dt, "cuda")
     klen = eng.output_len(0)
     eng.close()
     return {"ntaps": int(taps.size), "seconds": dt, "fir_ms_avg": fir_ms / max(nt, 1), "nco_ms_avg": nco_ms / max(nt, 1),

@@ -11,7 +11,12 @@
 //   taps        [tile][Tpad][ct] float2, tap i of the ct clients of a tile contiguous (one s_load_dwordx16)
 //   groups[ct]  XlGroup descriptors (<= 4 tiles of one class each)
 //   nco         XlNcoClient per client; phase[slot] running NCO phase per client
-//   phtab/out   [client][K_cap] float2: phase table and outputs, same indexing
+//   phtab[2]/out [client][K_cap] float2: phase tables (ping-pong) and outputs, same indexing
+//
+// NCO pipelining: the phase table of a block depends only on the running phases and on the block's output
+// counts, not on the data (xlating.c:70-73).  Its sequential float32 recurrence (K steps per client) is
+// therefore tabulated ONE BLOCK AHEAD on a side stream, assuming the next block has the same length; the
+// running phases are double-buffered (committed / next) so that a wrong guess is simply recomputed.
 //
 // Streaming rule: a client's outputs lie on the global grid n = k*D of ITS stream; output k's
 // newest sample is stream sample k*D.  With `consumed` = samples this client has seen before the block,
@@ -86,9 +91,18 @@ struct xlating_batch_t {
   void *h_block = nullptr;  // pinned staging
   float2 *d_taps = nullptr;
   XlNcoClient *d_nco = nullptr;
-  float2 *d_phase = nullptr;
+  hipStream_t nco_stream = nullptr;
+  float2 *d_phase[2] = {nullptr, nullptr};  // [pcur] = committed running phases, [pcur^1] = next
+  int pcur = 0;
   size_t phase_cap = 0;
-  float2 *d_phtab = nullptr;
+  float2 *d_phtab[2] = {nullptr, nullptr};
+  hipEvent_t ev_nco[2] = {nullptr, nullptr};  // table[i] written
+  hipEvent_t ev_fir[2] = {nullptr, nullptr};  // table[i] consumed
+  bool ev_fir_valid[2] = {false, false};
+  int tab = 0;             // table used by the block in flight
+  bool spec_valid = false;  // table[spec_tab] holds the phases of the NEXT block assuming spec_S samples
+  size_t spec_S = 0;
+  int spec_tab = 0;
   float2 *d_out = nullptr;
   size_t out_alloc = 0;
   float2 *h_out = nullptr;
@@ -96,10 +110,11 @@ struct xlating_batch_t {
   bool fetched = false;
 
   bool timing = false;
-  std::vector<hipEvent_t> ev;  // triples: nco start, fir start, fir stop
-  size_t ev_used = 0;
+  std::vector<hipEvent_t> ev;       // pairs: fir start, fir stop (on the launch stream)
+  std::vector<hipEvent_t> ev_ncot;  // pairs: nco start, nco stop (on the side stream)
   double fir_ms = 0.0, nco_ms = 0.0;
   int timed_launches = 0;
+  int timed_nco = 0;
 };
 
 static void xl_batch_free_plan(xlating_batch *b) {
@@ -119,14 +134,22 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   if (b->device >= 0) (void)hipSetDevice(b->device);
   if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
   if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
+  if (b->nco_stream) (void)hipStreamSynchronize(b->nco_stream);
   xl_batch_free_plan(b);
-  void *dev[] = {b->d_hist[0], b->d_hist[1], b->d_block, b->d_phase, b->d_phtab, b->d_out};
+  void *dev[] = {b->d_hist[0], b->d_hist[1], b->d_block,    b->d_phase[0],
+                 b->d_phase[1], b->d_phtab[0], b->d_phtab[1], b->d_out};
   for (void *p : dev)
     if (p) (void)hipFree(p);
   if (b->h_block) (void)hipHostFree(b->h_block);
   if (b->h_out) (void)hipHostFree(b->h_out);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : b->ev_ncot) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) {
+    if (b->ev_nco[i]) (void)hipEventDestroy(b->ev_nco[i]);
+    if (b->ev_fir[i]) (void)hipEventDestroy(b->ev_fir[i]);
+  }
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+  if (b->nco_stream) (void)hipStreamDestroy(b->nco_stream);
   delete b;
 }
 
@@ -152,6 +175,11 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
     const size_t bbytes = (size_t)b->max_samples * b->bps + 16;
     XL_TRY(hipSetDevice(dev));
     XL_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+    XL_TRY(hipStreamCreateWithFlags(&b->nco_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      XL_TRY(hipEventCreateWithFlags(&b->ev_nco[i], hipEventDisableTiming));
+      XL_TRY(hipEventCreateWithFlags(&b->ev_fir[i], hipEventDisableTiming));
+    }
     XL_TRY(hipMalloc(&b->d_hist[0], hbytes));
     XL_TRY(hipMalloc(&b->d_hist[1], hbytes));
     XL_TRY(hipMalloc(&b->d_block, bbytes));
@@ -207,29 +235,32 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
   c.out_cap = b->max_samples / decimation + 1;  // xlating.c:568
   b->nalive++;
   b->dirty = true;
-  // the running phase of a new client starts at 1 + 0j (xlating.c:543); slot = client id
+  // the running phase of a new client starts at 1 + 0j (xlating.c:543); slot = client id.  Any phase table
+  // tabulated ahead is for the old client set: drop it (the committed phases are untouched by it).
+  (void)hipSetDevice(b->device);
+  (void)hipStreamSynchronize(b->last_stream);
+  (void)hipStreamSynchronize(b->nco_stream);
+  b->spec_valid = false;
   if ((size_t)id >= b->phase_cap) {
-    (void)hipSetDevice(b->device);
-    (void)hipStreamSynchronize(b->last_stream);
     const size_t ncap = std::max<size_t>(1024, 2 * b->clients.size());
-    float2 *np = nullptr;
-    if (hipMalloc((void **)&np, ncap * sizeof(float2)) != hipSuccess) {
-      c.alive = false;
-      b->nalive--;
-      return -ENOMEM;
+    for (int i = 0; i < 2; ++i) {
+      float2 *np = nullptr;
+      if (hipMalloc((void **)&np, ncap * sizeof(float2)) != hipSuccess) {
+        c.alive = false;
+        b->nalive--;
+        return -ENOMEM;
+      }
+      if (b->d_phase[i]) {
+        (void)hipMemcpy(np, b->d_phase[i], b->phase_cap * sizeof(float2), hipMemcpyDeviceToDevice);
+        (void)hipFree(b->d_phase[i]);
+      }
+      b->d_phase[i] = np;
     }
-    if (b->d_phase) {
-      (void)hipMemcpy(np, b->d_phase, b->phase_cap * sizeof(float2), hipMemcpyDeviceToDevice);
-      (void)hipFree(b->d_phase);
-    }
-    b->d_phase = np;
     b->phase_cap = ncap;
   }
   {
-    (void)hipSetDevice(b->device);
-    (void)hipStreamSynchronize(b->last_stream);
     const float2 one = make_float2(1.0f, 0.0f);
-    if (hipMemcpy(b->d_phase + id, &one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess) return -EIO;
+    if (hipMemcpy(b->d_phase[b->pcur] + id, &one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess) return -EIO;
   }
   return id;
 }
@@ -246,6 +277,9 @@ extern "C" int xlating_batch_remove_client(xlating_batch *b, int id) {
 // (Re)build the resident plan: classes, tiles (register-tile heights 8/4/2/1), groups, tap image, NCO table.
 static int xl_batch_plan(xlating_batch *b) {
   (void)hipStreamSynchronize(b->last_stream);
+  (void)hipStreamSynchronize(b->nco_stream);
+  b->spec_valid = false;
+  b->ev_fir_valid[0] = b->ev_fir_valid[1] = false;
   xl_batch_free_plan(b);
   b->classes.clear();
   b->nco.clear();
@@ -343,17 +377,67 @@ static int xl_batch_plan(xlating_batch *b) {
   }
   if (b->out_total > b->out_alloc) {
     if (b->d_out) (void)hipFree(b->d_out);
-    if (b->d_phtab) (void)hipFree(b->d_phtab);
-    b->d_out = b->d_phtab = nullptr;
+    b->d_out = nullptr;
+    for (int i = 0; i < 2; ++i) {
+      if (b->d_phtab[i]) (void)hipFree(b->d_phtab[i]);
+      b->d_phtab[i] = nullptr;
+    }
     b->out_alloc = 0;
     XL_TRY(hipMalloc((void **)&b->d_out, b->out_total * sizeof(float2)));
-    XL_TRY(hipMalloc((void **)&b->d_phtab, b->out_total * sizeof(float2)));
+    XL_TRY(hipMalloc((void **)&b->d_phtab[0], b->out_total * sizeof(float2)));
+    XL_TRY(hipMalloc((void **)&b->d_phtab[1], b->out_total * sizeof(float2)));
     b->out_alloc = b->out_total;
   }
   b->dirty = false;
   return 0;
 fail:
   return -ENOMEM;
+}
+
+// Per-class numbers of a block of S samples, from the classes' current stream positions.
+static uint32_t xl_batch_dyn(const xlating_batch *b, size_t S, XlDynArgs *dyn) {
+  memset(dyn, 0, sizeof(*dyn));
+  uint32_t maxK = 0;
+  for (size_t k = 0; k < b->classes.size(); ++k) {
+    const ClassState &cs = b->classes[k];
+    const uint32_t j0 = (cs.D - cs.rem) % cs.D;
+    const uint32_t K = S > j0 ? (uint32_t)((S - j0 + cs.D - 1) / cs.D) : 0u;
+    dyn->d[k].base = XL_HCAP - (cs.T - 1) + j0;
+    dyn->d[k].K = K;
+    dyn->d[k].zero_below = XL_HCAP - cs.hv;
+    maxK = std::max(maxK, K);
+  }
+  return maxK;
+}
+
+// Tabulate the phases of a block on the side stream: committed phases -> table[tab] + next phases.
+static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab, bool timed) {
+  hipError_t e;
+  if (b->ev_fir_valid[tab]) {  // the FIR launch that last read table[tab] must be done with it
+    e = hipStreamWaitEvent(b->nco_stream, b->ev_fir[tab], 0);
+    if (e != hipSuccess) return e;
+  }
+  hipEvent_t n0 = nullptr, n1 = nullptr;
+  if (timed) {
+    for (int i = 0; i < 2; ++i) {
+      hipEvent_t ev;
+      e = hipEventCreate(&ev);
+      if (e != hipSuccess) return e;
+      b->ev_ncot.push_back(ev);
+    }
+    n0 = b->ev_ncot[b->ev_ncot.size() - 2];
+    n1 = b->ev_ncot[b->ev_ncot.size() - 1];
+    e = hipEventRecord(n0, b->nco_stream);
+    if (e != hipSuccess) return e;
+  }
+  e = xl_launch_nco_table(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[b->pcur], b->d_phase[b->pcur ^ 1],
+                          b->d_phtab[tab], dyn, b->nco_stream);
+  if (e != hipSuccess) return e;
+  if (timed) {
+    e = hipEventRecord(n1, b->nco_stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipEventRecord(b->ev_nco[tab], b->nco_stream);
 }
 
 static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len, int mode, hipStream_t s) {
@@ -368,16 +452,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
   if (b->nco.empty()) return 0;
 
   XlDynArgs dyn;
-  memset(&dyn, 0, sizeof(dyn));
-  uint32_t maxK = 0;
-  for (size_t k = 0; k < b->classes.size(); ++k) {
-    ClassState &cs = b->classes[k];
-    const uint32_t j0 = (cs.D - cs.rem) % cs.D;
-    const uint32_t K = S > j0 ? (uint32_t)((S - j0 + cs.D - 1) / cs.D) : 0u;
-    dyn.d[k].base = XL_HCAP - (cs.T - 1) + j0;
-    dyn.d[k].K = K;
-    dyn.d[k].zero_below = XL_HCAP - cs.hv;
-    maxK = std::max(maxK, K);
+  const uint32_t maxK = xl_batch_dyn(b, S, &dyn);
+  for (ClassState &cs : b->classes) {  // advance the stream positions past this block
     cs.rem = (uint32_t)((cs.rem + S) % cs.D);
     cs.hv = (uint32_t)std::min<uint64_t>((uint64_t)cs.hv + S, XL_HCAP);
   }
@@ -387,25 +463,31 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
     c.consumed += S;
   }
 
-  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-  if (b->timing) {
-    if (b->ev_used + 3 > b->ev.size()) {
-      for (int i = 0; i < 3; ++i) {
-        hipEvent_t e;
-        XL_TRY(hipEventCreate(&e));
-        b->ev.push_back(e);
-      }
-    }
-    e0 = b->ev[b->ev_used];
-    e1 = b->ev[b->ev_used + 1];
-    e2 = b->ev[b->ev_used + 2];
-    b->ev_used += 3;
+  // ---- this block's phase table: already tabulated ahead if the length guess was right
+  int tab;
+  if (b->spec_valid && b->spec_S == S) {
+    tab = b->spec_tab;
+  } else {
+    tab = b->spec_valid ? b->spec_tab : (b->tab ^ 1);
+    XL_TRY(xl_batch_nco(b, dyn, tab, b->timing));
   }
+  b->spec_valid = false;
+  b->pcur ^= 1;  // the phases written by that NCO launch are now the committed ones
+  b->tab = tab;
 
   if (maxK > 0) {
-    if (e0) XL_TRY(hipEventRecord(e0, s));
-    XL_TRY(xl_launch_nco_table(b->d_nco, (uint32_t)b->nco.size(), b->d_phase, b->d_phtab, dyn, s));
-    if (e1) XL_TRY(hipEventRecord(e1, s));
+    hipEvent_t f0 = nullptr, f1 = nullptr;
+    if (b->timing) {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t ev;
+        XL_TRY(hipEventCreate(&ev));
+        b->ev.push_back(ev);
+      }
+      f0 = b->ev[b->ev.size() - 2];
+      f1 = b->ev[b->ev.size() - 1];
+    }
+    XL_TRY(hipStreamWaitEvent(s, b->ev_nco[tab], 0));
+    if (f0) XL_TRY(hipEventRecord(f0, s));
     for (Launch &L : b->launches) {
       if (L.groups.empty()) continue;
       XlFirArgs a;
@@ -420,17 +502,27 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
       a.groups_per_xcd = (a.ngroups + 7) / 8;
       a.xtiles = (maxK + 63) / 64;
       a.taps = b->d_taps;
-      a.phtab = b->d_phtab;
+      a.phtab = b->d_phtab[tab];
       a.out = b->d_out;
       XL_TRY(xl_launch_fir(L.ct, mode, a, dyn, L.lds, s));
     }
-    if (e2) XL_TRY(hipEventRecord(e2, s));
-  } else if (b->timing) {
-    b->ev_used -= 3;
+    if (f1) XL_TRY(hipEventRecord(f1, s));
+    XL_TRY(hipEventRecord(b->ev_fir[tab], s));
+    b->ev_fir_valid[tab] = true;
   }
   // roll the raw history: the last XL_HCAP samples of [hist | block]
   XL_TRY(xl_launch_update_history(b->d_hist[b->hcur], d_block, XL_HCAP, (uint32_t)S, b->bps, b->d_hist[b->hcur ^ 1], s));
   b->hcur ^= 1;
+
+  // ---- tabulate the NEXT block's phases now, on the side stream, guessing it has the same length
+  {
+    XlDynArgs next;
+    (void)xl_batch_dyn(b, S, &next);
+    XL_TRY(xl_batch_nco(b, next, tab ^ 1, b->timing));
+    b->spec_valid = true;
+    b->spec_S = S;
+    b->spec_tab = tab ^ 1;
+  }
   return 0;
 fail:
   return -EIO;
@@ -518,8 +610,9 @@ extern "C" int xlating_batch_client_phase(xlating_batch *b, int id, float *re, f
   if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
   if (hipStreamSynchronize(b->last_stream) != hipSuccess) return -EIO;
+  if (hipStreamSynchronize(b->nco_stream) != hipSuccess) return -EIO;
   float2 p;
-  if (hipMemcpy(&p, b->d_phase + id, sizeof(p), hipMemcpyDeviceToHost) != hipSuccess) return -EIO;
+  if (hipMemcpy(&p, b->d_phase[b->pcur] + id, sizeof(p), hipMemcpyDeviceToHost) != hipSuccess) return -EIO;
   *re = p.x;
   *im = p.y;
   return 0;
@@ -527,15 +620,23 @@ extern "C" int xlating_batch_client_phase(xlating_batch *b, int id, float *re, f
 
 static int xl_batch_drain_events(xlating_batch *b) {
   if (hipStreamSynchronize(b->last_stream) != hipSuccess) return -EIO;
-  for (size_t i = 0; i + 3 <= b->ev_used; i += 3) {
-    float a = 0.0f, c = 0.0f;
-    if (hipEventElapsedTime(&a, b->ev[i], b->ev[i + 1]) != hipSuccess) return -EIO;
-    if (hipEventElapsedTime(&c, b->ev[i + 1], b->ev[i + 2]) != hipSuccess) return -EIO;
-    b->nco_ms += a;
-    b->fir_ms += c;
+  if (hipStreamSynchronize(b->nco_stream) != hipSuccess) return -EIO;
+  for (size_t i = 0; i + 2 <= b->ev.size(); i += 2) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]) != hipSuccess) return -EIO;
+    b->fir_ms += ms;
     b->timed_launches++;
   }
-  b->ev_used = 0;
+  for (size_t i = 0; i + 2 <= b->ev_ncot.size(); i += 2) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, b->ev_ncot[i], b->ev_ncot[i + 1]) != hipSuccess) return -EIO;
+    b->nco_ms += ms;
+    b->timed_nco++;
+  }
+  for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : b->ev_ncot) (void)hipEventDestroy(e);
+  b->ev.clear();
+  b->ev_ncot.clear();
   return 0;
 }
 
@@ -553,11 +654,12 @@ extern "C" int xlating_batch_timing_read(xlating_batch *b, double *fir_ms_total,
   int rc = xl_batch_drain_events(b);
   if (rc != 0) return rc;
   if (fir_ms_total) *fir_ms_total = b->fir_ms;
-  if (nco_ms_total) *nco_ms_total = b->nco_ms;
+  // the NCO launches are not one-to-one with blocks (one extra look-ahead): report the per-block equivalent
+  if (nco_ms_total) *nco_ms_total = b->timed_nco ? b->nco_ms / b->timed_nco * b->timed_launches : 0.0;
   const int n = b->timed_launches;
   if (reset) {
     b->fir_ms = b->nco_ms = 0.0;
-    b->timed_launches = 0;
+    b->timed_launches = b->timed_nco = 0;
   }
   return n;
 }

@@ -76,8 +76,9 @@ struct XlNcoClient {
 // ---- launchers (xl_kernels.hip).  All return hipError_t of the launch. -------------------------------------
 // mode: 0 native (bit-exact scalar order, unfused), 1 optimized (fma).  ct: 1, 2, 4 or 8.
 hipError_t xl_launch_fir(int ct, int mode, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds_bytes, hipStream_t s);
-hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, float2 *phase_state, float2 *phtab,
-                               const XlDynArgs &dyn, hipStream_t s);
+// reads the running phases from state_in[slot], writes the post-block phases to state_out[slot] (may alias)
+hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
+                               float2 *state_out, float2 *phtab, const XlDynArgs &dyn, hipStream_t s);
 // raw -> converted sample images of the single-filter path (xlating.c:352-433)
 hipError_t xl_launch_convert_cf32(const void *raw, int fmt, uint32_t nsamples, float2 *dst, hipStream_t s);
 hipError_t xl_launch_convert_q15(const void *raw, int fmt, uint32_t nelems, int16_t *dst, hipStream_t s);

@@ -201,7 +201,7 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     dyn.d[0].K = (uint32_t)K;
     dyn.d[0].zero_below = 0;
     dyn.d[0].pad = 0;
-    XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phtab, dyn, f->stream));
+    XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase, f->d_phtab, dyn, f->stream));
     XlFirArgs a;
     memset(&a, 0, sizeof(a));
     a.in0 = f->d_work_f;

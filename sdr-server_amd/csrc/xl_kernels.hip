@@ -216,17 +216,31 @@ hipError_t xl_launch_fir(int ct, int mode, const XlFirArgs &a, const XlDynArgs &
 // the block ahead of the FIR kernel; the recurrence itself must stay sequential to be bit-exact.
 // hypotf: glibc evaluates sqrt(x*x + y*y) in double and narrows; restated with IEEE double ops.
 __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
-                                                          float2 *__restrict__ state, float2 *__restrict__ tab,
+                                                          const float2 *state_in, float2 *state_out, float2 *__restrict__ tab,
                                                           const XlDynArgs dyn) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   const XlNcoClient k = cl[c];
   const uint32_t K = dyn.d[k.cls].K;
-  if (K == 0) return;
-  float pr = state[k.slot].x, pi = state[k.slot].y;
+  float pr = state_in[k.slot].x, pi = state_in[k.slot].y;
+  if (K == 0) {  // no output possible in this block: the reference leaves the phase untouched (xlating.c:58)
+    state_out[k.slot] = make_float2(pr, pi);
+    return;
+  }
   const float ir = k.incr.x, ii = k.incr.y;
   float2 *__restrict__ o = tab + k.out_off;
-  for (uint32_t m = 0; m < K; ++m) {
+  uint32_t m = 0;
+  for (; m + 8 <= K; m += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o[m + j] = make_float2(pr, pi);
+      const float nr = pr * ir - pi * ii;
+      const float ni = pr * ii + pi * ir;
+      pr = nr;
+      pi = ni;
+    }
+  }
+  for (; m < K; ++m) {
     o[m] = make_float2(pr, pi);
     const float nr = pr * ir - pi * ii;
     const float ni = pr * ii + pi * ir;
@@ -235,14 +249,14 @@ __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__r
   }
   const double mag2 = (double)pr * (double)pr + (double)pi * (double)pi;
   const float mag = (float)__dsqrt_rn(mag2);
-  state[k.slot] = make_float2(pr / mag, pi / mag);
+  state_out[k.slot] = make_float2(pr / mag, pi / mag);
 }
 
-hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, float2 *phase_state, float2 *phtab,
-                               const XlDynArgs &dyn, hipStream_t s) {
+hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
+                               float2 *state_out, float2 *phtab, const XlDynArgs &dyn, hipStream_t s) {
   if (nclients == 0) return hipSuccess;
-  hipLaunchKernelGGL(xl_nco_table_kernel, dim3((nclients + 63) / 64), dim3(64), 0, s, clients, nclients, phase_state,
-                     phtab, dyn);
+  hipLaunchKernelGGL(xl_nco_table_kernel, dim3((nclients + 63) / 64), dim3(64), 0, s, clients, nclients, state_in,
+                     state_out, phtab, dyn);
   return hipGetLastError();
 }
 

@@ -17,11 +17,14 @@ cat $OUT/ubench.log
 echo "== bench"
 timeout 600 python bench.py --steps 100 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json; tail -5 $OUT/bench.err
+echo "== sweep"
+timeout 600 python tools/sweep.py > $OUT/sweep.log 2>&1
+cat $OUT/sweep.log
 echo "== bench native"
 timeout 300 python bench.py --steps 50 --warmup 5 --mode native --no-cpu-baseline > $OUT/bench_native.json 2> $OUT/bench_native.err
 cat $OUT/bench_native.json; tail -3 $OUT/bench_native.err
 echo "== rocprofv3 kernel trace"
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-variants > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-variants > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err
 cd $GRAFT_REPO_ROOT
 tail -3 $OUT/prof.err
-find $OUT/prof -name "*stats*" | head; for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -12 $f; done
+find $OUT/prof -type f | head; for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -12 $f; done
