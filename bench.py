@@ -123,26 +123,29 @@ def cpu_baseline(ntaps_rate, seconds=12.0):
     }
 
 
-def run_workload(eng_cls, xl, torch, dist, args, rank, world, ntaps_rate, steps, warmup, dev_blocks, recv):
+def run_workload(xl, torch, dist, args, rank, world, ntaps_rate, steps, warmup, dev_blocks, recvs):
     """Build this rank's engine with its shard of clients and time `steps` blocks.  Returns dict of measurements."""
     code, taps = xl.create_low_pass_filter(1.0, FS, RATE // 2, RATE // ntaps_rate)
     assert code == 0
     total_clients = args.clients_per_gpu * world
     mine = shard_clients(total_clients, world, rank)
-    eng = eng_cls(FS, "cu8", BLOCK_BYTES, device=torch.cuda.current_device())
+    eng = xl.BatchEngine(FS, "cu8", BLOCK_BYTES, device=torch.cuda.current_device())
     for c in mine:
         eng.add_client(D, taps, client_center_freq(c))
     stream = torch.cuda.current_stream()
 
     def step(k):
         if world > 1:
-            ptr = broadcast_block(dist, recv, dev_blocks[k % len(dev_blocks)], rank).data_ptr()  # RCCL over xGMI
+            # two receive buffers alternate so that the broadcast of block k+1 can overlap the filtering of block k
+            src = dev_blocks[k % len(dev_blocks)] if rank == 0 else None
+            ptr = broadcast_block(dist, recvs[k % 2], src, rank).data_ptr()  # RCCL over xGMI
         else:
             ptr = dev_blocks[k % len(dev_blocks)].data_ptr()
         eng.process_device(ptr, BLOCK_BYTES, args.mode, stream.cuda_stream)
 
     for k in range(warmup):
         step(k)
+    eng.sync()
     torch.cuda.synchronize()
     eng.timing(True)
     if world > 1:
@@ -167,6 +170,7 @@ def run_workload(eng_cls, xl, torch, dist, args, rank, world, ntaps_rate, steps,
 
 
 def summarize(m, steps, world):
+    """value and roofline figures from the timed region of `m` (HIP-event duration of the FIR launches in it)."""
     units_per_step = m["total_clients"] * S
     value = units_per_step * steps / m["seconds"] / 1e6
     per_gpu_units = m["clients_this_rank"] * S
@@ -214,26 +218,23 @@ def main():
 
     blocks = make_blocks(8, 0x5DEECE66D)
     dev_blocks = [torch.from_numpy(b).cuda() for b in blocks] if (rank == 0 or world == 1) else []
-    recv = torch.empty(BLOCK_BYTES, dtype=torch.uint8, device="cuda") if world > 1 else None
-    if world > 1 and rank != 0:
-        dev_blocks = [recv]
+    recvs = [torch.empty(BLOCK_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else None
 
-    m = run_workload(xl.BatchEngine, xl, torch, dist, args, rank, world, args.lpf_cutoff_rate, args.steps, args.warmup,
-                     dev_blocks, recv)
+    m = run_workload(xl, torch, dist, args, rank, world, args.lpf_cutoff_rate, args.steps, args.warmup, dev_blocks, recvs)
     value, ach_gbs, ach_tf, bpu, fpu = summarize(m, args.steps, world)
 
     variants = {}
     if not args.no_variants:
         other_rate = 1 if args.lpf_cutoff_rate != 1 else 5
         vs = max(20, args.steps // 2)
-        mv = run_workload(xl.BatchEngine, xl, torch, dist, args, rank, world, other_rate, vs, min(args.warmup, 5),
-                          dev_blocks, recv)
+        mv = run_workload(xl, torch, dist, args, rank, world, other_rate, vs, min(args.warmup, 5), dev_blocks, recvs)
         v2, g2, t2, _, f2 = summarize(mv, vs, world)
         variants[f"lpf_cutoff_rate={other_rate} ({mv['ntaps']} taps)"] = {
             "value": round(v2, 1), "ms_per_step": round(mv["seconds"] / vs * 1e3, 4),
             "roofline_hbm_frac": round(g2 / HBM_PEAK_GBS, 4), "achieved_GBs": round(g2, 1),
             "fp32_frac": round(t2 / FP32_PEAK_TFLOPS, 4), "achieved_TFLOPs": round(t2, 2),
-            "fir_kernel_ms": round(mv["fir_ms_avg"], 4), "flop_per_unit": round(f2, 2)}
+            "fir_kernel_ms": round(mv["fir_ms_avg"], 4), "nco_table_kernel_ms": round(mv["nco_ms_avg"], 4),
+            "flop_per_unit": round(f2, 2)}
 
     if rank != 0:
         if world > 1:
@@ -272,7 +273,9 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": f"xl_fir_kernel<8,{1 if args.mode == 'optimized' else 0}>", "kernel_ms": round(m["fir_ms_avg"], 4),
+            "kernel": f"xl_fir_kernel<H,{1 if args.mode == 'optimized' else 0},1,true> (H = register-tile height chosen by the engine)",
+            "kernel_ms": round(m["fir_ms_avg"], 4),
+            "kernel_ms_note": "mean HIP-event duration of the FIR launch over the timed region, on its launch stream",
             "bytes_per_unit": round(bpu, 4), "units_per_launch": m["clients_this_rank"] * S,
             "model": "per-client-read (SURVEY 8(d)): 2 B in + 8/D B out per (client, input sample)",
             "fp32": {"achieved": round(ach_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -54,9 +54,9 @@ int xlating_batch_num_clients(const xlating_batch *batch);
 /* Process one block for ALL clients.  `input_len` = scalar elements, as in xlating.h.
  * _host:   `input` is host memory; copied H2D on the engine's stream.
  * _device: `d_input` is device memory on the engine's GPU (e.g. the receive buffer of an RCCL
- *          broadcast); read in place, not copied.  `hip_stream` (a hipStream_t, may be NULL = the
- *          engine's own stream) is the stream all work for this block is enqueued on; the call does
- *          not synchronise it.  The caller must keep d_input unmodified until that work has run.
+ *          broadcast); read in place, not copied.  `hip_stream` is a hipStream_t (NULL = HIP's legacy
+ *          default stream, as everywhere in HIP): the block's work is ordered behind what that stream
+ *          holds at the time of the call; the call does not synchronise it.  The caller must keep d_input unmodified until that work has run.
  * Results stay on the device until fetched.  Returns 0, -EINVAL (too long / bad mode), -EIO (HIP error). */
 int xlating_batch_process_host(xlating_batch *batch, const void *input, size_t input_len, int mode);
 int xlating_batch_process_device(xlating_batch *batch, const void *d_input, size_t input_len, int mode,

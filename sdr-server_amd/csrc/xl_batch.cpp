@@ -6,23 +6,26 @@
 // serve every client of this GPU, outputs stay in HBM until fetched.
 //
 // HBM layout (all resident across blocks; only XlDynArgs -- 16 B per class -- travels per block, as kernargs):
-//   hist[2]     raw history: the last XL_HCAP samples of the stream in the INPUT format (ping-pong)
-//   block       engine-owned copy of the current block (host path) -- or the caller's device buffer, in place
-//   taps        [tile][Tpad][ct] float2, tap i of the ct clients of a tile contiguous (one s_load_dwordx16)
-//   groups[ct]  XlGroup descriptors (<= 4 tiles of one class each)
-//   nco         XlNcoClient per client; phase[slot] running NCO phase per client
-//   phtab[2]/out [client][K_cap] float2: phase tables (ping-pong) and outputs, same indexing
-//
-// NCO pipelining: the phase table of a block depends only on the running phases and on the block's output
-// counts, not on the data (xlating.c:70-73).  Its sequential float32 recurrence (K steps per client) is
-// therefore tabulated ONE BLOCK AHEAD on a side stream, assuming the next block has the same length; the
-// running phases are double-buffered (committed / next) so that a wrong guess is simply recomputed.
+//   hist[2]      raw history (ping-pong): the last XL_HCAP samples of the stream in the INPUT format
+//   block        engine-owned copy of the current block (host path) -- or the caller's device buffer, in place
+//   taps         [tile][Tpad][ct] float2, tap i of the ct clients of a tile contiguous (one s_load_dwordx16)
+//   groups[ct]   XlGroup descriptors (<= 4 tiles of one class each)
+//   nco          XlNcoClient per client; phase[2][slot] running NCO phases (committed / next)
+//   phtab[2]     [client][K_cap] float2 phase tables (ping-pong), out[2] outputs (ping-pong), same indexing
 //
 // Streaming rule: a client's outputs lie on the global grid n = k*D of ITS stream; output k's
 // newest sample is stream sample k*D.  With `consumed` = samples this client has seen before the block,
 // j0 = (-consumed) mod D is the block-local index of the first output's newest sample, K = ceil((S - j0)/D),
 // and in [hist | block] coordinates the first window starts at XL_HCAP - (T-1) + j0.  Samples older than the
 // client (it joined mid-stream) must read as zero: zero_below = XL_HCAP - min(consumed, XL_HCAP).
+//
+// Streams.  A block's outputs depend on (raw history, block, phase table) only.  The phase table is data
+// independent (float32 recurrence p <- p * incr, xlating.c:70-73), so block b+1's table is tabulated on a side
+// stream while block b is filtered, guessing that b+1 has the same length; the running phases are double-buffered
+// (committed / next) so that a wrong guess is simply redone.  Everything else of a block -- the fused FIR launch,
+// which also rolls the raw history -- goes to the caller's stream, so results are stream-ordered behind the call.
+// (Measured and dropped: running consecutive blocks' FIR launches concurrently on two streams -- no gain, the
+// launches just share the chip; see DESIGN.md.)
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
@@ -38,6 +41,7 @@
 #include "xl_device.h"
 #include "xl_taps.h"
 
+#define XL_NLAUNCH 7
 #define XL_HCAP 16384u  // raw history kept on the device, in samples; needs T - 1 <= XL_HCAP
 
 namespace {
@@ -61,9 +65,12 @@ struct ClassState {
 
 struct Launch {
   int ct = 0;
+  int kt = 1;  // outputs per lane
+  int nw = XL_NW_DEFAULT;  // waves (tiles) per workgroup
   std::vector<XlGroup> groups;
   XlGroup *d_groups = nullptr;
-  size_t lds = 0;
+  size_t lds = 0, lds1 = 0, lds2 = 0;
+  bool all_wide = true;  // every group has an even decimation
 };
 
 }  // namespace
@@ -74,48 +81,76 @@ struct xlating_batch_t {
   uint32_t bps = 2;
   uint32_t max_samples = 0;
   int device = -1;
-  hipStream_t own_stream = nullptr;
-  hipStream_t last_stream = nullptr;
+  hipStream_t own_stream = nullptr;   // used when the caller passes no stream / host path
+  hipStream_t last_stream = nullptr;  // caller stream of the latest block
+  hipStream_t nco_stream = nullptr;
 
   std::vector<Client> clients;
   int nalive = 0;
   bool dirty = true;
   std::vector<ClassState> classes;
-  Launch launches[4];  // ct = 8, 4, 2, 1
+  Launch launches[XL_NLAUNCH];  // one per register-tile height 12, 10, 9, 8, 4, 2, 1
+  int plan_mode = -1;           // the tile heights depend on the arithmetic variant
   std::vector<XlNcoClient> nco;
   size_t out_total = 0;
+  uint64_t nblk = 0;  // blocks processed
 
   void *d_hist[2] = {nullptr, nullptr};
-  int hcur = 0;
+  int hcur = 0;  // d_hist[hcur] = history in front of the next block
   void *d_block = nullptr;
   void *h_block = nullptr;  // pinned staging
   float2 *d_taps = nullptr;
   XlNcoClient *d_nco = nullptr;
-  hipStream_t nco_stream = nullptr;
   float2 *d_phase[2] = {nullptr, nullptr};  // [pcur] = committed running phases, [pcur^1] = next
   int pcur = 0;
   size_t phase_cap = 0;
   float2 *d_phtab[2] = {nullptr, nullptr};
-  hipEvent_t ev_nco[2] = {nullptr, nullptr};  // table[i] written
-  hipEvent_t ev_fir[2] = {nullptr, nullptr};  // table[i] consumed
-  bool ev_fir_valid[2] = {false, false};
-  int tab = 0;             // table used by the block in flight
-  bool spec_valid = false;  // table[spec_tab] holds the phases of the NEXT block assuming spec_S samples
-  size_t spec_S = 0;
-  int spec_tab = 0;
-  float2 *d_out = nullptr;
+  float2 *d_out[2] = {nullptr, nullptr};
+  int ocur = 0;  // d_out[ocur] holds the latest block's outputs
   size_t out_alloc = 0;
   float2 *h_out = nullptr;
   size_t h_out_alloc = 0;
   bool fetched = false;
 
+  hipEvent_t ev_nco[2] = {nullptr, nullptr};       // table[i] written (nco stream)
+  hipEvent_t ev_tab_free[2] = {nullptr, nullptr};  // table[i] consumed by its FIR launch (caller's stream)
+  bool ev_tab_free_valid[2] = {false, false};
+  int tab = 0;              // table used by the latest block
+  bool spec_valid = false;  // table[spec_tab] holds the phases of the NEXT block assuming spec_S samples
+  size_t spec_S = 0;
+  int spec_tab = 0;
+
+  uint32_t exp_flags = 0;  // tuning knobs from XL_EXP_* environment variables
+  bool exp_same_taps = false;
+  int exp_kt = 0;
+  uint32_t nco_prio = 1;  // wave priority of the look-ahead NCO kernel (XL_EXP_NCOPRIO overrides)
+  int exp_h = 0;   // XL_EXP_H=8|9|10|12 forces the tile height of the large classes
+  const char *exp_trace = nullptr;  // XL_EXP_TRACE=<file>: dump per-wave timestamps of the latest FIR launch
+  unsigned long long *d_trace = nullptr;
+  size_t trace_cap = 0;
   bool timing = false;
-  std::vector<hipEvent_t> ev;       // pairs: fir start, fir stop (on the launch stream)
-  std::vector<hipEvent_t> ev_ncot;  // pairs: nco start, nco stop (on the side stream)
+  std::vector<hipEvent_t> ev;       // pairs: fir start, fir stop (on the FIR launch stream)
+  std::vector<hipEvent_t> ev_ncot;  // pairs: nco start, nco stop (on the nco stream)
+  std::vector<hipEvent_t> ev_pool;  // recycled timing events (hipEventCreate per block would bound the host)
   double fir_ms = 0.0, nco_ms = 0.0;
-  int timed_launches = 0;
-  int timed_nco = 0;
+  int timed_launches = 0, timed_nco = 0;
 };
+
+static hipError_t xl_batch_timing_event(xlating_batch *b, hipEvent_t *out) {
+  if (!b->ev_pool.empty()) {
+    *out = b->ev_pool.back();
+    b->ev_pool.pop_back();
+    return hipSuccess;
+  }
+  return hipEventCreate(out);
+}
+
+static void xl_batch_sync_all(xlating_batch *b) {
+  (void)hipStreamSynchronize(b->last_stream);  // may be the NULL (legacy default) stream: still a real stream
+  hipStream_t ss[] = {b->own_stream, b->nco_stream};
+  for (hipStream_t s : ss)
+    if (s) (void)hipStreamSynchronize(s);
+}
 
 static void xl_batch_free_plan(xlating_batch *b) {
   for (Launch &l : b->launches) {
@@ -132,24 +167,23 @@ static void xl_batch_free_plan(xlating_batch *b) {
 extern "C" void xlating_batch_destroy(xlating_batch *b) {
   if (b == nullptr) return;
   if (b->device >= 0) (void)hipSetDevice(b->device);
-  if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
-  if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
-  if (b->nco_stream) (void)hipStreamSynchronize(b->nco_stream);
+  xl_batch_sync_all(b);
   xl_batch_free_plan(b);
-  void *dev[] = {b->d_hist[0], b->d_hist[1], b->d_block,    b->d_phase[0],
-                 b->d_phase[1], b->d_phtab[0], b->d_phtab[1], b->d_out};
+  void *dev[] = {b->d_hist[0],  b->d_hist[1],  b->d_block,  b->d_phase[0], b->d_phase[1],
+                 b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_trace};
   for (void *p : dev)
     if (p) (void)hipFree(p);
   if (b->h_block) (void)hipHostFree(b->h_block);
   if (b->h_out) (void)hipHostFree(b->h_out);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_ncot) (void)hipEventDestroy(e);
-  for (int i = 0; i < 2; ++i) {
-    if (b->ev_nco[i]) (void)hipEventDestroy(b->ev_nco[i]);
-    if (b->ev_fir[i]) (void)hipEventDestroy(b->ev_fir[i]);
-  }
-  if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
-  if (b->nco_stream) (void)hipStreamDestroy(b->nco_stream);
+  for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
+  hipEvent_t evs[] = {b->ev_nco[0], b->ev_nco[1], b->ev_tab_free[0], b->ev_tab_free[1]};
+  for (hipEvent_t e : evs)
+    if (e) (void)hipEventDestroy(e);
+  hipStream_t ss[] = {b->own_stream, b->nco_stream};
+  for (hipStream_t s : ss)
+    if (s) (void)hipStreamDestroy(s);
   delete b;
 }
 
@@ -173,21 +207,25 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   {
     const size_t hbytes = (size_t)XL_HCAP * b->bps;
     const size_t bbytes = (size_t)b->max_samples * b->bps + 16;
+    hipStream_t *ss[] = {&b->own_stream, &b->nco_stream};
+    hipEvent_t *evs[] = {&b->ev_nco[0], &b->ev_nco[1], &b->ev_tab_free[0], &b->ev_tab_free[1]};
     XL_TRY(hipSetDevice(dev));
-    XL_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
-    XL_TRY(hipStreamCreateWithFlags(&b->nco_stream, hipStreamNonBlocking));
+    for (hipStream_t *s : ss) XL_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    for (hipEvent_t *e : evs) XL_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
-      XL_TRY(hipEventCreateWithFlags(&b->ev_nco[i], hipEventDisableTiming));
-      XL_TRY(hipEventCreateWithFlags(&b->ev_fir[i], hipEventDisableTiming));
+      XL_TRY(hipMalloc(&b->d_hist[i], hbytes));
+      XL_TRY(hipMemsetAsync(b->d_hist[i], 0, hbytes, b->own_stream));
     }
-    XL_TRY(hipMalloc(&b->d_hist[0], hbytes));
-    XL_TRY(hipMalloc(&b->d_hist[1], hbytes));
     XL_TRY(hipMalloc(&b->d_block, bbytes));
     XL_TRY(hipHostMalloc(&b->h_block, bbytes, hipHostMallocDefault));
-    XL_TRY(hipMemsetAsync(b->d_hist[0], 0, hbytes, b->own_stream));
-    XL_TRY(hipMemsetAsync(b->d_hist[1], 0, hbytes, b->own_stream));
     XL_TRY(hipStreamSynchronize(b->own_stream));
   }
+  if (getenv("XL_EXP_FLATPRIO")) b->exp_flags |= 2u;
+  if (getenv("XL_EXP_SAME_TAPS")) b->exp_same_taps = true;
+  if (getenv("XL_EXP_KT")) b->exp_kt = atoi(getenv("XL_EXP_KT"));
+  if (getenv("XL_EXP_H")) b->exp_h = atoi(getenv("XL_EXP_H"));
+  b->exp_trace = getenv("XL_EXP_TRACE");
+  if (getenv("XL_EXP_NCOPRIO")) b->nco_prio = (uint32_t)atoi(getenv("XL_EXP_NCOPRIO")) & 3u;
   b->last_stream = b->own_stream;
   *batch = b;
   return 0;
@@ -207,9 +245,9 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
     return -EINVAL;
   }
   const uint32_t Tpad = xl_roundup((uint32_t)taps_len, XL_TAP_UNROLL);
-  if (xl_fir_lds_bytes(decimation, Tpad) > 160 * 1024) {
+  if (xl_fir_lds_bytes(decimation, Tpad, 1) > 160 * 1024) {
     XL_LOG_ERR("decimation %u with %zu taps needs a %zu-byte window image (> 160 KiB LDS)", decimation, taps_len,
-               xl_fir_lds_bytes(decimation, Tpad));
+               xl_fir_lds_bytes(decimation, Tpad, 1));
     return -EINVAL;
   }
   int id = -1;
@@ -235,11 +273,10 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
   c.out_cap = b->max_samples / decimation + 1;  // xlating.c:568
   b->nalive++;
   b->dirty = true;
-  // the running phase of a new client starts at 1 + 0j (xlating.c:543); slot = client id.  Any phase table
+  // The running phase of a new client starts at 1 + 0j (xlating.c:543); slot = client id.  Any phase table
   // tabulated ahead is for the old client set: drop it (the committed phases are untouched by it).
   (void)hipSetDevice(b->device);
-  (void)hipStreamSynchronize(b->last_stream);
-  (void)hipStreamSynchronize(b->nco_stream);
+  xl_batch_sync_all(b);
   b->spec_valid = false;
   if ((size_t)id >= b->phase_cap) {
     const size_t ncap = std::max<size_t>(1024, 2 * b->clients.size());
@@ -275,11 +312,10 @@ extern "C" int xlating_batch_remove_client(xlating_batch *b, int id) {
 }
 
 // (Re)build the resident plan: classes, tiles (register-tile heights 8/4/2/1), groups, tap image, NCO table.
-static int xl_batch_plan(xlating_batch *b) {
-  (void)hipStreamSynchronize(b->last_stream);
-  (void)hipStreamSynchronize(b->nco_stream);
+static int xl_batch_plan(xlating_batch *b, int mode) {
+  xl_batch_sync_all(b);
   b->spec_valid = false;
-  b->ev_fir_valid[0] = b->ev_fir_valid[1] = false;
+  b->ev_tab_free_valid[0] = b->ev_tab_free_valid[1] = false;
   xl_batch_free_plan(b);
   b->classes.clear();
   b->nco.clear();
@@ -305,7 +341,7 @@ static int xl_batch_plan(xlating_batch *b) {
     c.cls = it->second;
     members[c.cls].push_back((int)i);
     c.out_off = off;
-    off += c.out_cap;
+    off += xl_roundup(c.out_cap, 4);  // rows stay 16-byte aligned (the NCO kernel stores float4 pairs)
     XlNcoClient nc;
     memset(&nc, 0, sizeof(nc));
     nc.incr = make_float2(c.incr[0], c.incr[1]);
@@ -316,49 +352,116 @@ static int xl_batch_plan(xlating_batch *b) {
   }
   b->out_total = off;
 
-  static const int kHeights[4] = {8, 4, 2, 1};
-  std::vector<float> image;  // tap image, floats
-  for (int li = 0; li < 4; ++li) {
-    b->launches[li].ct = kHeights[li];
-    b->launches[li].lds = 0;
-  }
-  for (size_t k = 0; k < members.size(); ++k) {
-    const ClassState &cs = b->classes[k];
-    const uint32_t Tpad = xl_roundup(cs.T, XL_TAP_UNROLL);
-    size_t next = 0;
-    const std::vector<int> &m = members[k];
-    for (int li = 0; li < 4; ++li) {
-      const int ct = kHeights[li];
-      Launch &L = b->launches[li];
-      XlGroup *g = nullptr;
-      while (m.size() - next >= (size_t)ct) {
-        if (g == nullptr || g->ntiles == XL_NW) {
-          L.groups.emplace_back();
-          g = &L.groups.back();
-          memset(g, 0, sizeof(*g));
-          g->D = cs.D;
-          g->T = cs.T;
-          g->Tpad = Tpad;
-          g->cls = (uint32_t)k;
-          g->wide = (cs.D % 2 == 0) ? 1u : 0u;
-          L.lds = std::max(L.lds, xl_fir_lds_bytes(cs.D, Tpad));
+  // ---- register-tile height.  Every wave does the same work (64 outputs x H clients x T taps) and a CU holds
+  // floor(160 KiB / window image) workgroups of 4 waves (6 at the server-default shape).  A launch whose workgroups
+  // do not all fit runs the surplus in a second round almost alone -- latency-bound, about one lone-workgroup
+  // duration (measured 48 us of a 161 us launch at 1024 clients with H = 8: 32 x 49 = 1568 workgroups on 1536
+  // slots).  Taller tiles trade a little per-wave time for fewer workgroups: pick the height whose launch costs
+  // least in (waves on the busiest SIMD) x (work per wave).  Classes with fewer than 8 clients use one small
+  // tile.  The native (bit-exact) kernels are register-hungry above 8, so they keep H <= 8.
+  static const int kHeights[XL_NLAUNCH] = {12, 10, 9, 8, 4, 2, 1};
+  int big_h = 8;
+  {
+    size_t lds1 = 0;
+    for (size_t k = 0; k < members.size(); ++k)
+      if (members[k].size() >= 8)
+        lds1 = std::max(lds1, xl_fir_lds_bytes(b->classes[k].D, xl_roundup(b->classes[k].T, 12), 1));
+    if (lds1 > 0 && mode == XL_MODE_OPTIMIZED) {
+      const long slots = std::max<long>(1, std::min<long>((long)(160 * 1024 / lds1), 7));
+      const long cap = slots * 256;
+      long best = -1;
+      static const int cand[4] = {8, 9, 10, 12};
+      for (int h : cand) {
+        long wgs = 0;
+        for (size_t k = 0; k < members.size(); ++k) {
+          const long n = (long)members[k].size();
+          if (n < 8) continue;
+          const long kest = b->max_samples / b->classes[k].D + 1;
+          wgs += (((n + h - 1) / h + XL_NW_MAX - 1) / XL_NW_MAX) * ((kest + 63) / 64);
         }
-        XlTile &t = g->tiles[g->ntiles++];
-        t.tap_off = (uint32_t)(image.size() / 2);
-        t.nclients = (uint32_t)ct;
-        image.resize(image.size() + (size_t)2 * Tpad * ct, 0.0f);
-        float *dst = image.data() + (size_t)2 * t.tap_off;
-        for (int j = 0; j < ct; ++j) {
-          const Client &c = b->clients[m[next + j]];
-          t.out_off[j] = c.out_off;
-          for (uint32_t i = 0; i < Tpad; ++i) {
-            dst[((size_t)i * ct + j) * 2] = c.rt[2 * i];
-            dst[((size_t)i * ct + j) * 2 + 1] = c.rt[2 * i + 1];
-          }
+        const long full = wgs / cap, rem = wgs % cap;
+        long cost = full * slots * h;
+        if (rem) cost += std::max<long>((rem + 255) / 256, 3) * h;
+        if (best < 0 || cost < best) {
+          best = cost;
+          big_h = h;
         }
-        next += ct;
       }
     }
+    if (b->exp_h == 8 || b->exp_h == 9 || b->exp_h == 10 || b->exp_h == 12) big_h = b->exp_h;
+  }
+  struct TileDesc {
+    uint32_t cls;
+    std::vector<int> ids;
+  };
+  std::vector<TileDesc> tiles_of[XL_NLAUNCH];
+  for (int li = 0; li < XL_NLAUNCH; ++li) {
+    b->launches[li].ct = kHeights[li];
+    b->launches[li].lds = b->launches[li].lds1 = b->launches[li].lds2 = 0;
+    b->launches[li].nw = XL_NW_DEFAULT;
+    b->launches[li].all_wide = true;
+  }
+  for (size_t k = 0; k < members.size(); ++k) {
+    const std::vector<int> &m = members[k];
+    int h = big_h;
+    if (m.size() < 8) h = m.size() > 4 ? 8 : (m.size() > 2 ? 4 : (m.size() > 1 ? 2 : 1));
+    int li = 0;
+    while (kHeights[li] != h) ++li;
+    for (size_t next = 0; next < m.size(); next += (size_t)h) {
+      const size_t cnt = std::min<size_t>((size_t)h, m.size() - next);
+      tiles_of[li].push_back(TileDesc{(uint32_t)k, std::vector<int>(m.begin() + next, m.begin() + next + cnt)});
+    }
+  }
+
+  std::vector<float> image;  // tap image, floats
+  for (int li = 0; li < XL_NLAUNCH; ++li) {
+    Launch &L = b->launches[li];
+    if (tiles_of[li].empty()) continue;
+    const int ct = L.ct;
+    int gi = -1;
+    uint32_t gcls = 0;
+    for (const TileDesc &td : tiles_of[li]) {
+      const ClassState &cs = b->classes[td.cls];
+      const uint32_t Tpad = xl_roundup(cs.T, xl_tap_step(ct));
+      if (gi < 0 || gcls != td.cls || L.groups[gi].ntiles == (uint32_t)L.nw) {
+        L.groups.emplace_back();
+        gi = (int)L.groups.size() - 1;
+        gcls = td.cls;
+        XlGroup *g = &L.groups[gi];
+        memset(g, 0, sizeof(*g));
+        g->D = cs.D;
+        g->T = cs.T;
+        g->Tpad = Tpad;
+        g->cls = td.cls;
+        g->wide = (cs.D % 2 == 0) ? 1u : 0u;
+        if (!g->wide) L.all_wide = false;
+        L.lds1 = std::max(L.lds1, xl_fir_lds_bytes(cs.D, Tpad, 1));
+        L.lds2 = std::max(L.lds2, xl_fir_lds_bytes(cs.D, Tpad, 2));
+      }
+      XlGroup *g = &L.groups[gi];
+      XlTile &t = g->tiles[g->ntiles++];
+      const uint32_t real_off = (uint32_t)(image.size() / 2);
+      t.tap_off = real_off;
+      t.nclients = (uint32_t)td.ids.size();  // a partial last tile keeps zero taps for the missing clients
+      image.resize(image.size() + (size_t)2 * Tpad * ct, 0.0f);
+      float *dst = image.data() + (size_t)2 * real_off;
+      if (b->exp_same_taps) t.tap_off = 0;  // tuning experiment: every tile streams the same taps (WRONG results)
+      for (size_t j = 0; j < td.ids.size(); ++j) {
+        const Client &c = b->clients[td.ids[j]];
+        t.out_off[j] = c.out_off;
+        for (uint32_t i = 0; i < cs.T; ++i) {
+          dst[((size_t)i * ct + j) * 2] = c.rt[2 * i];
+          dst[((size_t)i * ct + j) * 2 + 1] = c.rt[2 * i + 1];
+        }
+      }
+    }
+  }
+  for (Launch &L : b->launches) {
+    // One output per lane by default: PMC shows the KT=1 loop VALU-issue-bound (87 % VALU busy at 6 waves/SIMD),
+    // and KT=2 (half the scalar tap traffic per FMA, but half the resident waves) measured slower.
+    // XL_EXP_KT=2 selects it for tuning.
+    L.kt = (b->exp_kt == 2 && L.lds2 > 0 && L.lds2 <= 160 * 1024) ? 2 : 1;
+    L.lds = L.kt == 2 ? L.lds2 : L.lds1;
   }
 
   // upload
@@ -376,16 +479,16 @@ static int xl_batch_plan(xlating_batch *b) {
     XL_TRY(hipMemcpy(L.d_groups, L.groups.data(), L.groups.size() * sizeof(XlGroup), hipMemcpyHostToDevice));
   }
   if (b->out_total > b->out_alloc) {
-    if (b->d_out) (void)hipFree(b->d_out);
-    b->d_out = nullptr;
     for (int i = 0; i < 2; ++i) {
+      if (b->d_out[i]) (void)hipFree(b->d_out[i]);
       if (b->d_phtab[i]) (void)hipFree(b->d_phtab[i]);
-      b->d_phtab[i] = nullptr;
+      b->d_out[i] = b->d_phtab[i] = nullptr;
     }
     b->out_alloc = 0;
-    XL_TRY(hipMalloc((void **)&b->d_out, b->out_total * sizeof(float2)));
-    XL_TRY(hipMalloc((void **)&b->d_phtab[0], b->out_total * sizeof(float2)));
-    XL_TRY(hipMalloc((void **)&b->d_phtab[1], b->out_total * sizeof(float2)));
+    for (int i = 0; i < 2; ++i) {
+      XL_TRY(hipMalloc((void **)&b->d_out[i], b->out_total * sizeof(float2)));
+      XL_TRY(hipMalloc((void **)&b->d_phtab[i], b->out_total * sizeof(float2)));
+    }
     b->out_alloc = b->out_total;
   }
   b->dirty = false;
@@ -410,18 +513,18 @@ static uint32_t xl_batch_dyn(const xlating_batch *b, size_t S, XlDynArgs *dyn) {
   return maxK;
 }
 
-// Tabulate the phases of a block on the side stream: committed phases -> table[tab] + next phases.
-static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab, bool timed) {
+// Tabulate the phases of a block on the nco stream: committed phases -> table[tab] + next phases.
+static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab) {
   hipError_t e;
-  if (b->ev_fir_valid[tab]) {  // the FIR launch that last read table[tab] must be done with it
-    e = hipStreamWaitEvent(b->nco_stream, b->ev_fir[tab], 0);
+  if (b->ev_tab_free_valid[tab]) {  // the FIR launch that last read table[tab] must be done with it
+    e = hipStreamWaitEvent(b->nco_stream, b->ev_tab_free[tab], 0);
     if (e != hipSuccess) return e;
   }
   hipEvent_t n0 = nullptr, n1 = nullptr;
-  if (timed) {
+  if (b->timing) {
     for (int i = 0; i < 2; ++i) {
       hipEvent_t ev;
-      e = hipEventCreate(&ev);
+      e = xl_batch_timing_event(b, &ev);
       if (e != hipSuccess) return e;
       b->ev_ncot.push_back(ev);
     }
@@ -431,9 +534,9 @@ static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab, 
     if (e != hipSuccess) return e;
   }
   e = xl_launch_nco_table(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[b->pcur], b->d_phase[b->pcur ^ 1],
-                          b->d_phtab[tab], dyn, b->nco_stream);
+                          b->d_phtab[tab], dyn, b->nco_prio, b->nco_stream);
   if (e != hipSuccess) return e;
-  if (timed) {
+  if (n1) {
     e = hipEventRecord(n1, b->nco_stream);
     if (e != hipSuccess) return e;
   }
@@ -443,13 +546,17 @@ static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab, 
 static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len, int mode, hipStream_t s) {
   const size_t S = input_len / 2;
   if (S > b->max_samples || (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED)) return -EINVAL;
-  if (b->dirty) {
-    int rc = xl_batch_plan(b);
+  if (b->dirty || b->plan_mode != mode) {
+    int rc = xl_batch_plan(b, mode);
     if (rc != 0) return rc;
+    b->plan_mode = mode;
   }
   b->last_stream = s;
   b->fetched = false;
   if (b->nco.empty()) return 0;
+
+  const int p = (int)(b->nblk & 1);  // parity of this block: output buffer
+  const int hb = b->hcur, hn = b->hcur ^ 1;
 
   XlDynArgs dyn;
   const uint32_t maxK = xl_batch_dyn(b, S, &dyn);
@@ -469,56 +576,96 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
     tab = b->spec_tab;
   } else {
     tab = b->spec_valid ? b->spec_tab : (b->tab ^ 1);
-    XL_TRY(xl_batch_nco(b, dyn, tab, b->timing));
+    XL_TRY(xl_batch_nco(b, dyn, tab));
   }
   b->spec_valid = false;
   b->pcur ^= 1;  // the phases written by that NCO launch are now the committed ones
   b->tab = tab;
 
-  if (maxK > 0) {
+  // ---- the fused FIR launch(es) on the caller's stream: window images from [d_hist[hb] | block], phases from
+  // table[tab] -> d_out[p]; the first launch also rolls the raw history into d_hist[hn]
+  {
     hipEvent_t f0 = nullptr, f1 = nullptr;
-    if (b->timing) {
+    if (b->timing && maxK > 0) {
       for (int i = 0; i < 2; ++i) {
         hipEvent_t ev;
-        XL_TRY(hipEventCreate(&ev));
+        XL_TRY(xl_batch_timing_event(b, &ev));
         b->ev.push_back(ev);
       }
       f0 = b->ev[b->ev.size() - 2];
       f1 = b->ev[b->ev.size() - 1];
     }
-    XL_TRY(hipStreamWaitEvent(s, b->ev_nco[tab], 0));
-    if (f0) XL_TRY(hipEventRecord(f0, s));
-    for (Launch &L : b->launches) {
-      if (L.groups.empty()) continue;
-      XlFirArgs a;
-      memset(&a, 0, sizeof(a));
-      a.in0 = b->d_hist[b->hcur];
-      a.n0 = XL_HCAP;
-      a.in1 = d_block;
-      a.n1 = (uint32_t)S;
-      a.fmt = b->fmt;
-      a.groups = L.d_groups;
-      a.ngroups = (uint32_t)L.groups.size();
-      a.groups_per_xcd = (a.ngroups + 7) / 8;
-      a.xtiles = (maxK + 63) / 64;
-      a.taps = b->d_taps;
-      a.phtab = b->d_phtab[tab];
-      a.out = b->d_out;
-      XL_TRY(xl_launch_fir(L.ct, mode, a, dyn, L.lds, s));
+    bool rolled = false;
+    if (maxK > 0) {
+      XL_TRY(hipStreamWaitEvent(s, b->ev_nco[tab], 0));
+      if (f0) XL_TRY(hipEventRecord(f0, s));
+      for (Launch &L : b->launches) {
+        if (L.groups.empty()) continue;
+        XlFirArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in0 = b->d_hist[hb];
+        a.n0 = XL_HCAP;
+        a.in1 = d_block;
+        a.n1 = (uint32_t)S;
+        a.fmt = b->fmt;
+        a.groups = L.d_groups;
+        a.ngroups = (uint32_t)L.groups.size();
+        a.groups_per_xcd = (a.ngroups + 7) / 8;
+        a.xtiles = (maxK + 64 * L.kt - 1) / (64 * L.kt);
+        // wave-priority quartiles pay when the launch is about one round of workgroups, and cost when new
+        // workgroups keep arriving (they would outrank nearly finished ones): enable up to two rounds
+        const size_t wgs = (size_t)a.ngroups * a.xtiles;
+        const size_t cap = 256 * std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(L.lds, 1), 7));
+        const bool flat = (b->exp_flags & 2u) || wgs > 2 * cap;
+        a.flags = (L.all_wide ? 1u : 0u) | (flat ? 2u : 0u);
+        a.taps = b->d_taps;
+        a.phtab = b->d_phtab[tab];
+        a.out = b->d_out[p];
+        if (!rolled) {
+          a.hist_out = b->d_hist[hn];
+          a.hist_units = XL_HCAP * (b->bps / 2);
+          a.block_units = (uint32_t)S * (b->bps / 2);
+          rolled = true;
+        }
+        size_t trace_n = 0;
+        if (b->exp_trace) {  // tuning only
+          trace_n = (size_t)8 * ((a.ngroups * a.xtiles + 7) / 8) * XL_NW_MAX * 4;
+          if (trace_n > b->trace_cap) {
+            if (b->d_trace) (void)hipFree(b->d_trace);
+            b->d_trace = nullptr;
+            XL_TRY(hipMalloc((void **)&b->d_trace, trace_n * sizeof(unsigned long long)));
+            b->trace_cap = trace_n;
+          }
+          XL_TRY(hipMemsetAsync(b->d_trace, 0, trace_n * sizeof(unsigned long long), s));
+          a.trace = b->d_trace;
+        }
+        XL_TRY(xl_launch_fir(L.ct, mode, L.kt, L.nw, a, dyn, L.lds, s));
+        if (b->exp_trace) {
+          std::vector<unsigned long long> h(trace_n);
+          XL_TRY(hipStreamSynchronize(s));
+          XL_TRY(hipMemcpy(h.data(), b->d_trace, trace_n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+          if (FILE *f = fopen(b->exp_trace, "wb")) {
+            fwrite(h.data(), sizeof(unsigned long long), trace_n, f);
+            fclose(f);
+          }
+        }
+      }
+      if (f1) XL_TRY(hipEventRecord(f1, s));
+      XL_TRY(hipEventRecord(b->ev_tab_free[tab], s));
+      b->ev_tab_free_valid[tab] = true;
     }
-    if (f1) XL_TRY(hipEventRecord(f1, s));
-    XL_TRY(hipEventRecord(b->ev_fir[tab], s));
-    b->ev_fir_valid[tab] = true;
+    if (!rolled)  // no client produced output in this block (tiny block): roll the history on its own
+      XL_TRY(xl_launch_update_history(b->d_hist[hb], d_block, XL_HCAP, (uint32_t)S, b->bps, b->d_hist[hn], s));
   }
-  // roll the raw history: the last XL_HCAP samples of [hist | block]
-  XL_TRY(xl_launch_update_history(b->d_hist[b->hcur], d_block, XL_HCAP, (uint32_t)S, b->bps, b->d_hist[b->hcur ^ 1], s));
-  b->hcur ^= 1;
+  b->ocur = p;
+  b->hcur = hn;
+  b->nblk++;
 
-  // ---- tabulate the NEXT block's phases now, on the side stream, guessing it has the same length
+  // ---- tabulate the NEXT block's phases now, on the nco stream, guessing it has the same length
   {
     XlDynArgs next;
     (void)xl_batch_dyn(b, S, &next);
-    XL_TRY(xl_batch_nco(b, next, tab ^ 1, b->timing));
+    XL_TRY(xl_batch_nco(b, next, tab ^ 1));
     b->spec_valid = true;
     b->spec_S = S;
     b->spec_tab = tab ^ 1;
@@ -532,7 +679,8 @@ extern "C" int xlating_batch_process_device(xlating_batch *b, const void *d_inpu
                                             void *hip_stream) {
   if (b == nullptr || (d_input == nullptr && input_len > 0)) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
-  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : b->own_stream;
+  // NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is by default): pass it through
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
   return xl_batch_run(b, d_input, input_len, mode, s);
 }
 
@@ -542,8 +690,8 @@ extern "C" int xlating_batch_process_host(xlating_batch *b, const void *input, s
   if (S > b->max_samples) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
   hipStream_t s = b->own_stream;
-  // the pinned staging buffer is reused: wait for the previous block's H2D to have been consumed
-  if (hipStreamSynchronize(s) != hipSuccess) return -EIO;
+  // the pinned staging buffer and the device block buffer are reused: wait until the previous block is consumed
+  xl_batch_sync_all(b);
   const size_t bytes = S * b->bps;
   if (bytes) {
     memcpy(b->h_block, input, bytes);
@@ -565,10 +713,11 @@ extern "C" int xlating_batch_sync(xlating_batch *b) {
 
 extern "C" int xlating_batch_fetch(xlating_batch *b) {
   if (b == nullptr) return -EINVAL;
-  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
-  if (b->out_total == 0 || b->d_out == nullptr) {
+  int rc = xlating_batch_sync(b);
+  if (rc != 0) return rc;
+  if (b->out_total == 0 || b->d_out[b->ocur] == nullptr) {
     b->fetched = true;
-    return xlating_batch_sync(b);
+    return 0;
   }
   if (b->out_total > b->h_out_alloc) {
     if (b->h_out) (void)hipHostFree(b->h_out);
@@ -578,10 +727,10 @@ extern "C" int xlating_batch_fetch(xlating_batch *b) {
       return -ENOMEM;
     b->h_out_alloc = b->out_total;
   }
-  if (hipMemcpyAsync(b->h_out, b->d_out, b->out_total * sizeof(float2), hipMemcpyDeviceToHost, b->last_stream) !=
-      hipSuccess)
+  if (hipMemcpyAsync(b->h_out, b->d_out[b->ocur], b->out_total * sizeof(float2), hipMemcpyDeviceToHost,
+                     b->own_stream) != hipSuccess)
     return -EIO;
-  if (hipStreamSynchronize(b->last_stream) != hipSuccess) return -EIO;
+  if (hipStreamSynchronize(b->own_stream) != hipSuccess) return -EIO;
   b->fetched = true;
   return 0;
 }
@@ -598,10 +747,10 @@ extern "C" int xlating_batch_output_host(xlating_batch *b, int id, const float *
 
 extern "C" int xlating_batch_output_device(xlating_batch *b, int id, const void **d_output, size_t *output_len) {
   if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive || d_output == nullptr ||
-      output_len == nullptr || b->dirty)
+      output_len == nullptr || b->dirty || b->d_out[b->ocur] == nullptr)
     return -EINVAL;
   const Client &c = b->clients[id];
-  *d_output = b->d_out + c.out_off;
+  *d_output = b->d_out[b->ocur] + c.out_off;
   *output_len = c.last_K;
   return 0;
 }
@@ -609,18 +758,18 @@ extern "C" int xlating_batch_output_device(xlating_batch *b, int id, const void 
 extern "C" int xlating_batch_client_phase(xlating_batch *b, int id, float *re, float *im) {
   if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
-  if (hipStreamSynchronize(b->last_stream) != hipSuccess) return -EIO;
-  if (hipStreamSynchronize(b->nco_stream) != hipSuccess) return -EIO;
-  float2 p;
-  if (hipMemcpy(&p, b->d_phase[b->pcur] + id, sizeof(p), hipMemcpyDeviceToHost) != hipSuccess) return -EIO;
-  *re = p.x;
-  *im = p.y;
+  xl_batch_sync_all(b);
+  // the look-ahead NCO launch has already produced the phases AFTER the next block into d_phase[pcur^1];
+  // the committed ones (after the latest processed block) are d_phase[pcur]
+  float2 ph;
+  if (hipMemcpy(&ph, b->d_phase[b->pcur] + id, sizeof(ph), hipMemcpyDeviceToHost) != hipSuccess) return -EIO;
+  *re = ph.x;
+  *im = ph.y;
   return 0;
 }
 
 static int xl_batch_drain_events(xlating_batch *b) {
-  if (hipStreamSynchronize(b->last_stream) != hipSuccess) return -EIO;
-  if (hipStreamSynchronize(b->nco_stream) != hipSuccess) return -EIO;
+  xl_batch_sync_all(b);
   for (size_t i = 0; i + 2 <= b->ev.size(); i += 2) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]) != hipSuccess) return -EIO;
@@ -633,8 +782,8 @@ static int xl_batch_drain_events(xlating_batch *b) {
     b->nco_ms += ms;
     b->timed_nco++;
   }
-  for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
-  for (hipEvent_t e : b->ev_ncot) (void)hipEventDestroy(e);
+  b->ev_pool.insert(b->ev_pool.end(), b->ev.begin(), b->ev.end());
+  b->ev_pool.insert(b->ev_pool.end(), b->ev_ncot.begin(), b->ev_ncot.end());
   b->ev.clear();
   b->ev_ncot.clear();
   return 0;
@@ -644,6 +793,13 @@ extern "C" int xlating_batch_timing(xlating_batch *b, int enable) {
   if (b == nullptr) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
   if (b->timing && !enable) (void)xl_batch_drain_events(b);
+  if (enable && b->ev_pool.size() < 2048) {  // pre-create so that the timed region itself creates none
+    for (int i = 0; i < 2048; ++i) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) break;
+      b->ev_pool.push_back(e);
+    }
+  }
   b->timing = enable != 0;
   return 0;
 }

@@ -7,7 +7,7 @@
 //   client   one xlating filter = (decimation D, T reversed band-pass taps, NCO phase + increment)
 //   tile     up to CT clients that share (D, T, window grid) -> one wavefront's work, taps interleaved
 //            [tap i][client c] so that one scalar load fetches tap i of every client of the tile
-//   group    up to XL_NW tiles of the same class -> one workgroup; its waves share one LDS window image
+//   group    up to NW (<= XL_NW_MAX) tiles of the same class -> one workgroup; its waves share one LDS window image
 //   class    all groups sharing (D, T, stream offset mod D, valid-history length); only the per-block
 //            numbers of a class (window origin, output count) change from block to block and travel
 //            as kernel arguments, everything else is resident in HBM.
@@ -17,11 +17,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define XL_NW 4          // waves (tiles) per workgroup
-#define XL_WG (64 * XL_NW)
-#define XL_CT_MAX 8      // clients per tile (register-tile height)
-#define XL_TAP_UNROLL 4  // taps per inner-loop step; Tpad = roundup(T, 4)
+#define XL_NW_MAX 4      // waves (tiles) per workgroup: one per SIMD (5..7 measured slower: unbalanced SIMDs; 8 ties)
+#define XL_NW_DEFAULT 4
+#define XL_CT_MAX 12     // most clients per tile (register-tile height: 1, 2, 4, 8, 9, 10 or 12)
+#define XL_TAP_UNROLL 4  // taps per inner-loop step for heights <= 8 and 12; heights 9, 10 step by 6 (xl_tap_step)
 #define XL_MAX_CLASSES 48
+#define XL_ROLL_BLOCKS 16  // workgroups of a FIR launch that also roll the raw history
 
 enum { XLF_CU8 = 0, XLF_CS8 = 1, XLF_CS16 = 2, XLF_CF32 = 3 };
 
@@ -34,10 +35,10 @@ struct XlTile {
 struct XlGroup {
   uint32_t D, T, Tpad;
   uint32_t cls;                  // index into XlDynArgs::d
-  uint32_t ntiles;               // 1..XL_NW
-  uint32_t wide;                 // 1: 16-byte LDS reads are aligned & conflict-free for this D (D even)
+  uint32_t ntiles;               // 1..XL_NW_MAX (<= waves of the launch)
+  uint32_t wide;                 // 1: D even (informational; the launch-level flag selects the 16-byte read kernel)
   uint32_t pad0, pad1;
-  XlTile tiles[XL_NW];
+  XlTile tiles[XL_NW_MAX];
 };
 
 struct XlDyn {
@@ -58,11 +59,16 @@ struct XlFirArgs {
   int fmt;              // XLF_*
   const XlGroup *groups;
   uint32_t ngroups;
-  uint32_t groups_per_xcd;
-  uint32_t xtiles;      // ceil(max K / 64)
+  uint32_t groups_per_xcd;  // (unused by the kernel since the work list is cut evenly across XCDs)
+  uint32_t xtiles;      // ceil(max K / (64 * kt))
+  uint32_t flags;       // bit 0: every group of the launch has even D (16-byte LDS reads); bit 1: flat wave priority
   const float2 *taps;   // tap image
   const float2 *phtab;  // NCO phase table, indexed like out
   float2 *out;
+  void *hist_out;       // batch engine: where to write the rolled raw history (null: no roll)
+  uint32_t hist_units;  // history length in 2-byte units (= n0 * bytes-per-sample / 2)
+  uint32_t block_units; // block length in 2-byte units (= n1 * bytes-per-sample / 2)
+  unsigned long long *trace;  // tuning only: per wave 4 wall_clock64 stamps (entry, staged, filtered, stored) or null
 };
 
 struct XlNcoClient {
@@ -74,11 +80,15 @@ struct XlNcoClient {
 };
 
 // ---- launchers (xl_kernels.hip).  All return hipError_t of the launch. -------------------------------------
-// mode: 0 native (bit-exact scalar order, unfused), 1 optimized (fma).  ct: 1, 2, 4 or 8.
-hipError_t xl_launch_fir(int ct, int mode, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds_bytes, hipStream_t s);
-// reads the running phases from state_in[slot], writes the post-block phases to state_out[slot] (may alias)
+// mode: 0 native (bit-exact scalar order, unfused), 1 optimized (fma).  ct: 1, 2, 4, 8, 9, 10 or 12 clients per tile.
+// kt: 1 or 2 outputs per lane; a.xtiles = ceil(max K / (64 * kt)); lds_bytes = xl_fir_lds_bytes(D, Tpad, kt).
+// nw: waves per workgroup (>= the largest ntiles of the groups).
+hipError_t xl_launch_fir(int ct, int mode, int kt, int nw, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds_bytes,
+                         hipStream_t s);
+// reads the running phases from state_in[slot], writes the post-block phases to state_out[slot] (may alias).
+// Every client's out_off must be even (16-byte table stores).  prio: wave priority 0..3 of the kernel.
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
-                               float2 *state_out, float2 *phtab, const XlDynArgs &dyn, hipStream_t s);
+                               float2 *state_out, float2 *phtab, const XlDynArgs &dyn, uint32_t prio, hipStream_t s);
 // raw -> converted sample images of the single-filter path (xlating.c:352-433)
 hipError_t xl_launch_convert_cf32(const void *raw, int fmt, uint32_t nsamples, float2 *dst, hipStream_t s);
 hipError_t xl_launch_convert_q15(const void *raw, int fmt, uint32_t nelems, int16_t *dst, hipStream_t s);
@@ -93,6 +103,8 @@ hipError_t xl_launch_nco_table_q15(int16_t incr_re, int16_t incr_im, short2 *pha
 hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T, uint32_t D, uint32_t K,
                              const short2 *phtab, short2 *out, hipStream_t s);
 
-size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad);
+size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad, int kt);
+// taps consumed per inner-loop iteration by the kernel of tile height ct; Tpad must be a multiple of it
+static inline uint32_t xl_tap_step(int ct) { return (ct == 9 || ct == 10) ? 6u : 4u; }
 
 #endif

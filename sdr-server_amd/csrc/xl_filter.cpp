@@ -144,9 +144,9 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XL_TRY(hipMemcpyAsync(f->d_phase, &one, sizeof(one), hipMemcpyHostToDevice, f->stream));
   XL_TRY(hipMemcpyAsync(f->d_qphase, &qone, sizeof(qone), hipMemcpyHostToDevice, f->stream));
   XL_TRY(hipStreamSynchronize(f->stream));
-  if (xl_fir_lds_bytes(decimation, f->Tpad) > 160 * 1024) {
+  if (xl_fir_lds_bytes(decimation, f->Tpad, 1) > 160 * 1024) {
     XL_LOG_ERR("decimation %u with %zu taps needs a %zu-byte window image (> 160 KiB LDS)", decimation, taps_len,
-               xl_fir_lds_bytes(decimation, f->Tpad));
+               xl_fir_lds_bytes(decimation, f->Tpad, 1));
     xl_filter_free(f);
     return -EINVAL;
   }
@@ -201,7 +201,7 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     dyn.d[0].K = (uint32_t)K;
     dyn.d[0].zero_below = 0;
     dyn.d[0].pad = 0;
-    XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase, f->d_phtab, dyn, f->stream));
+    XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase, f->d_phtab, dyn, 0, f->stream));
     XlFirArgs a;
     memset(&a, 0, sizeof(a));
     a.in0 = f->d_work_f;
@@ -213,10 +213,11 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     a.ngroups = 1;
     a.groups_per_xcd = 1;
     a.xtiles = (uint32_t)((K + 63) / 64);
+    a.flags = (f->D % 2 == 0) ? 1u : 0u;
     a.taps = f->d_taps;
     a.phtab = f->d_phtab;
     a.out = f->d_out_f;
-    XL_TRY(xl_launch_fir(1, mode, a, dyn, xl_fir_lds_bytes(f->D, f->Tpad), f->stream));
+    XL_TRY(xl_launch_fir(1, mode, 1, XL_NW_DEFAULT, a, dyn, xl_fir_lds_bytes(f->D, f->Tpad, 1), f->stream));
     XL_TRY(hipMemcpyAsync(f->h_out_f, f->d_out_f, K * sizeof(float2), hipMemcpyDeviceToHost, f->stream));
   }
   {

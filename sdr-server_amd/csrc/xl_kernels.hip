@@ -19,11 +19,11 @@
 //                                                                                  CT complex MACs (4*CT FMAs)
 //   taps      = wave-uniform: fetched with SCALAR loads (s_load_dwordx16 = tap i of 8 clients) from a
 //               [tap][client] interleaved image and used as SGPR operands of v_fma_f32 -> zero VALU/LDS cost
-//   window    = converted once per workgroup into LDS as cf32; the 4 waves of a workgroup (4 tiles = up to 32
-//               clients) share it.  Lane m reads sample (m*D + i): for odd D ds_read_b64 is bank-conflict
+//   window    = converted once per workgroup into LDS as cf32; the NW (4..8) waves of a workgroup (NW tiles = up
+//               to 8*NW clients) share it.  Lane m reads sample (m*D + i): for odd D ds_read_b64 is bank-conflict
 //               free; for even D two samples are read per ds_read_b128 (conflict-free when D = 2 mod 4).
-//   grid      = (output tiles) x (groups), flattened so that every XCD owns a contiguous range of groups:
-//               all output tiles of a group re-read the same taps, which then stay in that XCD's L2.
+//   grid      = (groups) x (output tiles), group-major, cut into 8 equal contiguous chunks, one per XCD: the
+//               output tiles of a group re-read the same taps, which then stay in that XCD's L2.
 #include "xl_device.h"
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -33,6 +33,7 @@ typedef const float __attribute__((address_space(4))) *cfloat_p;
 typedef const uint32_t __attribute__((address_space(4))) *cu32_p;
 
 #define XL_DEV static __device__ __forceinline__
+#define XL_MEM __device__ __forceinline__
 
 // ------------------------------------------------------------------------------------------- sample converters
 // xlating.c:357-358 / 367-368 / 377-378: all three maps are exact in float32.
@@ -57,23 +58,41 @@ XL_DEV v2f xl_sample(const void *__restrict__ p, int fmt, uint32_t i) {
 }
 
 // ------------------------------------------------------------------------------------------- complex arithmetic
+// One complex accumulator per (output, client).
 // MODE 0 (native): the reference's scalar expression tree, xlating.c:68 `temp += x * h` in C99 complex float:
 //   p = (xr*hr - xi*hi) + j(xr*hi + xi*hr);  acc += p        -- 4 mul, 2 add/sub, 2 add, each rounded.
-// MODE 1 (optimized): 4 fused multiply-adds, same tap order.
+// MODE 1 (optimized): the sum is kept as two packed halves that need no negation inside the loop,
+//   a += xr * (hr, hi)      b += xi * (hi, hr)      acc = (a.x - b.x, a.y + b.y)
+//   = exactly two v_pk_fma_f32 per complex MAC (op_sel broadcasts xr / xi and swaps the tap), same tap order.
 template <int MODE>
-XL_DEV void xl_cmac(v2f &acc, const v2f x, const float hr, const float hi) {
-  if (MODE == 0) {
+struct XlAcc;
+
+template <>
+struct XlAcc<0> {
+  v2f s;
+  XL_MEM void clear() { s = (v2f){0.0f, 0.0f}; }
+  XL_MEM void mac(const v2f x, const float hr, const float hi) {
     const float pr = x.x * hr - x.y * hi;
     const float pi = x.x * hi + x.y * hr;
-    acc.x = acc.x + pr;
-    acc.y = acc.y + pi;
-  } else {
-    acc.x = __builtin_fmaf(x.x, hr, acc.x);
-    acc.x = __builtin_fmaf(-x.y, hi, acc.x);
-    acc.y = __builtin_fmaf(x.x, hi, acc.y);
-    acc.y = __builtin_fmaf(x.y, hr, acc.y);
+    s.x = s.x + pr;
+    s.y = s.y + pi;
   }
-}
+  XL_MEM v2f value() const { return s; }
+};
+
+template <>
+struct XlAcc<1> {
+  v2f a, b;
+  XL_MEM void clear() {
+    a = (v2f){0.0f, 0.0f};
+    b = (v2f){0.0f, 0.0f};
+  }
+  XL_MEM void mac(const v2f x, const float hr, const float hi) {
+    a = __builtin_elementwise_fma((v2f){x.x, x.x}, (v2f){hr, hi}, a);
+    b = __builtin_elementwise_fma((v2f){x.y, x.y}, (v2f){hi, hr}, b);
+  }
+  XL_MEM v2f value() const { return (v2f){a.x - b.x, a.y + b.y}; }
+};
 
 // xlating.c:70 `out = temp * phase`
 template <int MODE>
@@ -90,27 +109,56 @@ XL_DEV v2f xl_rotate(const v2f a, const v2f p) {
 }
 
 // ------------------------------------------------------------------------------------------- the FIR kernel
-template <int CT, int MODE>
-__global__ __launch_bounds__(XL_WG) void xl_fir_kernel(const XlFirArgs a, const XlDynArgs dyn) {
+// KT = outputs per lane (lane l of output tile x owns outputs x*64*KT + l + 64*j, j < KT).  Every scalar tap
+// fetch feeds KT*CT complex MACs per lane: KT = 2 halves the scalar-cache traffic per FMA, which is what
+// bounds KT = 1 (measured: ~3.7 B/clk/CU of missing s_load traffic vs 3.8 needed at full VALU rate).
+// SGPR cap 96: 64 hold one batch of taps; at <= 96 the CU admits 7 waves per SIMD instead of 6 (the allocation
+// granule is 16 and 800 SGPRs serve a SIMD), which lets a 5-wave-per-workgroup launch keep 25 waves per CU.
+template <int CT, int MODE, int KT, bool WIDE>
+__global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))) void xl_fir_kernel(
+    const XlFirArgs a, const XlDynArgs dyn) {
   extern __shared__ __attribute__((aligned(16))) v2f xl_win[];
+  constexpr uint32_t OT = 64u * KT;  // outputs per tile
 
-  // block -> (group y, output tile x); XCD k (= blockIdx % 8 on this part) owns groups [k*gpx, (k+1)*gpx)
+  // block -> (group y, output tile x).  The work list is group-major (w = y * xtiles + x, so that all tiles of a
+  // group -- which stream the same taps -- are neighbours) and is cut into 8 equal contiguous chunks, one per XCD
+  // (block b runs on XCD b % 8 on this part): each XCD's L2 then holds the taps of ~1/8 of the groups, and every
+  // XCD gets the same number of workgroups (whole groups per XCD left one XCD with 196 workgroups on 192 slots).
   const uint32_t b = blockIdx.x;
+  const unsigned long long t_entry = a.trace ? wall_clock64() : 0ull;
+
+  // ---- raw-history roll, folded into this launch: hist_out = the last hist_units 2-byte units of [in0 | in1].
+  // No workgroup of this launch reads hist_out (they read in0/in1), the next block's launch follows in stream order.
+  if (a.hist_out != nullptr && b < XL_ROLL_BLOCKS) {
+    const uint16_t *__restrict__ h0 = reinterpret_cast<const uint16_t *>(a.in0);
+    const uint16_t *__restrict__ h1 = reinterpret_cast<const uint16_t *>(a.in1);
+    uint16_t *__restrict__ ho = reinterpret_cast<uint16_t *>(a.hist_out);
+    const uint32_t hu = a.hist_units, nu = a.block_units;
+    for (uint32_t j = b * blockDim.x + threadIdx.x; j < hu; j += XL_ROLL_BLOCKS * blockDim.x) {
+      const uint32_t sidx = nu + j;
+      ho[j] = (sidx < hu) ? h0[sidx] : h1[sidx - hu];
+    }
+  }
   const uint32_t xcd = b & 7u, idx = b >> 3;
-  const uint32_t y = xcd * a.groups_per_xcd + idx / a.xtiles;
-  const uint32_t x = idx % a.xtiles;
+  const uint32_t total = a.ngroups * a.xtiles;
+  const uint32_t per = total >> 3, extra = total & 7u;
+  const uint32_t len = per + (xcd < extra ? 1u : 0u);
+  if (idx >= len) return;
+  const uint32_t wi = xcd * per + (xcd < extra ? xcd : extra) + idx;
+  const uint32_t y = wi / a.xtiles;
+  const uint32_t x = wi - y * a.xtiles;
   if (y >= a.ngroups) return;
 
   const cu32_p g = (cu32_p)(uintptr_t)(a.groups + y);  // XlGroup as dwords, scalar-loaded
-  const uint32_t D = g[0], Tpad = g[2], cls = g[3], ntiles = g[4], wide = g[5];
+  const uint32_t D = g[0], Tpad = g[2], cls = g[3], ntiles = g[4];
   const XlDyn d = dyn.d[cls];
   const uint32_t K = d.K;
-  if (x * 64u >= K) return;
+  if (x * OT >= K) return;
 
-  // ---- stage the window image: samples [win0, win0 + 63*D + Tpad) of the stream [in0 | in1], as cf32
-  const uint32_t win0 = d.base + x * 64u * D;
-  const uint32_t wlen = 63u * D + Tpad;
-  for (uint32_t j = threadIdx.x; j < wlen; j += XL_WG) {
+  // ---- stage the window image: samples [win0, win0 + (OT-1)*D + Tpad) of the stream [in0 | in1], as cf32
+  const uint32_t win0 = d.base + x * OT * D;
+  const uint32_t wlen = (OT - 1u) * D + Tpad;
+  for (uint32_t j = threadIdx.x; j < wlen; j += blockDim.x) {
     const uint32_t s = win0 + j;
     v2f v = {0.0f, 0.0f};
     if (s >= d.zero_below) {
@@ -127,98 +175,195 @@ __global__ __launch_bounds__(XL_WG) void xl_fir_kernel(const XlFirArgs a, const 
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (w >= ntiles) return;
   const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long *tr = a.trace ? a.trace + ((size_t)b * XL_NW_MAX + w) * 4 : nullptr;
+  if (tr && lane == 0) {
+    tr[0] = t_entry;
+    tr[1] = wall_clock64();
+  }
   const cu32_p t = g + 8 + w * (2 + XL_CT_MAX);  // XlTile of this wave
   const uint32_t ncl = t[1];
   const cfloat_p tp = (cfloat_p)(uintptr_t)(a.taps + t[0]);
 
-  v2f acc[CT];
+  XlAcc<MODE> acc[KT][CT];
 #pragma unroll
-  for (int c = 0; c < CT; ++c) acc[c] = (v2f){0.0f, 0.0f};
+  for (int j = 0; j < KT; ++j)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[j][c].clear();
 
+  constexpr int STEP = (CT == 9 || CT == 10) ? 6 : 4;  // taps per iteration (xl_tap_step): ~60 tap SGPRs in flight
   const v2f *lp = xl_win + lane * D;
-  if (wide) {
-    // even D: lane*D is even -> 16-byte aligned pairs of samples
-    for (uint32_t i = 0; i < Tpad; i += XL_TAP_UNROLL) {
-      const v4f q0 = *reinterpret_cast<const v4f *>(lp + i);
-      const v4f q1 = *reinterpret_cast<const v4f *>(lp + i + 2);
-      const v2f xs[4] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}};
-      const cfloat_p tq = tp + (size_t)i * (2 * CT);
-#pragma unroll
-      for (int u = 0; u < XL_TAP_UNROLL; ++u) {
-#pragma unroll
-        for (int c = 0; c < CT; ++c) xl_cmac<MODE>(acc[c], xs[u], tq[(u * CT + c) * 2], tq[(u * CT + c) * 2 + 1]);
-      }
-    }
+  const uint32_t jstride = 64u * D;  // samples between the windows of a lane's outputs
+  // The tap loop runs in four quarters with falling wave priority (3, 2, 1, 0).  The SIMD arbiter otherwise
+  // favours the oldest wave, so co-resident waves -- which all have the same work -- finish one after another and
+  // the last ones run alone, latency-bound (measured: identical waves ending between 57 and 142 us of a 144 us
+  // launch).  With priority = remaining-work quartile a wave that gets ahead yields to those behind, all waves
+  // of a SIMD finish together and the VALU stays fed to the end.
+  const uint32_t quarter = ((Tpad / STEP + 3u) / 4u) * STEP;
+  // one quarter of the tap loop; WIDE (even D: lane*D and 64*D even) reads 16-byte aligned pairs of samples
+#define XL_TAP_LOOP(I0, I1)                                                                       \
+  for (uint32_t i = (I0); i < (I1); i += STEP) {                                                  \
+    v2f xs[KT][STEP];                                                                             \
+    _Pragma("unroll") for (int j = 0; j < KT; ++j) {                                              \
+      if (WIDE) {                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < STEP; u += 2) {                                     \
+          const v4f q = *reinterpret_cast<const v4f *>(lp + j * jstride + i + u);                 \
+          xs[j][u] = (v2f){q.x, q.y};                                                             \
+          xs[j][u + 1] = (v2f){q.z, q.w};                                                         \
+        }                                                                                         \
+      } else {                                                                                    \
+        _Pragma("unroll") for (int u = 0; u < STEP; ++u) xs[j][u] = lp[j * jstride + i + u];      \
+      }                                                                                           \
+    }                                                                                             \
+    const cfloat_p tq = tp + (size_t)i * (2 * CT);                                                \
+    _Pragma("unroll") for (int u = 0; u < STEP; ++u) {                                            \
+      _Pragma("unroll") for (int c = 0; c < CT; ++c) {                                            \
+        const float hr = tq[(u * CT + c) * 2], hi = tq[(u * CT + c) * 2 + 1];                     \
+        _Pragma("unroll") for (int j = 0; j < KT; ++j) acc[j][c].mac(xs[j][u], hr, hi);           \
+      }                                                                                           \
+    }                                                                                             \
+  }
+  if (a.flags & 2u) {  // tuning: flat priority
+    XL_TAP_LOOP(0u, Tpad)
   } else {
-    for (uint32_t i = 0; i < Tpad; i += XL_TAP_UNROLL) {
-      v2f xs[4];
+    const uint32_t e1 = quarter < Tpad ? quarter : Tpad;
+    const uint32_t e2 = 2 * quarter < Tpad ? 2 * quarter : Tpad;
+    const uint32_t e3 = 3 * quarter < Tpad ? 3 * quarter : Tpad;
+    __builtin_amdgcn_s_setprio(3);
+    XL_TAP_LOOP(0u, e1)
+    __builtin_amdgcn_s_setprio(2);
+    XL_TAP_LOOP(e1, e2)
+    __builtin_amdgcn_s_setprio(1);
+    XL_TAP_LOOP(e2, e3)
+    __builtin_amdgcn_s_setprio(0);
+    XL_TAP_LOOP(e3, Tpad)
+  }
+#undef XL_TAP_LOOP
+
+  if (tr && lane == 0) tr[2] = wall_clock64();
+  // ---- epilogue: derotate with the tabulated NCO phase and store (coalesced: lanes = consecutive outputs)
+  const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
+  v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
 #pragma unroll
-      for (int u = 0; u < XL_TAP_UNROLL; ++u) xs[u] = lp[i + u];
-      const cfloat_p tq = tp + (size_t)i * (2 * CT);
+  for (int j = 0; j < KT; ++j) {
+    const uint32_t m = x * OT + 64u * j + lane;
+    if (m < K) {
 #pragma unroll
-      for (int u = 0; u < XL_TAP_UNROLL; ++u) {
-#pragma unroll
-        for (int c = 0; c < CT; ++c) xl_cmac<MODE>(acc[c], xs[u], tq[(u * CT + c) * 2], tq[(u * CT + c) * 2 + 1]);
+      for (int c = 0; c < CT; ++c) {
+        if ((uint32_t)c < ncl) {
+          const uint32_t off = t[2 + c] + m;
+          out[off] = xl_rotate<MODE>(acc[j][c].value(), ph[off]);
+        }
       }
     }
   }
-
-  // ---- epilogue: derotate with the tabulated NCO phase and store (coalesced: lanes = consecutive outputs)
-  const uint32_t m = x * 64u + lane;
-  if (m < K) {
-    const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
-    v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      if ((uint32_t)c < ncl) {
-        const uint32_t off = t[2 + c] + m;
-        out[off] = xl_rotate<MODE>(acc[c], ph[off]);
-      }
-    }
+  if (tr && lane == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    tr[3] = wall_clock64();
   }
 }
 
-size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad) { return (size_t)(63u * D + Tpad) * sizeof(v2f); }
+size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad, int kt) {
+  return (size_t)((64u * kt - 1u) * D + Tpad) * sizeof(v2f);
+}
 
-template <int CT, int MODE>
-static hipError_t xl_fir_go(const XlFirArgs &a, const XlDynArgs &dyn, size_t lds, hipStream_t s) {
+template <int CT, int MODE, int KT, bool WIDE>
+static hipError_t xl_fir_go2(int nw, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds, hipStream_t s) {
   static bool attr_done = false;  // per instantiation; benign race (idempotent)
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&xl_fir_kernel<CT, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&xl_fir_kernel<CT, MODE, KT, WIDE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const uint32_t nblocks = 8u * a.groups_per_xcd * a.xtiles;
+  const uint32_t nblocks = 8u * ((a.ngroups * a.xtiles + 7u) / 8u);
   if (nblocks == 0) return hipSuccess;
-  hipLaunchKernelGGL((xl_fir_kernel<CT, MODE>), dim3(nblocks), dim3(XL_WG), lds, s, a, dyn);
+  hipLaunchKernelGGL((xl_fir_kernel<CT, MODE, KT, WIDE>), dim3(nblocks), dim3(64 * nw), lds, s, a, dyn);
   return hipGetLastError();
 }
 
-hipError_t xl_launch_fir(int ct, int mode, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds, hipStream_t s) {
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+// a.flags bit 0 set by the caller = every group of the launch has an even decimation -> 16-byte LDS reads
+template <int CT, int MODE, int KT>
+static hipError_t xl_fir_go(int nw, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds, hipStream_t s) {
+  return (a.flags & 1u) ? xl_fir_go2<CT, MODE, KT, true>(nw, a, dyn, lds, s)
+                        : xl_fir_go2<CT, MODE, KT, false>(nw, a, dyn, lds, s);
+}
+
+template <int KT>
+static hipError_t xl_fir_dispatch(int ct, int mode, int nw, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds,
+                                  hipStream_t s) {
   switch (ct * 2 + (mode ? 1 : 0)) {
-    case 2: return xl_fir_go<1, 0>(a, dyn, lds, s);
-    case 3: return xl_fir_go<1, 1>(a, dyn, lds, s);
-    case 4: return xl_fir_go<2, 0>(a, dyn, lds, s);
-    case 5: return xl_fir_go<2, 1>(a, dyn, lds, s);
-    case 8: return xl_fir_go<4, 0>(a, dyn, lds, s);
-    case 9: return xl_fir_go<4, 1>(a, dyn, lds, s);
-    case 16: return xl_fir_go<8, 0>(a, dyn, lds, s);
-    case 17: return xl_fir_go<8, 1>(a, dyn, lds, s);
+    case 2: return xl_fir_go<1, 0, KT>(nw, a, dyn, lds, s);
+    case 3: return xl_fir_go<1, 1, KT>(nw, a, dyn, lds, s);
+    case 4: return xl_fir_go<2, 0, KT>(nw, a, dyn, lds, s);
+    case 5: return xl_fir_go<2, 1, KT>(nw, a, dyn, lds, s);
+    case 8: return xl_fir_go<4, 0, KT>(nw, a, dyn, lds, s);
+    case 9: return xl_fir_go<4, 1, KT>(nw, a, dyn, lds, s);
+    case 16: return xl_fir_go<8, 0, KT>(nw, a, dyn, lds, s);
+    case 17: return xl_fir_go<8, 1, KT>(nw, a, dyn, lds, s);
+    default: break;
+  }
+  if (KT != 1) return hipErrorInvalidValue;  // the tall tiles exist for one output per lane only
+  switch (ct * 2 + (mode ? 1 : 0)) {
+    case 18: return xl_fir_go<9, 0, 1>(nw, a, dyn, lds, s);
+    case 19: return xl_fir_go<9, 1, 1>(nw, a, dyn, lds, s);
+    case 20: return xl_fir_go<10, 0, 1>(nw, a, dyn, lds, s);
+    case 21: return xl_fir_go<10, 1, 1>(nw, a, dyn, lds, s);
+    case 24: return xl_fir_go<12, 0, 1>(nw, a, dyn, lds, s);
+    case 25: return xl_fir_go<12, 1, 1>(nw, a, dyn, lds, s);
     default: return hipErrorInvalidValue;
   }
 }
 
+// a.xtiles must be ceil(max K / (64 * kt))
+hipError_t xl_launch_fir(int ct, int mode, int kt, int nw, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds,
+                         hipStream_t s) {
+  if (lds > 160 * 1024 || nw < 1 || nw > XL_NW_MAX) return hipErrorInvalidValue;
+  if (kt == 1) return xl_fir_dispatch<1>(ct, mode, nw, a, dyn, lds, s);
+  if (kt == 2) return xl_fir_dispatch<2>(ct, mode, nw, a, dyn, lds, s);
+  return hipErrorInvalidValue;
+}
+
+#define XL_NCO_LANES 8u
 // ------------------------------------------------------------------------------------------- NCO phase table
 // xlating.c:70-73: the phasor is a float32 RECURRENCE p <- p * incr (never re-seeded), renormalised once per
 // call that could produce output.  It is data independent, so one lane per client tabulates the K phases of
 // the block ahead of the FIR kernel; the recurrence itself must stay sequential to be bit-exact.
 // hypotf: glibc evaluates sqrt(x*x + y*y) in double and narrows; restated with IEEE double ops.
+// One recurrence step p <- p * incr as the reference's C99 complex float product (xlating.c:71):
+//   re = pr*ir - pi*ii, im = pr*ii + pi*ir, every operation rounded once.  Written as scalar VALU instructions:
+// left to the compiler the four multiplies get SLP-packed into v_pk_mul/v_pk_add with register shuffles, a
+// dependent chain of ~50 cycles per step; this form is 4 independent multiplies + 2 independent add/sub.
+XL_DEV void xl_nco_step(float &pr, float &pi, const float ir, const float ii) {
+  float t1, t2, t3, t4;
+  asm volatile(
+      "v_mul_f32 %0, %4, %6\n\t"
+      "v_mul_f32 %1, %5, %7\n\t"
+      "v_mul_f32 %2, %4, %7\n\t"
+      "v_mul_f32 %3, %5, %6"
+      : "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+      : "v"(pr), "v"(pi), "v"(ir), "v"(ii));
+  asm volatile(
+      "v_sub_f32 %0, %2, %3\n\t"
+      "v_add_f32 %1, %4, %5"
+      : "=&v"(pr), "=&v"(pi)
+      : "v"(t1), "v"(t2), "v"(t3), "v"(t4));
+}
+
 __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
-                                                          const float2 *state_in, float2 *state_out, float2 *__restrict__ tab,
-                                                          const XlDynArgs dyn) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+                                                          const float2 *state_in, float2 *state_out,
+                                                          float2 *__restrict__ tab, const XlDynArgs dyn,
+                                                          const uint32_t prio) {
+  // Latency-critical and tiny (one lane per client).  It shares the chip with the previous block's FIR launch,
+  // whose waves run at priority 3..0 by remaining work; `prio` places it among them.
+  if (prio == 3) __builtin_amdgcn_s_setprio(3);
+  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  // Only XL_NCO_LANES lanes of a wave carry a client and the table is written two steps (16 bytes) per store:
+  // every store goes to the client's own table row (fully divergent addresses) and a wave can have only ~64
+  // stores in flight, so the store stream -- not the 6-instruction recurrence -- bounds this kernel.  The chip
+  // is otherwise idle for it, so spread the clients over 8x more waves and halve the store count.
+  if (threadIdx.x >= XL_NCO_LANES) return;
+  const uint32_t c = blockIdx.x * XL_NCO_LANES + threadIdx.x;
   if (c >= n) return;
   const XlNcoClient k = cl[c];
   const uint32_t K = dyn.d[k.cls].K;
@@ -228,24 +373,21 @@ __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__r
     return;
   }
   const float ir = k.incr.x, ii = k.incr.y;
-  float2 *__restrict__ o = tab + k.out_off;
+  float2 *__restrict__ o = tab + k.out_off;  // out_off is a multiple of 2 -> 16-byte aligned pairs
+  float4 *__restrict__ o4 = reinterpret_cast<float4 *>(o);
   uint32_t m = 0;
   for (; m + 8 <= K; m += 8) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      o[m + j] = make_float2(pr, pi);
-      const float nr = pr * ir - pi * ii;
-      const float ni = pr * ii + pi * ir;
-      pr = nr;
-      pi = ni;
+    for (int j = 0; j < 4; ++j) {
+      const float ar = pr, ai = pi;
+      xl_nco_step(pr, pi, ir, ii);
+      o4[(m >> 1) + j] = make_float4(ar, ai, pr, pi);
+      xl_nco_step(pr, pi, ir, ii);
     }
   }
   for (; m < K; ++m) {
     o[m] = make_float2(pr, pi);
-    const float nr = pr * ir - pi * ii;
-    const float ni = pr * ii + pi * ir;
-    pr = nr;
-    pi = ni;
+    xl_nco_step(pr, pi, ir, ii);
   }
   const double mag2 = (double)pr * (double)pr + (double)pi * (double)pi;
   const float mag = (float)__dsqrt_rn(mag2);
@@ -253,10 +395,10 @@ __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__r
 }
 
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
-                               float2 *state_out, float2 *phtab, const XlDynArgs &dyn, hipStream_t s) {
+                               float2 *state_out, float2 *phtab, const XlDynArgs &dyn, uint32_t prio, hipStream_t s) {
   if (nclients == 0) return hipSuccess;
-  hipLaunchKernelGGL(xl_nco_table_kernel, dim3((nclients + 63) / 64), dim3(64), 0, s, clients, nclients, state_in,
-                     state_out, phtab, dyn);
+  hipLaunchKernelGGL(xl_nco_table_kernel, dim3((nclients + XL_NCO_LANES - 1) / XL_NCO_LANES), dim3(64), 0, s, clients,
+                     nclients, state_in, state_out, phtab, dyn, prio);
   return hipGetLastError();
 }
 

@@ -165,6 +165,42 @@ def test_device_pointer_path_matches_host_path():
     e2.close()
 
 
+@pytest.mark.parametrize("variant", ["native", "optimized"])
+def test_lookahead_nco_with_ragged_blocks_and_late_fetch(variant):
+    """The phase table of block k+1 is tabulated ahead assuming block k's length.  Ragged blocks (wrong guess), a
+    tiny block without output, a client joining mid-stream and fetching only some blocks must all leave every
+    client's stream equal to the oracle's.  Inputs arrive as device buffers on the caller's (torch) stream."""
+    import torch
+
+    taps = lpf(FS, 24000, 9600)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    oracles = {}
+    for c in range(19):
+        cid = eng.add_client(42, taps, -700000 + 70001 * c)
+        oracles[cid] = Oracle(42, taps, -700000 + 70001 * c, FS, 262144)
+    lens = [262144, 262144, 100002, 262144, 262144, 8, 262144, 262144]
+    xs = [siggen.xs_u8(3000 + k, n) for k, n in enumerate(lens)]
+    recv = [torch.empty(262144, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    stream = torch.cuda.current_stream().cuda_stream
+    for k, x in enumerate(xs):
+        if k == 4:
+            cid = eng.add_client(42, taps, 4242)
+            oracles[cid] = Oracle(42, taps, 4242, FS, 262144)
+        buf = recv[k % 2]
+        buf[: x.size].copy_(torch.from_numpy(x), non_blocking=False)  # reuse of the buffer is stream-ordered
+        eng.process_device(buf.data_ptr(), x.size, variant, stream)
+        want = {cid: o.process("cu8", x) for cid, o in oracles.items()}
+        if k in (1, 2, 5, 7):
+            eng.fetch()
+            for cid in oracles:
+                got = eng.output(cid)
+                if variant == "native":
+                    assert bits_equal(got, want[cid]), (k, cid)
+                else:
+                    assert len(got) == len(want[cid]) and rel_err(got, want[cid]) <= REL_TOL, (k, cid)
+    eng.close()
+
+
 def test_full_size_1024_clients_properties():
     """BASELINE target size (1024 concurrent 48 kHz clients, 505 taps, 262144-byte blocks).  The oracle is too slow
     for all of it, so: (a) duplicated clients placed in different tiles/groups/XCDs must agree bit for bit,

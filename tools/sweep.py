@@ -21,14 +21,16 @@ def main():
     ap.add_argument("--rates", default="5,1")
     ap.add_argument("--modes", default="optimized")
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--depths", default="1")
     args = ap.parse_args()
     blocks = [torch.from_numpy(b).cuda() for b in bench.make_blocks(4, 123)]
     stream = torch.cuda.current_stream()
-    print(f"{'mode':10s} {'taps':>5s} {'clients':>7s} {'step_ms':>9s} {'fir_ms':>9s} {'nco_ms':>9s} {'TFLOP/s':>8s} {'algGB/s':>8s} {'Msps':>10s}")
+    depths = [int(d) for d in args.depths.split(",")]
+    print(f"{'mode':10s} {'dp':>2s} {'taps':>5s} {'clients':>7s} {'step_ms':>9s} {'fir_ms':>9s} {'nco_ms':>9s} {'TFLOP/s':>8s} {'algGB/s':>8s} {'Msps':>10s}")
     for mode in args.modes.split(","):
         for rate in [int(r) for r in args.rates.split(",")]:
             code, taps = xl.create_low_pass_filter(1.0, bench.FS, bench.RATE // 2, bench.RATE // rate)
-            for n in [int(c) for c in args.clients.split(",")]:
+            for n, depth in [(int(c), d) for c in args.clients.split(",") for d in depths]:
                 eng = xl.BatchEngine(bench.FS, "cu8", bench.BLOCK_BYTES)
                 for c in range(n):
                     eng.add_client(bench.D, taps, bench.client_center_freq(c))
@@ -48,7 +50,7 @@ def main():
                 units = n * bench.S
                 tf = units * bench.flops_per_unit(taps.size, bench.D) / (fir * 1e-3) / 1e12
                 gb = units * bench.algorithmic_bytes_per_unit(bench.D) / (fir * 1e-3) / 1e9
-                print(f"{mode:10s} {taps.size:5d} {n:7d} {dt*1e3:9.4f} {fir:9.4f} {nco:9.4f} {tf:8.2f} {gb:8.1f} {units/dt/1e6:10.0f}", flush=True)
+                print(f"{mode:10s} {depth:2d} {taps.size:5d} {n:7d} {dt*1e3:9.4f} {fir:9.4f} {nco:9.4f} {tf:8.2f} {gb:8.1f} {units/dt/1e6:10.0f}", flush=True)
 
 
 if __name__ == "__main__":
