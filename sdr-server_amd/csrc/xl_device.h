@@ -61,7 +61,7 @@ struct XlFirArgs {
   uint32_t ngroups;
   uint32_t groups_per_xcd;  // (unused by the kernel since the work list is cut evenly across XCDs)
   uint32_t xtiles;      // ceil(max K / (64 * kt))
-  uint32_t flags;       // bit 0: every group of the launch has even D (16-byte LDS reads); bit 1: flat wave priority
+  uint32_t flags;       // bit 0: every group of the launch has even D (16-byte LDS reads); bit 1: flat wave priority; bit 2: priority segments end at 1/2, 3/4, 7/8
   const float2 *taps;   // tap image
   const float2 *phtab;  // NCO phase table, indexed like out
   float2 *out;

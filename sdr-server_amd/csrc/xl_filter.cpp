@@ -213,7 +213,7 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     a.ngroups = 1;
     a.groups_per_xcd = 1;
     a.xtiles = (uint32_t)((K + 63) / 64);
-    a.flags = (f->D % 2 == 0) ? 1u : 0u;
+    a.flags = ((f->D % 2 == 0) ? 1u : 0u) | 4u;
     a.taps = f->d_taps;
     a.phtab = f->d_phtab;
     a.out = f->d_out_f;

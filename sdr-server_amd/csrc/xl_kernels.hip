@@ -26,6 +26,8 @@
 //               output tiles of a group re-read the same taps, which then stay in that XCD's L2.
 #include "xl_device.h"
 
+#include <stdlib.h>
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 // constant address space: uniform loads through these pointers are selected as scalar (SMEM) loads
@@ -108,6 +110,34 @@ XL_DEV v2f xl_rotate(const v2f a, const v2f p) {
   return r;
 }
 
+// Window staging: raw samples -> cf32 image in LDS.  Four independent loads per thread are issued before any is
+// consumed (every workgroup of a launch stages at the same time and all its waves wait at the barrier, so this
+// phase is pure latency: 12 dependent load->convert->write rounds measured 6 us of a 130 us launch).
+template <int FMT>
+XL_DEV void xl_stage_window(const XlFirArgs &a, const uint32_t zero_below, const uint32_t win0, const uint32_t wlen,
+                            v2f *__restrict__ win) {
+  const uint32_t bd = blockDim.x;
+  for (uint32_t j0 = threadIdx.x; j0 < wlen; j0 += 4u * bd) {
+    v2f v[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t j = j0 + u * bd;
+      const uint32_t s = win0 + j;
+      const bool first = s < a.n0;
+      ok[u] = j < wlen && s >= zero_below && (first || s - a.n0 < a.n1);
+      const void *src = (first || !ok[u]) ? a.in0 : a.in1;  // in0 always holds >= 1 sample: safe dummy address
+      const uint32_t idx = ok[u] ? (first ? s : s - a.n0) : 0u;
+      v[u] = xl_sample(src, FMT, idx);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t j = j0 + u * bd;
+      if (j < wlen) win[j] = ok[u] ? v[u] : (v2f){0.0f, 0.0f};
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- the FIR kernel
 // KT = outputs per lane (lane l of output tile x owns outputs x*64*KT + l + 64*j, j < KT).  Every scalar tap
 // fetch feeds KT*CT complex MACs per lane: KT = 2 halves the scalar-cache traffic per FMA, which is what
@@ -158,18 +188,10 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   // ---- stage the window image: samples [win0, win0 + (OT-1)*D + Tpad) of the stream [in0 | in1], as cf32
   const uint32_t win0 = d.base + x * OT * D;
   const uint32_t wlen = (OT - 1u) * D + Tpad;
-  for (uint32_t j = threadIdx.x; j < wlen; j += blockDim.x) {
-    const uint32_t s = win0 + j;
-    v2f v = {0.0f, 0.0f};
-    if (s >= d.zero_below) {
-      if (s < a.n0) {
-        v = xl_sample(a.in0, a.fmt, s);
-      } else if (s - a.n0 < a.n1) {
-        v = xl_sample(a.in1, a.fmt, s - a.n0);
-      }
-    }
-    xl_win[j] = v;
-  }
+  if (a.fmt == XLF_CU8) xl_stage_window<XLF_CU8>(a, d.zero_below, win0, wlen, xl_win);
+  else if (a.fmt == XLF_CS8) xl_stage_window<XLF_CS8>(a, d.zero_below, win0, wlen, xl_win);
+  else if (a.fmt == XLF_CS16) xl_stage_window<XLF_CS16>(a, d.zero_below, win0, wlen, xl_win);
+  else xl_stage_window<XLF_CF32>(a, d.zero_below, win0, wlen, xl_win);
   __syncthreads();
 
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -198,7 +220,6 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   // the last ones run alone, latency-bound (measured: identical waves ending between 57 and 142 us of a 144 us
   // launch).  With priority = remaining-work quartile a wave that gets ahead yields to those behind, all waves
   // of a SIMD finish together and the VALU stays fed to the end.
-  const uint32_t quarter = ((Tpad / STEP + 3u) / 4u) * STEP;
   // one quarter of the tap loop; WIDE (even D: lane*D and 64*D even) reads 16-byte aligned pairs of samples
 #define XL_TAP_LOOP(I0, I1)                                                                       \
   for (uint32_t i = (I0); i < (I1); i += STEP) {                                                  \
@@ -225,9 +246,14 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   if (a.flags & 2u) {  // tuning: flat priority
     XL_TAP_LOOP(0u, Tpad)
   } else {
-    const uint32_t e1 = quarter < Tpad ? quarter : Tpad;
-    const uint32_t e2 = 2 * quarter < Tpad ? 2 * quarter : Tpad;
-    const uint32_t e3 = 3 * quarter < Tpad ? 3 * quarter : Tpad;
+    // segment ends: quarters, or (flags bit 2) 1/2, 3/4, 7/8 of the taps -- a short last segment tightens the finish
+    const uint32_t steps = Tpad / STEP;
+    const uint32_t b1 = (a.flags & 4u) ? steps / 2 : (steps + 3) / 4;
+    const uint32_t b2 = (a.flags & 4u) ? (3 * steps) / 4 : 2 * ((steps + 3) / 4);
+    const uint32_t b3 = (a.flags & 4u) ? (7 * steps) / 8 : 3 * ((steps + 3) / 4);
+    const uint32_t e1 = b1 * STEP < Tpad ? b1 * STEP : Tpad;
+    const uint32_t e2 = b2 * STEP < Tpad ? b2 * STEP : Tpad;
+    const uint32_t e3 = b3 * STEP < Tpad ? b3 * STEP : Tpad;
     __builtin_amdgcn_s_setprio(3);
     XL_TAP_LOOP(0u, e1)
     __builtin_amdgcn_s_setprio(2);
@@ -323,72 +349,68 @@ hipError_t xl_launch_fir(int ct, int mode, int kt, int nw, const XlFirArgs &a, c
   return hipErrorInvalidValue;
 }
 
-#define XL_NCO_LANES 8u
+#define XL_NCO_LANES 16u
 // ------------------------------------------------------------------------------------------- NCO phase table
 // xlating.c:70-73: the phasor is a float32 RECURRENCE p <- p * incr (never re-seeded), renormalised once per
 // call that could produce output.  It is data independent, so one lane per client tabulates the K phases of
 // the block ahead of the FIR kernel; the recurrence itself must stay sequential to be bit-exact.
 // hypotf: glibc evaluates sqrt(x*x + y*y) in double and narrows; restated with IEEE double ops.
 // One recurrence step p <- p * incr as the reference's C99 complex float product (xlating.c:71):
-//   re = pr*ir - pi*ii, im = pr*ii + pi*ir, every operation rounded once.  Written as scalar VALU instructions:
-// left to the compiler the four multiplies get SLP-packed into v_pk_mul/v_pk_add with register shuffles, a
-// dependent chain of ~50 cycles per step; this form is 4 independent multiplies + 2 independent add/sub.
-XL_DEV void xl_nco_step(float &pr, float &pi, const float ir, const float ii) {
-  float t1, t2, t3, t4;
+//   re = pr*ir - pi*ii, im = pr*ii + pi*ir, every operation rounded once (IEEE mul / add, nothing fused).
+// A lone wave issues one VALU instruction every ~5-8 cycles whatever its width, so the step is written as THREE
+// packed instructions (left to the compiler it became 6-8 with register shuffles, ~50 cycles per step):
+//   t1 = (pr, pi) * (ir, ir)        t2 = (pr, pi) * (ii, ii)        p = (t1.x - t2.y, t1.y + t2.x)
+XL_DEV void xl_nco_step(v2f &p, const v2f inc) {
+  v2f t1, t2;
   asm volatile(
-      "v_mul_f32 %0, %4, %6\n\t"
-      "v_mul_f32 %1, %5, %7\n\t"
-      "v_mul_f32 %2, %4, %7\n\t"
-      "v_mul_f32 %3, %5, %6"
-      : "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
-      : "v"(pr), "v"(pi), "v"(ir), "v"(ii));
-  asm volatile(
-      "v_sub_f32 %0, %2, %3\n\t"
-      "v_add_f32 %1, %4, %5"
-      : "=&v"(pr), "=&v"(pi)
-      : "v"(t1), "v"(t2), "v"(t3), "v"(t4));
+      "v_pk_mul_f32 %0, %2, %3 op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,1]"
+      : "=&v"(t1), "=&v"(t2)
+      : "v"(p), "v"(inc));
+  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(p) : "v"(t1), "v"(t2));
 }
 
 __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
                                                           const float2 *state_in, float2 *state_out,
                                                           float2 *__restrict__ tab, const XlDynArgs dyn,
-                                                          const uint32_t prio) {
+                                                          const uint32_t prio, const uint32_t lanes) {
   // Latency-critical and tiny (one lane per client).  It shares the chip with the previous block's FIR launch,
   // whose waves run at priority 3..0 by remaining work; `prio` places it among them.
   if (prio == 3) __builtin_amdgcn_s_setprio(3);
   else if (prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (prio == 1) __builtin_amdgcn_s_setprio(1);
-  // Only XL_NCO_LANES lanes of a wave carry a client and the table is written two steps (16 bytes) per store:
-  // every store goes to the client's own table row (fully divergent addresses) and a wave can have only ~64
-  // stores in flight, so the store stream -- not the 6-instruction recurrence -- bounds this kernel.  The chip
-  // is otherwise idle for it, so spread the clients over 8x more waves and halve the store count.
-  if (threadIdx.x >= XL_NCO_LANES) return;
-  const uint32_t c = blockIdx.x * XL_NCO_LANES + threadIdx.x;
+  // `lanes` (default XL_NCO_LANES = 16) lanes of a wave carry a client and the table is written two steps (16 bytes)
+  // per store: every store goes to the client's own table row (fully divergent addresses).  The kernel is a pure
+  // dependent chain (~20 ns per step whatever the width), so few lanes per wave cost nothing; measured 8..32 lanes
+  // equal, 64 lanes ~15 % slower.
+  if (threadIdx.x >= lanes) return;
+  const uint32_t c = blockIdx.x * lanes + threadIdx.x;
   if (c >= n) return;
   const XlNcoClient k = cl[c];
   const uint32_t K = dyn.d[k.cls].K;
-  float pr = state_in[k.slot].x, pi = state_in[k.slot].y;
+  v2f p = {state_in[k.slot].x, state_in[k.slot].y};
   if (K == 0) {  // no output possible in this block: the reference leaves the phase untouched (xlating.c:58)
-    state_out[k.slot] = make_float2(pr, pi);
+    state_out[k.slot] = make_float2(p.x, p.y);
     return;
   }
-  const float ir = k.incr.x, ii = k.incr.y;
-  float2 *__restrict__ o = tab + k.out_off;  // out_off is a multiple of 2 -> 16-byte aligned pairs
-  float4 *__restrict__ o4 = reinterpret_cast<float4 *>(o);
+  const v2f inc = {k.incr.x, k.incr.y};
+  v2f *__restrict__ o = reinterpret_cast<v2f *>(tab + k.out_off);  // out_off is even -> 16-byte aligned pairs
+  v4f *__restrict__ o4 = reinterpret_cast<v4f *>(o);
   uint32_t m = 0;
   for (; m + 8 <= K; m += 8) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float ar = pr, ai = pi;
-      xl_nco_step(pr, pi, ir, ii);
-      o4[(m >> 1) + j] = make_float4(ar, ai, pr, pi);
-      xl_nco_step(pr, pi, ir, ii);
+      const v2f a = p;
+      xl_nco_step(p, inc);
+      o4[(m >> 1) + j] = (v4f){a.x, a.y, p.x, p.y};
+      xl_nco_step(p, inc);
     }
   }
   for (; m < K; ++m) {
-    o[m] = make_float2(pr, pi);
-    xl_nco_step(pr, pi, ir, ii);
+    o[m] = p;
+    xl_nco_step(p, inc);
   }
+  const float pr = p.x, pi = p.y;
   const double mag2 = (double)pr * (double)pr + (double)pi * (double)pi;
   const float mag = (float)__dsqrt_rn(mag2);
   state_out[k.slot] = make_float2(pr / mag, pi / mag);
@@ -397,8 +419,14 @@ __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__r
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
                                float2 *state_out, float2 *phtab, const XlDynArgs &dyn, uint32_t prio, hipStream_t s) {
   if (nclients == 0) return hipSuccess;
-  hipLaunchKernelGGL(xl_nco_table_kernel, dim3((nclients + XL_NCO_LANES - 1) / XL_NCO_LANES), dim3(64), 0, s, clients,
-                     nclients, state_in, state_out, phtab, dyn, prio);
+  static uint32_t lanes = 0;
+  if (lanes == 0) {
+    const char *e = getenv("XL_EXP_NCOLANES");  // tuning
+    lanes = e ? (uint32_t)atoi(e) : XL_NCO_LANES;
+    if (lanes < 1 || lanes > 64) lanes = XL_NCO_LANES;
+  }
+  hipLaunchKernelGGL(xl_nco_table_kernel, dim3((nclients + lanes - 1) / lanes), dim3(64), 0, s, clients, nclients,
+                     state_in, state_out, phtab, dyn, prio, lanes);
   return hipGetLastError();
 }
 
