@@ -119,6 +119,8 @@ struct xlating_batch_t {
   bool spec_valid = false;  // table[spec_tab] holds the phases of the NEXT block assuming spec_S samples
   size_t spec_S = 0;
   int spec_tab = 0;
+  bool spec_on_side = false;  // that table was tabulated on the side stream (wait for ev_nco) vs in-stream
+  bool exp_nofuse = false;    // XL_EXP_NOFUSE: keep the NCO tabulation a launch of its own (tuning)
 
   uint32_t exp_flags = 0;  // tuning knobs from XL_EXP_* environment variables
   bool exp_same_taps = false;
@@ -228,6 +230,7 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   if (getenv("XL_EXP_KT")) b->exp_kt = atoi(getenv("XL_EXP_KT"));
   if (getenv("XL_EXP_H")) b->exp_h = atoi(getenv("XL_EXP_H"));
   b->exp_trace = getenv("XL_EXP_TRACE");
+  b->exp_nofuse = getenv("XL_EXP_NOFUSE") != nullptr;
   if (getenv("XL_EXP_NCOPRIO")) b->nco_prio = (uint32_t)atoi(getenv("XL_EXP_NCOPRIO")) & 3u;
   b->last_stream = b->own_stream;
   *batch = b;
@@ -516,11 +519,14 @@ static uint32_t xl_batch_dyn(const xlating_batch *b, size_t S, XlDynArgs *dyn) {
   return maxK;
 }
 
-// Tabulate the phases of a block on the nco stream: committed phases -> table[tab] + next phases.
-static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab) {
+// Tabulate the phases of a block as a launch of its own: committed phases -> table[tab] + next phases.
+// in_stream == nullptr: on the nco (side) stream, fenced by events (native mode's look-ahead).
+// in_stream != nullptr: on that stream, ordered by it (optimized mode's fallback when no table was tabulated ahead).
+static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab, hipStream_t *in_stream) {
   hipError_t e;
-  if (b->ev_tab_free_valid[tab]) {  // the FIR launch that last read table[tab] must be done with it
-    e = hipStreamWaitEvent(b->nco_stream, b->ev_tab_free[tab], 0);
+  hipStream_t st = in_stream ? *in_stream : b->nco_stream;
+  if (!in_stream && b->ev_tab_free_valid[tab]) {  // the FIR launch that last read table[tab] must be done with it
+    e = hipStreamWaitEvent(st, b->ev_tab_free[tab], 0);
     if (e != hipSuccess) return e;
   }
   hipEvent_t n0 = nullptr, n1 = nullptr;
@@ -533,17 +539,17 @@ static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab) 
     }
     n0 = b->ev_ncot[b->ev_ncot.size() - 2];
     n1 = b->ev_ncot[b->ev_ncot.size() - 1];
-    e = hipEventRecord(n0, b->nco_stream);
+    e = hipEventRecord(n0, st);
     if (e != hipSuccess) return e;
   }
   e = xl_launch_nco_table(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[b->pcur], b->d_phase[b->pcur ^ 1],
-                          b->d_phtab[tab], dyn, b->nco_prio, b->nco_stream);
+                          b->d_phtab[tab], dyn, b->nco_prio, st);
   if (e != hipSuccess) return e;
   if (n1) {
-    e = hipEventRecord(n1, b->nco_stream);
+    e = hipEventRecord(n1, st);
     if (e != hipSuccess) return e;
   }
-  return hipEventRecord(b->ev_nco[tab], b->nco_stream);
+  return in_stream ? hipSuccess : hipEventRecord(b->ev_nco[tab], st);
 }
 
 static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len, int mode, hipStream_t s) {
@@ -561,7 +567,9 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
   const int p = (int)(b->nblk & 1);  // parity of this block: output buffer
   const int hb = b->hcur, hn = b->hcur ^ 1;
 
-  XlDynArgs dyn;
+  const bool fuse = mode == XL_MODE_OPTIMIZED && !b->exp_nofuse;
+  bool wait_side = false, nco_fused = false;
+  XlDynArgs dyn, next;
   const uint32_t maxK = xl_batch_dyn(b, S, &dyn);
   for (ClassState &cs : b->classes) {  // advance the stream positions past this block
     cs.rem = (uint32_t)((cs.rem + S) % cs.D);
@@ -573,20 +581,32 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
     c.consumed += S;
   }
 
-  // ---- this block's phase table: already tabulated ahead if the length guess was right
+  // ---- this block's phase table: already tabulated ahead if the length guess was right.
+  // Optimized mode: the table of block b+1 is tabulated by the first workgroups of block b's FIR launch ("NCO
+  // role"), so a block is ONE launch on the caller's stream and nothing has to be fenced.  Native mode (its kernels
+  // have no registers to spare for the role) tabulates ahead on the side stream, fenced by events.
   int tab;
   if (b->spec_valid && b->spec_S == S) {
     tab = b->spec_tab;
+    wait_side = b->spec_on_side;
   } else {
     tab = b->spec_valid ? b->spec_tab : (b->tab ^ 1);
-    XL_TRY(xl_batch_nco(b, dyn, tab));
+    if (fuse && !(b->spec_valid && b->spec_on_side)) {
+      XL_TRY(xl_batch_nco(b, dyn, tab, &s));
+    } else {
+      XL_TRY(xl_batch_nco(b, dyn, tab, nullptr));
+      wait_side = true;
+    }
   }
   b->spec_valid = false;
-  b->pcur ^= 1;  // the phases written by that NCO launch are now the committed ones
+  b->pcur ^= 1;  // the phases written by that tabulation are now the committed ones
   b->tab = tab;
 
+  (void)xl_batch_dyn(b, S, &next);  // per-class numbers of the NEXT block if it has the same length (the guess)
+
   // ---- the fused FIR launch(es) on the caller's stream: window images from [d_hist[hb] | block], phases from
-  // table[tab] -> d_out[p]; the first launch also rolls the raw history into d_hist[hn]
+  // table[tab] -> d_out[p]; the first launch also rolls the raw history into d_hist[hn] and, in optimized mode,
+  // tabulates table[tab ^ 1] for the next block
   {
     hipEvent_t f0 = nullptr, f1 = nullptr;
     if (b->timing && maxK > 0) {
@@ -600,7 +620,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
     }
     bool rolled = false;
     if (maxK > 0) {
-      XL_TRY(hipStreamWaitEvent(s, b->ev_nco[tab], 0));
+      if (wait_side) XL_TRY(hipStreamWaitEvent(s, b->ev_nco[tab], 0));
       if (f0) XL_TRY(hipEventRecord(f0, s));
       for (Launch &L : b->launches) {
         if (L.groups.empty()) continue;
@@ -615,7 +635,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         a.ngroups = (uint32_t)L.groups.size();
         a.groups_per_xcd = (a.ngroups + 7) / 8;
         a.xtiles = (maxK + 64 * L.kt - 1) / (64 * L.kt);
-        // wave-priority quartiles pay when the launch is about one round of workgroups, and cost when new
+        // wave-priority segments pay when the launch is about one round of workgroups, and cost when new
         // workgroups keep arriving (they would outrank nearly finished ones): enable up to two rounds
         const size_t wgs = (size_t)a.ngroups * a.xtiles;
         const size_t cap = 256 * std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(L.lds, 1), 7));
@@ -629,10 +649,19 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
           a.hist_units = XL_HCAP * (b->bps / 2);
           a.block_units = (uint32_t)S * (b->bps / 2);
           rolled = true;
+          if (fuse) {
+            a.nco_clients = b->d_nco;
+            a.nco_nclients = (uint32_t)b->nco.size();
+            a.nco_blocks = (a.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
+            a.nco_state_in = b->d_phase[b->pcur];
+            a.nco_state_out = b->d_phase[b->pcur ^ 1];
+            a.nco_tab = b->d_phtab[tab ^ 1];
+            nco_fused = true;
+          }
         }
         size_t trace_n = 0;
         if (b->exp_trace) {  // tuning only
-          trace_n = (size_t)8 * ((a.ngroups * a.xtiles + 7) / 8) * XL_NW_MAX * 4;
+          trace_n = ((size_t)a.nco_blocks + (size_t)8 * ((a.ngroups * a.xtiles + 7) / 8)) * XL_NW_MAX * 4;
           if (trace_n > b->trace_cap) {
             if (b->d_trace) (void)hipFree(b->d_trace);
             b->d_trace = nullptr;
@@ -642,7 +671,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
           XL_TRY(hipMemsetAsync(b->d_trace, 0, trace_n * sizeof(unsigned long long), s));
           a.trace = b->d_trace;
         }
-        XL_TRY(xl_launch_fir(L.ct, mode, L.kt, L.nw, a, dyn, L.lds, s));
+        XL_TRY(xl_launch_fir(L.ct, mode, L.kt, L.nw, a, dyn, next, L.lds, s));
         if (b->exp_trace) {
           std::vector<unsigned long long> h(trace_n);
           XL_TRY(hipStreamSynchronize(s));
@@ -654,8 +683,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         }
       }
       if (f1) XL_TRY(hipEventRecord(f1, s));
-      XL_TRY(hipEventRecord(b->ev_tab_free[tab], s));
-      b->ev_tab_free_valid[tab] = true;
+      if (!fuse) {
+        XL_TRY(hipEventRecord(b->ev_tab_free[tab], s));
+        b->ev_tab_free_valid[tab] = true;
+      }
     }
     if (!rolled)  // no client produced output in this block (tiny block): roll the history on its own
       XL_TRY(xl_launch_update_history(b->d_hist[hb], d_block, XL_HCAP, (uint32_t)S, b->bps, b->d_hist[hn], s));
@@ -664,12 +695,18 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
   b->hcur = hn;
   b->nblk++;
 
-  // ---- tabulate the NEXT block's phases now, on the nco stream, guessing it has the same length
-  {
-    XlDynArgs next;
-    (void)xl_batch_dyn(b, S, &next);
-    XL_TRY(xl_batch_nco(b, next, tab ^ 1));
+  // ---- the NEXT block's phases, guessing it has the same length: done inside the FIR launch above (optimized
+  // mode), otherwise tabulated now on the side stream (native mode) or, in optimized mode without a FIR launch
+  // (tiny block), left to the next call
+  if (nco_fused) {
     b->spec_valid = true;
+    b->spec_on_side = false;
+    b->spec_S = S;
+    b->spec_tab = tab ^ 1;
+  } else if (!fuse) {
+    XL_TRY(xl_batch_nco(b, next, tab ^ 1, nullptr));
+    b->spec_valid = true;
+    b->spec_on_side = true;
     b->spec_S = S;
     b->spec_tab = tab ^ 1;
   }

@@ -52,6 +52,14 @@ struct XlDynArgs {
   XlDyn d[XL_MAX_CLASSES];
 };
 
+struct XlNcoClient {
+  float2 incr;          // phase increment cexpf(-j*w0*D) (xlating.c:544)
+  uint32_t out_off;     // float2 index of the client's row in the phase-table image
+  uint32_t cls;         // index into XlDynArgs::d (K of this block)
+  uint32_t slot;        // index of the client's running phase in the phase-state array
+  uint32_t pad;
+};
+
 struct XlFirArgs {
   const void *in0;      // first part of the sample stream seen by this launch (history), n0 samples
   const void *in1;      // second part (the new block), n1 samples; may be null when n1 == 0
@@ -68,23 +76,26 @@ struct XlFirArgs {
   void *hist_out;       // batch engine: where to write the rolled raw history (null: no roll)
   uint32_t hist_units;  // history length in 2-byte units (= n0 * bytes-per-sample / 2)
   uint32_t block_units; // block length in 2-byte units (= n1 * bytes-per-sample / 2)
+  // "NCO role": the first nco_blocks workgroups of the launch tabulate the NEXT block's phase table instead of
+  // filtering (xl_batch.cpp).  All null/0 when the launch carries no NCO role.
+  const XlNcoClient *nco_clients;
+  uint32_t nco_nclients;
+  uint32_t nco_blocks;
+  const float2 *nco_state_in;
+  float2 *nco_state_out;
+  float2 *nco_tab;
   unsigned long long *trace;  // tuning only: per wave 4 wall_clock64 stamps (entry, staged, filtered, stored) or null
 };
 
-struct XlNcoClient {
-  float2 incr;          // phase increment cexpf(-j*w0*D) (xlating.c:544)
-  uint32_t out_off;     // float2 index of the client's row in the phase-table image
-  uint32_t cls;         // index into XlDynArgs::d (K of this block)
-  uint32_t slot;        // index of the client's running phase in the phase-state array
-  uint32_t pad;
-};
 
 // ---- launchers (xl_kernels.hip).  All return hipError_t of the launch. -------------------------------------
 // mode: 0 native (bit-exact scalar order, unfused), 1 optimized (fma).  ct: 1, 2, 4, 8, 9, 10 or 12 clients per tile.
 // kt: 1 or 2 outputs per lane; a.xtiles = ceil(max K / (64 * kt)); lds_bytes = xl_fir_lds_bytes(D, Tpad, kt).
 // nw: waves per workgroup (>= the largest ntiles of the groups).
-hipError_t xl_launch_fir(int ct, int mode, int kt, int nw, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds_bytes,
-                         hipStream_t s);
+// dyn_next: per-class numbers of the NEXT block, used only by the NCO role (a.nco_blocks > 0); may alias dyn.
+hipError_t xl_launch_fir(int ct, int mode, int kt, int nw, const XlFirArgs &a, const XlDynArgs &dyn,
+                         const XlDynArgs &dyn_next, size_t lds_bytes, hipStream_t s);
+#define XL_NCO_LANES 16u  // clients per workgroup in the NCO table kernel / NCO role
 // reads the running phases from state_in[slot], writes the post-block phases to state_out[slot] (may alias).
 // Every client's out_off must be even (16-byte table stores).  prio: wave priority 0..3 of the kernel.
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,

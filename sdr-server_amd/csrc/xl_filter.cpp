@@ -217,7 +217,7 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     a.taps = f->d_taps;
     a.phtab = f->d_phtab;
     a.out = f->d_out_f;
-    XL_TRY(xl_launch_fir(1, mode, 1, XL_NW_DEFAULT, a, dyn, xl_fir_lds_bytes(f->D, f->Tpad, 1), f->stream));
+    XL_TRY(xl_launch_fir(1, mode, 1, XL_NW_DEFAULT, a, dyn, dyn, xl_fir_lds_bytes(f->D, f->Tpad, 1), f->stream));
     XL_TRY(hipMemcpyAsync(f->h_out_f, f->d_out_f, K * sizeof(float2), hipMemcpyDeviceToHost, f->stream));
   }
   {

@@ -110,6 +110,75 @@ XL_DEV v2f xl_rotate(const v2f a, const v2f p) {
   return r;
 }
 
+// ------------------------------------------------------------------------------------------- NCO phase table
+// xlating.c:70-73: the phasor is a float32 RECURRENCE p <- p * incr (never re-seeded), renormalised once per
+// call that could produce output.  It is data independent, so one lane per client tabulates the K phases of
+// the block ahead of the FIR kernel; the recurrence itself must stay sequential to be bit-exact.
+// hypotf: glibc evaluates sqrt(x*x + y*y) in double and narrows; restated with IEEE double ops.
+// One recurrence step p <- p * incr as the reference's C99 complex float product (xlating.c:71):
+//   re = pr*ir - pi*ii, im = pr*ii + pi*ir, every operation rounded once (IEEE mul / add, nothing fused).
+// A lone wave issues one VALU instruction every ~5-8 cycles whatever its width, so the step is written as THREE
+// packed instructions (left to the compiler it became 6-8 with register shuffles, ~50 cycles per step):
+//   t1 = (pr, pi) * (ir, ir)        t2 = (pr, pi) * (ii, ii)        p = (t1.x - t2.y, t1.y + t2.x)
+XL_DEV void xl_nco_step(v2f &p, const v2f inc) {
+  v2f t1, t2;
+  asm volatile(
+      "v_pk_mul_f32 %0, %2, %3 op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,1]"
+      : "=&v"(t1), "=&v"(t2)
+      : "v"(p), "v"(inc));
+  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(p) : "v"(t1), "v"(t2));
+}
+
+// The work of one lane = one client: tabulate K phases, renormalise, store the post-block phase.
+XL_DEV void xl_nco_client(const XlNcoClient k, const uint32_t K, const float2 *state_in, float2 *state_out,
+                          float2 *__restrict__ tab) {
+  v2f p = {state_in[k.slot].x, state_in[k.slot].y};
+  if (K == 0) {  // no output possible in this block: the reference leaves the phase untouched (xlating.c:58)
+    state_out[k.slot] = make_float2(p.x, p.y);
+    return;
+  }
+  const v2f inc = {k.incr.x, k.incr.y};
+  v2f *__restrict__ o = reinterpret_cast<v2f *>(tab + k.out_off);  // out_off is even -> 16-byte aligned pairs
+  v4f *__restrict__ o4 = reinterpret_cast<v4f *>(o);
+  uint32_t m = 0;
+  for (; m + 8 <= K; m += 8) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const v2f a = p;
+      xl_nco_step(p, inc);
+      o4[(m >> 1) + j] = (v4f){a.x, a.y, p.x, p.y};
+      xl_nco_step(p, inc);
+    }
+  }
+  for (; m < K; ++m) {
+    o[m] = p;
+    xl_nco_step(p, inc);
+  }
+  const float pr = p.x, pi = p.y;
+  const double mag2 = (double)pr * (double)pr + (double)pi * (double)pi;
+  const float mag = (float)__dsqrt_rn(mag2);
+  state_out[k.slot] = make_float2(pr / mag, pi / mag);
+}
+
+// Stand-alone launch (single-filter path; first block / wrong length guess of the batch engine).  `lanes`
+// (XL_NCO_LANES = 16) lanes of a wave carry a client and the table is written two steps (16 bytes) per store: every
+// store goes to the client's own table row (fully divergent addresses).  The kernel is a pure dependent chain
+// (~20 ns per step whatever the width), so few lanes per wave cost nothing; measured 8..32 lanes equal, 64 ~15 % slower.
+__global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
+                                                          const float2 *state_in, float2 *state_out,
+                                                          float2 *__restrict__ tab, const XlDynArgs dyn,
+                                                          const uint32_t prio, const uint32_t lanes) {
+  if (prio == 3) __builtin_amdgcn_s_setprio(3);
+  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  if (threadIdx.x >= lanes) return;
+  const uint32_t c = blockIdx.x * lanes + threadIdx.x;
+  if (c >= n) return;
+  const XlNcoClient k = cl[c];
+  xl_nco_client(k, dyn.d[k.cls].K, state_in, state_out, tab);
+}
+
 // Window staging: raw samples -> cf32 image in LDS.  Four independent loads per thread are issued before any is
 // consumed (every workgroup of a launch stages at the same time and all its waves wait at the barrier, so this
 // phase is pure latency: 12 dependent load->convert->write rounds measured 6 us of a 130 us launch).
@@ -146,15 +215,32 @@ XL_DEV void xl_stage_window(const XlFirArgs &a, const uint32_t zero_below, const
 // granule is 16 and 800 SGPRs serve a SIMD), which lets a 5-wave-per-workgroup launch keep 25 waves per CU.
 template <int CT, int MODE, int KT, bool WIDE>
 __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))) void xl_fir_kernel(
-    const XlFirArgs a, const XlDynArgs dyn) {
+    const XlFirArgs a, const XlDynArgs dyn, const XlDynArgs dyn_next) {
   extern __shared__ __attribute__((aligned(16))) v2f xl_win[];
   constexpr uint32_t OT = 64u * KT;  // outputs per tile
+
+  // ---- NCO role: the first nco_blocks workgroups tabulate the NEXT block's phases (data independent float32
+  // recurrence, xlating.c:70-73) while the rest of this launch filters the current block.  One launch per block
+  // then does everything -- no side stream, no events between consecutive launches (they cost a 24 us gap).
+  // (compiled into the optimized kernels only: in the register-hungry native kernels it costs occupancy; the host
+  // gives native launches no NCO role and tabulates on the side stream instead)
+  if (MODE == 1 && blockIdx.x < a.nco_blocks) {
+    __builtin_amdgcn_s_setprio(3);  // a pure dependent chain: it must not queue behind the FIR waves
+    if (threadIdx.x < XL_NCO_LANES) {
+      const uint32_t c = blockIdx.x * XL_NCO_LANES + threadIdx.x;
+      if (c < a.nco_nclients) {
+        const XlNcoClient k = a.nco_clients[c];
+        xl_nco_client(k, dyn_next.d[k.cls].K, a.nco_state_in, a.nco_state_out, a.nco_tab);
+      }
+    }
+    return;
+  }
 
   // block -> (group y, output tile x).  The work list is group-major (w = y * xtiles + x, so that all tiles of a
   // group -- which stream the same taps -- are neighbours) and is cut into 8 equal contiguous chunks, one per XCD
   // (block b runs on XCD b % 8 on this part): each XCD's L2 then holds the taps of ~1/8 of the groups, and every
   // XCD gets the same number of workgroups (whole groups per XCD left one XCD with 196 workgroups on 192 slots).
-  const uint32_t b = blockIdx.x;
+  const uint32_t b = blockIdx.x - (MODE == 1 ? a.nco_blocks : 0u);
   const unsigned long long t_entry = a.trace ? wall_clock64() : 0ull;
 
   // ---- raw-history roll, folded into this launch: hist_out = the last hist_units 2-byte units of [in0 | in1].
@@ -293,7 +379,8 @@ size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad, int kt) {
 }
 
 template <int CT, int MODE, int KT, bool WIDE>
-static hipError_t xl_fir_go2(int nw, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds, hipStream_t s) {
+static hipError_t xl_fir_go2(int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, size_t lds,
+                             hipStream_t s) {
   static bool attr_done = false;  // per instantiation; benign race (idempotent)
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&xl_fir_kernel<CT, MODE, KT, WIDE>),
@@ -301,121 +388,57 @@ static hipError_t xl_fir_go2(int nw, const XlFirArgs &a, const XlDynArgs &dyn, s
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const uint32_t nblocks = 8u * ((a.ngroups * a.xtiles + 7u) / 8u);
+  if (MODE == 0 && a.nco_blocks != 0) return hipErrorInvalidValue;  // see the kernel: no NCO role in native
+  const uint32_t nblocks = a.nco_blocks + 8u * ((a.ngroups * a.xtiles + 7u) / 8u);
   if (nblocks == 0) return hipSuccess;
-  hipLaunchKernelGGL((xl_fir_kernel<CT, MODE, KT, WIDE>), dim3(nblocks), dim3(64 * nw), lds, s, a, dyn);
+  hipLaunchKernelGGL((xl_fir_kernel<CT, MODE, KT, WIDE>), dim3(nblocks), dim3(64 * nw), lds, s, a, dyn, dyn_next);
   return hipGetLastError();
 }
 
 // a.flags bit 0 set by the caller = every group of the launch has an even decimation -> 16-byte LDS reads
 template <int CT, int MODE, int KT>
-static hipError_t xl_fir_go(int nw, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds, hipStream_t s) {
-  return (a.flags & 1u) ? xl_fir_go2<CT, MODE, KT, true>(nw, a, dyn, lds, s)
-                        : xl_fir_go2<CT, MODE, KT, false>(nw, a, dyn, lds, s);
+static hipError_t xl_fir_go(int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, size_t lds,
+                            hipStream_t s) {
+  return (a.flags & 1u) ? xl_fir_go2<CT, MODE, KT, true>(nw, a, dyn, dyn_next, lds, s)
+                        : xl_fir_go2<CT, MODE, KT, false>(nw, a, dyn, dyn_next, lds, s);
 }
 
 template <int KT>
-static hipError_t xl_fir_dispatch(int ct, int mode, int nw, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds,
-                                  hipStream_t s) {
+static hipError_t xl_fir_dispatch(int ct, int mode, int nw, const XlFirArgs &a, const XlDynArgs &dyn,
+                                  const XlDynArgs &dyn_next, size_t lds, hipStream_t s) {
   switch (ct * 2 + (mode ? 1 : 0)) {
-    case 2: return xl_fir_go<1, 0, KT>(nw, a, dyn, lds, s);
-    case 3: return xl_fir_go<1, 1, KT>(nw, a, dyn, lds, s);
-    case 4: return xl_fir_go<2, 0, KT>(nw, a, dyn, lds, s);
-    case 5: return xl_fir_go<2, 1, KT>(nw, a, dyn, lds, s);
-    case 8: return xl_fir_go<4, 0, KT>(nw, a, dyn, lds, s);
-    case 9: return xl_fir_go<4, 1, KT>(nw, a, dyn, lds, s);
-    case 16: return xl_fir_go<8, 0, KT>(nw, a, dyn, lds, s);
-    case 17: return xl_fir_go<8, 1, KT>(nw, a, dyn, lds, s);
+    case 2: return xl_fir_go<1, 0, KT>(nw, a, dyn, dyn_next, lds, s);
+    case 3: return xl_fir_go<1, 1, KT>(nw, a, dyn, dyn_next, lds, s);
+    case 4: return xl_fir_go<2, 0, KT>(nw, a, dyn, dyn_next, lds, s);
+    case 5: return xl_fir_go<2, 1, KT>(nw, a, dyn, dyn_next, lds, s);
+    case 8: return xl_fir_go<4, 0, KT>(nw, a, dyn, dyn_next, lds, s);
+    case 9: return xl_fir_go<4, 1, KT>(nw, a, dyn, dyn_next, lds, s);
+    case 16: return xl_fir_go<8, 0, KT>(nw, a, dyn, dyn_next, lds, s);
+    case 17: return xl_fir_go<8, 1, KT>(nw, a, dyn, dyn_next, lds, s);
     default: break;
   }
   if (KT != 1) return hipErrorInvalidValue;  // the tall tiles exist for one output per lane only
   switch (ct * 2 + (mode ? 1 : 0)) {
-    case 18: return xl_fir_go<9, 0, 1>(nw, a, dyn, lds, s);
-    case 19: return xl_fir_go<9, 1, 1>(nw, a, dyn, lds, s);
-    case 20: return xl_fir_go<10, 0, 1>(nw, a, dyn, lds, s);
-    case 21: return xl_fir_go<10, 1, 1>(nw, a, dyn, lds, s);
-    case 24: return xl_fir_go<12, 0, 1>(nw, a, dyn, lds, s);
-    case 25: return xl_fir_go<12, 1, 1>(nw, a, dyn, lds, s);
+    case 18: return xl_fir_go<9, 0, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 19: return xl_fir_go<9, 1, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 20: return xl_fir_go<10, 0, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 21: return xl_fir_go<10, 1, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 24: return xl_fir_go<12, 0, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 25: return xl_fir_go<12, 1, 1>(nw, a, dyn, dyn_next, lds, s);
     default: return hipErrorInvalidValue;
   }
 }
 
 // a.xtiles must be ceil(max K / (64 * kt))
-hipError_t xl_launch_fir(int ct, int mode, int kt, int nw, const XlFirArgs &a, const XlDynArgs &dyn, size_t lds,
-                         hipStream_t s) {
+hipError_t xl_launch_fir(int ct, int mode, int kt, int nw, const XlFirArgs &a, const XlDynArgs &dyn,
+                         const XlDynArgs &dyn_next, size_t lds, hipStream_t s) {
   if (lds > 160 * 1024 || nw < 1 || nw > XL_NW_MAX) return hipErrorInvalidValue;
-  if (kt == 1) return xl_fir_dispatch<1>(ct, mode, nw, a, dyn, lds, s);
-  if (kt == 2) return xl_fir_dispatch<2>(ct, mode, nw, a, dyn, lds, s);
+  if (kt == 1) return xl_fir_dispatch<1>(ct, mode, nw, a, dyn, dyn_next, lds, s);
+  if (kt == 2) return xl_fir_dispatch<2>(ct, mode, nw, a, dyn, dyn_next, lds, s);
   return hipErrorInvalidValue;
 }
 
-#define XL_NCO_LANES 16u
-// ------------------------------------------------------------------------------------------- NCO phase table
-// xlating.c:70-73: the phasor is a float32 RECURRENCE p <- p * incr (never re-seeded), renormalised once per
-// call that could produce output.  It is data independent, so one lane per client tabulates the K phases of
-// the block ahead of the FIR kernel; the recurrence itself must stay sequential to be bit-exact.
-// hypotf: glibc evaluates sqrt(x*x + y*y) in double and narrows; restated with IEEE double ops.
-// One recurrence step p <- p * incr as the reference's C99 complex float product (xlating.c:71):
-//   re = pr*ir - pi*ii, im = pr*ii + pi*ir, every operation rounded once (IEEE mul / add, nothing fused).
-// A lone wave issues one VALU instruction every ~5-8 cycles whatever its width, so the step is written as THREE
-// packed instructions (left to the compiler it became 6-8 with register shuffles, ~50 cycles per step):
-//   t1 = (pr, pi) * (ir, ir)        t2 = (pr, pi) * (ii, ii)        p = (t1.x - t2.y, t1.y + t2.x)
-XL_DEV void xl_nco_step(v2f &p, const v2f inc) {
-  v2f t1, t2;
-  asm volatile(
-      "v_pk_mul_f32 %0, %2, %3 op_sel_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,1]"
-      : "=&v"(t1), "=&v"(t2)
-      : "v"(p), "v"(inc));
-  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(p) : "v"(t1), "v"(t2));
-}
-
-__global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
-                                                          const float2 *state_in, float2 *state_out,
-                                                          float2 *__restrict__ tab, const XlDynArgs dyn,
-                                                          const uint32_t prio, const uint32_t lanes) {
-  // Latency-critical and tiny (one lane per client).  It shares the chip with the previous block's FIR launch,
-  // whose waves run at priority 3..0 by remaining work; `prio` places it among them.
-  if (prio == 3) __builtin_amdgcn_s_setprio(3);
-  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-  else if (prio == 1) __builtin_amdgcn_s_setprio(1);
-  // `lanes` (default XL_NCO_LANES = 16) lanes of a wave carry a client and the table is written two steps (16 bytes)
-  // per store: every store goes to the client's own table row (fully divergent addresses).  The kernel is a pure
-  // dependent chain (~20 ns per step whatever the width), so few lanes per wave cost nothing; measured 8..32 lanes
-  // equal, 64 lanes ~15 % slower.
-  if (threadIdx.x >= lanes) return;
-  const uint32_t c = blockIdx.x * lanes + threadIdx.x;
-  if (c >= n) return;
-  const XlNcoClient k = cl[c];
-  const uint32_t K = dyn.d[k.cls].K;
-  v2f p = {state_in[k.slot].x, state_in[k.slot].y};
-  if (K == 0) {  // no output possible in this block: the reference leaves the phase untouched (xlating.c:58)
-    state_out[k.slot] = make_float2(p.x, p.y);
-    return;
-  }
-  const v2f inc = {k.incr.x, k.incr.y};
-  v2f *__restrict__ o = reinterpret_cast<v2f *>(tab + k.out_off);  // out_off is even -> 16-byte aligned pairs
-  v4f *__restrict__ o4 = reinterpret_cast<v4f *>(o);
-  uint32_t m = 0;
-  for (; m + 8 <= K; m += 8) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const v2f a = p;
-      xl_nco_step(p, inc);
-      o4[(m >> 1) + j] = (v4f){a.x, a.y, p.x, p.y};
-      xl_nco_step(p, inc);
-    }
-  }
-  for (; m < K; ++m) {
-    o[m] = p;
-    xl_nco_step(p, inc);
-  }
-  const float pr = p.x, pi = p.y;
-  const double mag2 = (double)pr * (double)pr + (double)pi * (double)pi;
-  const float mag = (float)__dsqrt_rn(mag2);
-  state_out[k.slot] = make_float2(pr / mag, pi / mag);
-}
-
+// (NCO phase-table code: see above the FIR kernel)
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
                                float2 *state_out, float2 *phtab, const XlDynArgs &dyn, uint32_t prio, hipStream_t s) {
   if (nclients == 0) return hipSuccess;
