@@ -67,6 +67,7 @@ struct Launch {
   int ct = 0;
   int kt = 1;  // outputs per lane
   int nw = XL_NW_DEFAULT;  // waves (tiles) per workgroup
+  uint32_t ota = 64;       // outputs per wave (smaller only when a 64-output window image exceeds the LDS)
   std::vector<XlGroup> groups;
   XlGroup *d_groups = nullptr;
   size_t lds = 0, lds1 = 0, lds2 = 0;
@@ -251,9 +252,9 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
     return -EINVAL;
   }
   const uint32_t Tpad = xl_roundup((uint32_t)taps_len, XL_TAP_UNROLL);
-  if (xl_fir_lds_bytes(decimation, Tpad, 1) > 160 * 1024) {
-    XL_LOG_ERR("decimation %u with %zu taps needs a %zu-byte window image (> 160 KiB LDS)", decimation, taps_len,
-               xl_fir_lds_bytes(decimation, Tpad, 1));
+  if (xl_fir_pick_ota(decimation, xl_roundup((uint32_t)taps_len, 12), 160 * 1024) == 0) {
+    XL_LOG_ERR("decimation %u with %zu taps needs a %zu-byte window image even for 8 outputs per wave (> 160 KiB LDS)",
+               decimation, taps_len, xl_fir_lds_bytes_ota(decimation, Tpad, 8));
     return -EINVAL;
   }
   int id = -1;
@@ -468,6 +469,18 @@ static int xl_batch_plan(xlating_batch *b, int mode) {
     // XL_EXP_KT=2 selects it for tuning.
     L.kt = (b->exp_kt == 2 && L.lds2 > 0 && L.lds2 <= 160 * 1024) ? 2 : 1;
     L.lds = L.kt == 2 ? L.lds2 : L.lds1;
+    L.ota = 64;
+    if (L.kt == 1 && L.lds1 > 160 * 1024) {  // huge decimation: fewer active lanes per wave so that the image fits
+      for (L.ota = 32; L.ota >= 8; L.ota >>= 1) {
+        size_t need = 0;
+        for (const XlGroup &g : L.groups) need = std::max(need, xl_fir_lds_bytes_ota(g.D, g.Tpad, L.ota));
+        if (need <= 160 * 1024) {
+          L.lds = need;
+          break;
+        }
+      }
+      if (L.ota < 8) return -EINVAL;  // (add_client already refused such a shape)
+    }
   }
 
   // upload
@@ -634,7 +647,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         a.groups = L.d_groups;
         a.ngroups = (uint32_t)L.groups.size();
         a.groups_per_xcd = (a.ngroups + 7) / 8;
-        a.xtiles = (maxK + 64 * L.kt - 1) / (64 * L.kt);
+        a.ota = L.ota;
+        a.xtiles = L.kt == 2 ? (maxK + 127) / 128 : (maxK + L.ota - 1) / L.ota;
         // wave-priority segments pay when the launch is about one round of workgroups, and cost when new
         // workgroups keep arriving (they would outrank nearly finished ones): enable up to two rounds
         const size_t wgs = (size_t)a.ngroups * a.xtiles;

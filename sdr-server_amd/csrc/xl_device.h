@@ -68,7 +68,9 @@ struct XlFirArgs {
   const XlGroup *groups;
   uint32_t ngroups;
   uint32_t groups_per_xcd;  // (unused by the kernel since the work list is cut evenly across XCDs)
-  uint32_t xtiles;      // ceil(max K / (64 * kt))
+  uint32_t xtiles;      // ceil(max K / outputs per tile)
+  uint32_t ota;         // outputs per wave: 64, or 32/16/8 (upper lanes idle) when a 64-output window image would
+                        // not fit the LDS (very large decimations); kt must be 1 when ota < 64
   uint32_t flags;       // bit 0: every group of the launch has even D (16-byte LDS reads); bit 1: flat wave priority; bit 2: priority segments end at 1/2, 3/4, 7/8
   const float2 *taps;   // tap image
   const float2 *phtab;  // NCO phase table, indexed like out
@@ -115,6 +117,10 @@ hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T,
                              const short2 *phtab, short2 *out, hipStream_t s);
 
 size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad, int kt);
+// window image bytes for `ota` outputs per tile (kt = 1)
+size_t xl_fir_lds_bytes_ota(uint32_t D, uint32_t Tpad, uint32_t ota);
+// largest outputs-per-wave in {64, 32, 16, 8} whose window image fits `budget` bytes of LDS; 0 if none
+uint32_t xl_fir_pick_ota(uint32_t D, uint32_t Tpad, size_t budget);
 // taps consumed per inner-loop iteration by the kernel of tile height ct; Tpad must be a multiple of it
 static inline uint32_t xl_tap_step(int ct) { return (ct == 9 || ct == 10) ? 6u : 4u; }
 

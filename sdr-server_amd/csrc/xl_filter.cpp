@@ -32,6 +32,7 @@ struct xlating_t {
   size_t out_cap = 0;
   int16_t qinc[2] = {0, 0};
   bool warned = false;
+  uint32_t ota = 64;       // outputs per wave (64 unless the window image would not fit the LDS)
 
   void *d_raw = nullptr;
   float2 *d_work_f = nullptr;
@@ -144,9 +145,10 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XL_TRY(hipMemcpyAsync(f->d_phase, &one, sizeof(one), hipMemcpyHostToDevice, f->stream));
   XL_TRY(hipMemcpyAsync(f->d_qphase, &qone, sizeof(qone), hipMemcpyHostToDevice, f->stream));
   XL_TRY(hipStreamSynchronize(f->stream));
-  if (xl_fir_lds_bytes(decimation, f->Tpad, 1) > 160 * 1024) {
-    XL_LOG_ERR("decimation %u with %zu taps needs a %zu-byte window image (> 160 KiB LDS)", decimation, taps_len,
-               xl_fir_lds_bytes(decimation, f->Tpad, 1));
+  f->ota = xl_fir_pick_ota(decimation, f->Tpad, 160 * 1024);
+  if (f->ota == 0) {
+    XL_LOG_ERR("decimation %u with %zu taps needs a %zu-byte window image even for 8 outputs per wave (> 160 KiB LDS)",
+               decimation, taps_len, xl_fir_lds_bytes_ota(decimation, f->Tpad, 8));
     xl_filter_free(f);
     return -EINVAL;
   }
@@ -212,12 +214,13 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     a.groups = f->d_group;
     a.ngroups = 1;
     a.groups_per_xcd = 1;
-    a.xtiles = (uint32_t)((K + 63) / 64);
+    a.ota = f->ota;
+    a.xtiles = (uint32_t)((K + f->ota - 1) / f->ota);
     a.flags = ((f->D % 2 == 0) ? 1u : 0u) | 4u;
     a.taps = f->d_taps;
     a.phtab = f->d_phtab;
     a.out = f->d_out_f;
-    XL_TRY(xl_launch_fir(1, mode, 1, XL_NW_DEFAULT, a, dyn, dyn, xl_fir_lds_bytes(f->D, f->Tpad, 1), f->stream));
+    XL_TRY(xl_launch_fir(1, mode, 1, XL_NW_DEFAULT, a, dyn, dyn, xl_fir_lds_bytes_ota(f->D, f->Tpad, f->ota), f->stream));
     XL_TRY(hipMemcpyAsync(f->h_out_f, f->d_out_f, K * sizeof(float2), hipMemcpyDeviceToHost, f->stream));
   }
   {

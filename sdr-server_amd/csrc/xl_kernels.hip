@@ -217,7 +217,8 @@ template <int CT, int MODE, int KT, bool WIDE>
 __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))) void xl_fir_kernel(
     const XlFirArgs a, const XlDynArgs dyn, const XlDynArgs dyn_next) {
   extern __shared__ __attribute__((aligned(16))) v2f xl_win[];
-  constexpr uint32_t OT = 64u * KT;  // outputs per tile
+  // outputs per tile: 64 per lane-slot, or fewer active lanes (a.ota = 32/16/8, KT = 1) for huge decimations
+  const uint32_t OT = (KT == 1) ? a.ota : 64u * KT;
 
   // ---- NCO role: the first nco_blocks workgroups tabulate the NEXT block's phases (data independent float32
   // recurrence, xlating.c:70-73) while the rest of this launch filters the current block.  One launch per block
@@ -245,12 +246,15 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
 
   // ---- raw-history roll, folded into this launch: hist_out = the last hist_units 2-byte units of [in0 | in1].
   // No workgroup of this launch reads hist_out (they read in0/in1), the next block's launch follows in stream order.
-  if (a.hist_out != nullptr && b < XL_ROLL_BLOCKS) {
+  const uint32_t roll_blocks = gridDim.x - (MODE == 1 ? a.nco_blocks : 0u) < XL_ROLL_BLOCKS
+                                   ? gridDim.x - (MODE == 1 ? a.nco_blocks : 0u)
+                                   : XL_ROLL_BLOCKS;  // small launches have fewer workgroups than XL_ROLL_BLOCKS
+  if (a.hist_out != nullptr && b < roll_blocks) {
     const uint16_t *__restrict__ h0 = reinterpret_cast<const uint16_t *>(a.in0);
     const uint16_t *__restrict__ h1 = reinterpret_cast<const uint16_t *>(a.in1);
     uint16_t *__restrict__ ho = reinterpret_cast<uint16_t *>(a.hist_out);
     const uint32_t hu = a.hist_units, nu = a.block_units;
-    for (uint32_t j = b * blockDim.x + threadIdx.x; j < hu; j += XL_ROLL_BLOCKS * blockDim.x) {
+    for (uint32_t j = b * blockDim.x + threadIdx.x; j < hu; j += roll_blocks * blockDim.x) {
       const uint32_t sidx = nu + j;
       ho[j] = (sidx < hu) ? h0[sidx] : h1[sidx - hu];
     }
@@ -299,8 +303,9 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
     for (int c = 0; c < CT; ++c) acc[j][c].clear();
 
   constexpr int STEP = (CT == 9 || CT == 10) ? 6 : 4;  // taps per iteration (xl_tap_step): ~60 tap SGPRs in flight
-  const v2f *lp = xl_win + lane * D;
-  const uint32_t jstride = 64u * D;  // samples between the windows of a lane's outputs
+  // idle lanes (lane >= OT when ota < 64) alias lane 0's window so that their reads stay inside the image
+  const v2f *lp = xl_win + ((KT == 1 && lane >= OT) ? 0u : lane) * D;
+  const uint32_t jstride = 64u * D;  // samples between the windows of a lane's outputs (KT = 2 only)
   // The tap loop runs in four quarters with falling wave priority (3, 2, 1, 0).  The SIMD arbiter otherwise
   // favours the oldest wave, so co-resident waves -- which all have the same work -- finish one after another and
   // the last ones run alone, latency-bound (measured: identical waves ending between 57 and 142 us of a 144 us
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
 #pragma unroll
   for (int j = 0; j < KT; ++j) {
     const uint32_t m = x * OT + 64u * j + lane;
-    if (m < K) {
+    if (m < K && (KT != 1 || lane < OT)) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         if ((uint32_t)c < ncl) {
@@ -376,6 +381,16 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
 
 size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad, int kt) {
   return (size_t)((64u * kt - 1u) * D + Tpad) * sizeof(v2f);
+}
+
+size_t xl_fir_lds_bytes_ota(uint32_t D, uint32_t Tpad, uint32_t ota) {
+  return ((size_t)(ota - 1u) * D + Tpad) * sizeof(v2f);
+}
+
+uint32_t xl_fir_pick_ota(uint32_t D, uint32_t Tpad, size_t budget) {
+  for (uint32_t ota = 64; ota >= 8; ota >>= 1)
+    if (xl_fir_lds_bytes_ota(D, Tpad, ota) <= budget) return ota;
+  return 0;
 }
 
 template <int CT, int MODE, int KT, bool WIDE>
@@ -433,6 +448,8 @@ static hipError_t xl_fir_dispatch(int ct, int mode, int nw, const XlFirArgs &a, 
 hipError_t xl_launch_fir(int ct, int mode, int kt, int nw, const XlFirArgs &a, const XlDynArgs &dyn,
                          const XlDynArgs &dyn_next, size_t lds, hipStream_t s) {
   if (lds > 160 * 1024 || nw < 1 || nw > XL_NW_MAX) return hipErrorInvalidValue;
+  if (a.ota != 64 && a.ota != 32 && a.ota != 16 && a.ota != 8) return hipErrorInvalidValue;
+  if (kt != 1 && a.ota != 64) return hipErrorInvalidValue;
   if (kt == 1) return xl_fir_dispatch<1>(ct, mode, nw, a, dyn, dyn_next, lds, s);
   if (kt == 2) return xl_fir_dispatch<2>(ct, mode, nw, a, dyn, dyn_next, lds, s);
   return hipErrorInvalidValue;

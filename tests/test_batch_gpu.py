@@ -201,6 +201,22 @@ def test_lookahead_nco_with_ragged_blocks_and_late_fetch(variant):
     eng.close()
 
 
+@pytest.mark.parametrize("nbytes", [200, 2000, 30])
+def test_small_blocks_streaming(nbytes):
+    """Many tiny blocks (launches of one or two workgroups, blocks shorter than the filter): history roll, phase
+    carry and the global output grid must survive (reference unit-test shape: 57 taps, D = 5, test_xlating.c:15-22)."""
+    taps = lpf(48000, 4800, 2000)
+    eng = xl.BatchEngine(48000, "cu8", 4000)
+    oracles = {}
+    for c in range(5):
+        cid = eng.add_client(5, taps, -12000 + 3000 * c)
+        oracles[cid] = Oracle(5, taps, -12000 + 3000 * c, 48000, 4000)
+    for k in range(12):
+        n = nbytes if k % 5 != 3 else nbytes + 2
+        check_clients(eng, oracles, "cu8", siggen.ramp_u8(k * 977, n), "native" if k % 2 == 0 else "optimized")
+    eng.close()
+
+
 def test_full_size_1024_clients_properties():
     """BASELINE target size (1024 concurrent 48 kHz clients, 505 taps, 262144-byte blocks).  The oracle is too slow
     for all of it, so: (a) duplicated clients placed in different tiles/groups/XCDs must agree bit for bit,

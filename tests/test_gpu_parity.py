@@ -204,3 +204,47 @@ def test_many_filters_threads():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+@pytest.mark.parametrize("variant", ["native", "optimized"])
+def test_huge_decimation_window_exceeds_lds(variant):
+    """HackRF-style 20 Msps -> 50 kHz: D = 400, 4819 taps.  A 64-output window image would need 240 KB of LDS, so the
+    launch falls back to 32 outputs per wave (upper lanes idle).  Single filter and batch engine vs the oracle."""
+    fs, rate = 20000000, 50000
+    taps = hip_lpf(1.0, fs, rate // 2, rate // 5)
+    assert taps.size == 4819
+    D = fs // rate
+    nbytes = 131072
+    f = xl.XlatingFilter(D, taps, -3000000, fs, nbytes)
+    o = Oracle(D, taps, -3000000, fs, nbytes)
+    eng = xl.BatchEngine(fs, "cs8", nbytes)
+    ob = {}
+    for c in range(3):
+        ob[eng.add_client(D, taps, 1000000 * c - 500000)] = Oracle(D, taps, 1000000 * c - 500000, fs, nbytes)
+    for k in range(3):
+        x = scenarios.siggen.xs_s8(600 + k, nbytes if k != 1 else 50002)
+        got, want = f.process(variant, "cs8", "cf32", x), o.process("cs8", x)
+        eng.process_host(x, variant)
+        eng.fetch()
+        if variant == "native":
+            assert bits_equal(got, want), k
+            for cid, oc in ob.items():
+                assert bits_equal(eng.output(cid), oc.process("cs8", x)), (k, cid)
+        else:
+            assert len(got) == len(want) and rel_err(got, want) <= REL_TOL
+            for cid, oc in ob.items():
+                w = oc.process("cs8", x)
+                assert rel_err(eng.output(cid), w) <= REL_TOL, (k, cid)
+    f.close()
+    o.close()
+    eng.close()
+
+
+def test_rejects_shapes_that_cannot_fit():
+    """T - 1 beyond the engine's raw-history capacity is refused with -EINVAL (not silently wrong)."""
+    taps = np.ones(20000, np.float32) / 20000
+    eng = xl.BatchEngine(2016000, "cu8", 262144)
+    with pytest.raises(xl.XlatingError) as e:
+        eng.add_client(42, taps, 0)
+    assert e.value.code == -22
+    eng.close()

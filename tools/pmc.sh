@@ -9,7 +9,7 @@ rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ|TCC|TCP|GRBM|TA|TD)_[A-Z0-9_]+" | sor
 wc -l $OUT/counters.txt
 run() { # name, counters...
   n=$1; shift
-  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -o p -- python $GRAFT_REPO_ROOT/tools/sweep.py --clients ${CLIENTS:-4096} --rates ${RATES:-5} --steps 6 > $OUT/$n.log 2>&1
+  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -o p -- python $GRAFT_REPO_ROOT/tools/sweep.py --clients ${CLIENTS:-1024} --rates ${RATES:-5} --steps 6 > $OUT/$n.log 2>&1
   f=$(find $OUT/$n -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" <<'PY'
 import csv, sys, collections
