@@ -241,3 +241,38 @@ def test_full_size_1024_clients_properties():
             assert bits_equal(outs[c], oracles[c].process("cu8", x)), c
         assert all(len(o) == len(outs[0]) for o in outs)
     eng.close()
+
+
+def test_bench_block_feeder_stream_plumbing():
+    """bench.py's multi-GPU feed (broadcast of block k+1 on a side stream while block k is filtered, two receive
+    buffers, event-ordered reuse) with a stand-in for torch.distributed whose broadcast is the identity (this box has
+    one GPU): the engine must see exactly the blocks in order."""
+    import torch
+
+    import bench
+
+    class FakeDist:
+        def broadcast(self, t, src=0):
+            return None
+
+    blocks = [siggen.xs_u8(8100 + k, bench.BLOCK_BYTES) for k in range(5)]
+    dev = [torch.from_numpy(b).cuda() for b in blocks]
+    feeder = bench.BlockFeeder(torch, FakeDist(), 0, 2, dev)
+    taps = lpf(FS, 24000, 48000)
+    eng = xl.BatchEngine(FS, "cu8", bench.BLOCK_BYTES)
+    oracles = {}
+    for c in range(12):
+        cid = eng.add_client(42, taps, bench.client_center_freq(c * 37))
+        oracles[cid] = Oracle(42, taps, bench.client_center_freq(c * 37), FS, bench.BLOCK_BYTES)
+    stream = torch.cuda.current_stream()
+    for k in range(9):
+        ptr = feeder.get(k, stream)
+        eng.process_device(ptr, bench.BLOCK_BYTES, "optimized", stream.cuda_stream)
+        feeder.consumed(k, stream)
+        want = {cid: o.process("cu8", blocks[k % 5]) for cid, o in oracles.items()}
+        if k % 3 == 2:
+            eng.fetch()
+            for cid in oracles:
+                assert rel_err(eng.output(cid), want[cid]) <= REL_TOL, (k, cid)
+    torch.cuda.synchronize()
+    eng.close()
