@@ -165,7 +165,7 @@ class BlockFeeder:
             self.free_valid[k % 2] = True
 
 
-def run_workload(xl, torch, dist, args, rank, world, ntaps_rate, steps, warmup, dev_blocks):
+def run_workload(xl, torch, dist, args, rank, world, ntaps_rate, steps, warmup, dev_blocks, mode=None):
     """Build this rank's engine with its shard of clients and time `steps` blocks.  Returns dict of measurements."""
     code, taps = xl.create_low_pass_filter(1.0, FS, RATE // 2, RATE // ntaps_rate)
     assert code == 0
@@ -179,7 +179,7 @@ def run_workload(xl, torch, dist, args, rank, world, ntaps_rate, steps, warmup, 
 
     def step(k):
         ptr = feeder.get(k, stream)
-        eng.process_device(ptr, BLOCK_BYTES, args.mode, stream.cuda_stream)
+        eng.process_device(ptr, BLOCK_BYTES, mode or args.mode, stream.cuda_stream)
         feeder.consumed(k, stream)
 
     for k in range(warmup):
@@ -273,6 +273,15 @@ def main():
             "fp32_frac": round(t2 / FP32_PEAK_TFLOPS, 4), "achieved_TFLOPs": round(t2, 2),
             "fir_kernel_ms": round(mv["fir_ms_avg"], 4),
             "flop_per_unit": round(f2, 2)}
+        # the other arithmetic variant on the headline workload (native = bit-exact reference arithmetic,
+        # the reference's default cpu_optimization; optimized = fused multiply-add)
+        other_mode = "native" if args.mode == "optimized" else "optimized"
+        mn = run_workload(xl, torch, dist, args, rank, world, args.lpf_cutoff_rate, vs, min(args.warmup, 5), dev_blocks,
+                          mode=other_mode)
+        v3, g3, t3, _, _ = summarize(mn, vs, world)
+        variants[f"process_{other_mode}_cu8_cf32 semantics ({mn['ntaps']} taps)"] = {
+            "value": round(v3, 1), "ms_per_step": round(mn["seconds"] / vs * 1e3, 4), "fir_kernel_ms": round(mn["fir_ms_avg"], 4),
+            "achieved_TFLOPs": round(t3, 2), "fp32_frac": round(t3 / FP32_PEAK_TFLOPS, 4)}
 
     if rank != 0:
         if world > 1:

@@ -20,12 +20,13 @@
 // client (it joined mid-stream) must read as zero: zero_below = XL_HCAP - min(consumed, XL_HCAP).
 //
 // Streams.  A block's outputs depend on (raw history, block, phase table) only.  The phase table is data
-// independent (float32 recurrence p <- p * incr, xlating.c:70-73), so block b+1's table is tabulated on a side
-// stream while block b is filtered, guessing that b+1 has the same length; the running phases are double-buffered
-// (committed / next) so that a wrong guess is simply redone.  Everything else of a block -- the fused FIR launch,
-// which also rolls the raw history -- goes to the caller's stream, so results are stream-ordered behind the call.
-// (Measured and dropped: running consecutive blocks' FIR launches concurrently on two streams -- no gain, the
-// launches just share the chip; see DESIGN.md.)
+// independent (float32 recurrence p <- p * incr, xlating.c:70-73), so block b+1's table is tabulated by the leading
+// workgroups of block b's FIR launch (the "NCO role"), guessing that b+1 has the same length; the running phases are
+// double-buffered (committed / next) so that a wrong guess is simply redone by a small launch of its own.  A block
+// is therefore ONE kernel launch on the caller's stream -- history roll, FIR, next block's phase table -- and its
+// results are stream-ordered behind the call.
+// (Measured and dropped: the phase table on a side stream fenced by events -- a steady 24 us gap between consecutive
+// FIR launches; consecutive blocks' FIR launches concurrently on two streams -- no gain.  See DESIGN.md.)
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
@@ -84,14 +85,12 @@ struct xlating_batch_t {
   int device = -1;
   hipStream_t own_stream = nullptr;   // used when the caller passes no stream / host path
   hipStream_t last_stream = nullptr;  // caller stream of the latest block
-  hipStream_t nco_stream = nullptr;
 
   std::vector<Client> clients;
   int nalive = 0;
   bool dirty = true;
   std::vector<ClassState> classes;
   Launch launches[XL_NLAUNCH];  // one per register-tile height 12, 10, 9, 8, 4, 2, 1
-  int plan_mode = -1;           // the tile heights depend on the arithmetic variant
   std::vector<XlNcoClient> nco;
   size_t out_total = 0;
   uint64_t nblk = 0;  // blocks processed
@@ -113,21 +112,17 @@ struct xlating_batch_t {
   size_t h_out_alloc = 0;
   bool fetched = false;
 
-  hipEvent_t ev_nco[2] = {nullptr, nullptr};       // table[i] written (nco stream)
-  hipEvent_t ev_tab_free[2] = {nullptr, nullptr};  // table[i] consumed by its FIR launch (caller's stream)
-  bool ev_tab_free_valid[2] = {false, false};
   int tab = 0;              // table used by the latest block
   bool spec_valid = false;  // table[spec_tab] holds the phases of the NEXT block assuming spec_S samples
   size_t spec_S = 0;
   int spec_tab = 0;
-  bool spec_on_side = false;  // that table was tabulated on the side stream (wait for ev_nco) vs in-stream
   bool exp_nofuse = false;    // XL_EXP_NOFUSE: keep the NCO tabulation a launch of its own (tuning)
 
   uint32_t exp_flags = 0;  // tuning knobs from XL_EXP_* environment variables
   bool exp_same_taps = false;
   int exp_kt = 0;
-  // Wave priority of the look-ahead NCO kernel.  3: it outranks the FIR waves it runs beside -- costs the 505-tap
-  // FIR launch ~1 % and keeps the NCO chain off the critical path for short filters (101 taps: step 0.094 -> 0.084 ms).
+  // Wave priority of the NCO role / NCO launch (3: a pure dependent chain must not queue behind the FIR waves;
+  // 1..3 measured equal for 505 taps, 3 best for short filters).
   uint32_t nco_prio = 3;
   int exp_h = 0;   // XL_EXP_H=8|9|10|12 forces the tile height of the large classes
   const char *exp_trace = nullptr;  // XL_EXP_TRACE=<file>: dump per-wave timestamps of the latest FIR launch
@@ -135,7 +130,7 @@ struct xlating_batch_t {
   size_t trace_cap = 0;
   bool timing = false;
   std::vector<hipEvent_t> ev;       // pairs: fir start, fir stop (on the FIR launch stream)
-  std::vector<hipEvent_t> ev_ncot;  // pairs: nco start, nco stop (on the nco stream)
+  std::vector<hipEvent_t> ev_ncot;  // pairs: start, stop of stand-alone NCO launches (rare)
   std::vector<hipEvent_t> ev_pool;  // recycled timing events (hipEventCreate per block would bound the host)
   double fir_ms = 0.0, nco_ms = 0.0;
   int timed_launches = 0, timed_nco = 0;
@@ -152,9 +147,7 @@ static hipError_t xl_batch_timing_event(xlating_batch *b, hipEvent_t *out) {
 
 static void xl_batch_sync_all(xlating_batch *b) {
   (void)hipStreamSynchronize(b->last_stream);  // may be the NULL (legacy default) stream: still a real stream
-  hipStream_t ss[] = {b->own_stream, b->nco_stream};
-  for (hipStream_t s : ss)
-    if (s) (void)hipStreamSynchronize(s);
+  if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
 }
 
 static void xl_batch_free_plan(xlating_batch *b) {
@@ -183,12 +176,7 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_ncot) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
-  hipEvent_t evs[] = {b->ev_nco[0], b->ev_nco[1], b->ev_tab_free[0], b->ev_tab_free[1]};
-  for (hipEvent_t e : evs)
-    if (e) (void)hipEventDestroy(e);
-  hipStream_t ss[] = {b->own_stream, b->nco_stream};
-  for (hipStream_t s : ss)
-    if (s) (void)hipStreamDestroy(s);
+  if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
 }
 
@@ -212,11 +200,8 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   {
     const size_t hbytes = (size_t)XL_HCAP * b->bps;
     const size_t bbytes = (size_t)b->max_samples * b->bps + 16;
-    hipStream_t *ss[] = {&b->own_stream, &b->nco_stream};
-    hipEvent_t *evs[] = {&b->ev_nco[0], &b->ev_nco[1], &b->ev_tab_free[0], &b->ev_tab_free[1]};
     XL_TRY(hipSetDevice(dev));
-    for (hipStream_t *s : ss) XL_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-    for (hipEvent_t *e : evs) XL_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    XL_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
       XL_TRY(hipMalloc(&b->d_hist[i], hbytes));
       XL_TRY(hipMemsetAsync(b->d_hist[i], 0, hbytes, b->own_stream));
@@ -226,7 +211,8 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
     XL_TRY(hipStreamSynchronize(b->own_stream));
   }
   if (getenv("XL_EXP_FLATPRIO")) b->exp_flags |= 2u;
-  if (getenv("XL_EXP_PRIOQUARTERS")) b->exp_flags |= 4u;  // default: segments end at 1/2, 3/4, 7/8
+  if (getenv("XL_EXP_PRIOQUARTERS")) b->exp_flags |= 4u;
+  if (getenv("XL_EXP_PRIO4")) b->exp_flags |= 8u;  // default: segments end at 1/2, 3/4, 7/8
   if (getenv("XL_EXP_SAME_TAPS")) b->exp_same_taps = true;
   if (getenv("XL_EXP_KT")) b->exp_kt = atoi(getenv("XL_EXP_KT"));
   if (getenv("XL_EXP_H")) b->exp_h = atoi(getenv("XL_EXP_H"));
@@ -319,10 +305,9 @@ extern "C" int xlating_batch_remove_client(xlating_batch *b, int id) {
 }
 
 // (Re)build the resident plan: classes, tiles (register-tile heights 8/4/2/1), groups, tap image, NCO table.
-static int xl_batch_plan(xlating_batch *b, int mode) {
+static int xl_batch_plan(xlating_batch *b) {
   xl_batch_sync_all(b);
   b->spec_valid = false;
-  b->ev_tab_free_valid[0] = b->ev_tab_free_valid[1] = false;
   xl_batch_free_plan(b);
   b->classes.clear();
   b->nco.clear();
@@ -365,7 +350,7 @@ static int xl_batch_plan(xlating_batch *b, int mode) {
   // duration (measured 48 us of a 161 us launch at 1024 clients with H = 8: 32 x 49 = 1568 workgroups on 1536
   // slots).  Taller tiles trade a little per-wave time for fewer workgroups: pick the height whose launch costs
   // least in (waves on the busiest SIMD) x (work per wave).  Classes with fewer than 8 clients use one small
-  // tile.  The native (bit-exact) kernels are register-hungry above 8, so they keep H <= 8.
+  // tile.
   static const int kHeights[XL_NLAUNCH] = {12, 10, 9, 8, 4, 2, 1};
   int big_h = 8;
   {
@@ -373,7 +358,7 @@ static int xl_batch_plan(xlating_batch *b, int mode) {
     for (size_t k = 0; k < members.size(); ++k)
       if (members[k].size() >= 8)
         lds1 = std::max(lds1, xl_fir_lds_bytes(b->classes[k].D, xl_roundup(b->classes[k].T, 12), 1));
-    if (lds1 > 0 && mode == XL_MODE_OPTIMIZED) {
+    if (lds1 > 0) {
       const long slots = std::max<long>(1, std::min<long>((long)(160 * 1024 / lds1), 7));
       const long cap = slots * 256;
       long best = -1;
@@ -532,16 +517,10 @@ static uint32_t xl_batch_dyn(const xlating_batch *b, size_t S, XlDynArgs *dyn) {
   return maxK;
 }
 
-// Tabulate the phases of a block as a launch of its own: committed phases -> table[tab] + next phases.
-// in_stream == nullptr: on the nco (side) stream, fenced by events (native mode's look-ahead).
-// in_stream != nullptr: on that stream, ordered by it (optimized mode's fallback when no table was tabulated ahead).
-static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab, hipStream_t *in_stream) {
+// Tabulate the phases of a block as a launch of its own on stream `st`: committed phases -> table[tab] + next
+// phases.  Only needed when no table was tabulated ahead (first block, changed block length, changed client set).
+static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab, hipStream_t st) {
   hipError_t e;
-  hipStream_t st = in_stream ? *in_stream : b->nco_stream;
-  if (!in_stream && b->ev_tab_free_valid[tab]) {  // the FIR launch that last read table[tab] must be done with it
-    e = hipStreamWaitEvent(st, b->ev_tab_free[tab], 0);
-    if (e != hipSuccess) return e;
-  }
   hipEvent_t n0 = nullptr, n1 = nullptr;
   if (b->timing) {
     for (int i = 0; i < 2; ++i) {
@@ -558,20 +537,15 @@ static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab, 
   e = xl_launch_nco_table(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[b->pcur], b->d_phase[b->pcur ^ 1],
                           b->d_phtab[tab], dyn, b->nco_prio, st);
   if (e != hipSuccess) return e;
-  if (n1) {
-    e = hipEventRecord(n1, st);
-    if (e != hipSuccess) return e;
-  }
-  return in_stream ? hipSuccess : hipEventRecord(b->ev_nco[tab], st);
+  return n1 ? hipEventRecord(n1, st) : hipSuccess;
 }
 
 static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len, int mode, hipStream_t s) {
   const size_t S = input_len / 2;
   if (S > b->max_samples || (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED)) return -EINVAL;
-  if (b->dirty || b->plan_mode != mode) {
-    int rc = xl_batch_plan(b, mode);
+  if (b->dirty) {
+    int rc = xl_batch_plan(b);
     if (rc != 0) return rc;
-    b->plan_mode = mode;
   }
   b->last_stream = s;
   b->fetched = false;
@@ -580,8 +554,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
   const int p = (int)(b->nblk & 1);  // parity of this block: output buffer
   const int hb = b->hcur, hn = b->hcur ^ 1;
 
-  const bool fuse = mode == XL_MODE_OPTIMIZED && !b->exp_nofuse;
-  bool wait_side = false, nco_fused = false;
+  const bool fuse = !b->exp_nofuse;  // tuning: XL_EXP_NOFUSE tabulates by a launch of its own before every block
+  bool nco_fused = false;
   XlDynArgs dyn, next;
   const uint32_t maxK = xl_batch_dyn(b, S, &dyn);
   for (ClassState &cs : b->classes) {  // advance the stream positions past this block
@@ -594,22 +568,13 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
     c.consumed += S;
   }
 
-  // ---- this block's phase table: already tabulated ahead if the length guess was right.
-  // Optimized mode: the table of block b+1 is tabulated by the first workgroups of block b's FIR launch ("NCO
-  // role"), so a block is ONE launch on the caller's stream and nothing has to be fenced.  Native mode (its kernels
-  // have no registers to spare for the role) tabulates ahead on the side stream, fenced by events.
+  // ---- this block's phase table: tabulated ahead by the previous block's launch if the length guess was right
   int tab;
   if (b->spec_valid && b->spec_S == S) {
     tab = b->spec_tab;
-    wait_side = b->spec_on_side;
   } else {
     tab = b->spec_valid ? b->spec_tab : (b->tab ^ 1);
-    if (fuse && !(b->spec_valid && b->spec_on_side)) {
-      XL_TRY(xl_batch_nco(b, dyn, tab, &s));
-    } else {
-      XL_TRY(xl_batch_nco(b, dyn, tab, nullptr));
-      wait_side = true;
-    }
+    XL_TRY(xl_batch_nco(b, dyn, tab, s));
   }
   b->spec_valid = false;
   b->pcur ^= 1;  // the phases written by that tabulation are now the committed ones
@@ -618,8 +583,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
   (void)xl_batch_dyn(b, S, &next);  // per-class numbers of the NEXT block if it has the same length (the guess)
 
   // ---- the fused FIR launch(es) on the caller's stream: window images from [d_hist[hb] | block], phases from
-  // table[tab] -> d_out[p]; the first launch also rolls the raw history into d_hist[hn] and, in optimized mode,
-  // tabulates table[tab ^ 1] for the next block
+  // table[tab] -> d_out[p]; the first launch also rolls the raw history into d_hist[hn] and tabulates
+  // table[tab ^ 1] for the next block
   {
     hipEvent_t f0 = nullptr, f1 = nullptr;
     if (b->timing && maxK > 0) {
@@ -633,7 +598,6 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
     }
     bool rolled = false;
     if (maxK > 0) {
-      if (wait_side) XL_TRY(hipStreamWaitEvent(s, b->ev_nco[tab], 0));
       if (f0) XL_TRY(hipEventRecord(f0, s));
       for (Launch &L : b->launches) {
         if (L.groups.empty()) continue;
@@ -654,7 +618,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         const size_t wgs = (size_t)a.ngroups * a.xtiles;
         const size_t cap = 256 * std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(L.lds, 1), 7));
         const bool flat = (b->exp_flags & 2u) || wgs > 2 * cap;
-        a.flags = (L.all_wide ? 1u : 0u) | (flat ? 2u : 0u) | ((b->exp_flags & 4u) ? 0u : 4u);
+        a.flags = (L.all_wide ? 1u : 0u) | (flat ? 2u : 0u) | ((b->exp_flags & 4u) ? 0u : 4u) | ((b->nco_prio & 3u) << 4) | (b->exp_flags & 8u);
         a.taps = b->d_taps;
         a.phtab = b->d_phtab[tab];
         a.out = b->d_out[p];
@@ -697,10 +661,6 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         }
       }
       if (f1) XL_TRY(hipEventRecord(f1, s));
-      if (!fuse) {
-        XL_TRY(hipEventRecord(b->ev_tab_free[tab], s));
-        b->ev_tab_free_valid[tab] = true;
-      }
     }
     if (!rolled)  // no client produced output in this block (tiny block): roll the history on its own
       XL_TRY(xl_launch_update_history(b->d_hist[hb], d_block, XL_HCAP, (uint32_t)S, b->bps, b->d_hist[hn], s));
@@ -709,18 +669,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
   b->hcur = hn;
   b->nblk++;
 
-  // ---- the NEXT block's phases, guessing it has the same length: done inside the FIR launch above (optimized
-  // mode), otherwise tabulated now on the side stream (native mode) or, in optimized mode without a FIR launch
-  // (tiny block), left to the next call
+  // ---- the NEXT block's phases, guessing it has the same length, were tabulated inside the FIR launch above;
+  // without one (tiny block, or the tuning switch) the next call tabulates for itself
   if (nco_fused) {
     b->spec_valid = true;
-    b->spec_on_side = false;
-    b->spec_S = S;
-    b->spec_tab = tab ^ 1;
-  } else if (!fuse) {
-    XL_TRY(xl_batch_nco(b, next, tab ^ 1, nullptr));
-    b->spec_valid = true;
-    b->spec_on_side = true;
     b->spec_S = S;
     b->spec_tab = tab ^ 1;
   }

@@ -73,11 +73,20 @@ template <>
 struct XlAcc<0> {
   v2f s;
   XL_MEM void clear() { s = (v2f){0.0f, 0.0f}; }
+  // Same roundings as the scalar tree  pr = xr*hr - xi*hi;  pi = xr*hi + xi*hr;  s += (pr, pi)  (every product and
+  // sum rounded once, nothing fused: this TU is compiled -ffp-contract=off), arranged so that each step is one packed
+  // instruction without register shuffles:  p1 = xr*(hr,hi)   p2 = xi*(hi,hr)   p = (p1.x - p2.x, p1.y + p2.y)   s += p
   XL_MEM void mac(const v2f x, const float hr, const float hi) {
-    const float pr = x.x * hr - x.y * hi;
-    const float pi = x.x * hi + x.y * hr;
-    s.x = s.x + pr;
-    s.y = s.y + pi;
+    // hand-placed: the compiler builds the (-p2.x, p2.y) operand with an extra v_pk_add and a v_mov (6 VALU per
+    // MAC); op_sel / neg_lo do it for free (4 VALU per MAC).  IEEE mul/add, one rounding each, nothing fused.
+    const v2f h = {hr, hi};
+    v2f p1, p2;
+    asm("v_pk_mul_f32 %0, %3, %4 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %3, %4 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1 neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %2, %2, %0"
+        : "=&v"(p1), "=&v"(p2), "+v"(s)
+        : "v"(x), "s"(h));
   }
   XL_MEM v2f value() const { return s; }
 };
@@ -223,10 +232,11 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   // ---- NCO role: the first nco_blocks workgroups tabulate the NEXT block's phases (data independent float32
   // recurrence, xlating.c:70-73) while the rest of this launch filters the current block.  One launch per block
   // then does everything -- no side stream, no events between consecutive launches (they cost a 24 us gap).
-  // (compiled into the optimized kernels only: in the register-hungry native kernels it costs occupancy; the host
-  // gives native launches no NCO role and tabulates on the side stream instead)
-  if (MODE == 1 && blockIdx.x < a.nco_blocks) {
-    __builtin_amdgcn_s_setprio(3);  // a pure dependent chain: it must not queue behind the FIR waves
+  if (blockIdx.x < a.nco_blocks) {
+    // a pure dependent chain that must not starve behind the FIR waves; flags bits 4-5: its priority (tuning)
+    if (((a.flags >> 4) & 3u) == 3u) __builtin_amdgcn_s_setprio(3);
+    else if (((a.flags >> 4) & 3u) == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (((a.flags >> 4) & 3u) == 1u) __builtin_amdgcn_s_setprio(1);
     if (threadIdx.x < XL_NCO_LANES) {
       const uint32_t c = blockIdx.x * XL_NCO_LANES + threadIdx.x;
       if (c < a.nco_nclients) {
@@ -241,14 +251,16 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   // group -- which stream the same taps -- are neighbours) and is cut into 8 equal contiguous chunks, one per XCD
   // (block b runs on XCD b % 8 on this part): each XCD's L2 then holds the taps of ~1/8 of the groups, and every
   // XCD gets the same number of workgroups (whole groups per XCD left one XCD with 196 workgroups on 192 slots).
-  const uint32_t b = blockIdx.x - (MODE == 1 ? a.nco_blocks : 0u);
+  // Enter at top priority: a workgroup still staging its window at the default priority 0 starves against
+  // neighbours already in the tap loop at priority 3 (measured: staging up to 68 us instead of 4 us; those
+  // workgroups then finish last and set the launch time).
+  if (!(a.flags & 2u)) __builtin_amdgcn_s_setprio(3);
+  const uint32_t b = blockIdx.x - a.nco_blocks;
   const unsigned long long t_entry = a.trace ? wall_clock64() : 0ull;
 
   // ---- raw-history roll, folded into this launch: hist_out = the last hist_units 2-byte units of [in0 | in1].
   // No workgroup of this launch reads hist_out (they read in0/in1), the next block's launch follows in stream order.
-  const uint32_t roll_blocks = gridDim.x - (MODE == 1 ? a.nco_blocks : 0u) < XL_ROLL_BLOCKS
-                                   ? gridDim.x - (MODE == 1 ? a.nco_blocks : 0u)
-                                   : XL_ROLL_BLOCKS;  // small launches have fewer workgroups than XL_ROLL_BLOCKS
+  const uint32_t roll_blocks = gridDim.x - a.nco_blocks < XL_ROLL_BLOCKS ? gridDim.x - a.nco_blocks : XL_ROLL_BLOCKS;  // small launches have fewer workgroups than XL_ROLL_BLOCKS
   if (a.hist_out != nullptr && b < roll_blocks) {
     const uint16_t *__restrict__ h0 = reinterpret_cast<const uint16_t *>(a.in0);
     const uint16_t *__restrict__ h1 = reinterpret_cast<const uint16_t *>(a.in1);
@@ -306,11 +318,11 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   // idle lanes (lane >= OT when ota < 64) alias lane 0's window so that their reads stay inside the image
   const v2f *lp = xl_win + ((KT == 1 && lane >= OT) ? 0u : lane) * D;
   const uint32_t jstride = 64u * D;  // samples between the windows of a lane's outputs (KT = 2 only)
-  // The tap loop runs in four quarters with falling wave priority (3, 2, 1, 0).  The SIMD arbiter otherwise
-  // favours the oldest wave, so co-resident waves -- which all have the same work -- finish one after another and
-  // the last ones run alone, latency-bound (measured: identical waves ending between 57 and 142 us of a 144 us
-  // launch).  With priority = remaining-work quartile a wave that gets ahead yields to those behind, all waves
-  // of a SIMD finish together and the VALU stays fed to the end.
+  // The tap loop runs in segments of falling wave priority.  The SIMD arbiter otherwise favours the oldest wave,
+  // so co-resident waves -- which all have the same work -- finish one after another and the last ones run alone,
+  // latency-bound (measured: identical waves ending between 57 and 142 us of a 144 us launch).  With priority =
+  // remaining work a wave that gets ahead yields to those behind, all waves of a SIMD finish together and the
+  // VALU stays fed to the end.
   // one quarter of the tap loop; WIDE (even D: lane*D and 64*D even) reads 16-byte aligned pairs of samples
 #define XL_TAP_LOOP(I0, I1)                                                                       \
   for (uint32_t i = (I0); i < (I1); i += STEP) {                                                  \
@@ -334,25 +346,37 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
       }                                                                                           \
     }                                                                                             \
   }
-  if (a.flags & 2u) {  // tuning: flat priority
+  if (a.flags & 2u) {  // flat priority (multi-round launches, tuning)
     XL_TAP_LOOP(0u, Tpad)
   } else {
-    // segment ends: quarters, or (flags bit 2) 1/2, 3/4, 7/8 of the taps -- a short last segment tightens the finish
+    // priority 3 is reserved for the short latency-bound phases (staging above, epilogue below, NCO role): a
+    // workgroup that is still staging must outrank its neighbours' tap loops or it starves (measured: the last
+    // dispatched workgroups of every XCD staged for 56 us instead of 4 us and then set the launch time).
+    // The tap loop itself runs at 2, 1, 0 over [0, 1/2), [1/2, 7/8), [7/8, 1] of the taps (bit 2 of flags;
+    // otherwise thirds): remaining-work priority, short last segment = tight finish.
     const uint32_t steps = Tpad / STEP;
-    const uint32_t b1 = (a.flags & 4u) ? steps / 2 : (steps + 3) / 4;
-    const uint32_t b2 = (a.flags & 4u) ? (3 * steps) / 4 : 2 * ((steps + 3) / 4);
-    const uint32_t b3 = (a.flags & 4u) ? (7 * steps) / 8 : 3 * ((steps + 3) / 4);
-    const uint32_t e1 = b1 * STEP < Tpad ? b1 * STEP : Tpad;
-    const uint32_t e2 = b2 * STEP < Tpad ? b2 * STEP : Tpad;
-    const uint32_t e3 = b3 * STEP < Tpad ? b3 * STEP : Tpad;
+    if (a.flags & 8u) {  // tuning: four loop levels 3,2,1,0 over [0,1/2) [1/2,3/4) [3/4,7/8) [7/8,1]
+      const uint32_t e1 = (steps / 2) * STEP, e2 = ((3 * steps) / 4) * STEP, e3 = ((7 * steps) / 8) * STEP;
+      XL_TAP_LOOP(0u, e1)
+      __builtin_amdgcn_s_setprio(2);
+      XL_TAP_LOOP(e1, e2)
+      __builtin_amdgcn_s_setprio(1);
+      XL_TAP_LOOP(e2, e3)
+      __builtin_amdgcn_s_setprio(0);
+      XL_TAP_LOOP(e3, Tpad)
+    } else {
+      const uint32_t b1 = (a.flags & 4u) ? steps / 2 : (steps + 2) / 3;
+      const uint32_t b2 = (a.flags & 4u) ? (7 * steps) / 8 : 2 * ((steps + 2) / 3);
+      const uint32_t e1 = b1 * STEP < Tpad ? b1 * STEP : Tpad;
+      const uint32_t e2 = b2 * STEP < Tpad ? b2 * STEP : Tpad;
+      __builtin_amdgcn_s_setprio(2);
+      XL_TAP_LOOP(0u, e1)
+      __builtin_amdgcn_s_setprio(1);
+      XL_TAP_LOOP(e1, e2)
+      __builtin_amdgcn_s_setprio(0);
+      XL_TAP_LOOP(e2, Tpad)
+    }
     __builtin_amdgcn_s_setprio(3);
-    XL_TAP_LOOP(0u, e1)
-    __builtin_amdgcn_s_setprio(2);
-    XL_TAP_LOOP(e1, e2)
-    __builtin_amdgcn_s_setprio(1);
-    XL_TAP_LOOP(e2, e3)
-    __builtin_amdgcn_s_setprio(0);
-    XL_TAP_LOOP(e3, Tpad)
   }
 #undef XL_TAP_LOOP
 
@@ -403,7 +427,6 @@ static hipError_t xl_fir_go2(int nw, const XlFirArgs &a, const XlDynArgs &dyn, c
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  if (MODE == 0 && a.nco_blocks != 0) return hipErrorInvalidValue;  // see the kernel: no NCO role in native
   const uint32_t nblocks = a.nco_blocks + 8u * ((a.ngroups * a.xtiles + 7u) / 8u);
   if (nblocks == 0) return hipSuccess;
   hipLaunchKernelGGL((xl_fir_kernel<CT, MODE, KT, WIDE>), dim3(nblocks), dim3(64 * nw), lds, s, a, dyn, dyn_next);

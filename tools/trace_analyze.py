@@ -27,3 +27,16 @@ for k in range(8):
     m = xcd == k
     if m.any():
         print(f"  xcd {k}: waves {m.sum():5d}  first start {us[m,0].min():6.1f}  last end {us[m,3].max():6.1f}")
+# ---- which workgroups stage slowly / finish last?
+bidx = np.repeat(blocks[:, None], 4, axis=1)[valid]
+widx = np.repeat(np.arange(4)[None, :], t.shape[0], axis=0)[valid]
+stg = d[:, 0]
+order = np.argsort(-stg)[:24]
+print("  slowest staging (block, wave, xcd, staging us, loop us, end us):")
+print("   ", " ".join(f"({bidx[i]},{widx[i]},{bidx[i]%8},{stg[i]:.0f},{d[i,1]:.0f},{us[i,3]:.0f})" for i in order))
+slow = stg > 3 * np.median(stg)
+print(f"  slow-staging waves: {slow.sum()}  distinct blocks: {len(set(bidx[slow]))}  block idx range: {bidx[slow].min() if slow.any() else 0}..{bidx[slow].max() if slow.any() else 0}")
+h, e = np.histogram(bidx[slow], bins=16, range=(0, t.shape[0]))
+print("  slow-staging waves by block-index sixteenth:", h.tolist())
+last = np.argsort(-us[:, 3])[:16]
+print("  last finishing (block, wave, start, staged, end):", " ".join(f"({bidx[i]},{widx[i]},{us[i,0]:.0f},{us[i,1]:.0f},{us[i,3]:.0f})" for i in last))
