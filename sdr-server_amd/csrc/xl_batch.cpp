@@ -639,7 +639,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         }
         size_t trace_n = 0;
         if (b->exp_trace) {  // tuning only
-          trace_n = ((size_t)a.nco_blocks + (size_t)8 * ((a.ngroups * a.xtiles + 7) / 8)) * XL_NW_MAX * 4;
+          trace_n = ((size_t)a.nco_blocks + (size_t)8 * ((a.ngroups * a.xtiles + 7) / 8)) * XL_NW_MAX * 6;
           if (trace_n > b->trace_cap) {
             if (b->d_trace) (void)hipFree(b->d_trace);
             b->d_trace = nullptr;

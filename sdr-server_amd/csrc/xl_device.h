@@ -86,7 +86,7 @@ struct XlFirArgs {
   const float2 *nco_state_in;
   float2 *nco_state_out;
   float2 *nco_tab;
-  unsigned long long *trace;  // tuning only: per wave 4 wall_clock64 stamps (entry, staged, filtered, stored) or null
+  unsigned long long *trace;  // tuning only: per wave 6 words (wall_clock64 at entry, staged, filtered, stored; HW_ID; XCC_ID)
 };
 
 

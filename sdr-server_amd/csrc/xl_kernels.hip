@@ -238,10 +238,18 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
     else if (((a.flags >> 4) & 3u) == 2u) __builtin_amdgcn_s_setprio(2);
     else if (((a.flags >> 4) & 3u) == 1u) __builtin_amdgcn_s_setprio(1);
     if (threadIdx.x < XL_NCO_LANES) {
+      const unsigned long long t0 = a.trace ? wall_clock64() : 0ull;
       const uint32_t c = blockIdx.x * XL_NCO_LANES + threadIdx.x;
       if (c < a.nco_nclients) {
         const XlNcoClient k = a.nco_clients[c];
         xl_nco_client(k, dyn_next.d[k.cls].K, a.nco_state_in, a.nco_state_out, a.nco_tab);
+      }
+      if (a.trace && threadIdx.x == 0) {  // tuning: stamp the NCO-role wave (stamps 1, 2 stay 0 = "NCO role")
+        unsigned long long *tn = a.trace + (size_t)blockIdx.x * XL_NW_MAX * 6;
+        tn[0] = t0;
+        tn[3] = wall_clock64();
+        tn[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        tn[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
       }
     }
     return;
@@ -299,10 +307,12 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (w >= ntiles) return;
   const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long *tr = a.trace ? a.trace + ((size_t)b * XL_NW_MAX + w) * 4 : nullptr;
+  unsigned long long *tr = a.trace ? a.trace + ((size_t)blockIdx.x * XL_NW_MAX + w) * 6 : nullptr;
   if (tr && lane == 0) {
     tr[0] = t_entry;
     tr[1] = wall_clock64();
+    tr[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+    tr[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
   }
   const cu32_p t = g + 8 + w * (2 + XL_CT_MAX);  // XlTile of this wave
   const uint32_t ncl = t[1];
