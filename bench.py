@@ -327,6 +327,9 @@ def main():
             "kernel_ms_note": "mean HIP-event duration of the FIR launch over the timed region, on its launch stream",
             "bytes_per_unit": round(bpu, 4), "units_per_launch": m["clients_this_rank"] * S,
             "model": "per-client-read (SURVEY 8(d)): 2 B in + 8/D B out per (client, input sample)",
+            "shared_read_model": {"bytes_per_unit": round(2.0 / m["clients_this_rank"] + 8.0 / D, 5),
+                                  "achieved_GBs": round(m["clients_this_rank"] * S * (2.0 / m["clients_this_rank"] + 8.0 / D) / (m["fir_ms_avg"] * 1e-3) / 1e9, 1),
+                                  "note": "the block is read once per GPU and shared through L2/LDS: 2/N + 8/D B per unit (SURVEY 8(d))"},
             "fp32": {"achieved": round(ach_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach_tf / FP32_PEAK_TFLOPS, 4), "flop_per_unit": round(fpu, 2),
                      "note": "binding ceiling at this tap count (SURVEY H2): HBM frac cannot exceed "

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""tools/measure_configs.py -- numbers for every BASELINE.json config on one MI355X (parity for them is in tests/):
+ [1] 1 client, 2.016 Msps -> 48 kHz through the drop-in process_* API (latency-bound: us per 262144-byte block)
+ [2] 64 clients at mixed 48/96 kHz sharing one block (batch engine, device-resident input)
+ [3] per-GPU share of the 8-GPU 1024-client config (128 clients) and the 1-GPU 1024-client target
+ [4] cf32 input at 10 Msps, D=100, 257 taps, 256 clients (HBM-roofline style config)
+ plus the PCIe-inclusive host path (process_host + fetch of every client's output).
+Prints one JSON object."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import siggen  # noqa: E402
+import sdr_server_amd as xl  # noqa: E402
+
+FS = 2016000
+out = {"device": xl.device_info()}
+
+
+def lpf(fs, cut, tw):
+    return xl.create_low_pass_filter(1.0, fs, cut, tw)[1]
+
+
+# ---- [1] drop-in single filter
+x = siggen.xs_u8(1, 262144)
+res = {}
+for rate, name in ((5, "505 taps"), (1, "101 taps")):
+    taps = lpf(FS, 24000, 48000 // rate)
+    for variant in ("native", "optimized"):
+        f = xl.XlatingFilter(42, taps, -12000, FS, 262144)
+        for _ in range(20):
+            f.process(variant, "cu8", "cf32", x)
+        t0 = time.perf_counter()
+        n = 300
+        for _ in range(n):
+            f.process(variant, "cu8", "cf32", x)
+        dt = (time.perf_counter() - t0) / n
+        f.close()
+        res[f"{name} {variant}"] = {"us_per_block": round(dt * 1e6, 1), "Msps": round(131072 / dt / 1e6, 1)}
+out["config1_single_client_dropin_process_cu8_cf32"] = res
+
+
+def run_batch(fs, fmt, nbytes_per_block, clients, blocks, steps=60, variant="optimized", host=False):
+    eng = xl.BatchEngine(fs, fmt, nbytes_per_block if fmt in ("cu8", "cs8") else nbytes_per_block)
+    for D, taps, fc in clients:
+        eng.add_client(D, taps, fc)
+    stream = torch.cuda.current_stream()
+    dev = [torch.from_numpy(b).cuda() for b in blocks]
+    nelem = blocks[0].size
+
+    def step(k):
+        if host:
+            eng.process_host(blocks[k % len(blocks)], variant)
+            eng.fetch()
+        else:
+            eng.process_device(dev[k % len(dev)].data_ptr(), nelem, variant, stream.cuda_stream)
+
+    for k in range(8):
+        step(k)
+    torch.cuda.synchronize()
+    eng.timing(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    nt, fir, _ = eng.timing_read()
+    eng.close()
+    return dt, fir / max(nt, 1)
+
+
+t48, t96 = lpf(FS, 24000, 9600), lpf(FS, 48000, 19200)
+blocks = [siggen.xs_u8(100 + k, 262144) for k in range(4)]
+S = 131072
+# ---- [2] 64 mixed clients
+cl = [((42, t48) if c % 2 == 0 else (21, t96)) + (-900000 + c * 28000,) for c in range(64)]
+dt, fir = run_batch(FS, "cu8", 262144, cl, blocks)
+out["config2_64_clients_mixed_48k_96k"] = {"ms_per_block": round(dt * 1e3, 4), "fir_launch_ms": round(fir, 4),
+                                           "Msps_all_clients": round(64 * S / dt / 1e6, 0)}
+# ---- [3] 128 and 1024 clients, 505 taps
+for n in (128, 1024):
+    cl = [(42, t48, -984000 + 1920 * c) for c in range(n)]
+    dt, fir = run_batch(FS, "cu8", 262144, cl, blocks)
+    out[f"config3_{n}_clients_48k_505taps"] = {"ms_per_block": round(dt * 1e3, 4), "fir_launch_ms": round(fir, 4),
+                                               "Msps_all_clients": round(n * S / dt / 1e6, 0)}
+# ---- PCIe-inclusive host path
+for n in (64, 1024):
+    cl = [(42, t48, -984000 + 1920 * c) for c in range(n)]
+    dt, fir = run_batch(FS, "cu8", 262144, cl, blocks, steps=30, host=True)
+    out[f"host_path_pcie_inclusive_{n}_clients"] = {"ms_per_block": round(dt * 1e3, 3), "Msps_all_clients": round(n * S / dt / 1e6, 0),
+                                                    "note": "process_host (H2D of the block) + fetch (D2H of every client's output), synchronous"}
+# ---- [4] cf32 10 Msps, D=100, 257 taps
+taps = siggen.hamming_sinc(257, 0.004)
+fblocks = [(siggen.xs_s16(300 + k, 2 * S).astype(np.float32) / np.float32(32768)) for k in range(3)]
+for n in (64, 256, 1024):
+    cl = [(100, taps, -4000000 + (8000000 // n) * c) for c in range(n)]
+    dt, fir = run_batch(10000000, "cf32", 2 * S, cl, fblocks)
+    bpu = 8 + 8 / 100
+    out[f"config4_cf32_10Msps_D100_257taps_{n}_clients"] = {
+        "ms_per_block": round(dt * 1e3, 4), "fir_launch_ms": round(fir, 4), "Msps_all_clients": round(n * S / dt / 1e6, 0),
+        "algorithmic_GBs_launch": round(n * S * bpu / (fir * 1e-3) / 1e9, 0), "hbm_frac_launch": round(n * S * bpu / (fir * 1e-3) / 8e12, 3)}
+print(json.dumps(out, indent=1))
