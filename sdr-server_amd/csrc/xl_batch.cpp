@@ -66,12 +66,12 @@ struct ClassState {
 
 struct Launch {
   int ct = 0;
-  int kt = 1;  // outputs per lane
   int nw = XL_NW_DEFAULT;  // waves (tiles) per workgroup
   uint32_t ota = 64;       // outputs per wave (smaller only when a 64-output window image exceeds the LDS)
   std::vector<XlGroup> groups;
   XlGroup *d_groups = nullptr;
-  size_t lds = 0, lds1 = 0, lds2 = 0;
+  size_t lds = 0;  // window image bytes of the launch (max over its groups)
+  uint32_t idle_waves = 0;  // spare waves over all groups (NCO rider slots per output tile)
   bool all_wide = true;  // every group has an even decimation
 };
 
@@ -120,10 +120,12 @@ struct xlating_batch_t {
 
   uint32_t exp_flags = 0;  // tuning knobs from XL_EXP_* environment variables
   bool exp_same_taps = false;
-  int exp_kt = 0;
   // Wave priority of the NCO role / NCO launch (3: a pure dependent chain must not queue behind the FIR waves;
   // 1..3 measured equal for 505 taps, 3 best for short filters).
   uint32_t nco_prio = 3;
+  uint32_t nco_wpw = 1;   // waves per NCO-role workgroup that carry clients
+  bool riders = true;     // NCO role rides in spare waves of the FIR workgroups when the plan has some
+  int riders_min_wgs = 512;
   int exp_h = 0;   // XL_EXP_H=8|9|10|12 forces the tile height of the large classes
   const char *exp_trace = nullptr;  // XL_EXP_TRACE=<file>: dump per-wave timestamps of the latest FIR launch
   unsigned long long *d_trace = nullptr;
@@ -214,11 +216,13 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   if (getenv("XL_EXP_PRIOQUARTERS")) b->exp_flags |= 4u;
   if (getenv("XL_EXP_PRIO4")) b->exp_flags |= 8u;  // default: segments end at 1/2, 3/4, 7/8
   if (getenv("XL_EXP_SAME_TAPS")) b->exp_same_taps = true;
-  if (getenv("XL_EXP_KT")) b->exp_kt = atoi(getenv("XL_EXP_KT"));
   if (getenv("XL_EXP_H")) b->exp_h = atoi(getenv("XL_EXP_H"));
   b->exp_trace = getenv("XL_EXP_TRACE");
   b->exp_nofuse = getenv("XL_EXP_NOFUSE") != nullptr;
   if (getenv("XL_EXP_NCOPRIO")) b->nco_prio = (uint32_t)atoi(getenv("XL_EXP_NCOPRIO")) & 3u;
+  if (getenv("XL_EXP_NCOWPW")) b->nco_wpw = (uint32_t)atoi(getenv("XL_EXP_NCOWPW"));
+  if (getenv("XL_EXP_RIDERS")) b->riders = atoi(getenv("XL_EXP_RIDERS")) != 0;
+  if (getenv("XL_EXP_RIDERS_MIN")) b->riders_min_wgs = atoi(getenv("XL_EXP_RIDERS_MIN"));
   b->last_stream = b->own_stream;
   *batch = b;
   return 0;
@@ -305,6 +309,19 @@ extern "C" int xlating_batch_remove_client(xlating_batch *b, int id) {
 }
 
 // (Re)build the resident plan: classes, tiles (register-tile heights 8/4/2/1), groups, tap image, NCO table.
+// NCO riders (xl_kernels.hip) pay in a window: the launch is one round of workgroups (all resident at once -- in a
+// multi-round launch the dispatcher evens things out by itself and riders, which sit in one XCD's share of the work
+// list, measured 5-12 % slower), and the FIR work of a SIMD clearly outlasts the chain (~18.5 ns per output; when the
+// chain is the critical path -- short filters, few clients -- it is quicker alone in workgroups of its own: no
+// staging first, 16 lanes).  Measured at 505 taps, D = 42: 384..1024 clients 3-8 % faster with riders; 101 taps
+// 25 % slower.
+static bool xl_riders_window(size_t wgs, int nw, uint32_t Tpad, int ct, uint32_t K, size_t lds, int min_wgs) {
+  const size_t cap = 256 * std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(lds, 1), 7));
+  const double fir_us = (double)wgs * nw / 1024.0 * (double)Tpad * ct * 8.0 / 2000.0;  // 4-cycle packed FMAs at ~2 GHz
+  const double chain_us = 0.0185 * (double)K;
+  return min_wgs <= 1 || (wgs >= (size_t)min_wgs && wgs <= cap && fir_us >= 1.3 * chain_us);
+}
+
 static int xl_batch_plan(xlating_batch *b) {
   xl_batch_sync_all(b);
   b->spec_valid = false;
@@ -357,7 +374,7 @@ static int xl_batch_plan(xlating_batch *b) {
     size_t lds1 = 0;
     for (size_t k = 0; k < members.size(); ++k)
       if (members[k].size() >= 8)
-        lds1 = std::max(lds1, xl_fir_lds_bytes(b->classes[k].D, xl_roundup(b->classes[k].T, 12), 1));
+        lds1 = std::max(lds1, xl_fir_lds_bytes_ota(b->classes[k].D, xl_roundup(b->classes[k].T, 12), 64));
     if (lds1 > 0) {
       const long slots = std::max<long>(1, std::min<long>((long)(160 * 1024 / lds1), 7));
       const long cap = slots * 256;
@@ -389,7 +406,7 @@ static int xl_batch_plan(xlating_batch *b) {
   std::vector<TileDesc> tiles_of[XL_NLAUNCH];
   for (int li = 0; li < XL_NLAUNCH; ++li) {
     b->launches[li].ct = kHeights[li];
-    b->launches[li].lds = b->launches[li].lds1 = b->launches[li].lds2 = 0;
+    b->launches[li].lds = 0;
     b->launches[li].nw = XL_NW_DEFAULT;
     b->launches[li].all_wide = true;
   }
@@ -427,8 +444,7 @@ static int xl_batch_plan(xlating_batch *b) {
         g->cls = td.cls;
         g->wide = (cs.D % 2 == 0) ? 1u : 0u;
         if (!g->wide) L.all_wide = false;
-        L.lds1 = std::max(L.lds1, xl_fir_lds_bytes(cs.D, Tpad, 1));
-        L.lds2 = std::max(L.lds2, xl_fir_lds_bytes(cs.D, Tpad, 2));
+        L.lds = std::max(L.lds, xl_fir_lds_bytes_ota(cs.D, Tpad, 64));
       }
       XlGroup *g = &L.groups[gi];
       XlTile &t = g->tiles[g->ntiles++];
@@ -448,14 +464,40 @@ static int xl_batch_plan(xlating_batch *b) {
       }
     }
   }
+  // ---- spare waves for the NCO riders (xl_kernels.hip): groups with fewer tiles than the launch has waves.  The
+  // launch that carries the role (the first one with groups) gets a spare wave by splitting its last full group
+  // into 3 + 1 tiles when it has none and the engine is big enough for the balance to matter.
+  {
+    bool first = true;
+    for (Launch &L : b->launches) {
+      if (L.groups.empty()) continue;
+      uint32_t idle = 0;
+      for (const XlGroup &g : L.groups) idle += (uint32_t)L.nw - g.ntiles;
+      const uint32_t kest = b->max_samples / L.groups[0].D + 1;
+      if (first && idle == 0 && b->riders && L.nw == XL_NW_MAX &&
+          xl_riders_window((L.groups.size() + 1) * ((kest + 63) / 64), L.nw, L.groups[0].Tpad, L.ct, kest, L.lds,
+                           b->riders_min_wgs)) {
+        XlGroup &last = L.groups.back();
+        XlGroup extra = last;
+        extra.ntiles = 1;
+        extra.tiles[0] = last.tiles[XL_NW_MAX - 1];
+        last.ntiles = XL_NW_MAX - 1;
+        L.groups.push_back(extra);
+      }
+      // (riders are only used in one-round launches -- xl_riders_window -- where every workgroup is dispatched within
+      // ~10 us of the start, so the groups with spare waves can stay where they are: last, which suits the tail)
+      idle = 0;
+      for (XlGroup &g : L.groups) {
+        g.idle_before = idle;
+        idle += (uint32_t)L.nw - g.ntiles;
+      }
+      L.idle_waves = idle;
+      first = false;
+    }
+  }
   for (Launch &L : b->launches) {
-    // One output per lane by default: PMC shows the KT=1 loop VALU-issue-bound (87 % VALU busy at 6 waves/SIMD),
-    // and KT=2 (half the scalar tap traffic per FMA, but half the resident waves) measured slower.
-    // XL_EXP_KT=2 selects it for tuning.
-    L.kt = (b->exp_kt == 2 && L.lds2 > 0 && L.lds2 <= 160 * 1024) ? 2 : 1;
-    L.lds = L.kt == 2 ? L.lds2 : L.lds1;
     L.ota = 64;
-    if (L.kt == 1 && L.lds1 > 160 * 1024) {  // huge decimation: fewer active lanes per wave so that the image fits
+    if (L.lds > 160 * 1024) {  // huge decimation: fewer active lanes per wave so that the window image fits
       for (L.ota = 32; L.ota >= 8; L.ota >>= 1) {
         size_t need = 0;
         for (const XlGroup &g : L.groups) need = std::max(need, xl_fir_lds_bytes_ota(g.D, g.Tpad, L.ota));
@@ -610,9 +652,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         a.fmt = b->fmt;
         a.groups = L.d_groups;
         a.ngroups = (uint32_t)L.groups.size();
-        a.groups_per_xcd = (a.ngroups + 7) / 8;
         a.ota = L.ota;
-        a.xtiles = L.kt == 2 ? (maxK + 127) / 128 : (maxK + L.ota - 1) / L.ota;
+        a.xtiles = (maxK + L.ota - 1) / L.ota;
         // wave-priority segments pay when the launch is about one round of workgroups, and cost when new
         // workgroups keep arriving (they would outrank nearly finished ones): enable up to two rounds
         const size_t wgs = (size_t)a.ngroups * a.xtiles;
@@ -630,7 +671,16 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
           if (fuse) {
             a.nco_clients = b->d_nco;
             a.nco_nclients = (uint32_t)b->nco.size();
-            a.nco_blocks = (a.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
+            const uint32_t slots = L.idle_waves * a.xtiles;
+            const uint32_t want = (a.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
+            if (b->riders && slots > 0 && (uint64_t)slots * 64u >= a.nco_nclients &&
+                xl_riders_window(wgs, L.nw, L.groups[0].Tpad, L.ct, maxK, L.lds, b->riders_min_wgs)) {
+              a.nco_slots = std::min(slots, want);
+              a.nco_lanes = (a.nco_nclients + a.nco_slots - 1) / a.nco_slots;
+            } else {
+              a.nco_wpw = std::max<uint32_t>(1, std::min<uint32_t>(b->nco_wpw, (uint32_t)L.nw));
+              a.nco_blocks = (a.nco_nclients + XL_NCO_LANES * a.nco_wpw - 1) / (XL_NCO_LANES * a.nco_wpw);
+            }
             a.nco_state_in = b->d_phase[b->pcur];
             a.nco_state_out = b->d_phase[b->pcur ^ 1];
             a.nco_tab = b->d_phtab[tab ^ 1];
@@ -649,7 +699,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
           XL_TRY(hipMemsetAsync(b->d_trace, 0, trace_n * sizeof(unsigned long long), s));
           a.trace = b->d_trace;
         }
-        XL_TRY(xl_launch_fir(L.ct, mode, L.kt, L.nw, a, dyn, next, L.lds, s));
+        XL_TRY(xl_launch_fir(L.ct, mode, L.nw, a, dyn, next, L.lds, s));
         if (b->exp_trace) {
           std::vector<unsigned long long> h(trace_n);
           XL_TRY(hipStreamSynchronize(s));

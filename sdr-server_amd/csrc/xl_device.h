@@ -37,7 +37,8 @@ struct XlGroup {
   uint32_t cls;                  // index into XlDynArgs::d
   uint32_t ntiles;               // 1..XL_NW_MAX (<= waves of the launch)
   uint32_t wide;                 // 1: D even (informational; the launch-level flag selects the 16-byte read kernel)
-  uint32_t pad0, pad1;
+  uint32_t idle_before;          // spare waves (launch waves - ntiles) of the groups before this one: rider slot base
+  uint32_t pad1;
   XlTile tiles[XL_NW_MAX];
 };
 
@@ -67,10 +68,9 @@ struct XlFirArgs {
   int fmt;              // XLF_*
   const XlGroup *groups;
   uint32_t ngroups;
-  uint32_t groups_per_xcd;  // (unused by the kernel since the work list is cut evenly across XCDs)
   uint32_t xtiles;      // ceil(max K / outputs per tile)
   uint32_t ota;         // outputs per wave: 64, or 32/16/8 (upper lanes idle) when a 64-output window image would
-                        // not fit the LDS (very large decimations); kt must be 1 when ota < 64
+                        // not fit the LDS (very large decimations)
   uint32_t flags;       // bit 0: every group of the launch has even D (16-byte LDS reads); bit 1: flat wave priority; bit 2: priority segments end at 1/2, 3/4, 7/8
   const float2 *taps;   // tap image
   const float2 *phtab;  // NCO phase table, indexed like out
@@ -82,7 +82,12 @@ struct XlFirArgs {
   // filtering (xl_batch.cpp).  All null/0 when the launch carries no NCO role.
   const XlNcoClient *nco_clients;
   uint32_t nco_nclients;
-  uint32_t nco_blocks;
+  uint32_t nco_blocks;   // = ceil(nco_nclients / (XL_NCO_LANES * nco_wpw))
+  uint32_t nco_wpw;      // waves of an NCO-role workgroup that carry clients (1..waves per workgroup)
+  // "riders": instead of workgroups of its own the NCO role rides in the spare waves of groups with fewer tiles than
+  // the launch has waves (slot = (idle_before + wave - ntiles) * xtiles + x); slots < nco_slots carry nco_lanes clients.
+  uint32_t nco_lanes;    // 0: no riders (nco_blocks workgroups do the role, if any)
+  uint32_t nco_slots;
   const float2 *nco_state_in;
   float2 *nco_state_out;
   float2 *nco_tab;
@@ -92,11 +97,11 @@ struct XlFirArgs {
 
 // ---- launchers (xl_kernels.hip).  All return hipError_t of the launch. -------------------------------------
 // mode: 0 native (bit-exact scalar order, unfused), 1 optimized (fma).  ct: 1, 2, 4, 8, 9, 10 or 12 clients per tile.
-// kt: 1 or 2 outputs per lane; a.xtiles = ceil(max K / (64 * kt)); lds_bytes = xl_fir_lds_bytes(D, Tpad, kt).
+// a.xtiles = ceil(max K / a.ota); lds_bytes = xl_fir_lds_bytes_ota(D, Tpad, a.ota) maximised over the groups.
 // nw: waves per workgroup (>= the largest ntiles of the groups).
 // dyn_next: per-class numbers of the NEXT block, used only by the NCO role (a.nco_blocks > 0); may alias dyn.
-hipError_t xl_launch_fir(int ct, int mode, int kt, int nw, const XlFirArgs &a, const XlDynArgs &dyn,
-                         const XlDynArgs &dyn_next, size_t lds_bytes, hipStream_t s);
+hipError_t xl_launch_fir(int ct, int mode, int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next,
+                         size_t lds_bytes, hipStream_t s);
 #define XL_NCO_LANES 16u  // clients per workgroup in the NCO table kernel / NCO role
 // reads the running phases from state_in[slot], writes the post-block phases to state_out[slot] (may alias).
 // Every client's out_off must be even (16-byte table stores).  prio: wave priority 0..3 of the kernel.
@@ -116,8 +121,7 @@ hipError_t xl_launch_nco_table_q15(int16_t incr_re, int16_t incr_im, short2 *pha
 hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T, uint32_t D, uint32_t K,
                              const short2 *phtab, short2 *out, hipStream_t s);
 
-size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad, int kt);
-// window image bytes for `ota` outputs per tile (kt = 1)
+// window image bytes for `ota` outputs per tile
 size_t xl_fir_lds_bytes_ota(uint32_t D, uint32_t Tpad, uint32_t ota);
 // largest outputs-per-wave in {64, 32, 16, 8} whose window image fits `budget` bytes of LDS; 0 if none
 uint32_t xl_fir_pick_ota(uint32_t D, uint32_t Tpad, size_t budget);

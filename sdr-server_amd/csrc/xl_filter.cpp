@@ -213,14 +213,13 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     a.fmt = XLF_CF32;
     a.groups = f->d_group;
     a.ngroups = 1;
-    a.groups_per_xcd = 1;
     a.ota = f->ota;
     a.xtiles = (uint32_t)((K + f->ota - 1) / f->ota);
     a.flags = ((f->D % 2 == 0) ? 1u : 0u) | 4u;
     a.taps = f->d_taps;
     a.phtab = f->d_phtab;
     a.out = f->d_out_f;
-    XL_TRY(xl_launch_fir(1, mode, 1, XL_NW_DEFAULT, a, dyn, dyn, xl_fir_lds_bytes_ota(f->D, f->Tpad, f->ota), f->stream));
+    XL_TRY(xl_launch_fir(1, mode, XL_NW_DEFAULT, a, dyn, dyn, xl_fir_lds_bytes_ota(f->D, f->Tpad, f->ota), f->stream));
     XL_TRY(hipMemcpyAsync(f->h_out_f, f->d_out_f, K * sizeof(float2), hipMemcpyDeviceToHost, f->stream));
   }
   {

@@ -217,17 +217,16 @@ XL_DEV void xl_stage_window(const XlFirArgs &a, const uint32_t zero_below, const
 }
 
 // ------------------------------------------------------------------------------------------- the FIR kernel
-// KT = outputs per lane (lane l of output tile x owns outputs x*64*KT + l + 64*j, j < KT).  Every scalar tap
-// fetch feeds KT*CT complex MACs per lane: KT = 2 halves the scalar-cache traffic per FMA, which is what
-// bounds KT = 1 (measured: ~3.7 B/clk/CU of missing s_load traffic vs 3.8 needed at full VALU rate).
+// (A two-outputs-per-lane variant -- half the scalar tap traffic per FMA, which at ~3.7 B/clk/CU of missing s_load
+// traffic sits right behind the VALU as the second ceiling -- was measured slower: it halves the resident waves.)
 // SGPR cap 96: 64 hold one batch of taps; at <= 96 the CU admits 7 waves per SIMD instead of 6 (the allocation
 // granule is 16 and 800 SGPRs serve a SIMD), which lets a 5-wave-per-workgroup launch keep 25 waves per CU.
-template <int CT, int MODE, int KT, bool WIDE>
+template <int CT, int MODE, bool WIDE>
 __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))) void xl_fir_kernel(
     const XlFirArgs a, const XlDynArgs dyn, const XlDynArgs dyn_next) {
   extern __shared__ __attribute__((aligned(16))) v2f xl_win[];
-  // outputs per tile: 64 per lane-slot, or fewer active lanes (a.ota = 32/16/8, KT = 1) for huge decimations
-  const uint32_t OT = (KT == 1) ? a.ota : 64u * KT;
+  // outputs per tile: 64 (one per lane), or fewer active lanes (a.ota = 32/16/8) for huge decimations
+  const uint32_t OT = a.ota;
 
   // ---- NCO role: the first nco_blocks workgroups tabulate the NEXT block's phases (data independent float32
   // recurrence, xlating.c:70-73) while the rest of this launch filters the current block.  One launch per block
@@ -237,15 +236,16 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
     if (((a.flags >> 4) & 3u) == 3u) __builtin_amdgcn_s_setprio(3);
     else if (((a.flags >> 4) & 3u) == 2u) __builtin_amdgcn_s_setprio(2);
     else if (((a.flags >> 4) & 3u) == 1u) __builtin_amdgcn_s_setprio(1);
-    if (threadIdx.x < XL_NCO_LANES) {
+    const uint32_t nwave = threadIdx.x >> 6, nlane = threadIdx.x & 63u;
+    if (nwave < a.nco_wpw && nlane < XL_NCO_LANES) {
       const unsigned long long t0 = a.trace ? wall_clock64() : 0ull;
-      const uint32_t c = blockIdx.x * XL_NCO_LANES + threadIdx.x;
+      const uint32_t c = (blockIdx.x * a.nco_wpw + nwave) * XL_NCO_LANES + nlane;
       if (c < a.nco_nclients) {
         const XlNcoClient k = a.nco_clients[c];
         xl_nco_client(k, dyn_next.d[k.cls].K, a.nco_state_in, a.nco_state_out, a.nco_tab);
       }
-      if (a.trace && threadIdx.x == 0) {  // tuning: stamp the NCO-role wave (stamps 1, 2 stay 0 = "NCO role")
-        unsigned long long *tn = a.trace + (size_t)blockIdx.x * XL_NW_MAX * 6;
+      if (a.trace && nlane == 0) {  // tuning: stamp the NCO-role wave (stamps 1, 2 stay 0 = "NCO role")
+        unsigned long long *tn = a.trace + ((size_t)blockIdx.x * XL_NW_MAX + nwave) * 6;
         tn[0] = t0;
         tn[3] = wall_clock64();
         tn[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
@@ -293,19 +293,47 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   const uint32_t D = g[0], Tpad = g[2], cls = g[3], ntiles = g[4];
   const XlDyn d = dyn.d[cls];
   const uint32_t K = d.K;
-  if (x * OT >= K) return;
+  const bool live = x * OT < K;
+  if (!live && a.nco_lanes == 0u) return;
 
   // ---- stage the window image: samples [win0, win0 + (OT-1)*D + Tpad) of the stream [in0 | in1], as cf32
-  const uint32_t win0 = d.base + x * OT * D;
-  const uint32_t wlen = (OT - 1u) * D + Tpad;
-  if (a.fmt == XLF_CU8) xl_stage_window<XLF_CU8>(a, d.zero_below, win0, wlen, xl_win);
-  else if (a.fmt == XLF_CS8) xl_stage_window<XLF_CS8>(a, d.zero_below, win0, wlen, xl_win);
-  else if (a.fmt == XLF_CS16) xl_stage_window<XLF_CS16>(a, d.zero_below, win0, wlen, xl_win);
-  else xl_stage_window<XLF_CF32>(a, d.zero_below, win0, wlen, xl_win);
+  if (live) {
+    const uint32_t win0 = d.base + x * OT * D;
+    const uint32_t wlen = (OT - 1u) * D + Tpad;
+    if (a.fmt == XLF_CU8) xl_stage_window<XLF_CU8>(a, d.zero_below, win0, wlen, xl_win);
+    else if (a.fmt == XLF_CS8) xl_stage_window<XLF_CS8>(a, d.zero_below, win0, wlen, xl_win);
+    else if (a.fmt == XLF_CS16) xl_stage_window<XLF_CS16>(a, d.zero_below, win0, wlen, xl_win);
+    else xl_stage_window<XLF_CF32>(a, d.zero_below, win0, wlen, xl_win);
+  }
   __syncthreads();
 
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (w >= ntiles) return;
+  if (w >= ntiles) {
+    // ---- NCO rider: a wave this group has no tile for tabulates the NEXT block's phases of nco_lanes clients.
+    // It shares its SIMD with one FIR wave fewer than the others do, which is about what the chain costs the SIMD
+    // (3 packed ops per step at top priority ~ a third of the issue slots for ~57 us ~ one FIR wave): workgroups
+    // of their own for the role put it ON TOP of a full set of FIR waves and those finished ~18 us late.
+    const uint32_t nlane = threadIdx.x & 63u;
+    const uint32_t slot = (g[6] + (w - ntiles)) * a.xtiles + x;
+    if (a.nco_lanes != 0u && slot < a.nco_slots && nlane < a.nco_lanes) {
+      __builtin_amdgcn_s_setprio(3);  // a pure dependent chain: must not starve behind the FIR waves
+      const unsigned long long t0 = a.trace ? wall_clock64() : 0ull;
+      const uint32_t c = slot * a.nco_lanes + nlane;
+      if (c < a.nco_nclients) {
+        const XlNcoClient k = a.nco_clients[c];
+        xl_nco_client(k, dyn_next.d[k.cls].K, a.nco_state_in, a.nco_state_out, a.nco_tab);
+      }
+      if (a.trace && nlane == 0) {
+        unsigned long long *tn = a.trace + ((size_t)blockIdx.x * XL_NW_MAX + w) * 6;
+        tn[0] = t0;
+        tn[3] = wall_clock64();
+        tn[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        tn[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+      }
+    }
+    return;
+  }
+  if (!live) return;
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long *tr = a.trace ? a.trace + ((size_t)blockIdx.x * XL_NW_MAX + w) * 6 : nullptr;
   if (tr && lane == 0) {
@@ -318,16 +346,13 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   const uint32_t ncl = t[1];
   const cfloat_p tp = (cfloat_p)(uintptr_t)(a.taps + t[0]);
 
-  XlAcc<MODE> acc[KT][CT];
+  XlAcc<MODE> acc[CT];
 #pragma unroll
-  for (int j = 0; j < KT; ++j)
-#pragma unroll
-    for (int c = 0; c < CT; ++c) acc[j][c].clear();
+  for (int c = 0; c < CT; ++c) acc[c].clear();
 
   constexpr int STEP = (CT == 9 || CT == 10) ? 6 : 4;  // taps per iteration (xl_tap_step): ~60 tap SGPRs in flight
   // idle lanes (lane >= OT when ota < 64) alias lane 0's window so that their reads stay inside the image
-  const v2f *lp = xl_win + ((KT == 1 && lane >= OT) ? 0u : lane) * D;
-  const uint32_t jstride = 64u * D;  // samples between the windows of a lane's outputs (KT = 2 only)
+  const v2f *lp = xl_win + (lane >= OT ? 0u : lane) * D;
   // The tap loop runs in segments of falling wave priority.  The SIMD arbiter otherwise favours the oldest wave,
   // so co-resident waves -- which all have the same work -- finish one after another and the last ones run alone,
   // latency-bound (measured: identical waves ending between 57 and 142 us of a 144 us launch).  With priority =
@@ -336,24 +361,20 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   // one quarter of the tap loop; WIDE (even D: lane*D and 64*D even) reads 16-byte aligned pairs of samples
 #define XL_TAP_LOOP(I0, I1)                                                                       \
   for (uint32_t i = (I0); i < (I1); i += STEP) {                                                  \
-    v2f xs[KT][STEP];                                                                             \
-    _Pragma("unroll") for (int j = 0; j < KT; ++j) {                                              \
-      if (WIDE) {                                                                                 \
-        _Pragma("unroll") for (int u = 0; u < STEP; u += 2) {                                     \
-          const v4f q = *reinterpret_cast<const v4f *>(lp + j * jstride + i + u);                 \
-          xs[j][u] = (v2f){q.x, q.y};                                                             \
-          xs[j][u + 1] = (v2f){q.z, q.w};                                                         \
-        }                                                                                         \
-      } else {                                                                                    \
-        _Pragma("unroll") for (int u = 0; u < STEP; ++u) xs[j][u] = lp[j * jstride + i + u];      \
+    v2f xs[STEP];                                                                                 \
+    if (WIDE) {                                                                                   \
+      _Pragma("unroll") for (int u = 0; u < STEP; u += 2) {                                       \
+        const v4f q = *reinterpret_cast<const v4f *>(lp + i + u);                                 \
+        xs[u] = (v2f){q.x, q.y};                                                                  \
+        xs[u + 1] = (v2f){q.z, q.w};                                                              \
       }                                                                                           \
+    } else {                                                                                      \
+      _Pragma("unroll") for (int u = 0; u < STEP; ++u) xs[u] = lp[i + u];                         \
     }                                                                                             \
     const cfloat_p tq = tp + (size_t)i * (2 * CT);                                                \
     _Pragma("unroll") for (int u = 0; u < STEP; ++u) {                                            \
-      _Pragma("unroll") for (int c = 0; c < CT; ++c) {                                            \
-        const float hr = tq[(u * CT + c) * 2], hi = tq[(u * CT + c) * 2 + 1];                     \
-        _Pragma("unroll") for (int j = 0; j < KT; ++j) acc[j][c].mac(xs[j][u], hr, hi);           \
-      }                                                                                           \
+      _Pragma("unroll") for (int c = 0; c < CT; ++c)                                              \
+        acc[c].mac(xs[u], tq[(u * CT + c) * 2], tq[(u * CT + c) * 2 + 1]);                        \
     }                                                                                             \
   }
   if (a.flags & 2u) {  // flat priority (multi-round launches, tuning)
@@ -394,15 +415,14 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   // ---- epilogue: derotate with the tabulated NCO phase and store (coalesced: lanes = consecutive outputs)
   const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
   v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
-#pragma unroll
-  for (int j = 0; j < KT; ++j) {
-    const uint32_t m = x * OT + 64u * j + lane;
-    if (m < K && (KT != 1 || lane < OT)) {
+  {
+    const uint32_t m = x * OT + lane;
+    if (m < K && lane < OT) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         if ((uint32_t)c < ncl) {
           const uint32_t off = t[2 + c] + m;
-          out[off] = xl_rotate<MODE>(acc[j][c].value(), ph[off]);
+          out[off] = xl_rotate<MODE>(acc[c].value(), ph[off]);
         }
       }
     }
@@ -411,10 +431,6 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
     __builtin_amdgcn_s_waitcnt(0);
     tr[3] = wall_clock64();
   }
-}
-
-size_t xl_fir_lds_bytes(uint32_t D, uint32_t Tpad, int kt) {
-  return (size_t)((64u * kt - 1u) * D + Tpad) * sizeof(v2f);
 }
 
 size_t xl_fir_lds_bytes_ota(uint32_t D, uint32_t Tpad, uint32_t ota) {
@@ -427,65 +443,52 @@ uint32_t xl_fir_pick_ota(uint32_t D, uint32_t Tpad, size_t budget) {
   return 0;
 }
 
-template <int CT, int MODE, int KT, bool WIDE>
+template <int CT, int MODE, bool WIDE>
 static hipError_t xl_fir_go2(int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, size_t lds,
                              hipStream_t s) {
   static bool attr_done = false;  // per instantiation; benign race (idempotent)
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&xl_fir_kernel<CT, MODE, KT, WIDE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&xl_fir_kernel<CT, MODE, WIDE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const uint32_t nblocks = a.nco_blocks + 8u * ((a.ngroups * a.xtiles + 7u) / 8u);
   if (nblocks == 0) return hipSuccess;
-  hipLaunchKernelGGL((xl_fir_kernel<CT, MODE, KT, WIDE>), dim3(nblocks), dim3(64 * nw), lds, s, a, dyn, dyn_next);
+  hipLaunchKernelGGL((xl_fir_kernel<CT, MODE, WIDE>), dim3(nblocks), dim3(64 * nw), lds, s, a, dyn, dyn_next);
   return hipGetLastError();
 }
 
 // a.flags bit 0 set by the caller = every group of the launch has an even decimation -> 16-byte LDS reads
-template <int CT, int MODE, int KT>
+template <int CT, int MODE>
 static hipError_t xl_fir_go(int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, size_t lds,
                             hipStream_t s) {
-  return (a.flags & 1u) ? xl_fir_go2<CT, MODE, KT, true>(nw, a, dyn, dyn_next, lds, s)
-                        : xl_fir_go2<CT, MODE, KT, false>(nw, a, dyn, dyn_next, lds, s);
+  return (a.flags & 1u) ? xl_fir_go2<CT, MODE, true>(nw, a, dyn, dyn_next, lds, s)
+                        : xl_fir_go2<CT, MODE, false>(nw, a, dyn, dyn_next, lds, s);
 }
 
-template <int KT>
-static hipError_t xl_fir_dispatch(int ct, int mode, int nw, const XlFirArgs &a, const XlDynArgs &dyn,
-                                  const XlDynArgs &dyn_next, size_t lds, hipStream_t s) {
-  switch (ct * 2 + (mode ? 1 : 0)) {
-    case 2: return xl_fir_go<1, 0, KT>(nw, a, dyn, dyn_next, lds, s);
-    case 3: return xl_fir_go<1, 1, KT>(nw, a, dyn, dyn_next, lds, s);
-    case 4: return xl_fir_go<2, 0, KT>(nw, a, dyn, dyn_next, lds, s);
-    case 5: return xl_fir_go<2, 1, KT>(nw, a, dyn, dyn_next, lds, s);
-    case 8: return xl_fir_go<4, 0, KT>(nw, a, dyn, dyn_next, lds, s);
-    case 9: return xl_fir_go<4, 1, KT>(nw, a, dyn, dyn_next, lds, s);
-    case 16: return xl_fir_go<8, 0, KT>(nw, a, dyn, dyn_next, lds, s);
-    case 17: return xl_fir_go<8, 1, KT>(nw, a, dyn, dyn_next, lds, s);
-    default: break;
-  }
-  if (KT != 1) return hipErrorInvalidValue;  // the tall tiles exist for one output per lane only
-  switch (ct * 2 + (mode ? 1 : 0)) {
-    case 18: return xl_fir_go<9, 0, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 19: return xl_fir_go<9, 1, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 20: return xl_fir_go<10, 0, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 21: return xl_fir_go<10, 1, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 24: return xl_fir_go<12, 0, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 25: return xl_fir_go<12, 1, 1>(nw, a, dyn, dyn_next, lds, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-// a.xtiles must be ceil(max K / (64 * kt))
-hipError_t xl_launch_fir(int ct, int mode, int kt, int nw, const XlFirArgs &a, const XlDynArgs &dyn,
-                         const XlDynArgs &dyn_next, size_t lds, hipStream_t s) {
+// a.xtiles must be ceil(max K / a.ota)
+hipError_t xl_launch_fir(int ct, int mode, int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next,
+                         size_t lds, hipStream_t s) {
   if (lds > 160 * 1024 || nw < 1 || nw > XL_NW_MAX) return hipErrorInvalidValue;
   if (a.ota != 64 && a.ota != 32 && a.ota != 16 && a.ota != 8) return hipErrorInvalidValue;
-  if (kt != 1 && a.ota != 64) return hipErrorInvalidValue;
-  if (kt == 1) return xl_fir_dispatch<1>(ct, mode, nw, a, dyn, dyn_next, lds, s);
-  if (kt == 2) return xl_fir_dispatch<2>(ct, mode, nw, a, dyn, dyn_next, lds, s);
-  return hipErrorInvalidValue;
+  switch (ct * 2 + (mode ? 1 : 0)) {
+    case 2: return xl_fir_go<1, 0>(nw, a, dyn, dyn_next, lds, s);
+    case 3: return xl_fir_go<1, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 4: return xl_fir_go<2, 0>(nw, a, dyn, dyn_next, lds, s);
+    case 5: return xl_fir_go<2, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 8: return xl_fir_go<4, 0>(nw, a, dyn, dyn_next, lds, s);
+    case 9: return xl_fir_go<4, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 16: return xl_fir_go<8, 0>(nw, a, dyn, dyn_next, lds, s);
+    case 17: return xl_fir_go<8, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 18: return xl_fir_go<9, 0>(nw, a, dyn, dyn_next, lds, s);
+    case 19: return xl_fir_go<9, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 20: return xl_fir_go<10, 0>(nw, a, dyn, dyn_next, lds, s);
+    case 21: return xl_fir_go<10, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 24: return xl_fir_go<12, 0>(nw, a, dyn, dyn_next, lds, s);
+    case 25: return xl_fir_go<12, 1>(nw, a, dyn, dyn_next, lds, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 // (NCO phase-table code: see above the FIR kernel)

@@ -243,6 +243,48 @@ def test_full_size_1024_clients_properties():
     eng.close()
 
 
+@pytest.mark.parametrize("nclients", [13, 24, 70])
+def test_nco_riders_forced_small(nclients, monkeypatch):
+    """The NCO role riding in the spare waves of partially filled workgroups (xl_kernels.hip "riders"; normally only
+    chosen for ~400-1200 clients) forced on for small engines, so that the oracle can check EVERY client: the tables
+    the riders tabulate ahead must be the reference's recurrence (xlating.c:70-73) bit for bit, through ragged
+    block lengths (wrong length guess -> stand-alone tabulation) and a mixed-rate class."""
+    monkeypatch.setenv("XL_EXP_RIDERS_MIN", "1")
+    t48, t96 = lpf(FS, 24000, 9600), lpf(FS, 48000, 19200)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    oracles = {}
+    for c in range(nclients):
+        fc = -900000 + c * 25000
+        D, taps = (21, t96) if (nclients == 70 and c % 7 == 3) else (42, t48)
+        cid = eng.add_client(D, taps, fc)
+        oracles[cid] = Oracle(D, taps, fc, FS, 262144)
+    for k, n in enumerate((262144, 262144, 100002, 100002, 262144, 262144)):
+        check_clients(eng, oracles, "cu8", siggen.xs_u8(siggen.XS_SEED + 40 + k, n), "native" if k != 4 else "optimized")
+    eng.close()
+
+
+def test_1000_clients_split_group_riders():
+    """1000 clients = exactly 25 full groups of 4 x 10: the planner splits the last group 3 + 1 to make room for the
+    riders.  Duplicates must agree bit for bit and 12 sampled clients must match the oracle over three blocks."""
+    taps = lpf(FS, 24000, 9600)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    fcs = [-984000 + 1920 * (c % 500) for c in range(1000)]
+    for fc in fcs:
+        eng.add_client(42, taps, fc)
+    sample = [0, 9, 10, 499, 500, 959, 960, 969, 970, 989, 990, 999]
+    oracles = {c: Oracle(42, taps, fcs[c], FS, 262144) for c in sample}
+    for k in range(3):
+        x = siggen.xs_u8(7000 + k, 262144)
+        eng.process_host(x, "native")
+        eng.fetch()
+        outs = [eng.output(c) for c in range(1000)]
+        for c in range(500):
+            assert bits_equal(outs[c], outs[c + 500]), c
+        for c in sample:
+            assert bits_equal(outs[c], oracles[c].process("cu8", x)), c
+    eng.close()
+
+
 def test_bench_block_feeder_stream_plumbing():
     """bench.py's multi-GPU feed (broadcast of block k+1 on a side stream while block k is filtered, two receive
     buffers, event-ordered reuse) with a stand-in for torch.distributed whose broadcast is the identity (this box has
