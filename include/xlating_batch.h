@@ -84,6 +84,11 @@ int xlating_batch_sync(xlating_batch *batch);
 int xlating_batch_timing(xlating_batch *batch, int enable);
 int xlating_batch_timing_read(xlating_batch *batch, double *fir_ms_total, double *nco_ms_total, int reset);
 
+/* One-line description of the resident plan (builds it if clients changed), e.g.
+ * "clients 1024 classes 1 | direct: h10 x 104 groups | polyphase: cls0 D42 T505 cols1024 V244".  For logs and tests:
+ * which arithmetic path the optimized mode takes for which class.  Returns the length written (excluding NUL). */
+int xlating_batch_describe(xlating_batch *batch, char *buf, size_t buf_len);
+
 void xlating_batch_destroy(xlating_batch *batch);
 
 /* Build/selection information, e.g. "HIP gfx950 (AMD Instinct MI355X), 256 CUs". Never NULL. */

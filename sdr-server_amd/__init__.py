@@ -36,7 +36,8 @@ EXPORTED_SYMBOLS = (
     + ["xlating_batch_create", "xlating_batch_add_client", "xlating_batch_remove_client", "xlating_batch_num_clients",
        "xlating_batch_process_host", "xlating_batch_process_device", "xlating_batch_output_len", "xlating_batch_fetch",
        "xlating_batch_output_host", "xlating_batch_output_device", "xlating_batch_client_phase", "xlating_batch_sync",
-       "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_destroy", "xlating_hip_device_info"]
+       "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_describe", "xlating_batch_destroy",
+       "xlating_hip_device_info"]
 )
 
 _lib = None
@@ -95,6 +96,8 @@ def lib():
     L.xlating_batch_timing.restype = C.c_int
     L.xlating_batch_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
     L.xlating_batch_timing_read.restype = C.c_int
+    L.xlating_batch_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.xlating_batch_describe.restype = C.c_int
     L.xlating_batch_destroy.argtypes = [C.c_void_p]
     L.xlating_batch_destroy.restype = None
     L.xlating_hip_device_info.argtypes = []
@@ -264,6 +267,14 @@ class BatchEngine:
 
     def timing(self, enable):
         lib().xlating_batch_timing(self.h, 1 if enable else 0)
+
+    def describe(self):
+        """The resident plan in one line (which classes take which arithmetic path)."""
+        buf = C.create_string_buffer(1024)
+        n = lib().xlating_batch_describe(self.h, buf, 1024)
+        if n < 0:
+            raise XlatingError("xlating_batch_describe", n)
+        return buf.value.decode()
 
     def timing_read(self, reset=True):
         """-> (n_timed_blocks, fir_ms_total, nco_ms_total)"""

@@ -34,12 +34,14 @@
 #include <algorithm>
 #include <map>
 #include <new>
+#include <string>
 #include <tuple>
 #include <vector>
 
 #include "../../include/xlating_batch.h"
 #include "xl_common.h"
 #include "xl_device.h"
+#include "xl_polyphase.h"
 #include "xl_taps.h"
 
 #define XL_NLAUNCH 7
@@ -75,6 +77,16 @@ struct Launch {
   bool all_wide = true;  // every group has an even decimation
 };
 
+// A class of clients evaluated by the polyphase overlap-save path (xl_polyphase.hip) in optimized mode.
+struct PolyClass {
+  uint32_t cls = 0, D = 0, Dpad = 0, T = 0, A = 0, V = 0;
+  uint32_t ncols = 0, nsg = 0, nseg_cap = 0;
+  float2 *d_R = nullptr;     // branch spectra [nsg][Dpad][M][256] (+ XLP_BSTEP rows of tail padding)
+  float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
+  float2 *d_Y = nullptr;     // mixed spectra  [nsg][nseg_cap][M][256]
+  uint32_t *d_col = nullptr; // column -> output row offset
+};
+
 }  // namespace
 
 struct xlating_batch_t {
@@ -90,7 +102,15 @@ struct xlating_batch_t {
   int nalive = 0;
   bool dirty = true;
   std::vector<ClassState> classes;
-  Launch launches[XL_NLAUNCH];  // one per register-tile height 12, 10, 9, 8, 4, 2, 1
+  Launch launches[XL_NLAUNCH];  // one per register-tile height 12, 10, 9, 8, 4, 2, 1: ALL clients (native mode)
+  Launch launches_rest[XL_NLAUNCH];  // same, over the classes that are not in `poly` (optimized mode)
+  std::vector<PolyClass> poly;       // classes on the polyphase overlap-save path in optimized mode
+  float2 *d_W = nullptr;             // e^{-2 pi j n/256}
+  float2 *d_phase_run = nullptr;     // running phases between the NCO slices of a block
+  size_t phase_run_cap = 0;
+  int poly_mode = -1;        // XL_EXP_POLY: 0 never, 1 whenever the shape allows, -1 (default) by the size rule
+  uint32_t poly_min_clients = 96;
+  uint32_t poly_slice1 = 6000, poly_slice2 = 42000;  // NCO slice boundaries in 1/65536 of the block (forward | mix | inverse)
   std::vector<XlNcoClient> nco;
   size_t out_total = 0;
   uint64_t nblk = 0;  // blocks processed
@@ -153,11 +173,19 @@ static void xl_batch_sync_all(xlating_batch *b) {
 }
 
 static void xl_batch_free_plan(xlating_batch *b) {
-  for (Launch &l : b->launches) {
-    if (l.d_groups) (void)hipFree(l.d_groups);
-    l.d_groups = nullptr;
-    l.groups.clear();
+  for (Launch *set : {b->launches, b->launches_rest})
+    for (int i = 0; i < XL_NLAUNCH; ++i) {
+      Launch &l = set[i];
+      if (l.d_groups) (void)hipFree(l.d_groups);
+      l.d_groups = nullptr;
+      l.groups.clear();
+    }
+  for (PolyClass &pc : b->poly) {
+    void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_col};
+    for (void *q : dev)
+      if (q) (void)hipFree(q);
   }
+  b->poly.clear();
   if (b->d_taps) (void)hipFree(b->d_taps);
   if (b->d_nco) (void)hipFree(b->d_nco);
   b->d_taps = nullptr;
@@ -170,7 +198,8 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   xl_batch_sync_all(b);
   xl_batch_free_plan(b);
   void *dev[] = {b->d_hist[0],  b->d_hist[1],  b->d_block,  b->d_phase[0], b->d_phase[1],
-                 b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_trace};
+                 b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_trace,
+                 b->d_W,        b->d_phase_run};
   for (void *p : dev)
     if (p) (void)hipFree(p);
   if (b->h_block) (void)hipHostFree(b->h_block);
@@ -223,6 +252,9 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   if (getenv("XL_EXP_NCOWPW")) b->nco_wpw = (uint32_t)atoi(getenv("XL_EXP_NCOWPW"));
   if (getenv("XL_EXP_RIDERS")) b->riders = atoi(getenv("XL_EXP_RIDERS")) != 0;
   if (getenv("XL_EXP_RIDERS_MIN")) b->riders_min_wgs = atoi(getenv("XL_EXP_RIDERS_MIN"));
+  if (getenv("XL_EXP_POLY")) b->poly_mode = atoi(getenv("XL_EXP_POLY"));
+  if (getenv("XL_EXP_POLY_MIN")) b->poly_min_clients = (uint32_t)atoi(getenv("XL_EXP_POLY_MIN"));
+  if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
   b->last_stream = b->own_stream;
   *batch = b;
   return 0;
@@ -399,115 +431,151 @@ static int xl_batch_plan(xlating_batch *b) {
     }
     if (b->exp_h == 8 || b->exp_h == 9 || b->exp_h == 10 || b->exp_h == 12) big_h = b->exp_h;
   }
-  struct TileDesc {
-    uint32_t cls;
-    std::vector<int> ids;
-  };
-  std::vector<TileDesc> tiles_of[XL_NLAUNCH];
-  for (int li = 0; li < XL_NLAUNCH; ++li) {
-    b->launches[li].ct = kHeights[li];
-    b->launches[li].lds = 0;
-    b->launches[li].nw = XL_NW_DEFAULT;
-    b->launches[li].all_wide = true;
-  }
-  for (size_t k = 0; k < members.size(); ++k) {
-    const std::vector<int> &m = members[k];
-    int h = big_h;
-    if (m.size() < 8) h = m.size() > 4 ? 8 : (m.size() > 2 ? 4 : (m.size() > 1 ? 2 : 1));
-    int li = 0;
-    while (kHeights[li] != h) ++li;
-    for (size_t next = 0; next < m.size(); next += (size_t)h) {
-      const size_t cnt = std::min<size_t>((size_t)h, m.size() - next);
-      tiles_of[li].push_back(TileDesc{(uint32_t)k, std::vector<int>(m.begin() + next, m.begin() + next + cnt)});
+  std::vector<float> image;  // tap image, floats (shared by both launch sets)
+  // Builds one set of direct-FIR launches over the classes selected by use_cls: tiles, groups, tap image rows.
+  auto build_launches = [&](Launch *Ls, const std::vector<bool> &use_cls) -> int {
+    struct TileDesc {
+      uint32_t cls;
+      std::vector<int> ids;
+    };
+    std::vector<TileDesc> tiles_of[XL_NLAUNCH];
+    for (int li = 0; li < XL_NLAUNCH; ++li) {
+      Ls[li].ct = kHeights[li];
+      Ls[li].lds = 0;
+      Ls[li].nw = XL_NW_DEFAULT;
+      Ls[li].all_wide = true;
     }
-  }
+    for (size_t k = 0; k < members.size(); ++k) {
+      if (!use_cls[k]) continue;
+      const std::vector<int> &m = members[k];
+      int h = big_h;
+      if (m.size() < 8) h = m.size() > 4 ? 8 : (m.size() > 2 ? 4 : (m.size() > 1 ? 2 : 1));
+      int li = 0;
+      while (kHeights[li] != h) ++li;
+      for (size_t next = 0; next < m.size(); next += (size_t)h) {
+        const size_t cnt = std::min<size_t>((size_t)h, m.size() - next);
+        tiles_of[li].push_back(TileDesc{(uint32_t)k, std::vector<int>(m.begin() + next, m.begin() + next + cnt)});
+      }
+    }
 
-  std::vector<float> image;  // tap image, floats
-  for (int li = 0; li < XL_NLAUNCH; ++li) {
-    Launch &L = b->launches[li];
-    if (tiles_of[li].empty()) continue;
-    const int ct = L.ct;
-    int gi = -1;
-    uint32_t gcls = 0;
-    for (const TileDesc &td : tiles_of[li]) {
-      const ClassState &cs = b->classes[td.cls];
-      const uint32_t Tpad = xl_roundup(cs.T, xl_tap_step(ct));
-      if (gi < 0 || gcls != td.cls || L.groups[gi].ntiles == (uint32_t)L.nw) {
-        L.groups.emplace_back();
-        gi = (int)L.groups.size() - 1;
-        gcls = td.cls;
+    for (int li = 0; li < XL_NLAUNCH; ++li) {
+      Launch &L = Ls[li];
+      if (tiles_of[li].empty()) continue;
+      const int ct = L.ct;
+      int gi = -1;
+      uint32_t gcls = 0;
+      for (const TileDesc &td : tiles_of[li]) {
+        const ClassState &cs = b->classes[td.cls];
+        const uint32_t Tpad = xl_roundup(cs.T, xl_tap_step(ct));
+        if (gi < 0 || gcls != td.cls || L.groups[gi].ntiles == (uint32_t)L.nw) {
+          L.groups.emplace_back();
+          gi = (int)L.groups.size() - 1;
+          gcls = td.cls;
+          XlGroup *g = &L.groups[gi];
+          memset(g, 0, sizeof(*g));
+          g->D = cs.D;
+          g->T = cs.T;
+          g->Tpad = Tpad;
+          g->cls = td.cls;
+          g->wide = (cs.D % 2 == 0) ? 1u : 0u;
+          if (!g->wide) L.all_wide = false;
+          L.lds = std::max(L.lds, xl_fir_lds_bytes_ota(cs.D, Tpad, 64));
+        }
         XlGroup *g = &L.groups[gi];
-        memset(g, 0, sizeof(*g));
-        g->D = cs.D;
-        g->T = cs.T;
-        g->Tpad = Tpad;
-        g->cls = td.cls;
-        g->wide = (cs.D % 2 == 0) ? 1u : 0u;
-        if (!g->wide) L.all_wide = false;
-        L.lds = std::max(L.lds, xl_fir_lds_bytes_ota(cs.D, Tpad, 64));
-      }
-      XlGroup *g = &L.groups[gi];
-      XlTile &t = g->tiles[g->ntiles++];
-      const uint32_t real_off = (uint32_t)(image.size() / 2);
-      t.tap_off = real_off;
-      t.nclients = (uint32_t)td.ids.size();  // a partial last tile keeps zero taps for the missing clients
-      image.resize(image.size() + (size_t)2 * Tpad * ct, 0.0f);
-      float *dst = image.data() + (size_t)2 * real_off;
-      if (b->exp_same_taps) t.tap_off = 0;  // tuning experiment: every tile streams the same taps (WRONG results)
-      for (size_t j = 0; j < td.ids.size(); ++j) {
-        const Client &c = b->clients[td.ids[j]];
-        t.out_off[j] = c.out_off;
-        for (uint32_t i = 0; i < cs.T; ++i) {
-          dst[((size_t)i * ct + j) * 2] = c.rt[2 * i];
-          dst[((size_t)i * ct + j) * 2 + 1] = c.rt[2 * i + 1];
+        XlTile &t = g->tiles[g->ntiles++];
+        const uint32_t real_off = (uint32_t)(image.size() / 2);
+        t.tap_off = real_off;
+        t.nclients = (uint32_t)td.ids.size();  // a partial last tile keeps zero taps for the missing clients
+        image.resize(image.size() + (size_t)2 * Tpad * ct, 0.0f);
+        float *dst = image.data() + (size_t)2 * real_off;
+        if (b->exp_same_taps) t.tap_off = 0;  // tuning experiment: every tile streams the same taps (WRONG results)
+        for (size_t j = 0; j < td.ids.size(); ++j) {
+          const Client &c = b->clients[td.ids[j]];
+          t.out_off[j] = c.out_off;
+          for (uint32_t i = 0; i < cs.T; ++i) {
+            dst[((size_t)i * ct + j) * 2] = c.rt[2 * i];
+            dst[((size_t)i * ct + j) * 2 + 1] = c.rt[2 * i + 1];
+          }
         }
       }
     }
+    // ---- spare waves for the NCO riders (xl_kernels.hip): groups with fewer tiles than the launch has waves.  The
+    // launch that carries the role (the first one with groups) gets a spare wave by splitting its last full group
+    // into 3 + 1 tiles when it has none and the engine is big enough for the balance to matter.
+    {
+      bool first = true;
+      for (int lq = 0; lq < XL_NLAUNCH; ++lq) {
+        Launch &L = Ls[lq];
+        if (L.groups.empty()) continue;
+        uint32_t idle = 0;
+        for (const XlGroup &g : L.groups) idle += (uint32_t)L.nw - g.ntiles;
+        const uint32_t kest = b->max_samples / L.groups[0].D + 1;
+        if (first && idle == 0 && b->riders && L.nw == XL_NW_MAX &&
+            xl_riders_window((L.groups.size() + 1) * ((kest + 63) / 64), L.nw, L.groups[0].Tpad, L.ct, kest, L.lds,
+                             b->riders_min_wgs)) {
+          XlGroup &last = L.groups.back();
+          XlGroup extra = last;
+          extra.ntiles = 1;
+          extra.tiles[0] = last.tiles[XL_NW_MAX - 1];
+          last.ntiles = XL_NW_MAX - 1;
+          L.groups.push_back(extra);
+        }
+        // (riders are only used in one-round launches -- xl_riders_window -- where every workgroup is dispatched within
+        // ~10 us of the start, so the groups with spare waves can stay where they are: last, which suits the tail)
+        idle = 0;
+        for (XlGroup &g : L.groups) {
+          g.idle_before = idle;
+          idle += (uint32_t)L.nw - g.ntiles;
+        }
+        L.idle_waves = idle;
+        first = false;
+      }
+    }
+    for (int lq = 0; lq < XL_NLAUNCH; ++lq) {
+        Launch &L = Ls[lq];
+      L.ota = 64;
+      if (L.lds > 160 * 1024) {  // huge decimation: fewer active lanes per wave so that the window image fits
+        for (L.ota = 32; L.ota >= 8; L.ota >>= 1) {
+          size_t need = 0;
+          for (const XlGroup &g : L.groups) need = std::max(need, xl_fir_lds_bytes_ota(g.D, g.Tpad, L.ota));
+          if (need <= 160 * 1024) {
+            L.lds = need;
+            break;
+          }
+        }
+        if (L.ota < 8) return -EINVAL;  // (add_client already refused such a shape)
+      }
+    }
+
+    return 0;
+  };
+
+  // ---- classes that take the polyphase overlap-save path in optimized mode: many clients (its lanes are client
+  // columns and its cost per client does not depend on the tap count) with a filter long enough to be worth it
+  std::vector<bool> all_cls(members.size(), true), rest_cls(members.size(), true);
+  for (size_t k = 0; k < members.size(); ++k) {
+    const ClassState &cs = b->classes[k];
+    const uint32_t A = (cs.T + cs.D - 1) / cs.D;
+    const bool fits = A >= 2 && A <= XLP_M / 2 && cs.D <= 4096;
+    const bool pays = members[k].size() >= b->poly_min_clients && cs.T >= 3 * cs.D && cs.T >= 192;
+    if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
+    PolyClass pc;
+    pc.cls = (uint32_t)k;
+    pc.D = cs.D;
+    pc.Dpad = xl_roundup(cs.D, XLP_BSTEP);
+    pc.T = cs.T;
+    pc.A = A;
+    pc.V = XLP_M - A + 1;
+    pc.ncols = (uint32_t)members[k].size();
+    pc.nsg = (pc.ncols + XLP_COLS - 1) / XLP_COLS;
+    pc.nseg_cap = (b->max_samples / cs.D + 1 + pc.V - 1) / pc.V;
+    b->poly.push_back(pc);
+    rest_cls[k] = false;
   }
-  // ---- spare waves for the NCO riders (xl_kernels.hip): groups with fewer tiles than the launch has waves.  The
-  // launch that carries the role (the first one with groups) gets a spare wave by splitting its last full group
-  // into 3 + 1 tiles when it has none and the engine is big enough for the balance to matter.
   {
-    bool first = true;
-    for (Launch &L : b->launches) {
-      if (L.groups.empty()) continue;
-      uint32_t idle = 0;
-      for (const XlGroup &g : L.groups) idle += (uint32_t)L.nw - g.ntiles;
-      const uint32_t kest = b->max_samples / L.groups[0].D + 1;
-      if (first && idle == 0 && b->riders && L.nw == XL_NW_MAX &&
-          xl_riders_window((L.groups.size() + 1) * ((kest + 63) / 64), L.nw, L.groups[0].Tpad, L.ct, kest, L.lds,
-                           b->riders_min_wgs)) {
-        XlGroup &last = L.groups.back();
-        XlGroup extra = last;
-        extra.ntiles = 1;
-        extra.tiles[0] = last.tiles[XL_NW_MAX - 1];
-        last.ntiles = XL_NW_MAX - 1;
-        L.groups.push_back(extra);
-      }
-      // (riders are only used in one-round launches -- xl_riders_window -- where every workgroup is dispatched within
-      // ~10 us of the start, so the groups with spare waves can stay where they are: last, which suits the tail)
-      idle = 0;
-      for (XlGroup &g : L.groups) {
-        g.idle_before = idle;
-        idle += (uint32_t)L.nw - g.ntiles;
-      }
-      L.idle_waves = idle;
-      first = false;
-    }
-  }
-  for (Launch &L : b->launches) {
-    L.ota = 64;
-    if (L.lds > 160 * 1024) {  // huge decimation: fewer active lanes per wave so that the window image fits
-      for (L.ota = 32; L.ota >= 8; L.ota >>= 1) {
-        size_t need = 0;
-        for (const XlGroup &g : L.groups) need = std::max(need, xl_fir_lds_bytes_ota(g.D, g.Tpad, L.ota));
-        if (need <= 160 * 1024) {
-          L.lds = need;
-          break;
-        }
-      }
-      if (L.ota < 8) return -EINVAL;  // (add_client already refused such a shape)
-    }
+    int rc = build_launches(b->launches, all_cls);
+    if (rc == 0 && !b->poly.empty()) rc = build_launches(b->launches_rest, rest_cls);
+    if (rc != 0) return rc;
   }
 
   // upload
@@ -519,10 +587,62 @@ static int xl_batch_plan(xlating_batch *b) {
   XL_TRY(hipMemcpy(b->d_taps, image.data(), image.size() * sizeof(float), hipMemcpyHostToDevice));
   XL_TRY(hipMalloc((void **)&b->d_nco, b->nco.size() * sizeof(XlNcoClient)));
   XL_TRY(hipMemcpy(b->d_nco, b->nco.data(), b->nco.size() * sizeof(XlNcoClient), hipMemcpyHostToDevice));
-  for (Launch &L : b->launches) {
-    if (L.groups.empty()) continue;
-    XL_TRY(hipMalloc((void **)&L.d_groups, L.groups.size() * sizeof(XlGroup)));
-    XL_TRY(hipMemcpy(L.d_groups, L.groups.data(), L.groups.size() * sizeof(XlGroup), hipMemcpyHostToDevice));
+  for (Launch *set : {b->launches, b->launches_rest})
+    for (int i = 0; i < XL_NLAUNCH; ++i) {
+      Launch &L = set[i];
+      if (L.groups.empty()) continue;
+      XL_TRY(hipMalloc((void **)&L.d_groups, L.groups.size() * sizeof(XlGroup)));
+      XL_TRY(hipMemcpy(L.d_groups, L.groups.data(), L.groups.size() * sizeof(XlGroup), hipMemcpyHostToDevice));
+    }
+  // ---- polyphase classes: images and the per-client branch spectra (device kernel, double arithmetic)
+  if (!b->poly.empty()) {
+    if (b->d_W == nullptr) {
+      std::vector<float> w(2 * XLP_M);
+      for (uint32_t n = 0; n < XLP_M; ++n) {
+        const double ang = -2.0 * M_PI * (double)n / (double)XLP_M;
+        w[2 * n] = (float)cos(ang);
+        w[2 * n + 1] = (float)sin(ang);
+      }
+      w[0] = 1.0f, w[1] = 0.0f;
+      w[2 * 64] = 0.0f, w[2 * 64 + 1] = -1.0f;
+      w[2 * 128] = -1.0f, w[2 * 128 + 1] = 0.0f;
+      w[2 * 192] = 0.0f, w[2 * 192 + 1] = 1.0f;
+      XL_TRY(hipMalloc((void **)&b->d_W, XLP_M * sizeof(float2)));
+      XL_TRY(hipMemcpy(b->d_W, w.data(), XLP_M * sizeof(float2), hipMemcpyHostToDevice));
+    }
+    if (b->phase_run_cap < b->phase_cap) {
+      if (b->d_phase_run) (void)hipFree(b->d_phase_run);
+      b->d_phase_run = nullptr;
+      b->phase_run_cap = 0;
+      XL_TRY(hipMalloc((void **)&b->d_phase_run, b->phase_cap * sizeof(float2)));
+      b->phase_run_cap = b->phase_cap;
+    }
+    for (PolyClass &pc : b->poly) {
+      const std::vector<int> &m = members[pc.cls];
+      const size_t rows = (size_t)pc.nsg * pc.Dpad + XLP_BSTEP;
+      const uint32_t passes = (pc.nseg_cap + XLP_SEG - 1) / XLP_SEG;
+      XL_TRY(hipMalloc((void **)&pc.d_R, rows * XLP_M * XLP_COLS * sizeof(float2)));
+      XL_TRY(hipMemset(pc.d_R, 0, rows * XLP_M * XLP_COLS * sizeof(float2)));
+      XL_TRY(hipMalloc((void **)&pc.d_X, (size_t)passes * pc.Dpad * XLP_M * XLP_XS * sizeof(float2)));
+      XL_TRY(hipMemset(pc.d_X, 0, (size_t)passes * pc.Dpad * XLP_M * XLP_XS * sizeof(float2)));
+      XL_TRY(hipMalloc((void **)&pc.d_Y, (size_t)pc.nsg * pc.nseg_cap * XLP_M * XLP_COLS * sizeof(float2)));
+      std::vector<uint32_t> col((size_t)pc.nsg * XLP_COLS, 0xFFFFFFFFu);
+      std::vector<float> rt((size_t)pc.ncols * pc.T * 2);
+      for (size_t j = 0; j < m.size(); ++j) {
+        const Client &c = b->clients[m[j]];
+        col[j] = c.out_off;
+        memcpy(rt.data() + j * pc.T * 2, c.rt.data(), (size_t)pc.T * 2 * sizeof(float));
+      }
+      XL_TRY(hipMalloc((void **)&pc.d_col, col.size() * sizeof(uint32_t)));
+      XL_TRY(hipMemcpy(pc.d_col, col.data(), col.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      float2 *d_rt = nullptr;
+      XL_TRY(hipMalloc((void **)&d_rt, rt.size() * sizeof(float)));
+      hipError_t e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = xlp_launch_tables(d_rt, pc.ncols, pc.T, pc.D, pc.Dpad, pc.A, pc.nsg, pc.d_R, b->own_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(b->own_stream);
+      (void)hipFree(d_rt);
+      if (e != hipSuccess) goto fail;
+    }
   }
   if (b->out_total > b->out_alloc) {
     for (int i = 0; i < 2; ++i) {
@@ -639,9 +759,14 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
       f1 = b->ev[b->ev.size() - 1];
     }
     bool rolled = false;
+    // optimized mode: the polyphase classes leave the direct launches (tiny blocks stay direct: a segment is 256
+    // branch samples whatever the block holds)
+    const bool use_poly = mode == XL_MODE_OPTIMIZED && !b->poly.empty() && maxK >= 2 * XLP_M;
+    Launch *const Ls = use_poly ? b->launches_rest : b->launches;
     if (maxK > 0) {
       if (f0) XL_TRY(hipEventRecord(f0, s));
-      for (Launch &L : b->launches) {
+      for (int lq = 0; lq < XL_NLAUNCH; ++lq) {
+        Launch &L = Ls[lq];
         if (L.groups.empty()) continue;
         XlFirArgs a;
         memset(&a, 0, sizeof(a));
@@ -710,6 +835,66 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
           }
         }
       }
+      if (use_poly) {
+        for (PolyClass &pc : b->poly) {
+          const uint32_t K = dyn.d[pc.cls].K;
+          if (K == 0) continue;
+          if (!rolled) {
+            XL_TRY(xl_launch_update_history(b->d_hist[hb], d_block, XL_HCAP, (uint32_t)S, b->bps, b->d_hist[hn], s));
+            rolled = true;
+          }
+          XlpArgs pa;
+          memset(&pa, 0, sizeof(pa));
+          pa.in0 = b->d_hist[hb];
+          pa.n0 = XL_HCAP;
+          pa.in1 = d_block;
+          pa.n1 = (uint32_t)S;
+          pa.fmt = (uint32_t)b->fmt;
+          pa.cls = pc.cls;
+          pa.D = pc.D;
+          pa.Dpad = pc.Dpad;
+          pa.T = pc.T;
+          pa.A = pc.A;
+          pa.V = pc.V;
+          pa.nseg = (K + pc.V - 1) / pc.V;
+          pa.nseg_cap = pc.nseg_cap;
+          pa.nsg = pc.nsg;
+          pa.W = b->d_W;
+          pa.X = pc.d_X;
+          pa.R = pc.d_R;
+          pa.Y = pc.d_Y;
+          pa.col_out = pc.d_col;
+          pa.phtab = b->d_phtab[tab];
+          pa.out = b->d_out[p];
+          // the NEXT block's phase recurrence rides in these three launches as three slices (a direct launch
+          // above carries all of it if there is one)
+          const bool carry = fuse && !nco_fused;
+          if (carry) {
+            pa.nco_clients = b->d_nco;
+            pa.nco_nclients = (uint32_t)b->nco.size();
+            pa.nco_blocks = (pa.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
+            pa.nco_tab = b->d_phtab[tab ^ 1];
+            pa.nco_k0 = 0;
+            pa.nco_k1 = b->poly_slice1;
+            pa.nco_state_src = b->d_phase[b->pcur];
+            pa.nco_state_dst = b->d_phase_run;
+          }
+          XL_TRY(xlp_launch_forward(pa, dyn, next, s));
+          if (carry) {
+            pa.nco_k0 = b->poly_slice1;
+            pa.nco_k1 = b->poly_slice2;
+            pa.nco_state_src = b->d_phase_run;
+          }
+          XL_TRY(xlp_launch_mix(pa, next, s));
+          if (carry) {
+            pa.nco_k0 = b->poly_slice2;
+            pa.nco_k1 = 65536;
+            pa.nco_state_dst = b->d_phase[b->pcur ^ 1];
+            nco_fused = true;
+          }
+          XL_TRY(xlp_launch_inverse(pa, dyn, next, s));
+        }
+      }
       if (f1) XL_TRY(hipEventRecord(f1, s));
     }
     if (!rolled)  // no client produced output in this block (tiny block): roll the history on its own
@@ -729,6 +914,37 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
   return 0;
 fail:
   return -EIO;
+}
+
+extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
+  if (b == nullptr || buf == nullptr || n == 0) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  if (b->dirty) {
+    int rc = xl_batch_plan(b);
+    if (rc != 0) return rc;
+  }
+  std::string d = "clients " + std::to_string(b->nalive) + " classes " + std::to_string(b->classes.size()) + " | direct:";
+  for (const Launch &L : b->launches)
+    if (!L.groups.empty()) d += " h" + std::to_string(L.ct) + " x " + std::to_string(L.groups.size()) + " groups";
+  d += " | polyphase:";
+  if (b->poly.empty()) d += " none";
+  for (const PolyClass &pc : b->poly)
+    d += " cls" + std::to_string(pc.cls) + " D" + std::to_string(pc.D) + " T" + std::to_string(pc.T) + " cols" +
+         std::to_string(pc.ncols) + " V" + std::to_string(pc.V);
+  if (!b->poly.empty()) {
+    d += " | optimized-mode direct:";
+    bool any = false;
+    for (const Launch &L : b->launches_rest)
+      if (!L.groups.empty()) {
+        d += " h" + std::to_string(L.ct) + " x " + std::to_string(L.groups.size()) + " groups";
+        any = true;
+      }
+    if (!any) d += " none";
+  }
+  const size_t len = std::min(d.size(), n - 1);
+  memcpy(buf, d.data(), len);
+  buf[len] = 0;
+  return (int)len;
 }
 
 extern "C" int xlating_batch_process_device(xlating_batch *b, const void *d_input, size_t input_len, int mode,

@@ -24,152 +24,15 @@
 //               free; for even D two samples are read per ds_read_b128 (conflict-free when D = 2 mod 4).
 //   grid      = (groups) x (output tiles), group-major, cut into 8 equal contiguous chunks, one per XCD: the
 //               output tiles of a group re-read the same taps, which then stay in that XCD's L2.
-#include "xl_device.h"
+#include "xl_dev_inline.h"
 
 #include <stdlib.h>
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-// constant address space: uniform loads through these pointers are selected as scalar (SMEM) loads
-typedef const float __attribute__((address_space(4))) *cfloat_p;
-typedef const uint32_t __attribute__((address_space(4))) *cu32_p;
-
-#define XL_DEV static __device__ __forceinline__
-#define XL_MEM __device__ __forceinline__
-
-// ------------------------------------------------------------------------------------------- sample converters
-// xlating.c:357-358 / 367-368 / 377-378: all three maps are exact in float32.
-XL_DEV v2f xl_sample(const void *__restrict__ p, int fmt, uint32_t i) {
-  v2f r;
-  if (fmt == XLF_CU8) {
-    const uint32_t v = reinterpret_cast<const uint16_t *>(p)[i];
-    r.x = ((float)(v & 0xFFu) - 127.5f) / 128.0f;
-    r.y = ((float)(v >> 8) - 127.5f) / 128.0f;
-  } else if (fmt == XLF_CS8) {
-    const int32_t v = reinterpret_cast<const int16_t *>(p)[i];
-    r.x = (float)((int32_t)(int8_t)(v & 0xFF)) / 128.0f;
-    r.y = (float)(v >> 8) / 128.0f;
-  } else if (fmt == XLF_CS16) {
-    const int32_t v = reinterpret_cast<const int32_t *>(p)[i];
-    r.x = (float)((int32_t)(int16_t)(v & 0xFFFF)) / 32768.0f;
-    r.y = (float)(v >> 16) / 32768.0f;
-  } else {
-    r = reinterpret_cast<const v2f *>(p)[i];
-  }
-  return r;
-}
-
-// ------------------------------------------------------------------------------------------- complex arithmetic
-// One complex accumulator per (output, client).
-// MODE 0 (native): the reference's scalar expression tree, xlating.c:68 `temp += x * h` in C99 complex float:
-//   p = (xr*hr - xi*hi) + j(xr*hi + xi*hr);  acc += p        -- 4 mul, 2 add/sub, 2 add, each rounded.
-// MODE 1 (optimized): the sum is kept as two packed halves that need no negation inside the loop,
-//   a += xr * (hr, hi)      b += xi * (hi, hr)      acc = (a.x - b.x, a.y + b.y)
-//   = exactly two v_pk_fma_f32 per complex MAC (op_sel broadcasts xr / xi and swaps the tap), same tap order.
-template <int MODE>
-struct XlAcc;
-
-template <>
-struct XlAcc<0> {
-  v2f s;
-  XL_MEM void clear() { s = (v2f){0.0f, 0.0f}; }
-  // Same roundings as the scalar tree  pr = xr*hr - xi*hi;  pi = xr*hi + xi*hr;  s += (pr, pi)  (every product and
-  // sum rounded once, nothing fused: this TU is compiled -ffp-contract=off), arranged so that each step is one packed
-  // instruction without register shuffles:  p1 = xr*(hr,hi)   p2 = xi*(hi,hr)   p = (p1.x - p2.x, p1.y + p2.y)   s += p
-  XL_MEM void mac(const v2f x, const float hr, const float hi) {
-    // hand-placed: the compiler builds the (-p2.x, p2.y) operand with an extra v_pk_add and a v_mov (6 VALU per
-    // MAC); op_sel / neg_lo do it for free (4 VALU per MAC).  IEEE mul/add, one rounding each, nothing fused.
-    const v2f h = {hr, hi};
-    v2f p1, p2;
-    asm("v_pk_mul_f32 %0, %3, %4 op_sel_hi:[0,1]\n\t"
-        "v_pk_mul_f32 %1, %3, %4 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-        "v_pk_add_f32 %0, %0, %1 neg_lo:[0,1]\n\t"
-        "v_pk_add_f32 %2, %2, %0"
-        : "=&v"(p1), "=&v"(p2), "+v"(s)
-        : "v"(x), "s"(h));
-  }
-  XL_MEM v2f value() const { return s; }
-};
-
-template <>
-struct XlAcc<1> {
-  v2f a, b;
-  XL_MEM void clear() {
-    a = (v2f){0.0f, 0.0f};
-    b = (v2f){0.0f, 0.0f};
-  }
-  XL_MEM void mac(const v2f x, const float hr, const float hi) {
-    a = __builtin_elementwise_fma((v2f){x.x, x.x}, (v2f){hr, hi}, a);
-    b = __builtin_elementwise_fma((v2f){x.y, x.y}, (v2f){hi, hr}, b);
-  }
-  XL_MEM v2f value() const { return (v2f){a.x - b.x, a.y + b.y}; }
-};
-
-// xlating.c:70 `out = temp * phase`
-template <int MODE>
-XL_DEV v2f xl_rotate(const v2f a, const v2f p) {
-  v2f r;
-  if (MODE == 0) {
-    r.x = a.x * p.x - a.y * p.y;
-    r.y = a.x * p.y + a.y * p.x;
-  } else {
-    r.x = __builtin_fmaf(-a.y, p.y, a.x * p.x);
-    r.y = __builtin_fmaf(a.y, p.x, a.x * p.y);
-  }
-  return r;
-}
 
 // ------------------------------------------------------------------------------------------- NCO phase table
 // xlating.c:70-73: the phasor is a float32 RECURRENCE p <- p * incr (never re-seeded), renormalised once per
 // call that could produce output.  It is data independent, so one lane per client tabulates the K phases of
 // the block ahead of the FIR kernel; the recurrence itself must stay sequential to be bit-exact.
 // hypotf: glibc evaluates sqrt(x*x + y*y) in double and narrows; restated with IEEE double ops.
-// One recurrence step p <- p * incr as the reference's C99 complex float product (xlating.c:71):
-//   re = pr*ir - pi*ii, im = pr*ii + pi*ir, every operation rounded once (IEEE mul / add, nothing fused).
-// A lone wave issues one VALU instruction every ~5-8 cycles whatever its width, so the step is written as THREE
-// packed instructions (left to the compiler it became 6-8 with register shuffles, ~50 cycles per step):
-//   t1 = (pr, pi) * (ir, ir)        t2 = (pr, pi) * (ii, ii)        p = (t1.x - t2.y, t1.y + t2.x)
-XL_DEV void xl_nco_step(v2f &p, const v2f inc) {
-  v2f t1, t2;
-  asm volatile(
-      "v_pk_mul_f32 %0, %2, %3 op_sel_hi:[1,0]\n\t"
-      "v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,1]"
-      : "=&v"(t1), "=&v"(t2)
-      : "v"(p), "v"(inc));
-  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(p) : "v"(t1), "v"(t2));
-}
-
-// The work of one lane = one client: tabulate K phases, renormalise, store the post-block phase.
-XL_DEV void xl_nco_client(const XlNcoClient k, const uint32_t K, const float2 *state_in, float2 *state_out,
-                          float2 *__restrict__ tab) {
-  v2f p = {state_in[k.slot].x, state_in[k.slot].y};
-  if (K == 0) {  // no output possible in this block: the reference leaves the phase untouched (xlating.c:58)
-    state_out[k.slot] = make_float2(p.x, p.y);
-    return;
-  }
-  const v2f inc = {k.incr.x, k.incr.y};
-  v2f *__restrict__ o = reinterpret_cast<v2f *>(tab + k.out_off);  // out_off is even -> 16-byte aligned pairs
-  v4f *__restrict__ o4 = reinterpret_cast<v4f *>(o);
-  uint32_t m = 0;
-  for (; m + 8 <= K; m += 8) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const v2f a = p;
-      xl_nco_step(p, inc);
-      o4[(m >> 1) + j] = (v4f){a.x, a.y, p.x, p.y};
-      xl_nco_step(p, inc);
-    }
-  }
-  for (; m < K; ++m) {
-    o[m] = p;
-    xl_nco_step(p, inc);
-  }
-  const float pr = p.x, pi = p.y;
-  const double mag2 = (double)pr * (double)pr + (double)pi * (double)pi;
-  const float mag = (float)__dsqrt_rn(mag2);
-  state_out[k.slot] = make_float2(pr / mag, pi / mag);
-}
-
 // Stand-alone launch (single-filter path; first block / wrong length guess of the batch engine).  `lanes`
 // (XL_NCO_LANES = 16) lanes of a wave carry a client and the table is written two steps (16 bytes) per store: every
 // store goes to the client's own table row (fully divergent addresses).  The kernel is a pure dependent chain

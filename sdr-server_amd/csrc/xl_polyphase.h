@@ -1,0 +1,67 @@
+// xl_polyphase.h -- launchers of the polyphase overlap-save path (xl_polyphase.hip): the batch engine's OPTIMIZED
+// arithmetic for big classes of clients with long filters.  Same linear operator as xlating.c:52-72, evaluated in
+// the frequency domain of the D polyphase branches:
+//
+//   y[k] = sum_{i<T} r[i] x[kD + i]                      (r = reversed band-pass taps, xlating.c:525-535)
+//        = sum_{b<D} sum_{a<A} r_b[a] x_b[k + a]         r_b[a] = r[D a + b], x_b[n] = x[D n + b], A = ceil(T/D)
+//
+// i.e. D short correlations at the OUTPUT rate.  Over a segment of M = 256 branch samples each correlation is a
+// circular one, exact for the first V = M - A + 1 outputs:
+//
+//   y_seg = IDFT_M( sum_b DFT_M(x_b) * R_b ),            R_b[m] = sum_a r_b[a] e^{+2 pi j a m / M}
+//
+// DFT_M(x_b) is shared by ALL clients of the class (D transforms per segment, whatever the client count) and the
+// per-client work is D complex MACs per spectrum bin plus one inverse transform per segment: ~45 complex MACs per
+// output instead of T (= 505 at the server default).  The NCO derotation (exact float32 recurrence table) and the
+// streaming rules (global output grid, history, late joiners) are those of the direct kernels.
+// Measured against the oracle: max|d|/max|y| <= 1e-6, which is the reference's own float32 summation noise (an
+// all-double evaluation of the same operator differs from the reference by the same amount).
+#ifndef XL_POLYPHASE_H_
+#define XL_POLYPHASE_H_
+#include "xl_device.h"
+
+#define XLP_M 256u     // transform length (branch samples per segment)
+#define XLP_SEG 13u    // segments accumulated per lane in one pass of the mix kernel
+#define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: XLP_SEG padded to 128 bytes
+#define XLP_COLS 256u  // client columns per supergroup (= threads of a mix workgroup)
+#define XLP_BSTEP 6u   // branches per software-pipeline stage of the mix kernel (images are padded to a multiple)
+
+struct XlpArgs {
+  // input stream [in0 | in1] as in XlFirArgs
+  const void *in0;
+  const void *in1;
+  uint32_t n0, n1;
+  uint32_t fmt;
+  uint32_t cls;        // index into XlDynArgs::d
+  uint32_t D, Dpad;    // decimation = number of branches; padded to a multiple of XLP_BSTEP in the images
+  uint32_t T, A, V;    // taps, taps per branch, valid outputs per segment
+  uint32_t nseg;       // segments of this block = ceil(K / V)
+  uint32_t nseg_cap;   // segment capacity of the Y image
+  uint32_t nsg;        // supergroups of XLP_COLS client columns
+  const float2 *W;     // e^{-2 pi j n / 256}, n < 256
+  float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
+  const float2 *R;     // branch spectra   [sg][Dpad][M][XLP_COLS]
+  float2 *Y;           // mixed spectra    [sg][nseg_cap][M][XLP_COLS]
+  const uint32_t *col_out;  // per column: float2 index of the client's row in out / phtab, 0xFFFFFFFF = empty column
+  const float2 *phtab;
+  float2 *out;
+  // NCO role pieces (see XlFirArgs): each of the three launches of a block carries a slice [nco_k0, nco_k1) of the
+  // NEXT block's phase recurrence; the slice that ends the block renormalises (xlating.c:73).
+  const XlNcoClient *nco_clients;
+  uint32_t nco_nclients;
+  uint32_t nco_blocks;
+  uint32_t nco_k0, nco_k1;  // in 1/65536 of the block's outputs: slice = [K*k0 >> 16, K*k1 >> 16)
+  const float2 *nco_state_src;  // phases at the start of the slice (committed phases for the first slice)
+  float2 *nco_state_dst;        // phases after the slice (renormalised post-block phases for the last slice)
+  float2 *nco_tab;
+};
+
+// reversed band-pass taps of every column -> branch spectra R (double arithmetic, rounded once to float)
+//   rt: [ncols][T] float2 (column-major clients), ncols <= nsg * XLP_COLS; columns >= ncols and branches >= D get 0
+hipError_t xlp_launch_tables(const float2 *rt, uint32_t ncols, uint32_t T, uint32_t D, uint32_t Dpad, uint32_t A,
+                             uint32_t nsg, float2 *R, hipStream_t s);
+hipError_t xlp_launch_forward(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s);
+hipError_t xlp_launch_mix(const XlpArgs &a, const XlDynArgs &dyn_next, hipStream_t s);
+hipError_t xlp_launch_inverse(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s);
+
+#endif  // XL_POLYPHASE_H_

@@ -285,6 +285,119 @@ def test_1000_clients_split_group_riders():
     eng.close()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Polyphase overlap-save path (xl_polyphase.hip): the optimized arithmetic of big classes.  Same operator as the
+# direct kernels, so the same oracle and the same 1e-5 bar; XL_EXP_POLY=1 forces it for classes of any size so
+# that the oracle can check every client.
+def _poly_engine(monkeypatch, fmt="cu8", max_input=262144, fs=FS):
+    monkeypatch.setenv("XL_EXP_POLY", "1")
+    return xl.BatchEngine(fs, fmt, max_input)
+
+
+def test_polyphase_forced_server_default_ragged_and_join(monkeypatch):
+    """D=42, 505 taps: ragged block lengths (output grid offset changes every block), a client joining mid-stream
+    (zero history below its join point, phase 1), a native block in between (both paths share history and phases)."""
+    taps = lpf(FS, 24000, 9600)
+    eng = _poly_engine(monkeypatch)
+    oracles = {}
+    for c in range(20):
+        fc = -900000 + c * 91000
+        oracles[eng.add_client(42, taps, fc)] = Oracle(42, taps, fc, FS, 262144)
+    assert "polyphase: cls0 D42 T505 cols20 V244" in eng.describe(), eng.describe()
+    worst = 0.0
+    for k, n in enumerate((262144, 262144, 100002, 100002, 262144, 50000, 262144)):
+        if k == 3:
+            oracles[eng.add_client(42, taps, 123456)] = Oracle(42, taps, 123456, FS, 262144)
+        x = siggen.xs_u8(siggen.XS_SEED + 80 + k, n)
+        variant = "native" if k == 4 else "optimized"
+        eng.process_host(x, variant)
+        eng.fetch()
+        for cid, o in oracles.items():
+            want = o.process("cu8", x)
+            got = eng.output(cid)
+            assert len(got) == len(want)
+            if variant == "native":
+                assert bits_equal(got, want)
+            else:
+                worst = max(worst, rel_err(got, want))
+    assert worst <= REL_TOL, worst
+    eng.close()
+
+
+def test_polyphase_forced_mixed_rates_and_fixture_shape(monkeypatch):
+    """Two classes on the path at once (48 kHz: D=42/T=505, 96 kHz: D=21/T=253), then the reference's own test
+    shape (test_xlating.c: 57 taps, D=5, fs 48000, fc -12000) on a long ramp input."""
+    t48, t96 = lpf(FS, 24000, 9600), lpf(FS, 48000, 19200)
+    eng = _poly_engine(monkeypatch)
+    oracles = {}
+    for c in range(40):
+        fc = -700000 + c * 35000
+        D, taps = (42, t48) if c % 2 == 0 else (21, t96)
+        oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, FS, 262144)
+    for k in range(3):
+        check_clients(eng, oracles, "cu8", siggen.xs_u8(siggen.XS_SEED + 90 + k, 262144 if k != 1 else 131074), "optimized")
+    eng.close()
+    code, t57 = xl.create_low_pass_filter(1.0, 48000, 4800, 2000)
+    assert code == 0 and len(t57) == 57
+    eng = _poly_engine(monkeypatch, max_input=100000, fs=48000)
+    oracles = {}
+    for fc in (-12000, 0, 7000):
+        oracles[eng.add_client(5, t57, fc)] = Oracle(5, t57, fc, 48000, 100000)
+    assert "polyphase: cls0 D5 T57 cols3 V245" in eng.describe(), eng.describe()
+    for k in range(3):
+        check_clients(eng, oracles, "cu8", siggen.ramp_u8(k * 31, 100000 - 2 * k), "optimized")
+    eng.close()
+
+
+@pytest.mark.parametrize("fmt", ["cs8", "cs16", "cf32"])
+def test_polyphase_forced_other_formats(fmt, monkeypatch):
+    taps = lpf(FS, 24000, 9600)
+    n = 65536
+    eng = _poly_engine(monkeypatch, fmt=fmt)
+    oracles = {}
+    for c in range(6):
+        fc = -500000 + c * 200000
+        oracles[eng.add_client(42, taps, fc)] = Oracle(42, taps, fc, FS, 262144)
+    for k in range(2):
+        if fmt == "cs8":
+            x = siggen.xs_s8(4000 + k, 2 * n)
+        elif fmt == "cs16":
+            x = siggen.xs_s16(4000 + k, 2 * n)
+        else:
+            x = (siggen.xs_s16(4000 + k, 2 * n).astype(np.float32) / 32768.0).astype(np.float32)
+        check_clients(eng, oracles, fmt, x, "optimized")
+    eng.close()
+
+
+def test_polyphase_default_rule_1024_clients():
+    """The bench shape (1024 x 48 kHz, 505 taps): the size rule selects the path by itself.  Duplicated clients in
+    different columns agree bit for bit, 16 sampled clients match the oracle within 1e-5 over three blocks, and a
+    native block in between is still bit-exact (shared history / phase state)."""
+    taps = lpf(FS, 24000, 9600)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    fcs = [-984000 + 1920 * (c % 512) for c in range(1024)]
+    for fc in fcs:
+        eng.add_client(42, taps, fc)
+    assert "polyphase: cls0 D42 T505 cols1024" in eng.describe() and "optimized-mode direct: none" in eng.describe()
+    rng = np.random.default_rng(11)
+    sample = sorted(rng.choice(1024, 16, replace=False).tolist())
+    oracles = {c: Oracle(42, taps, fcs[c], FS, 262144) for c in sample}
+    for k, variant in enumerate(("optimized", "optimized", "native", "optimized")):
+        x = siggen.xs_u8(9000 + k, 262144)
+        eng.process_host(x, variant)
+        eng.fetch()
+        outs = [eng.output(c) for c in range(1024)]
+        for c in range(512):
+            assert bits_equal(outs[c], outs[c + 512]), c
+        for c in sample:
+            want = oracles[c].process("cu8", x)
+            if variant == "native":
+                assert bits_equal(outs[c], want), c
+            else:
+                assert rel_err(outs[c], want) <= REL_TOL, (c, rel_err(outs[c], want))
+    eng.close()
+
+
 def test_bench_block_feeder_stream_plumbing():
     """bench.py's multi-GPU feed (broadcast of block k+1 on a side stream while block k is filtered, two receive
     buffers, event-ordered reuse) with a stand-in for torch.distributed whose broadcast is the identity (this box has
