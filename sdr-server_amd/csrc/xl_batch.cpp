@@ -80,11 +80,12 @@ struct Launch {
 // A class of clients evaluated by the polyphase overlap-save path (xl_polyphase.hip) in optimized mode.
 struct PolyClass {
   uint32_t cls = 0, D = 0, Dpad = 0, T = 0, A = 0, V = 0;
-  uint32_t ncols = 0, nsg = 0, nseg_cap = 0;
-  float2 *d_R = nullptr;     // branch spectra [nsg][Dpad][M][256] (+ XLP_BSTEP rows of tail padding)
+  uint32_t ncols = 0, ncg = 0, nseg_cap = 0;
+  float2 *d_R = nullptr;     // branch spectra [ncg][Dpad][M][128] (+ XLP_BSTEP rows of tail padding)
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
-  float2 *d_Y = nullptr;     // mixed spectra  [nsg][nseg_cap][M][256]
+  float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
   uint32_t *d_col = nullptr; // column -> output row offset
+  float2 *d_colinc = nullptr; // column -> NCO phase increment
 };
 
 }  // namespace
@@ -110,6 +111,7 @@ struct xlating_batch_t {
   size_t phase_run_cap = 0;
   int poly_mode = -1;        // XL_EXP_POLY: 0 never, 1 whenever the shape allows, -1 (default) by the size rule
   uint32_t poly_min_clients = 96;
+  uint32_t poly_exp = 0;     // XL_EXP_POLY_EXP: tuning switches of the mix kernel (wrong results)
   uint32_t poly_slice1 = 6000, poly_slice2 = 42000;  // NCO slice boundaries in 1/65536 of the block (forward | mix | inverse)
   std::vector<XlNcoClient> nco;
   size_t out_total = 0;
@@ -181,7 +183,7 @@ static void xl_batch_free_plan(xlating_batch *b) {
       l.groups.clear();
     }
   for (PolyClass &pc : b->poly) {
-    void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_col};
+    void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_col, pc.d_colinc};
     for (void *q : dev)
       if (q) (void)hipFree(q);
   }
@@ -253,6 +255,7 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   if (getenv("XL_EXP_RIDERS")) b->riders = atoi(getenv("XL_EXP_RIDERS")) != 0;
   if (getenv("XL_EXP_RIDERS_MIN")) b->riders_min_wgs = atoi(getenv("XL_EXP_RIDERS_MIN"));
   if (getenv("XL_EXP_POLY")) b->poly_mode = atoi(getenv("XL_EXP_POLY"));
+  if (getenv("XL_EXP_POLY_EXP")) b->poly_exp = (uint32_t)atoi(getenv("XL_EXP_POLY_EXP"));
   if (getenv("XL_EXP_POLY_MIN")) b->poly_min_clients = (uint32_t)atoi(getenv("XL_EXP_POLY_MIN"));
   if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
   b->last_stream = b->own_stream;
@@ -382,7 +385,8 @@ static int xl_batch_plan(xlating_batch *b) {
     c.cls = it->second;
     members[c.cls].push_back((int)i);
     c.out_off = off;
-    off += xl_roundup(c.out_cap, 4);  // rows stay 16-byte aligned (the NCO kernel stores float4 pairs)
+    off += xl_roundup(c.out_cap, 8);  // rows start at multiples of 8: the NCO role stores pairs of table entries
+                                      // (every 4th phase) as 16 bytes
     XlNcoClient nc;
     memset(&nc, 0, sizeof(nc));
     nc.incr = make_float2(c.incr[0], c.incr[1]);
@@ -492,6 +496,7 @@ static int xl_batch_plan(xlating_batch *b) {
         for (size_t j = 0; j < td.ids.size(); ++j) {
           const Client &c = b->clients[td.ids[j]];
           t.out_off[j] = c.out_off;
+          t.incr[j] = make_float2(c.incr[0], c.incr[1]);
           for (uint32_t i = 0; i < cs.T; ++i) {
             dst[((size_t)i * ct + j) * 2] = c.rt[2 * i];
             dst[((size_t)i * ct + j) * 2 + 1] = c.rt[2 * i + 1];
@@ -567,7 +572,7 @@ static int xl_batch_plan(xlating_batch *b) {
     pc.A = A;
     pc.V = XLP_M - A + 1;
     pc.ncols = (uint32_t)members[k].size();
-    pc.nsg = (pc.ncols + XLP_COLS - 1) / XLP_COLS;
+    pc.ncg = (pc.ncols + XLP_COLS - 1) / XLP_COLS;
     pc.nseg_cap = (b->max_samples / cs.D + 1 + pc.V - 1) / pc.V;
     b->poly.push_back(pc);
     rest_cls[k] = false;
@@ -619,26 +624,31 @@ static int xl_batch_plan(xlating_batch *b) {
     }
     for (PolyClass &pc : b->poly) {
       const std::vector<int> &m = members[pc.cls];
-      const size_t rows = (size_t)pc.nsg * pc.Dpad + XLP_BSTEP;
+      const size_t rows = (size_t)pc.ncg * pc.Dpad + XLP_BSTEP;
       const uint32_t passes = (pc.nseg_cap + XLP_SEG - 1) / XLP_SEG;
       XL_TRY(hipMalloc((void **)&pc.d_R, rows * XLP_M * XLP_COLS * sizeof(float2)));
       XL_TRY(hipMemset(pc.d_R, 0, rows * XLP_M * XLP_COLS * sizeof(float2)));
       XL_TRY(hipMalloc((void **)&pc.d_X, (size_t)passes * pc.Dpad * XLP_M * XLP_XS * sizeof(float2)));
       XL_TRY(hipMemset(pc.d_X, 0, (size_t)passes * pc.Dpad * XLP_M * XLP_XS * sizeof(float2)));
-      XL_TRY(hipMalloc((void **)&pc.d_Y, (size_t)pc.nsg * pc.nseg_cap * XLP_M * XLP_COLS * sizeof(float2)));
-      std::vector<uint32_t> col((size_t)pc.nsg * XLP_COLS, 0xFFFFFFFFu);
+      XL_TRY(hipMalloc((void **)&pc.d_Y, (size_t)pc.ncg * pc.nseg_cap * XLP_M * XLP_COLS * sizeof(float2)));
+      std::vector<uint32_t> col((size_t)pc.ncg * XLP_COLS, 0xFFFFFFFFu);
       std::vector<float> rt((size_t)pc.ncols * pc.T * 2);
+      std::vector<float> colinc(2 * col.size(), 0.0f);
       for (size_t j = 0; j < m.size(); ++j) {
         const Client &c = b->clients[m[j]];
         col[j] = c.out_off;
+        colinc[2 * j] = c.incr[0];
+        colinc[2 * j + 1] = c.incr[1];
         memcpy(rt.data() + j * pc.T * 2, c.rt.data(), (size_t)pc.T * 2 * sizeof(float));
       }
       XL_TRY(hipMalloc((void **)&pc.d_col, col.size() * sizeof(uint32_t)));
       XL_TRY(hipMemcpy(pc.d_col, col.data(), col.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      XL_TRY(hipMalloc((void **)&pc.d_colinc, colinc.size() * sizeof(float)));
+      XL_TRY(hipMemcpy(pc.d_colinc, colinc.data(), colinc.size() * sizeof(float), hipMemcpyHostToDevice));
       float2 *d_rt = nullptr;
       XL_TRY(hipMalloc((void **)&d_rt, rt.size() * sizeof(float)));
       hipError_t e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = xlp_launch_tables(d_rt, pc.ncols, pc.T, pc.D, pc.Dpad, pc.A, pc.nsg, pc.d_R, b->own_stream);
+      if (e == hipSuccess) e = xlp_launch_tables(d_rt, pc.ncols, pc.T, pc.D, pc.Dpad, pc.A, pc.ncg, pc.d_R, b->own_stream);
       if (e == hipSuccess) e = hipStreamSynchronize(b->own_stream);
       (void)hipFree(d_rt);
       if (e != hipSuccess) goto fail;
@@ -653,7 +663,7 @@ static int xl_batch_plan(xlating_batch *b) {
     b->out_alloc = 0;
     for (int i = 0; i < 2; ++i) {
       XL_TRY(hipMalloc((void **)&b->d_out[i], b->out_total * sizeof(float2)));
-      XL_TRY(hipMalloc((void **)&b->d_phtab[i], b->out_total * sizeof(float2)));
+      XL_TRY(hipMalloc((void **)&b->d_phtab[i], (b->out_total / XL_PH_STRIDE + 8) * sizeof(float2)));  // every 4th phase
     }
     b->out_alloc = b->out_total;
   }
@@ -839,12 +849,15 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         for (PolyClass &pc : b->poly) {
           const uint32_t K = dyn.d[pc.cls].K;
           if (K == 0) continue;
-          if (!rolled) {
-            XL_TRY(xl_launch_update_history(b->d_hist[hb], d_block, XL_HCAP, (uint32_t)S, b->bps, b->d_hist[hn], s));
-            rolled = true;
-          }
           XlpArgs pa;
           memset(&pa, 0, sizeof(pa));
+          if (!rolled) {  // the forward launch also rolls the raw history
+            pa.hist_out = b->d_hist[hn];
+            pa.hist_units = XL_HCAP * (b->bps / 2);
+            pa.block_units = (uint32_t)S * (b->bps / 2);
+            pa.roll_blocks = 32;
+            rolled = true;
+          }
           pa.in0 = b->d_hist[hb];
           pa.n0 = XL_HCAP;
           pa.in1 = d_block;
@@ -858,12 +871,14 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
           pa.V = pc.V;
           pa.nseg = (K + pc.V - 1) / pc.V;
           pa.nseg_cap = pc.nseg_cap;
-          pa.nsg = pc.nsg;
+          pa.ncg = pc.ncg;
+          pa.exp = b->poly_exp;
           pa.W = b->d_W;
           pa.X = pc.d_X;
           pa.R = pc.d_R;
           pa.Y = pc.d_Y;
           pa.col_out = pc.d_col;
+          pa.col_incr = pc.d_colinc;
           pa.phtab = b->d_phtab[tab];
           pa.out = b->d_out[p];
           // the NEXT block's phase recurrence rides in these three launches as three slices (a direct launch
@@ -880,6 +895,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_state_dst = b->d_phase_run;
           }
           XL_TRY(xlp_launch_forward(pa, dyn, next, s));
+          pa.roll_blocks = 0;
           if (carry) {
             pa.nco_k0 = b->poly_slice1;
             pa.nco_k1 = b->poly_slice2;

@@ -115,9 +115,22 @@ XL_DEV void xl_nco_step(v2f &p, const v2f inc) {
   asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(p) : "v"(t1), "v"(t2));
 }
 
-// The work of one lane = one client: tabulate the phases [kb, ke) of a block of K outputs (kb even unless kb == ke),
-// reading the running phase from state_src[slot]; the slice that ends the block (`final`) renormalises and stores
-// the post-block phase to state_dst[slot], any other slice stores the running phase there.
+// the same step into a fresh register pair (xl_nco_client_slice keeps 16 phases live for the table stores)
+XL_DEV v2f xl_nco_next(const v2f p, const v2f inc) {
+  v2f t1, t2, r;
+  asm volatile(
+      "v_pk_mul_f32 %0, %3, %4 op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f32 %1, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_add_f32 %2, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+      : "=&v"(t1), "=&v"(t2), "=&v"(r)
+      : "v"(p), "v"(inc));
+  return r;
+}
+
+// The work of one lane = one client: advance the recurrence over the outputs [kb, ke) of a block of K (kb a multiple
+// of 8 unless kb == ke), tabulating every XL_PH_STRIDE-th phase (entry (out_off + m) / 4 for m = 0 mod 4), reading the
+// running phase from state_src[slot]; the slice that ends the block (`final`) renormalises and stores the
+// post-block phase to state_dst[slot], any other slice stores the running phase there.
 XL_DEV void xl_nco_client_slice(const XlNcoClient k, const uint32_t K, const uint32_t kb, const uint32_t ke,
                                 const bool final, const float2 *state_src, float2 *state_dst,
                                 float2 *__restrict__ tab) {
@@ -127,21 +140,25 @@ XL_DEV void xl_nco_client_slice(const XlNcoClient k, const uint32_t K, const uin
     return;
   }
   const v2f inc = {k.incr.x, k.incr.y};
-  v2f *__restrict__ o = reinterpret_cast<v2f *>(tab + k.out_off);  // out_off is even -> 16-byte aligned pairs
+  v2f *__restrict__ o = reinterpret_cast<v2f *>(tab) + (k.out_off >> 2);  // out_off = 0 mod 8 -> 16-byte entry pairs
   v4f *__restrict__ o4 = reinterpret_cast<v4f *>(o);
   uint32_t m = kb;
-  for (; m + 8 <= ke; m += 8) {
+  // 16 steps per trip; the 4 phases that are stored sit in distinct register pairs (a store reads its data registers
+  // asynchronously; a step that overwrote them right away would wait for that read)
+  for (; m + 16 <= ke; m += 16) {
+    v2f q[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const v2f a = p;
-      xl_nco_step(p, inc);
-      o4[(m >> 1) + j] = (v4f){a.x, a.y, p.x, p.y};
-      xl_nco_step(p, inc);
+      q[j] = p;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p = xl_nco_next(p, inc);
     }
+    o4[m >> 3] = (v4f){q[0].x, q[0].y, q[1].x, q[1].y};
+    o4[(m >> 3) + 1] = (v4f){q[2].x, q[2].y, q[3].x, q[3].y};
   }
   for (; m < ke; ++m) {
-    o[m] = p;
-    xl_nco_step(p, inc);
+    if ((m & 3u) == 0u) o[m >> 2] = p;
+    p = xl_nco_next(p, inc);
   }
   if (!final) {
     state_dst[k.slot] = make_float2(p.x, p.y);
@@ -151,6 +168,21 @@ XL_DEV void xl_nco_client_slice(const XlNcoClient k, const uint32_t K, const uin
   const double mag2 = (double)pr * (double)pr + (double)pi * (double)pi;
   const float mag = (float)__dsqrt_rn(mag2);
   state_dst[k.slot] = make_float2(pr / mag, pi / mag);
+}
+
+// Consumer side: the phase of output m of the client whose table row starts at entry (out_off / 4) = `row`:
+// the tabulated phase of output m - m % 4 advanced by m % 4 exact recurrence steps (same three IEEE operations as the
+// producer: bit-identical to a table of every phase).
+XL_DEV v2f xl_phase_advance(v2f p, const uint32_t r, const v2f inc) {  // r <= 3 steps
+#pragma unroll
+  for (uint32_t j = 0; j < 3u; ++j) {
+    const v2f n = xl_nco_next(p, inc);
+    p = j < r ? n : p;
+  }
+  return p;
+}
+XL_DEV v2f xl_phase_at(const v2f *__restrict__ row, const uint32_t m, const v2f inc) {
+  return xl_phase_advance(row[m >> 2], m & 3u, inc);
 }
 
 // whole block

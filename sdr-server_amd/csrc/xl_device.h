@@ -26,11 +26,17 @@
 
 enum { XLF_CU8 = 0, XLF_CS8 = 1, XLF_CS16 = 2, XLF_CF32 = 3 };
 
+#define XL_PH_STRIDE 4u  // the NCO phase table holds every 4th phase: entry (out_off + m) / 4 = phase of output m,
+                         // m = 0 mod 4; consumers take the remaining <= 3 recurrence steps themselves (bit-identical,
+                         // xl_phase_at).  Every 8 bytes of table store cost the dependent chain ~6-10 ns of issue time
+                         // on top of ~9 ns per step (tools/ubench_chain2.hip), whatever the layout.
 struct XlTile {
   uint32_t tap_off;              // float2 index into the tap image; layout [Tpad][ct]
   uint32_t nclients;             // 1..ct real clients (the rest of the tile has zero taps)
-  uint32_t out_off[XL_CT_MAX];   // per client: float2 index into the output / phase-table images
+  uint32_t out_off[XL_CT_MAX];   // per client: float2 index into the output image; / XL_PH_STRIDE into the phase table
+  float2 incr[XL_CT_MAX];        // per client: NCO phase increment (xlating.c:544)
 };
+#define XL_TILE_DWORDS (2u + 3u * XL_CT_MAX)
 
 struct XlGroup {
   uint32_t D, T, Tpad;
@@ -73,7 +79,7 @@ struct XlFirArgs {
                         // not fit the LDS (very large decimations)
   uint32_t flags;       // bit 0: every group of the launch has even D (16-byte LDS reads); bit 1: flat wave priority; bit 2: priority segments end at 1/2, 3/4, 7/8
   const float2 *taps;   // tap image
-  const float2 *phtab;  // NCO phase table, indexed like out
+  const float2 *phtab;  // NCO phase table: every XL_PH_STRIDE-th phase, entry (out index) / XL_PH_STRIDE
   float2 *out;
   void *hist_out;       // batch engine: where to write the rolled raw history (null: no roll)
   uint32_t hist_units;  // history length in 2-byte units (= n0 * bytes-per-sample / 2)
@@ -102,9 +108,10 @@ struct XlFirArgs {
 // dyn_next: per-class numbers of the NEXT block, used only by the NCO role (a.nco_blocks > 0); may alias dyn.
 hipError_t xl_launch_fir(int ct, int mode, int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next,
                          size_t lds_bytes, hipStream_t s);
-#define XL_NCO_LANES 16u  // clients per workgroup in the NCO table kernel / NCO role
+#define XL_NCO_LANES 64u  // clients per wave in the NCO table kernel / NCO role (with every 4th phase stored the
+                          // stores are rare enough that a full wave costs the chain nothing: 8.8 vs 10.6 ns per step)
 // reads the running phases from state_in[slot], writes the post-block phases to state_out[slot] (may alias).
-// Every client's out_off must be even (16-byte table stores).  prio: wave priority 0..3 of the kernel.
+// Every client's out_off must be a multiple of 8 (16-byte stores of table entry pairs).  prio: wave priority 0..3 of the kernel.
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
                                float2 *state_out, float2 *phtab, const XlDynArgs &dyn, uint32_t prio, hipStream_t s);
 // raw -> converted sample images of the single-filter path (xlating.c:352-433)

@@ -109,6 +109,7 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   g.wide = (decimation % 2 == 0) ? 1u : 0u;
   g.tiles[0].tap_off = 0;
   g.tiles[0].nclients = 1;
+  g.tiles[0].incr[0] = make_float2(incr[0], incr[1]);
   XlNcoClient nc;
   memset(&nc, 0, sizeof(nc));
   nc.incr = make_float2(incr[0], incr[1]);
@@ -124,7 +125,7 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XL_TRY(hipMalloc((void **)&f->d_work_q, work_n * sizeof(short2)));
   XL_TRY(hipMalloc((void **)&f->d_out_f, f->out_cap * sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_out_q, f->out_cap * sizeof(short2)));
-  XL_TRY(hipMalloc((void **)&f->d_phtab, f->out_cap * sizeof(float2)));
+  XL_TRY(hipMalloc((void **)&f->d_phtab, (f->out_cap / XL_PH_STRIDE + 8) * sizeof(float2)));  // every 4th phase
   XL_TRY(hipMalloc((void **)&f->d_qphtab, f->out_cap * sizeof(short2)));
   XL_TRY(hipMalloc((void **)&f->d_phase, sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_qphase, sizeof(short2)));

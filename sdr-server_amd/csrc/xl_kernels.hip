@@ -34,9 +34,9 @@
 // the block ahead of the FIR kernel; the recurrence itself must stay sequential to be bit-exact.
 // hypotf: glibc evaluates sqrt(x*x + y*y) in double and narrows; restated with IEEE double ops.
 // Stand-alone launch (single-filter path; first block / wrong length guess of the batch engine).  `lanes`
-// (XL_NCO_LANES = 16) lanes of a wave carry a client and the table is written two steps (16 bytes) per store: every
-// store goes to the client's own table row (fully divergent addresses).  The kernel is a pure dependent chain
-// (~20 ns per step whatever the width), so few lanes per wave cost nothing; measured 8..32 lanes equal, 64 ~15 % slower.
+// (XL_NCO_LANES) lanes of a wave carry a client each; every 4th phase is stored, two entries (16 bytes) per store, to
+// the client's own table row.  The kernel is a pure dependent chain: ~9 ns per step (two dependent packed
+// operations) plus the store issue time, which is why only every 4th phase is tabulated (tools/ubench_chain2.hip).
 __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
                                                           const float2 *state_in, float2 *state_out,
                                                           float2 *__restrict__ tab, const XlDynArgs dyn,
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
     tr[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
     tr[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
   }
-  const cu32_p t = g + 8 + w * (2 + XL_CT_MAX);  // XlTile of this wave
+  const cu32_p t = g + 8 + w * XL_TILE_DWORDS;  // XlTile of this wave
   const uint32_t ncl = t[1];
   const cfloat_p tp = (cfloat_p)(uintptr_t)(a.taps + t[0]);
 
@@ -284,8 +284,10 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         if ((uint32_t)c < ncl) {
-          const uint32_t off = t[2 + c] + m;
-          out[off] = xl_rotate<MODE>(acc[c].value(), ph[off]);
+          const uint32_t off = t[2 + c];
+          const cfloat_p ti = (cfloat_p)(t + 2 + XL_CT_MAX);  // XlTile::incr
+          const v2f inc = {ti[2 * c], ti[2 * c + 1]};
+          out[off + m] = xl_rotate<MODE>(acc[c].value(), xl_phase_at(ph + (off >> 2), m, inc));
         }
       }
     }

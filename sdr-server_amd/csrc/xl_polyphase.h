@@ -23,7 +23,7 @@
 #define XLP_M 256u     // transform length (branch samples per segment)
 #define XLP_SEG 13u    // segments accumulated per lane in one pass of the mix kernel
 #define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: XLP_SEG padded to 128 bytes
-#define XLP_COLS 256u  // client columns per supergroup (= threads of a mix workgroup)
+#define XLP_COLS 128u  // client columns per column group (= one mix workgroup: a wave with two columns per lane)
 #define XLP_BSTEP 6u   // branches per software-pipeline stage of the mix kernel (images are padded to a multiple)
 
 struct XlpArgs {
@@ -37,14 +37,19 @@ struct XlpArgs {
   uint32_t T, A, V;    // taps, taps per branch, valid outputs per segment
   uint32_t nseg;       // segments of this block = ceil(K / V)
   uint32_t nseg_cap;   // segment capacity of the Y image
-  uint32_t nsg;        // supergroups of XLP_COLS client columns
+  uint32_t ncg;        // column groups of XLP_COLS client columns
+  uint32_t exp;        // tuning switches (0 in production)
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
-  const float2 *R;     // branch spectra   [sg][Dpad][M][XLP_COLS]
-  float2 *Y;           // mixed spectra    [sg][nseg_cap][M][XLP_COLS]
-  const uint32_t *col_out;  // per column: float2 index of the client's row in out / phtab, 0xFFFFFFFF = empty column
+  const float2 *R;     // branch spectra   [cg][Dpad][M][XLP_COLS]
+  float2 *Y;           // mixed spectra    [cg][nseg_cap][M][XLP_COLS]
+  const uint32_t *col_out;  // per column: float2 index of the client's row in out (/ 4 in phtab), 0xFFFFFFFF = empty
+  const float2 *col_incr;   // per column: NCO phase increment
   const float2 *phtab;
   float2 *out;
+  // raw-history roll, carried by the forward launch (as XlFirArgs): null / 0 = none
+  void *hist_out;
+  uint32_t hist_units, block_units, roll_blocks;
   // NCO role pieces (see XlFirArgs): each of the three launches of a block carries a slice [nco_k0, nco_k1) of the
   // NEXT block's phase recurrence; the slice that ends the block renormalises (xlating.c:73).
   const XlNcoClient *nco_clients;
@@ -57,9 +62,9 @@ struct XlpArgs {
 };
 
 // reversed band-pass taps of every column -> branch spectra R (double arithmetic, rounded once to float)
-//   rt: [ncols][T] float2 (column-major clients), ncols <= nsg * XLP_COLS; columns >= ncols and branches >= D get 0
+//   rt: [ncols][T] float2 (column-major clients), ncols <= ncg * XLP_COLS; columns >= ncols and branches >= D get 0
 hipError_t xlp_launch_tables(const float2 *rt, uint32_t ncols, uint32_t T, uint32_t D, uint32_t Dpad, uint32_t A,
-                             uint32_t nsg, float2 *R, hipStream_t s);
+                             uint32_t ncg, float2 *R, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, const XlDynArgs &dyn_next, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s);

@@ -4,10 +4,10 @@
 // Three launches per block and class (stream order is the only synchronisation):
 //   xlp_forward_kernel  one wave per (segment, branch): raw samples -> cf32 (xlating.c:357-378, exact) -> 256-point
 //                       DFT of the branch -> shared spectra X[pass][b][m][s].  D * nseg small transforms: ~1 MB.
-//   xlp_mix_kernel      Y[c][s][m] = sum_b X[s][b][m] * R[c][b][m].  lane = client column (256 per workgroup), m is
-//                       workgroup-uniform: X comes through SCALAR loads as SGPR operands of v_pk_fma_f32 (13 segments
-//                       per row = two s_load_dwordx16), R is streamed exactly once, coalesced (8 bytes per lane, 2 KB
-//                       per workgroup and branch).  HBM-bound on R: 8 * D * M bytes per client and block.
+//   xlp_mix_kernel      Y[c][s][m] = sum_b X[s][b][m] * R[c][b][m].  lane = two client columns, the bin m is
+//                       workgroup-uniform: its column of X is staged in LDS once and broadcast-read row by row, R is
+//                       streamed exactly once, coalesced (16 bytes per lane and branch).  HBM-bound on R:
+//                       8 * D * M bytes per client and block.
 //   xlp_inverse_kernel  per (segment, 16 columns): Y tile -> LDS (transposed) -> 256-point inverse DFT per column ->
 //                       scale, NCO rotate (xlating.c:70) with the tabulated float32 phase -> out[k], k < K.
 // Each launch also carries a slice of the NEXT block's NCO phase recurrence (a ~57 us dependent chain per block
@@ -22,37 +22,74 @@ XL_DEV v2f xlp_cmul(const v2f a, const v2f b) {
 
 // 256-point DFT by one wave: radix-4 Stockham autosort, passes p = 1, 4, 16, 64; lane j holds points j + 64 r.
 // In: u[r] = x[j + 64 r].  Out: u[r] = X[j + 64 r] (natural order).  SIGN -1 forward, +1 inverse (unnormalised).
-// W[n] = e^{-2 pi j n / 256}.  `lds` = 256 complex of scratch owned by this wave; LDS operations of one wave execute
-// in order, so no barrier is needed between a pass's scatter and the next gather.
+// The twiddles of a lane depend only on (pass, r, j): xlp_twiddles() fetches the nine of them once (one exposed
+// global latency instead of three), e^{-2 pi j n / 256} from the table W, conjugated for the inverse.
+// `lds` = XLP_ROW complex owned by this wave, addressed through XLP_POS (may be the input row itself); LDS operations of one wave execute in
+// order, so no barrier is needed between a pass's scatter and the next gather.
+struct XlpTw {
+  v2f w[3][3];  // [pass - 1][r - 1]
+};
+// LDS position of transform element i: one pad element per four.  The scatter of pass p writes elements
+// jo + r p with jo = 4 (j - j % p) + j % p -- strides of 4, 16, 64 elements of 8 bytes across lanes, a 4- to 16-way
+// bank conflict on a dense row (measured: the inverse kernel spent ~20 of its 28 us there); with the pad the 16
+// lanes of a quarter-wave hit 16 distinct bank pairs in passes 0 and 1 and at most 2-way conflicts elsewhere.
+#define XLP_POS(i) ((i) + ((i) >> 2))
+#define XLP_ROW (XLP_M + XLP_M / 4)  // padded row length in elements
+
 template <int SIGN>
-XL_DEV void xlp_dft256(v2f (&u)[4], v2f *__restrict__ lds, const v2f *__restrict__ W, const uint32_t j) {
+XL_DEV XlpTw xlp_twiddles(const v2f *__restrict__ W, const uint32_t j) {
+  XlpTw t;
+#pragma unroll
+  for (int pass = 1; pass < 4; ++pass) {
+    const uint32_t p = 1u << (2 * pass);
+    const uint32_t k = j & (p - 1u);
+    const uint32_t step = 64u >> (2 * pass);  // 256 / (4 p)
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      v2f w = W[(r * k * step) & 255u];
+      if (SIGN > 0) w.y = -w.y;
+      t.w[pass - 1][r - 1] = w;
+    }
+  }
+  return t;
+}
+
+// one pass (butterflies) on registers
+template <int SIGN>
+XL_DEV void xlp_dft256_butterfly(v2f (&u)[4], const XlpTw &tw, const int pass) {
+  if (pass > 0) {
+#pragma unroll
+    for (int r = 1; r < 4; ++r) u[r] = xlp_cmul(u[r], tw.w[pass - 1][r - 1]);
+  }
+  const v2f v0 = u[0] + u[2], v1 = u[0] - u[2], v2 = u[1] + u[3], t = u[1] - u[3];
+  const v2f v3 = SIGN > 0 ? (v2f){-t.y, t.x} : (v2f){t.y, -t.x};  // * (SIGN * j)
+  u[0] = v0 + v2;
+  u[1] = v1 + v3;
+  u[2] = v0 - v2;
+  u[3] = v1 - v3;
+}
+
+// NI independent transforms interleaved (instruction-level parallelism for a wave that runs almost alone)
+template <int SIGN, int NI>
+XL_DEV void xlp_dft256(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, const uint32_t j) {
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const uint32_t p = 1u << (2 * pass);
     const uint32_t k = j & (p - 1u);
-    if (pass > 0) {
-      const uint32_t step = 64u >> (2 * pass);  // 256 / (4 p)
 #pragma unroll
-      for (int r = 1; r < 4; ++r) {
-        v2f w = W[(r * k * step) & 255u];
-        if (SIGN > 0) w.y = -w.y;
-        u[r] = xlp_cmul(u[r], w);
-      }
-    }
-    const v2f v0 = u[0] + u[2], v1 = u[0] - u[2], v2 = u[1] + u[3], t = u[1] - u[3];
-    const v2f v3 = SIGN > 0 ? (v2f){-t.y, t.x} : (v2f){t.y, -t.x};  // * (SIGN * j)
-    v2f y[4] = {v0 + v2, v1 + v3, v0 - v2, v1 - v3};
+    for (int n = 0; n < NI; ++n) xlp_dft256_butterfly<SIGN>(u[n], tw, pass);
     if (pass < 3) {
       const uint32_t jo = ((j - k) << 2) + k;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lds[jo + r * p] = y[r];
+      for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[n][XLP_POS(jo + r * p)] = u[n][r];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) u[r] = lds[j + 64u * r];
-      __builtin_amdgcn_wave_barrier();
-    } else {
+      for (int n = 0; n < NI; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) u[r] = y[r];
+        for (int r = 0; r < 4; ++r) u[n][r] = lds[n][XLP_POS(j + 64u * r)];
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -65,28 +102,43 @@ XL_DEV void xlp_nco_role(const XlpArgs &a, const XlDynArgs &dyn_next) {
   if (c >= a.nco_nclients) return;
   const XlNcoClient k = a.nco_clients[c];
   const uint32_t K = dyn_next.d[k.cls].K;
-  const uint32_t kb = a.nco_k0 == 0u ? 0u : (uint32_t)(((uint64_t)K * a.nco_k0) >> 16) & ~1u;
+  const uint32_t kb = a.nco_k0 == 0u ? 0u : (uint32_t)(((uint64_t)K * a.nco_k0) >> 16) & ~7u;
   const bool final = a.nco_k1 >= 65536u;
-  const uint32_t ke = final ? K : (uint32_t)(((uint64_t)K * a.nco_k1) >> 16) & ~1u;
+  const uint32_t ke = final ? K : (uint32_t)(((uint64_t)K * a.nco_k1) >> 16) & ~7u;
   xl_nco_client_slice(k, K, kb, ke, final, a.nco_state_src, a.nco_state_dst, a.nco_tab);
 }
 
 // ------------------------------------------------------------------------------------------- forward transforms
+// grid = nco_blocks + nseg * D transform workgroups (one wave each) + a.roll_blocks history-roll workgroups.
 __global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a, const XlDynArgs dyn,
                                                          const XlDynArgs dyn_next) {
-  __shared__ v2f lds[XLP_M];
+  __shared__ v2f lds[XLP_ROW];
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a, dyn_next);
     return;
   }
   const uint32_t bid = blockIdx.x - a.nco_blocks;
   const uint32_t j = threadIdx.x;
+  if (bid >= a.nseg * a.D) {
+    // raw-history roll (as in xl_fir_kernel): hist_out = the last hist_units 2-byte units of [in0 | in1]; nothing in
+    // this block's launches reads hist_out
+    const uint32_t rb = bid - a.nseg * a.D;
+    const uint16_t *__restrict__ h0 = reinterpret_cast<const uint16_t *>(a.in0);
+    const uint16_t *__restrict__ h1 = reinterpret_cast<const uint16_t *>(a.in1);
+    uint16_t *__restrict__ ho = reinterpret_cast<uint16_t *>(a.hist_out);
+    for (uint32_t i = rb * 64u + j; i < a.hist_units; i += a.roll_blocks * 64u) {
+      const uint32_t sidx = a.block_units + i;
+      ho[i] = (sidx < a.hist_units) ? h0[sidx] : h1[sidx - a.hist_units];
+    }
+    return;
+  }
+  const XlpTw tw = xlp_twiddles<-1>(reinterpret_cast<const v2f *>(a.W), j);
   const uint32_t s = bid / a.D, b = bid - s * a.D;
   const XlDyn d = dyn.d[a.cls];
   // branch sample n of segment s = stream sample base + (s V + n) D + b   (base: first tap of output 0)
   const uint32_t first = d.base + s * a.V * a.D + b;
   const uint32_t end = a.n0 + a.n1;
-  v2f u[4];
+  v2f u[1][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint32_t idx = first + (j + 64u * r) * a.D;
@@ -95,118 +147,190 @@ __global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a, const 
     const bool lo = idx < a.n0;
     const void *src = (lo || !ok) ? a.in0 : a.in1;
     const v2f v = xl_sample(src, (int)a.fmt, ok ? (lo ? idx : idx - a.n0) : 0u);
-    u[r] = ok ? v : (v2f){0.0f, 0.0f};
+    u[0][r] = ok ? v : (v2f){0.0f, 0.0f};
   }
-  xlp_dft256<-1>(u, lds, reinterpret_cast<const v2f *>(a.W), j);
+  v2f *const bufs[1] = {lds};
+  xlp_dft256<-1, 1>(u, bufs, tw, j);
   const uint32_t pass = s / XLP_SEG, si = s - pass * XLP_SEG;
   v2f *__restrict__ X = reinterpret_cast<v2f *>(a.X);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) X[(((size_t)pass * a.Dpad + b) * XLP_M + (j + 64u * r)) * XLP_XS + si] = u[r];
+  for (int r = 0; r < 4; ++r) X[(((size_t)pass * a.Dpad + b) * XLP_M + (j + 64u * r)) * XLP_XS + si] = u[0][r];
 }
 
 // ------------------------------------------------------------------------------------------- mix (the hot kernel)
-// grid = nco_blocks + M * nsg * passes workgroups of 256 threads; thread t = client column sg * 256 + t.
-__global__ __launch_bounds__(256) void xlp_mix_kernel(const XlpArgs a, const XlDynArgs dyn_next) {
+// acc += r * x with ONE accumulator pair: two v_pk_fma_f32, the second negates x.im in its low half (neg_lo) --
+//   acc.re += r.re*x.re;  acc.im += r.re*x.im;      acc.re += r.im*(-x.im);  acc.im += r.im*x.re
+XL_DEV void xlp_cmac(v2f &acc, const v2f r, const v2f x) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "+v"(acc)
+      : "v"(r), "v"(x));
+}
+
+// grid = nco_blocks + M * ncg * passes workgroups of ONE wave; lane l = client columns cg*128 + 2l, 2l+1; the spectrum
+// bin m is workgroup-uniform.  The bin's column of the shared spectra (Dpad rows of 13 segments, 128 bytes each) is
+// staged in LDS once and read back row by row as broadcast reads (every lane the same address): uniform operands
+// with short, in-order latency (scalar loads of the rows were measured latency-bound: ~27 us per 1024 clients).
+// R is streamed exactly once: 16 bytes per lane and branch, XLP_BSTEP branches in flight ahead of the multiply.
+__global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDynArgs dyn_next) {
+  extern __shared__ __attribute__((aligned(16))) v4f xlp_xcol[];  // [Dpad][8]
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a, dyn_next);
     return;
   }
   const uint32_t bid = blockIdx.x - a.nco_blocks;
+  const uint32_t lane = threadIdx.x;
   const uint32_t m = bid % XLP_M;
   const uint32_t q = bid / XLP_M;
-  const uint32_t sg = q % a.nsg, pass = q / a.nsg;
-  const v2f *__restrict__ Rp =
-      reinterpret_cast<const v2f *>(a.R) + ((size_t)sg * a.Dpad * XLP_M + m) * XLP_COLS + threadIdx.x;
-  const size_t rstride = (size_t)XLP_M * XLP_COLS;
-  const cfloat_p Xp = (cfloat_p)(uintptr_t)(a.X + ((size_t)pass * a.Dpad * XLP_M + m) * XLP_XS);
-  const size_t xstride = (size_t)XLP_M * XLP_XS * 2;  // floats per branch
-  XlAcc<1> acc[XLP_SEG];
-#pragma unroll
-  for (int i = 0; i < (int)XLP_SEG; ++i) acc[i].clear();
-  // branches in stages of XLP_BSTEP: the R rows of the next stage are in flight while this one is multiplied
-  v2f r[XLP_BSTEP], rn[XLP_BSTEP];
+  const uint32_t cg = q % a.ncg, pass = q / a.ncg;
+  const v4f *__restrict__ Rp =
+      reinterpret_cast<const v4f *>(a.R) + ((size_t)cg * a.Dpad * XLP_M + m) * (XLP_COLS / 2) + lane;
+  const size_t rstride = (size_t)XLP_M * (XLP_COLS / 2);
+  v4f r[XLP_BSTEP], rn[XLP_BSTEP];
 #pragma unroll
   for (int u = 0; u < (int)XLP_BSTEP; ++u) r[u] = Rp[(size_t)u * rstride];
+  {
+    const v4f *__restrict__ Xc =
+        reinterpret_cast<const v4f *>(a.X + ((size_t)pass * a.Dpad * XLP_M + m) * XLP_XS);  // row stride M * 8 v4f
+    const uint32_t n8 = a.Dpad * 8u;
+    for (uint32_t base = 0; base < n8; base += 512u) {  // one trip for D <= 64; all loads of a trip in flight together
+      v4f t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t i = base + lane + 64u * u;
+        const uint32_t ic = i < n8 ? i : 0u;
+        t[u] = Xc[(size_t)(ic >> 3) * (XLP_M * 8u) + (ic & 7u)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t i = base + lane + 64u * u;
+        if (i < n8) xlp_xcol[i] = t[u];
+      }
+    }
+  }
+  __syncthreads();
+  v2f acc0[XLP_SEG], acc1[XLP_SEG];
+#pragma unroll
+  for (int i = 0; i < (int)XLP_SEG; ++i) acc0[i] = acc1[i] = (v2f){0.0f, 0.0f};
   for (uint32_t b0 = 0; b0 < a.Dpad; b0 += XLP_BSTEP) {
-    // (the last stage prefetches rows past this supergroup's image: the next supergroup's, or the XLP_BSTEP rows of
+    // (the last stage prefetches rows past this column group's image: the next group's, or the XLP_BSTEP rows of
     // tail padding the engine allocates -- loaded, never used)
 #pragma unroll
-    for (int u = 0; u < (int)XLP_BSTEP; ++u) rn[u] = Rp[(size_t)(b0 + XLP_BSTEP + u) * rstride];
+    for (int u = 0; u < (int)XLP_BSTEP; ++u)
+      rn[u] = Rp[(size_t)(((a.exp & 1u) ? 0u : b0 + XLP_BSTEP) + u) * rstride];  // exp bit 0 (tuning): re-read stage 0
 #pragma unroll
     for (int u = 0; u < (int)XLP_BSTEP; ++u) {
-      const cfloat_p x = Xp + (size_t)(b0 + u) * xstride;
+      const v4f *__restrict__ xr = xlp_xcol + ((a.exp & 2u) ? 0u : (b0 + u)) * 8u;  // exp bit 1 (tuning)
+      const v2f ra = {r[u].x, r[u].y}, rb = {r[u].z, r[u].w};
 #pragma unroll
-      for (int i = 0; i < (int)XLP_SEG; ++i) acc[i].mac(r[u], x[2 * i], x[2 * i + 1]);
+      for (int i = 0; i < 6; ++i) {
+        const v4f x2 = xr[i];
+        const v2f xa = {x2.x, x2.y}, xb = {x2.z, x2.w};
+        xlp_cmac(acc0[2 * i], ra, xa);
+        xlp_cmac(acc1[2 * i], rb, xa);
+        xlp_cmac(acc0[2 * i + 1], ra, xb);
+        xlp_cmac(acc1[2 * i + 1], rb, xb);
+      }
+      const v4f x2 = xr[6];
+      const v2f xa = {x2.x, x2.y};
+      xlp_cmac(acc0[12], ra, xa);
+      xlp_cmac(acc1[12], rb, xa);
     }
 #pragma unroll
     for (int u = 0; u < (int)XLP_BSTEP; ++u) r[u] = rn[u];
   }
   const uint32_t s0 = pass * XLP_SEG;
-  v2f *__restrict__ Yp =
-      reinterpret_cast<v2f *>(a.Y) + (((size_t)sg * a.nseg_cap + s0) * XLP_M + m) * XLP_COLS + threadIdx.x;
+  v4f *__restrict__ Yp =
+      reinterpret_cast<v4f *>(a.Y) + (((size_t)cg * a.nseg_cap + s0) * XLP_M + m) * (XLP_COLS / 2) + lane;
 #pragma unroll
   for (int i = 0; i < (int)XLP_SEG; ++i)
-    if (s0 + i < a.nseg) Yp[(size_t)i * XLP_M * XLP_COLS] = acc[i].value();
+    if (s0 + i < a.nseg) Yp[(size_t)i * XLP_M * (XLP_COLS / 2)] = (v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y};
 }
 
 // ------------------------------------------------------------------------------------------- inverse + epilogue
-// grid = nco_blocks + nseg * nsg * 16 workgroups of 256 threads; workgroup = (segment, 16 columns).
+// grid = nco_blocks + nseg * ncg * 8 workgroups of 256 threads; workgroup = (segment, 16 columns).  The tile rows
+// double as the transforms' scratch; each wave runs its four columns' transforms interleaved.
 __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const XlDynArgs dyn,
                                                           const XlDynArgs dyn_next) {
-  __shared__ v2f tile[16][XLP_M];     // [column][bin]
-  __shared__ v2f scratch[4][XLP_M];   // per wave
+  __shared__ v2f tile[16][XLP_ROW];  // [column][padded bin position]
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a, dyn_next);
     return;
   }
   const uint32_t bid = blockIdx.x - a.nco_blocks;
-  const uint32_t sub = bid & 15u;
-  const uint32_t q = bid >> 4;
-  const uint32_t sg = q % a.nsg, s = q / a.nsg;
+  const uint32_t sub = bid & 7u;
+  const uint32_t q = bid >> 3;
+  const uint32_t cg = q % a.ncg, s = q / a.ncg;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = threadIdx.x & 63u;
+  const XlpTw tw = xlp_twiddles<+1>(reinterpret_cast<const v2f *>(a.W), j);
   {
     const uint32_t m = threadIdx.x;
     const v4f *__restrict__ src = reinterpret_cast<const v4f *>(
-        a.Y + (((size_t)sg * a.nseg_cap + s) * XLP_M + m) * XLP_COLS + sub * 16u);
+        a.Y + (((size_t)cg * a.nseg_cap + s) * XLP_M + m) * XLP_COLS + sub * 16u);
+    v4f v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = src[i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const v4f v = src[i];
-      tile[2 * i][m] = (v2f){v.x, v.y};
-      tile[2 * i + 1][m] = (v2f){v.z, v.w};
+      tile[2 * i][XLP_POS(m)] = (v2f){v[i].x, v[i].y};
+      tile[2 * i + 1][XLP_POS(m)] = (v2f){v[i].z, v[i].w};
     }
   }
-  __syncthreads();
-  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = threadIdx.x & 63u;
+  // the epilogue's operands, requested before the transforms: row offsets, increments and the tabulated NCO phases
+  // (every 4th output) of this wave's 4 columns -- all 16 loads in flight together, the <= 3 recurrence steps that
+  // complete a phase come after the transforms
   const uint32_t K = dyn.d[a.cls].K;
   const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
   v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
-  for (uint32_t ci = 0; ci < 4u; ++ci) {
-    const uint32_t i = 4u * w + ci;
-    const uint32_t off = a.col_out[sg * XLP_COLS + sub * 16u + i];
-    if (off == 0xFFFFFFFFu) continue;
-    v2f u[4];
+  uint32_t off[4];
+  v2f inc[4];
+  v2f pz[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) u[r] = tile[i][j + 64u * r];
-    xlp_dft256<+1>(u, scratch[w], reinterpret_cast<const v2f *>(a.W), j);
+  for (int n = 0; n < 4; ++n) {
+    const uint32_t col = cg * XLP_COLS + sub * 16u + 4u * w + n;
+    off[n] = a.col_out[col];
+    const float2 ci = a.col_incr[col];
+    inc[n] = (v2f){ci.x, ci.y};
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const uint32_t qo = j + 64u * r;
-      const uint32_t k = s * a.V + qo;
-      if (qo < a.V && k < K) {
-        const v2f y = u[r] * (1.0f / (float)XLP_M);  // exact scaling by 2^-8
-        out[off + k] = xl_rotate<1>(y, ph[off + k]);
+      const uint32_t qo = j + 64u * r, k = s * a.V + qo;
+      const bool ok = off[n] != 0xFFFFFFFFu && qo < a.V && k < K;
+      pz[n][r] = ph[ok ? (off[n] >> 2) + (k >> 2) : 0u];
+    }
+  }
+  __syncthreads();
+  v2f u[4][4];
+  v2f *const rows[4] = {tile[4 * w], tile[4 * w + 1], tile[4 * w + 2], tile[4 * w + 3]};
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[n][r] = rows[n][XLP_POS(j + 64u * r)];
+  __builtin_amdgcn_wave_barrier();
+  xlp_dft256<+1, 4>(u, rows, tw, j);
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t qo = j + 64u * r, k = s * a.V + qo;
+      if (off[n] != 0xFFFFFFFFu && qo < a.V && k < K) {
+        const v2f y = u[n][r] * (1.0f / (float)XLP_M);  // exact scaling by 2^-8
+        out[off[n] + k] = xl_rotate<1>(y, xl_phase_advance(pz[n][r], k & 3u, inc[n]));
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------- branch spectra
-// R[sg][b][m][col] = sum_{a<A} r_col[D a + b] e^{+2 pi j a m / M}, in double, rounded once.  One-time per plan.
-__global__ __launch_bounds__(256) void xlp_tables_kernel(const float2 *__restrict__ rt, uint32_t ncols, uint32_t T,
+// R[cg][b][m][col] = sum_{a<A} r_col[D a + b] e^{+2 pi j a m / M}, in double, rounded once.  One-time per plan.
+__global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__restrict__ rt, uint32_t ncols, uint32_t T,
                                                          uint32_t D, uint32_t Dpad, uint32_t A, float2 *__restrict__ R) {
   const uint32_t m = blockIdx.x % XLP_M;
   const uint32_t q = blockIdx.x / XLP_M;
-  const uint32_t b = q % Dpad, sg = q / Dpad;
-  const uint32_t col = sg * XLP_COLS + threadIdx.x;
+  const uint32_t b = q % Dpad, cg = q / Dpad;
+  const uint32_t col = cg * XLP_COLS + threadIdx.x;
   double sr = 0.0, si = 0.0;
   if (col < ncols && b < D) {
     const float2 *__restrict__ t = rt + (size_t)col * T;
@@ -220,28 +344,31 @@ __global__ __launch_bounds__(256) void xlp_tables_kernel(const float2 *__restric
       si += tr * sn + ti * cs;
     }
   }
-  R[(((size_t)sg * Dpad + b) * XLP_M + m) * XLP_COLS + threadIdx.x] = make_float2((float)sr, (float)si);
+  R[(((size_t)cg * Dpad + b) * XLP_M + m) * XLP_COLS + threadIdx.x] = make_float2((float)sr, (float)si);
 }
 
 // ------------------------------------------------------------------------------------------- launchers
 hipError_t xlp_launch_tables(const float2 *rt, uint32_t ncols, uint32_t T, uint32_t D, uint32_t Dpad, uint32_t A,
-                             uint32_t nsg, float2 *R, hipStream_t s) {
-  hipLaunchKernelGGL(xlp_tables_kernel, dim3(XLP_M * Dpad * nsg), dim3(256), 0, s, rt, ncols, T, D, Dpad, A, R);
+                             uint32_t ncg, float2 *R, hipStream_t s) {
+  hipLaunchKernelGGL(xlp_tables_kernel, dim3(XLP_M * Dpad * ncg), dim3(XLP_COLS), 0, s, rt, ncols, T, D, Dpad, A, R);
   return hipGetLastError();
 }
 
 hipError_t xlp_launch_forward(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s) {
-  hipLaunchKernelGGL(xlp_forward_kernel, dim3(a.nco_blocks + a.nseg * a.D), dim3(64), 0, s, a, dyn, dyn_next);
+  hipLaunchKernelGGL(xlp_forward_kernel, dim3(a.nco_blocks + a.nseg * a.D + a.roll_blocks), dim3(64), 0, s, a, dyn,
+                     dyn_next);
   return hipGetLastError();
 }
 
 hipError_t xlp_launch_mix(const XlpArgs &a, const XlDynArgs &dyn_next, hipStream_t s) {
   const uint32_t passes = (a.nseg + XLP_SEG - 1) / XLP_SEG;
-  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + XLP_M * a.nsg * passes), dim3(256), 0, s, a, dyn_next);
+  const size_t lds = (size_t)a.Dpad * 8u * sizeof(v4f);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + XLP_M * a.ncg * passes), dim3(64), lds, s, a, dyn_next);
   return hipGetLastError();
 }
 
 hipError_t xlp_launch_inverse(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s) {
-  hipLaunchKernelGGL(xlp_inverse_kernel, dim3(a.nco_blocks + a.nseg * a.nsg * 16u), dim3(256), 0, s, a, dyn, dyn_next);
+  hipLaunchKernelGGL(xlp_inverse_kernel, dim3(a.nco_blocks + a.nseg * a.ncg * 8u), dim3(256), 0, s, a, dyn, dyn_next);
   return hipGetLastError();
 }

@@ -1,0 +1,14 @@
+#!/bin/bash
+OUT=$GRAFT_REPO_ROOT/gpurun_out/s32; mkdir -p $OUT
+echo "== pytest polyphase"; timeout 600 python -m pytest tests/test_batch_gpu.py -m gpu -q -x --timeout=300 -k "polyphase" 2>&1 | tail -15 | tee $OUT/pytest_poly.log
+echo "== poly check"; timeout 600 python tools/poly_check.py 1024,4096 2>&1 | grep -v amdgpu.ids | tee $OUT/poly_check.log
+export TMPDIR=/tmp; cd /tmp
+for n in 1024 4096; do
+XL_EXP_POLY=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof$n -o p -- python $GRAFT_REPO_ROOT/tools/sweep.py --clients $n --rates 5 --modes optimized --steps 50 > $OUT/prof$n.log 2>&1
+echo "== $n clients"; grep -v amdgpu $OUT/prof$n.log | grep optimized
+python3 - $OUT/prof$n/p_kernel_stats.csv <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'xl' in r['Name']: print(r['Name'][:50].ljust(50), r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'])
+PY
+done
