@@ -81,8 +81,12 @@ int xlating_batch_sync(xlating_batch *batch);
 /* Kernel timing with HIP events recorded on the launch stream around the FIR kernel of every block
  * (for bench.py's roofline figures).  enable: 0/1.  _read returns the number of timed launches since
  * the last reset and their summed duration in milliseconds; it synchronises the stream. */
-int xlating_batch_timing(xlating_batch *batch, int enable);
+int xlating_batch_timing(xlating_batch *batch, int enable);  /* 2: additionally time the three polyphase launches */
 int xlating_batch_timing_read(xlating_batch *batch, double *fir_ms_total, double *nco_ms_total, int reset);
+
+/* enable == 2 only: summed durations (ms) of the forward / mix / inverse launches of the polyphase path since the last
+ * reset; returns the number of timed blocks. */
+int xlating_batch_timing_polyphase(xlating_batch *batch, double ms_total[3], int reset);
 
 /* One-line description of the resident plan (builds it if clients changed), e.g.
  * "clients 1024 classes 1 | direct: h10 x 104 groups | polyphase: cls0 D42 T505 cols1024 V244".  For logs and tests:

@@ -81,7 +81,7 @@ struct Launch {
 struct PolyClass {
   uint32_t cls = 0, D = 0, Dpad = 0, T = 0, A = 0, V = 0;
   uint32_t ncols = 0, ncg = 0, nseg_cap = 0;
-  float2 *d_R = nullptr;     // branch spectra [ncg][Dpad][M][128] (+ XLP_BSTEP rows of tail padding)
+  float2 *d_R = nullptr;     // branch spectra [ncg][M][Dpad][256] (+ XLP_BSTEP rows of tail padding)
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
   float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
   uint32_t *d_col = nullptr; // column -> output row offset
@@ -110,7 +110,7 @@ struct xlating_batch_t {
   float2 *d_phase_run = nullptr;     // running phases between the NCO slices of a block
   size_t phase_run_cap = 0;
   int poly_mode = -1;        // XL_EXP_POLY: 0 never, 1 whenever the shape allows, -1 (default) by the size rule
-  uint32_t poly_min_clients = 96;
+  uint32_t poly_min_clients = 192;  // measured crossover at 505 taps, D = 42: ~190 clients (profiles/r01_polyphase_crossover.txt)
   uint32_t poly_exp = 0;     // XL_EXP_POLY_EXP: tuning switches of the mix kernel (wrong results)
   uint32_t poly_slice1 = 6000, poly_slice2 = 42000;  // NCO slice boundaries in 1/65536 of the block (forward | mix | inverse)
   std::vector<XlNcoClient> nco;
@@ -152,9 +152,12 @@ struct xlating_batch_t {
   const char *exp_trace = nullptr;  // XL_EXP_TRACE=<file>: dump per-wave timestamps of the latest FIR launch
   unsigned long long *d_trace = nullptr;
   size_t trace_cap = 0;
-  bool timing = false;
+  int timing = 0;  // 1: bracket every block's launches; 2: also time the three polyphase launches separately
   std::vector<hipEvent_t> ev;       // pairs: fir start, fir stop (on the FIR launch stream)
   std::vector<hipEvent_t> ev_ncot;  // pairs: start, stop of stand-alone NCO launches (rare)
+  std::vector<hipEvent_t> ev_poly;  // quadruples: before forward, after forward, after mix, after inverse (timing == 2)
+  double poly_ms[3] = {0.0, 0.0, 0.0};
+  int timed_poly = 0;
   std::vector<hipEvent_t> ev_pool;  // recycled timing events (hipEventCreate per block would bound the host)
   double fir_ms = 0.0, nco_ms = 0.0;
   int timed_launches = 0, timed_nco = 0;
@@ -208,6 +211,7 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   if (b->h_out) (void)hipHostFree(b->h_out);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_ncot) (void)hipEventDestroy(e);
+  for (hipEvent_t e : b->ev_poly) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
@@ -562,7 +566,7 @@ static int xl_batch_plan(xlating_batch *b) {
     const ClassState &cs = b->classes[k];
     const uint32_t A = (cs.T + cs.D - 1) / cs.D;
     const bool fits = A >= 2 && A <= XLP_M / 2 && cs.D <= 4096;
-    const bool pays = members[k].size() >= b->poly_min_clients && cs.T >= 3 * cs.D && cs.T >= 192;
+    const bool pays = members[k].size() >= b->poly_min_clients && 2 * cs.T >= 9 * cs.D;  // crossover ~4.5 taps per branch
     if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
     PolyClass pc;
     pc.cls = (uint32_t)k;
@@ -624,7 +628,7 @@ static int xl_batch_plan(xlating_batch *b) {
     }
     for (PolyClass &pc : b->poly) {
       const std::vector<int> &m = members[pc.cls];
-      const size_t rows = (size_t)pc.ncg * pc.Dpad + XLP_BSTEP;
+      const size_t rows = (size_t)pc.ncg * pc.Dpad + 1;  // (+1 x M rows: covers the XLP_BSTEP rows of tail padding)
       const uint32_t passes = (pc.nseg_cap + XLP_SEG - 1) / XLP_SEG;
       XL_TRY(hipMalloc((void **)&pc.d_R, rows * XLP_M * XLP_COLS * sizeof(float2)));
       XL_TRY(hipMemset(pc.d_R, 0, rows * XLP_M * XLP_COLS * sizeof(float2)));
@@ -639,7 +643,10 @@ static int xl_batch_plan(xlating_batch *b) {
         col[j] = c.out_off;
         colinc[2 * j] = c.incr[0];
         colinc[2 * j + 1] = c.incr[1];
-        memcpy(rt.data() + j * pc.T * 2, c.rt.data(), (size_t)pc.T * 2 * sizeof(float));
+        for (uint32_t i = 0; i < pc.T; ++i) {  // [tap][column]
+          rt[((size_t)i * pc.ncols + j) * 2] = c.rt[2 * i];
+          rt[((size_t)i * pc.ncols + j) * 2 + 1] = c.rt[2 * i + 1];
+        }
       }
       XL_TRY(hipMalloc((void **)&pc.d_col, col.size() * sizeof(uint32_t)));
       XL_TRY(hipMemcpy(pc.d_col, col.data(), col.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -894,7 +901,16 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_state_src = b->d_phase[b->pcur];
             pa.nco_state_dst = b->d_phase_run;
           }
+          hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
+          if (b->timing == 2) {
+            for (int i = 0; i < 4; ++i) {
+              XL_TRY(xl_batch_timing_event(b, &pe[i]));
+              b->ev_poly.push_back(pe[i]);
+            }
+            XL_TRY(hipEventRecord(pe[0], s));
+          }
           XL_TRY(xlp_launch_forward(pa, dyn, next, s));
+          if (pe[1]) XL_TRY(hipEventRecord(pe[1], s));
           pa.roll_blocks = 0;
           if (carry) {
             pa.nco_k0 = b->poly_slice1;
@@ -902,6 +918,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_state_src = b->d_phase_run;
           }
           XL_TRY(xlp_launch_mix(pa, next, s));
+          if (pe[2]) XL_TRY(hipEventRecord(pe[2], s));
           if (carry) {
             pa.nco_k0 = b->poly_slice2;
             pa.nco_k1 = 65536;
@@ -909,6 +926,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             nco_fused = true;
           }
           XL_TRY(xlp_launch_inverse(pa, dyn, next, s));
+          if (pe[3]) XL_TRY(hipEventRecord(pe[3], s));
         }
       }
       if (f1) XL_TRY(hipEventRecord(f1, s));
@@ -1070,6 +1088,16 @@ static int xl_batch_drain_events(xlating_batch *b) {
     b->nco_ms += ms;
     b->timed_nco++;
   }
+  for (size_t i = 0; i + 4 <= b->ev_poly.size(); i += 4) {
+    for (int k = 0; k < 3; ++k) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, b->ev_poly[i + k], b->ev_poly[i + k + 1]) != hipSuccess) return -EIO;
+      b->poly_ms[k] += ms;
+    }
+    b->timed_poly++;
+  }
+  b->ev_pool.insert(b->ev_pool.end(), b->ev_poly.begin(), b->ev_poly.end());
+  b->ev_poly.clear();
   b->ev_pool.insert(b->ev_pool.end(), b->ev.begin(), b->ev.end());
   b->ev_pool.insert(b->ev_pool.end(), b->ev_ncot.begin(), b->ev_ncot.end());
   b->ev.clear();
@@ -1081,15 +1109,29 @@ extern "C" int xlating_batch_timing(xlating_batch *b, int enable) {
   if (b == nullptr) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
   if (b->timing && !enable) (void)xl_batch_drain_events(b);
-  if (enable && b->ev_pool.size() < 2048) {  // pre-create so that the timed region itself creates none
+  if (enable > 0 && b->ev_pool.size() < 2048) {  // pre-create so that the timed region itself creates none
     for (int i = 0; i < 2048; ++i) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) break;
       b->ev_pool.push_back(e);
     }
   }
-  b->timing = enable != 0;
+  b->timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
   return 0;
+}
+
+extern "C" int xlating_batch_timing_polyphase(xlating_batch *b, double ms_total[3], int reset) {
+  if (b == nullptr || ms_total == nullptr) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  int rc = xl_batch_drain_events(b);
+  if (rc != 0) return rc;
+  for (int k = 0; k < 3; ++k) ms_total[k] = b->poly_ms[k];
+  const int n = b->timed_poly;
+  if (reset) {
+    b->poly_ms[0] = b->poly_ms[1] = b->poly_ms[2] = 0.0;
+    b->timed_poly = 0;
+  }
+  return n;
 }
 
 extern "C" int xlating_batch_timing_read(xlating_batch *b, double *fir_ms_total, double *nco_ms_total, int reset) {

@@ -21,10 +21,11 @@
 #include "xl_device.h"
 
 #define XLP_M 256u     // transform length (branch samples per segment)
-#define XLP_SEG 13u    // segments accumulated per lane in one pass of the mix kernel
-#define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: XLP_SEG padded to 128 bytes
-#define XLP_COLS 128u  // client columns per column group (= one mix workgroup: a wave with two columns per lane)
-#define XLP_BSTEP 6u   // branches per software-pipeline stage of the mix kernel (images are padded to a multiple)
+#define XLP_SEG 14u    // segments per pass of the mix kernel: two halves of 7 (one wave of the workgroup each)
+#define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: segment i of a pass sits in slot
+                       // i + i / 7 (slots 7 and 15 stay zero), so that each half starts on a 64-byte boundary
+#define XLP_COLS 256u  // client columns per column group (= one mix workgroup: four columns per lane)
+#define XLP_BSTEP 6u   // slots of the mix kernel's R-row register ring (branch count is padded to a multiple in the images)
 
 struct XlpArgs {
   // input stream [in0 | in1] as in XlFirArgs
@@ -41,7 +42,7 @@ struct XlpArgs {
   uint32_t exp;        // tuning switches (0 in production)
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
-  const float2 *R;     // branch spectra   [cg][Dpad][M][XLP_COLS]
+  const float2 *R;     // branch spectra   [cg][M][Dpad][XLP_COLS] (+ XLP_BSTEP rows of tail padding)
   float2 *Y;           // mixed spectra    [cg][nseg_cap][M][XLP_COLS]
   const uint32_t *col_out;  // per column: float2 index of the client's row in out (/ 4 in phtab), 0xFFFFFFFF = empty
   const float2 *col_incr;   // per column: NCO phase increment
@@ -62,7 +63,7 @@ struct XlpArgs {
 };
 
 // reversed band-pass taps of every column -> branch spectra R (double arithmetic, rounded once to float)
-//   rt: [ncols][T] float2 (column-major clients), ncols <= ncg * XLP_COLS; columns >= ncols and branches >= D get 0
+//   rt: [T][ncols] float2 (tap-major), ncols <= ncg * XLP_COLS; columns >= ncols and branches >= D get 0
 hipError_t xlp_launch_tables(const float2 *rt, uint32_t ncols, uint32_t T, uint32_t D, uint32_t Dpad, uint32_t A,
                              uint32_t ncg, float2 *R, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s);

@@ -19,7 +19,7 @@ for r in rows:
     k = r.get("Kernel_Name", "")[:40]
     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
-    if "fir" not in k and "nco" not in k: continue
+    if "fir" not in k and "nco" not in k and "xlp" not in k: continue
     print(k, {c: round(sum(v)/len(v)) for c, v in d.items()}, "n=%d" % len(next(iter(d.values()))))
 PY
 }

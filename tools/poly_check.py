@@ -30,11 +30,12 @@ def run(n, poly, rate=5, steps=100, mode="optimized"):
     eng.close()
     return desc, dt, fir / max(nt, 1), outs
 
+rates = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "5,1").split(",")]
 for n in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1024").split(",")]:
-    for rate in (5, 1):
+    for rate in rates:
         d0, t0, f0, o0 = run(n, "0", rate)
         d1, t1, f1, o1 = run(n, "1", rate)
         err = max(float(np.abs(a.astype(np.complex128) - b.astype(np.complex128)).max() / np.abs(a).max()) for a, b in zip(o0, o1))
-        print(f"clients {n} rate {rate}: direct {t0*1e3:.4f} ms (kernels {f0:.4f})  polyphase {t1*1e3:.4f} ms (kernels {f1:.4f})  "
+        print(f"clients {n} rate {rate} ({d1.split(' T')[1].split(' ')[0] if ' T' in d1 else '?'} taps): direct {t0*1e3:.4f} ms (kernels {f0:.4f})  polyphase {t1*1e3:.4f} ms (kernels {f1:.4f})  "
               f"x{t0/t1:.2f}  max rel diff {err:.2e}  Msps {n*bench.S/t1/1e6:.0f}")
         print("   ", d1)
