@@ -369,6 +369,36 @@ def test_polyphase_forced_other_formats(fmt, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("shape", ["perf_2429_taps", "cf32_d100_257_taps", "d400_4819_taps"])
+def test_polyphase_forced_other_shapes(shape, monkeypatch):
+    """Other branch counts / taps per branch on the path: the reference's perf shape (test/perf_xlating.c: 2429 taps,
+    D=42 -> 58 taps per branch, 199 valid outputs per segment), BASELINE config 5 (cf32 in, D=100, 257 taps -> 3 taps
+    per branch) and a huge decimation (20 Msps -> 50 kHz: D=400, 4819 taps)."""
+    if shape == "perf_2429_taps":
+        fs, D, fmt, nbytes = FS, 42, "cu8", 262144
+        taps = lpf(fs, 24000, 2000)
+        assert len(taps) == 2429
+        x = [siggen.staircase_u8(nbytes), siggen.xs_u8(77, nbytes - 4)]
+    elif shape == "cf32_d100_257_taps":
+        fs, D, fmt, nbytes = 10000000, 100, "cf32", 262144
+        taps = siggen.hamming_sinc(257, 0.004)
+        x = [(siggen.xs_s16(300 + k, 131072).astype(np.float32) / np.float32(32768)).astype(np.float32) for k in range(2)]
+    else:
+        fs, D, fmt, nbytes = 20000000, 400, "cu8", 1048576
+        taps = lpf(fs, 25000, 10000)
+        assert len(taps) == 4819
+        x = [siggen.xs_u8(500 + k, nbytes) for k in range(2)]
+    eng = _poly_engine(monkeypatch, fmt=fmt, max_input=nbytes, fs=fs)
+    oracles = {}
+    for c in range(5):
+        fc = int(-0.3 * fs + c * 0.15 * fs)
+        oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, fs, nbytes)
+    assert "polyphase: cls0 D%d T%d cols5" % (D, len(taps)) in eng.describe(), eng.describe()
+    for xb in x:
+        check_clients(eng, oracles, fmt, xb, "optimized")
+    eng.close()
+
+
 def test_polyphase_default_rule_1024_clients():
     """The bench shape (1024 x 48 kHz, 505 taps): the size rule selects the path by itself.  Duplicated clients in
     different columns agree bit for bit, 16 sampled clients match the oracle within 1e-5 over three blocks, and a
