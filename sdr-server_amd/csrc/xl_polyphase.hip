@@ -267,7 +267,7 @@ __global__ __launch_bounds__(128) void xlp_mix_kernel(const XlpArgs a, const XlD
 // double as the transforms' scratch; each wave runs its four columns' transforms interleaved.
 __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const XlDynArgs dyn,
                                                           const XlDynArgs dyn_next) {
-  __shared__ v2f tile[16][XLP_ROW];  // [column][padded bin position]
+  __shared__ v2f tile[16][XLP_ROW + 2];  // [column][padded bin position]; +2: rows 4 banks apart (tile fill: 8 lanes = 8 column pairs)
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a, dyn_next);
     return;
@@ -279,16 +279,19 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = threadIdx.x & 63u;
   const XlpTw tw = xlp_twiddles<+1>(reinterpret_cast<const v2f *>(a.W), j);
   {
-    const uint32_t m = threadIdx.x;
+    // Y tile: 256 bins x 16 columns = 256 chunks of 128 contiguous bytes, 2 KB apart.  Eight lanes share a chunk
+    // (16 bytes = 2 columns each), so a load instruction touches 8 full lines instead of 64 partial ones.
+    const uint32_t part = threadIdx.x & 7u, mrow = threadIdx.x >> 3;  // mrow 0..31
     const v4f *__restrict__ src = reinterpret_cast<const v4f *>(
-        a.Y + (((size_t)cg * a.nseg_cap + s) * XLP_M + m) * XLP_COLS + sub * 16u);
+        a.Y + (((size_t)cg * a.nseg_cap + s) * XLP_M) * XLP_COLS + sub * 16u) + part;
     v4f v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = src[i];
+    for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(mrow + 32u * i) * (XLP_COLS / 2)];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      tile[2 * i][XLP_POS(m)] = (v2f){v[i].x, v[i].y};
-      tile[2 * i + 1][XLP_POS(m)] = (v2f){v[i].z, v[i].w};
+      const uint32_t m = mrow + 32u * i;
+      tile[2 * part][XLP_POS(m)] = (v2f){v[i].x, v[i].y};
+      tile[2 * part + 1][XLP_POS(m)] = (v2f){v[i].z, v[i].w};
     }
   }
   // the epilogue's operands, requested before the transforms: row offsets, increments and the tabulated NCO phases
