@@ -84,6 +84,10 @@ int xlating_batch_sync(xlating_batch *batch);
 int xlating_batch_timing(xlating_batch *batch, int enable);  /* 2: additionally time the three polyphase launches */
 int xlating_batch_timing_read(xlating_batch *batch, double *fir_ms_total, double *nco_ms_total, int reset);
 
+/* Bracket only every n-th block with events (default 1 = every block).  An event pair costs a few microseconds of stream
+ * time, which is not negligible against a 60 us block. */
+int xlating_batch_timing_stride(xlating_batch *batch, unsigned every_n);
+
 /* enable == 2 only: summed durations (ms) of the forward / mix / inverse launches of the polyphase path since the last
  * reset; returns the number of timed blocks. */
 int xlating_batch_timing_polyphase(xlating_batch *batch, double ms_total[3], int reset);

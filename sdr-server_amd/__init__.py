@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     + ["xlating_batch_create", "xlating_batch_add_client", "xlating_batch_remove_client", "xlating_batch_num_clients",
        "xlating_batch_process_host", "xlating_batch_process_device", "xlating_batch_output_len", "xlating_batch_fetch",
        "xlating_batch_output_host", "xlating_batch_output_device", "xlating_batch_client_phase", "xlating_batch_sync",
-       "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_timing_polyphase", "xlating_batch_describe", "xlating_batch_destroy",
+       "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_timing_polyphase", "xlating_batch_timing_stride", "xlating_batch_describe", "xlating_batch_destroy",
        "xlating_hip_device_info"]
 )
 
@@ -96,6 +96,8 @@ def lib():
     L.xlating_batch_timing.restype = C.c_int
     L.xlating_batch_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
     L.xlating_batch_timing_read.restype = C.c_int
+    L.xlating_batch_timing_stride.argtypes = [C.c_void_p, C.c_uint]
+    L.xlating_batch_timing_stride.restype = C.c_int
     L.xlating_batch_timing_polyphase.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     L.xlating_batch_timing_polyphase.restype = C.c_int
     L.xlating_batch_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -270,6 +272,10 @@ class BatchEngine:
     def timing(self, enable):
         """False/0 off, True/1 bracket every block's launches, 2 also time the three polyphase launches separately."""
         lib().xlating_batch_timing(self.h, int(enable))
+
+    def timing_stride(self, every_n):
+        """Bracket only every n-th block with events (an event pair costs a few us of stream time)."""
+        lib().xlating_batch_timing_stride(self.h, int(every_n))
 
     def timing_polyphase(self, reset=True):
         """-> (n_timed_blocks, [forward_ms_total, mix_ms_total, inverse_ms_total]) -- needs timing(2)"""

@@ -81,7 +81,7 @@ struct Launch {
 struct PolyClass {
   uint32_t cls = 0, D = 0, Dpad = 0, T = 0, A = 0, V = 0;
   uint32_t ncols = 0, ncg = 0, nseg_cap = 0;
-  float2 *d_R = nullptr;     // branch spectra [ncg][M][Dpad][256] (+ XLP_BSTEP rows of tail padding)
+  float2 *d_R = nullptr;     // branch spectra [ncg][M][Dpad][128] (+ XLP_BSTEP rows of tail padding)
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
   float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
   uint32_t *d_col = nullptr; // column -> output row offset
@@ -152,6 +152,7 @@ struct xlating_batch_t {
   const char *exp_trace = nullptr;  // XL_EXP_TRACE=<file>: dump per-wave timestamps of the latest FIR launch
   unsigned long long *d_trace = nullptr;
   size_t trace_cap = 0;
+  uint32_t timing_every = 1;  // XL_TIMING_EVERY: bracket only every n-th block (each event pair costs a few us of stream time)
   int timing = 0;  // 1: bracket every block's launches; 2: also time the three polyphase launches separately
   std::vector<hipEvent_t> ev;       // pairs: fir start, fir stop (on the FIR launch stream)
   std::vector<hipEvent_t> ev_ncot;  // pairs: start, stop of stand-alone NCO launches (rare)
@@ -258,6 +259,7 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   if (getenv("XL_EXP_NCOWPW")) b->nco_wpw = (uint32_t)atoi(getenv("XL_EXP_NCOWPW"));
   if (getenv("XL_EXP_RIDERS")) b->riders = atoi(getenv("XL_EXP_RIDERS")) != 0;
   if (getenv("XL_EXP_RIDERS_MIN")) b->riders_min_wgs = atoi(getenv("XL_EXP_RIDERS_MIN"));
+  if (getenv("XL_TIMING_EVERY")) b->timing_every = std::max(1, atoi(getenv("XL_TIMING_EVERY")));
   if (getenv("XL_EXP_POLY")) b->poly_mode = atoi(getenv("XL_EXP_POLY"));
   if (getenv("XL_EXP_POLY_EXP")) b->poly_exp = (uint32_t)atoi(getenv("XL_EXP_POLY_EXP"));
   if (getenv("XL_EXP_POLY_MIN")) b->poly_min_clients = (uint32_t)atoi(getenv("XL_EXP_POLY_MIN"));
@@ -766,7 +768,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
   // table[tab ^ 1] for the next block
   {
     hipEvent_t f0 = nullptr, f1 = nullptr;
-    if (b->timing && maxK > 0) {
+    if (b->timing && maxK > 0 && b->nblk % b->timing_every == 0) {
       for (int i = 0; i < 2; ++i) {
         hipEvent_t ev;
         XL_TRY(xl_batch_timing_event(b, &ev));
@@ -1117,6 +1119,12 @@ extern "C" int xlating_batch_timing(xlating_batch *b, int enable) {
     }
   }
   b->timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+  return 0;
+}
+
+extern "C" int xlating_batch_timing_stride(xlating_batch *b, unsigned every_n) {
+  if (b == nullptr) return -EINVAL;
+  b->timing_every = every_n ? every_n : 1;
   return 0;
 }
 

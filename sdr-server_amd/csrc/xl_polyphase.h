@@ -21,11 +21,10 @@
 #include "xl_device.h"
 
 #define XLP_M 256u     // transform length (branch samples per segment)
-#define XLP_SEG 14u    // segments per pass of the mix kernel: two halves of 7 (one wave of the workgroup each)
-#define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: segment i of a pass sits in slot
-                       // i + i / 7 (slots 7 and 15 stay zero), so that each half starts on a 64-byte boundary
-#define XLP_COLS 256u  // client columns per column group (= one mix workgroup: four columns per lane)
-#define XLP_BSTEP 6u   // slots of the mix kernel's R-row register ring (branch count is padded to a multiple in the images)
+#define XLP_SEG 14u    // segments accumulated per lane in one pass of the mix kernel
+#define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: XLP_SEG padded to 128 bytes
+#define XLP_COLS 128u  // client columns per column group (= one mix workgroup: a wave with two columns per lane)
+#define XLP_BSTEP 7u   // slots of the mix kernel's R-row register ring (branch count is padded to a multiple in the images)
 
 struct XlpArgs {
   // input stream [in0 | in1] as in XlFirArgs

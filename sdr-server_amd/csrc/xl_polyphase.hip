@@ -153,9 +153,8 @@ __global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a, const 
   xlp_dft256<-1, 1>(u, bufs, tw, j);
   const uint32_t pass = s / XLP_SEG, si = s - pass * XLP_SEG;
   v2f *__restrict__ X = reinterpret_cast<v2f *>(a.X);
-  const uint32_t slot = si + si / 7u;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) X[(((size_t)pass * a.Dpad + b) * XLP_M + (j + 64u * r)) * XLP_XS + slot] = u[0][r];
+  for (int r = 0; r < 4; ++r) X[(((size_t)pass * a.Dpad + b) * XLP_M + (j + 64u * r)) * XLP_XS + si] = u[0][r];
 }
 
 // ------------------------------------------------------------------------------------------- mix (the hot kernel)
@@ -168,102 +167,84 @@ XL_DEV void xlp_cmac(v2f &acc, const v2f r, const v2f x) {
       : "v"(r), "v"(x));
 }
 
-// grid = nco_blocks + M * ncg * passes workgroups of TWO waves; lane l = client columns cg*256 + 4l .. 4l+3, wave h =
-// segments 7h .. 7h+6 of the pass; the spectrum bin m is workgroup-uniform.  The bin's column of the shared spectra
-// (Dpad rows of 128 bytes) is staged in LDS once and read back row by row as broadcast reads (every lane the same
-// address).  Operand economics: a broadcast ds_read_b128 costs the LDS ~14 clocks whatever it carries (measured;
-// with 2 columns x 13 segments per lane the kernel was LDS-bound at 16 us per 1024 clients), so each 64-byte half
-// row read feeds 4 x 7 complex MACs per lane here.  R is streamed from HBM once: 32 bytes per lane and branch (the
-// second wave of the workgroup re-reads the same lines from L1), XLP_BSTEP branches in flight ahead of the multiply.
-__global__ __launch_bounds__(128) void xlp_mix_kernel(const XlpArgs a, const XlDynArgs dyn_next) {
+// grid = nco_blocks + M * ncg * passes workgroups of ONE wave; lane l = client columns cg*128 + 2l, 2l+1; the spectrum
+// bin m is workgroup-uniform.  The bin's column of the shared spectra (Dpad rows of 14 segments, 128 bytes each) is
+// staged in LDS once and read back row by row as broadcast reads (every lane the same address): a uniform operand with
+// short, in-order latency (scalar loads of the rows were latency-bound).  R is streamed from HBM exactly once, by
+// exactly one wave: 16 bytes per lane and branch through a ring of XLP_BSTEP register slots, XLP_BSTEP - 1 rows ahead
+// of the multiply (a stage-wise double buffer ran one short stage ahead and every stage waited out a memory latency;
+// a two-wave workgroup sharing the R rows through L1 was 15 % slower at 4096 clients).
+__global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDynArgs dyn_next) {
   extern __shared__ __attribute__((aligned(16))) v4f xlp_xcol[];  // [Dpad][8]
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a, dyn_next);
     return;
   }
   const uint32_t bid = blockIdx.x - a.nco_blocks;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x;
   const uint32_t m = bid % XLP_M;
   const uint32_t q = bid / XLP_M;
   const uint32_t cg = q % a.ncg, pass = q / a.ncg;
-  // R image [cg][m][Dpad][256 columns]: the Dpad rows of a workgroup are one contiguous run (84 KB at D = 42) -- with
-  // the branch index outermost every row of a wave was 512 KB from the last one and the kernel waited on memory
-  // half the time at ~3 TB/s
+  // R image [cg][m][Dpad][128 columns]: the Dpad rows of a workgroup are one contiguous run (42 KB at D = 42)
   const v4f *__restrict__ Rp =
-      reinterpret_cast<const v4f *>(a.R) + ((size_t)cg * XLP_M + m) * a.Dpad * (XLP_COLS / 2) + 2u * lane;
+      reinterpret_cast<const v4f *>(a.R) + ((size_t)cg * XLP_M + m) * a.Dpad * (XLP_COLS / 2) + lane;
   const size_t rstride = XLP_COLS / 2;
-  // R rows live in a ring of XLP_BSTEP (6) register slots: the row XLP_BSTEP - 1 ahead is requested before the current
-  // one is multiplied, so ~10 KB per wave are in flight (a stage-wise double buffer ran one short stage ahead and
-  // every stage waited out a memory latency: measured 27 us per 1024 clients, waves waiting on memory half the time)
-  v4f r[XLP_BSTEP][2];
+  v4f r[XLP_BSTEP];
 #pragma unroll
-  for (int u = 0; u < (int)XLP_BSTEP - 1; ++u) {
-    r[u][0] = Rp[(size_t)u * rstride];
-    r[u][1] = Rp[(size_t)u * rstride + 1];
-  }
+  for (int u = 0; u < (int)XLP_BSTEP - 1; ++u) r[u] = Rp[(size_t)u * rstride];
   {
     const v4f *__restrict__ Xc =
         reinterpret_cast<const v4f *>(a.X + ((size_t)pass * a.Dpad * XLP_M + m) * XLP_XS);  // row stride M * 8 v4f
     const uint32_t n8 = a.Dpad * 8u;
     for (uint32_t base = 0; base < n8; base += 512u) {  // one trip for D <= 64; all loads of a trip in flight together
-      v4f t[4];
+      v4f t[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t i = base + threadIdx.x + 128u * u;
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t i = base + lane + 64u * u;
         const uint32_t ic = i < n8 ? i : 0u;
         t[u] = Xc[(size_t)(ic >> 3) * (XLP_M * 8u) + (ic & 7u)];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t i = base + threadIdx.x + 128u * u;
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t i = base + lane + 64u * u;
         if (i < n8) xlp_xcol[i] = t[u];
       }
     }
   }
   __syncthreads();
-  v2f acc[4][7];
+  v2f acc0[XLP_SEG], acc1[XLP_SEG];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int i = 0; i < 7; ++i) acc[c][i] = (v2f){0.0f, 0.0f};
-  const v4f *__restrict__ xh = xlp_xcol + 4u * h;  // this wave's half rows
+  for (int i = 0; i < (int)XLP_SEG; ++i) acc0[i] = acc1[i] = (v2f){0.0f, 0.0f};
   for (uint32_t b0 = 0; b0 < a.Dpad; b0 += XLP_BSTEP) {
 #pragma unroll
     for (int u = 0; u < (int)XLP_BSTEP; ++u) {
       // (the last trips request rows past this workgroup's: the next one's, or the tail padding the engine
       // allocates -- loaded, never used)
       constexpr int PF = (int)XLP_BSTEP - 1;
-      r[(u + PF) % (int)XLP_BSTEP][0] = Rp[(size_t)(b0 + u + PF) * rstride];
-      r[(u + PF) % (int)XLP_BSTEP][1] = Rp[(size_t)(b0 + u + PF) * rstride + 1];
-      const v4f *__restrict__ xr = xh + (b0 + u) * 8u;
-      const v2f rc[4] = {{r[u][0].x, r[u][0].y}, {r[u][0].z, r[u][0].w}, {r[u][1].x, r[u][1].y}, {r[u][1].z, r[u][1].w}};
+      r[(u + PF) % (int)XLP_BSTEP] = Rp[(size_t)(b0 + u + PF) * rstride];
+      const v4f *__restrict__ xr = xlp_xcol + (b0 + u) * 8u;
+      const v2f ra = {r[u].x, r[u].y}, rb = {r[u].z, r[u].w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < (int)XLP_SEG / 2; ++i) {
         const v4f x2 = xr[i];
         const v2f xa = {x2.x, x2.y}, xb = {x2.z, x2.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) xlp_cmac(acc[c][2 * i], rc[c], xa);
-        if (i < 3) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) xlp_cmac(acc[c][2 * i + 1], rc[c], xb);
-        }
+        xlp_cmac(acc0[2 * i], ra, xa);
+        xlp_cmac(acc1[2 * i], rb, xa);
+        xlp_cmac(acc0[2 * i + 1], ra, xb);
+        xlp_cmac(acc1[2 * i + 1], rb, xb);
       }
     }
   }
-  const uint32_t s0 = pass * XLP_SEG + 7u * h;
+  const uint32_t s0 = pass * XLP_SEG;
   v4f *__restrict__ Yp =
-      reinterpret_cast<v4f *>(a.Y) + (((size_t)cg * a.nseg_cap + s0) * XLP_M + m) * (XLP_COLS / 2) + 2u * lane;
+      reinterpret_cast<v4f *>(a.Y) + (((size_t)cg * a.nseg_cap + s0) * XLP_M + m) * (XLP_COLS / 2) + lane;
 #pragma unroll
-  for (int i = 0; i < 7; ++i)
-    if (s0 + i < a.nseg) {
-      Yp[(size_t)i * XLP_M * (XLP_COLS / 2)] = (v4f){acc[0][i].x, acc[0][i].y, acc[1][i].x, acc[1][i].y};
-      Yp[(size_t)i * XLP_M * (XLP_COLS / 2) + 1] = (v4f){acc[2][i].x, acc[2][i].y, acc[3][i].x, acc[3][i].y};
-    }
+  for (int i = 0; i < (int)XLP_SEG; ++i)
+    if (s0 + i < a.nseg) Yp[(size_t)i * XLP_M * (XLP_COLS / 2)] = (v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y};
 }
 
 // ------------------------------------------------------------------------------------------- inverse + epilogue
-// grid = nco_blocks + nseg * ncg * 16 workgroups of 256 threads; workgroup = (segment, 16 columns).  The tile rows
+// grid = nco_blocks + nseg * ncg * 8 workgroups of 256 threads; workgroup = (segment, 16 columns).  The tile rows
 // double as the transforms' scratch; each wave runs its four columns' transforms interleaved.
 __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const XlDynArgs dyn,
                                                           const XlDynArgs dyn_next) {
@@ -273,8 +254,8 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
     return;
   }
   const uint32_t bid = blockIdx.x - a.nco_blocks;
-  const uint32_t sub = bid & 15u;
-  const uint32_t q = bid >> 4;
+  const uint32_t sub = bid & 7u;
+  const uint32_t q = bid >> 3;
   const uint32_t cg = q % a.ncg, s = q / a.ncg;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = threadIdx.x & 63u;
   const XlpTw tw = xlp_twiddles<+1>(reinterpret_cast<const v2f *>(a.W), j);
@@ -385,11 +366,11 @@ hipError_t xlp_launch_mix(const XlpArgs &a, const XlDynArgs &dyn_next, hipStream
   const uint32_t passes = (a.nseg + XLP_SEG - 1) / XLP_SEG;
   const size_t lds = (size_t)a.Dpad * 8u * sizeof(v4f);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + XLP_M * a.ncg * passes), dim3(128), lds, s, a, dyn_next);
+  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + XLP_M * a.ncg * passes), dim3(64), lds, s, a, dyn_next);
   return hipGetLastError();
 }
 
 hipError_t xlp_launch_inverse(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s) {
-  hipLaunchKernelGGL(xlp_inverse_kernel, dim3(a.nco_blocks + a.nseg * a.ncg * 16u), dim3(256), 0, s, a, dyn, dyn_next);
+  hipLaunchKernelGGL(xlp_inverse_kernel, dim3(a.nco_blocks + a.nseg * a.ncg * 8u), dim3(256), 0, s, a, dyn, dyn_next);
   return hipGetLastError();
 }

@@ -45,7 +45,7 @@ def main():
                 dt = (time.perf_counter() - t0) / args.steps
                 nt, fir, nco = eng.timing_read()
                 eng.close()
-                fir /= max(nt, 1)
+                fir = fir / nt if nt else dt * 1e3
                 nco /= max(nt, 1)
                 units = n * bench.S
                 tf = units * bench.flops_per_unit(taps.size, bench.D) / (fir * 1e-3) / 1e12
