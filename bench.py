@@ -129,46 +129,58 @@ def cpu_baseline(ntaps_rate, seconds=12.0):
     }
 
 
-class BlockFeeder:
-    """Delivers block k to this rank: N = 1 -> a resident device buffer; N > 1 -> rank 0's block broadcast over
-    RCCL/xGMI into one of two alternating receive buffers ON A SEPARATE STREAM, so that the broadcast of block k+1
-    overlaps the filtering of block k (events order buffer reuse: the broadcast into a buffer waits until the FIR
-    launch that read it two blocks ago has been passed by the compute stream)."""
+FEED_GROUP = 8  # blocks per RCCL broadcast (SURVEY 8(d) config 4 names the 8-block super-block): the cross-stream event
+                # pair that orders a broadcast against the filtering costs ~10 us of stream time (tools/feed_overhead.py:
+                # 58.7 -> 68.8 us per block with one pair per block), a sixth of a block's launches
 
-    def __init__(self, torch, dist, rank, world, dev_blocks):
+
+class BlockFeeder:
+    """Delivers block k to this rank: N = 1 -> a resident device buffer; N > 1 -> rank 0's blocks broadcast over
+    RCCL/xGMI, FEED_GROUP blocks per broadcast, into one of two alternating receive buffers ON A SEPARATE STREAM, so
+    that the broadcast of group g+1 overlaps the filtering of group g (events order buffer reuse: the broadcast into a
+    buffer waits until the launches that read it two groups ago have been passed by the compute stream)."""
+
+    def __init__(self, torch, dist, rank, world, dev_blocks, group=FEED_GROUP):
         self.torch, self.dist, self.rank, self.world, self.blocks = torch, dist, rank, world, dev_blocks
-        self.issued = 0
+        self.group = group
+        self.issued = 0  # groups issued
         if world > 1:
-            self.recv = [torch.empty(BLOCK_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            self.recv = [torch.empty(group * BLOCK_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)]
             self.comm = torch.cuda.Stream()
             self.ready = [torch.cuda.Event() for _ in range(2)]
             self.free = [torch.cuda.Event() for _ in range(2)]
             self.free_valid = [False, False]
 
-    def _issue(self, k):
+    def _issue(self, g):
         torch = self.torch
-        i = k % 2
+        i = g % 2
         if self.free_valid[i]:
             self.comm.wait_event(self.free[i])
         with torch.cuda.stream(self.comm):
-            src = self.blocks[k % len(self.blocks)] if self.rank == 0 else None
-            broadcast_block(self.dist, self.recv[i], src, self.rank)
+            if self.rank == 0:
+                for j in range(self.group):
+                    src = self.blocks[(g * self.group + j) % len(self.blocks)]
+                    self.recv[i][j * BLOCK_BYTES:(j + 1) * BLOCK_BYTES].copy_(src, non_blocking=True)
+            self.dist.broadcast(self.recv[i], src=0)  # the path's only exchange step
             self.ready[i].record(self.comm)
-        self.issued = k + 1
+        self.issued = g + 1
 
     def get(self, k, stream):
         """Device pointer of block k, valid on `stream`; call consumed(k, stream) after enqueuing its consumer."""
         if self.world == 1:
             return self.blocks[k % len(self.blocks)].data_ptr()
-        while self.issued <= k + 1:  # keep one broadcast in flight ahead of the consumer
+        g, j = divmod(k, self.group)
+        while self.issued <= g + 1:  # keep one broadcast in flight ahead of the consumer
             self._issue(self.issued)
-        stream.wait_event(self.ready[k % 2])
-        return self.recv[k % 2].data_ptr()
+        if j == 0:
+            stream.wait_event(self.ready[g % 2])
+        return self.recv[g % 2].data_ptr() + j * BLOCK_BYTES
 
     def consumed(self, k, stream):
-        if self.world > 1:
-            self.free[k % 2].record(stream)
-            self.free_valid[k % 2] = True
+        if self.world > 1 and k % self.group == self.group - 1:
+            g = k // self.group
+            self.free[g % 2].record(stream)
+            self.free_valid[g % 2] = True
 
 
 def run_workload(xl, torch, dist, args, rank, world, ntaps_rate, steps, warmup, dev_blocks, mode=None, poly=None):
@@ -415,8 +427,8 @@ def main():
                         f"D={D}, {m['ntaps']} taps (lpf_cutoff_rate={args.lpf_cutoff_rate}), process_{args.mode}_cu8_cf32 semantics "
                         f"(BASELINE configs[3] per-GPU share x8 = the 1-GPU >=1000-client target)",
             "clients_total": m["total_clients"], "block_samples": S, "outputs_per_client_per_block": m["K"],
-            "parallelism": (f"clients sharded c%{world}; one RCCL broadcast of the raw IQ block per step on a separate "
-                            "stream (overlaps the previous block's filtering), no other collective") if world > 1 else "single GPU",
+            "parallelism": (f"clients sharded c%{world}; one RCCL broadcast per {FEED_GROUP} raw IQ blocks ({FEED_GROUP * BLOCK_BYTES} bytes) "
+                            "on a separate stream (overlaps the previous group's filtering), no other collective") if world > 1 else "single GPU",
         },
         "roofline": roofline,
         "plan": m["plan"],
