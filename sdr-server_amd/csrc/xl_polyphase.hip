@@ -248,7 +248,10 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDy
 // double as the transforms' scratch; each wave runs its four columns' transforms interleaved.
 __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const XlDynArgs dyn,
                                                           const XlDynArgs dyn_next) {
-  __shared__ v2f tile[16][XLP_ROW + 2];  // [column][padded bin position]; +2: rows 4 banks apart (tile fill: 8 lanes = 8 column pairs)
+  // [column][padded bin position].  Row length 319 (= XLP_POS(255) + 1): 638 dwords = -2 banks per row, so the 8 lanes
+  // that fill 8 different rows of one bin hit distinct bank pairs; and 16 x 319 x 8 B = 40832 B lets a CU hold four
+  // workgroups (at 41.2 KB it held three: 768 slots for the 832 workgroups of a 1024-client block -> a second round)
+  __shared__ v2f tile[16][XLP_ROW - 1];
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a, dyn_next);
     return;
