@@ -308,6 +308,10 @@ def test_polyphase_forced_server_default_ragged_and_join(monkeypatch):
     for k, n in enumerate((262144, 262144, 100002, 100002, 262144, 50000, 262144)):
         if k == 3:
             oracles[eng.add_client(42, taps, 123456)] = Oracle(42, taps, 123456, FS, 262144)
+        if k == 5:  # a client leaves: the plan (columns, branch spectra) is rebuilt, everybody else streams on
+            gone = sorted(oracles)[7]
+            eng.remove_client(gone)
+            oracles.pop(gone).close()
         x = siggen.xs_u8(siggen.XS_SEED + 80 + k, n)
         variant = "native" if k == 4 else "optimized"
         eng.process_host(x, variant)
@@ -396,6 +400,24 @@ def test_polyphase_forced_other_shapes(shape, monkeypatch):
     assert "polyphase: cls0 D%d T%d cols5" % (D, len(taps)) in eng.describe(), eng.describe()
     for xb in x:
         check_clients(eng, oracles, fmt, xb, "optimized")
+    eng.close()
+
+
+def test_polyphase_class_next_to_direct_classes():
+    """The size rule at work inside one engine: 200 x 48 kHz clients (505 taps) take the polyphase path, 9 x 96 kHz
+    clients (253 taps, too few for it) stay on the direct kernel, whose launch then carries the NCO role for ALL
+    clients and rolls the history; optimized and native blocks alternate.  Sampled 48 kHz clients and every 96 kHz
+    client are checked against the oracle."""
+    t48, t96 = lpf(FS, 24000, 9600), lpf(FS, 48000, 19200)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    cfg = [(42, t48, -950000 + 9000 * c) for c in range(200)] + [(21, t96, -800000 + 170000 * c) for c in range(9)]
+    ids = [eng.add_client(D, taps, fc) for D, taps, fc in cfg]
+    d = eng.describe()
+    assert "polyphase: cls0 D42 T505 cols200" in d and "optimized-mode direct: h" in d, d
+    sample = [0, 1, 63, 64, 127, 128, 199] + list(range(200, 209))
+    oracles = {ids[i]: Oracle(cfg[i][0], cfg[i][1], cfg[i][2], FS, 262144) for i in sample}
+    for k, (n, variant) in enumerate(((262144, "optimized"), (262144, "optimized"), (131074, "native"), (262144, "optimized"))):
+        check_clients(eng, oracles, "cu8", siggen.xs_u8(siggen.XS_SEED + 120 + k, n), variant)
     eng.close()
 
 
