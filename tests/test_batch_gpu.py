@@ -305,7 +305,8 @@ def test_polyphase_forced_server_default_ragged_and_join(monkeypatch):
         oracles[eng.add_client(42, taps, fc)] = Oracle(42, taps, fc, FS, 262144)
     assert "polyphase: cls0 D42 T505 cols20 V244" in eng.describe(), eng.describe()
     worst = 0.0
-    for k, n in enumerate((262144, 262144, 100002, 100002, 262144, 50000, 262144)):
+    # (blocks of 2000 and 30 bytes hold fewer than 512 outputs: those fall back to the direct kernel in between)
+    for k, n in enumerate((262144, 262144, 100002, 100002, 262144, 50000, 262144, 2000, 262144, 30, 262144)):
         if k == 3:
             oracles[eng.add_client(42, taps, 123456)] = Oracle(42, taps, 123456, FS, 262144)
         if k == 5:  # a client leaves: the plan (columns, branch spectra) is rebuilt, everybody else streams on
