@@ -38,6 +38,9 @@ EXPORTED_SYMBOLS = (
        "xlating_batch_output_host", "xlating_batch_output_device", "xlating_batch_client_phase", "xlating_batch_sync",
        "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_timing_polyphase", "xlating_batch_timing_stride", "xlating_batch_describe", "xlating_batch_destroy",
        "xlating_hip_device_info"]
+    + ["xlating_sinks_create", "xlating_sinks_attach_fd", "xlating_sinks_attach_file", "xlating_sinks_write",
+       "xlating_sinks_submit", "xlating_sinks_failed", "xlating_sinks_flush", "xlating_sinks_detach", "xlating_sinks_stats",
+       "xlating_sinks_destroy"]
 )
 
 _lib = None
@@ -96,6 +99,26 @@ def lib():
     L.xlating_batch_timing.restype = C.c_int
     L.xlating_batch_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
     L.xlating_batch_timing_read.restype = C.c_int
+    L.xlating_sinks_create.argtypes = [C.c_uint, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.xlating_sinks_create.restype = C.c_int
+    L.xlating_sinks_attach_fd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.xlating_sinks_attach_fd.restype = C.c_int
+    L.xlating_sinks_attach_file.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    L.xlating_sinks_attach_file.restype = C.c_int
+    L.xlating_sinks_write.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.xlating_sinks_write.restype = C.c_int
+    L.xlating_sinks_submit.argtypes = [C.c_void_p, C.c_void_p]
+    L.xlating_sinks_submit.restype = C.c_int
+    L.xlating_sinks_failed.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_size_t]
+    L.xlating_sinks_failed.restype = C.c_size_t
+    L.xlating_sinks_flush.argtypes = [C.c_void_p]
+    L.xlating_sinks_flush.restype = C.c_int
+    L.xlating_sinks_detach.argtypes = [C.c_void_p, C.c_int]
+    L.xlating_sinks_detach.restype = C.c_int
+    L.xlating_sinks_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.xlating_sinks_stats.restype = None
+    L.xlating_sinks_destroy.argtypes = [C.c_void_p]
+    L.xlating_sinks_destroy.restype = None
     L.xlating_batch_timing_stride.argtypes = [C.c_void_p, C.c_uint]
     L.xlating_batch_timing_stride.restype = C.c_int
     L.xlating_batch_timing_polyphase.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
@@ -304,6 +327,57 @@ class BatchEngine:
     def close(self):
         if getattr(self, "h", None):
             lib().xlating_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Sinks:
+    """ctypes mirror of include/xlating_sinks.h (per-client output delivery of the batched path; host-only)."""
+
+    def __init__(self, writer_threads=4, queue_bytes=16 * 25600):
+        h = C.c_void_p()
+        code = lib().xlating_sinks_create(writer_threads, queue_bytes, C.byref(h))
+        if code != 0:
+            raise XlatingError("xlating_sinks_create", code)
+        self.h = h
+
+    def attach_fd(self, client_id, fd, close_on_detach=False):
+        return lib().xlating_sinks_attach_fd(self.h, client_id, fd, 1 if close_on_detach else 0)
+
+    def attach_file(self, client_id, base_path, use_gzip=False):
+        return lib().xlating_sinks_attach_file(self.h, client_id, str(base_path).encode(), 1 if use_gzip else 0)
+
+    def write(self, client_id, samples):
+        a = np.ascontiguousarray(samples, dtype=np.complex64)
+        return lib().xlating_sinks_write(self.h, client_id, a.ctypes.data_as(C.c_void_p), a.size)
+
+    def submit(self, engine):
+        return lib().xlating_sinks_submit(self.h, engine.h)
+
+    def failed(self, cap=4096):
+        ids = (C.c_int * cap)()
+        n = lib().xlating_sinks_failed(self.h, ids, cap)
+        return [ids[i] for i in range(n)]
+
+    def flush(self):
+        return lib().xlating_sinks_flush(self.h)
+
+    def detach(self, client_id):
+        return lib().xlating_sinks_detach(self.h, client_id)
+
+    def stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        lib().xlating_sinks_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().xlating_sinks_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,0 +1,404 @@
+// xl_sinks.cpp -- per-client output sinks of the batched path (include/xlating_sinks.h).
+//
+// What the reference does per client thread (src/dsp_worker.c:10-39 write_to_file / write_to_socket, :74-86 "close the
+// client on failure", :126-144 <base>/<id>.cf32[.gz]) is done here by a small pool of writer threads behind bounded
+// per-client byte queues.  Host-only: no HIP in this file.
+#include <errno.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <sys/types.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <poll.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/xlating_batch.h"
+#include "../../include/xlating_sinks.h"
+#include "xl_common.h"
+
+namespace {
+
+enum Kind { K_FD = 0, K_FILE = 1, K_GZ = 2 };
+
+struct Sink {
+  int id = -1;
+  Kind kind = K_FD;
+  int fd = -1;
+  bool close_fd = false;
+  FILE *file = nullptr;
+  gzFile gz = nullptr;
+  std::vector<uint8_t> ring;  // byte queue
+  size_t head = 0, used = 0;  // head = read position
+  bool busy = false;          // a writer thread holds bytes popped from the ring
+  bool failed = false, reported = false;
+  std::atomic<bool> cancel{false};  // abandon an in-flight write (the sink failed or is being torn down)
+};
+
+struct Worker {
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::map<int, std::unique_ptr<Sink>> sinks;  // the sinks this thread serves (id % nthreads)
+  std::thread th;
+  bool stop = false;
+  int rr = 0;  // round-robin start for fairness
+};
+
+}  // namespace
+
+struct xlating_sinks_t {
+  std::vector<std::unique_ptr<Worker>> workers;
+  size_t queue_bytes = 0;
+  std::mutex stats_m;
+  uint64_t bytes_written = 0, blocks_dropped = 0;
+};
+
+namespace {
+
+const size_t kChunk = 1u << 20;  // most bytes a writer takes out of a queue at a time
+
+// write_to_socket() semantics (dsp_worker.c:28-39): every byte, or failure -- but never stuck on a peer for good: the
+// writes are non-blocking, and while the descriptor is not writable the sink's cancel flag is polled every 50 ms (set
+// when the client's queue overflowed behind this very write, or at teardown).
+bool xl_write_all_fd(int fd, const uint8_t *p, size_t n, const std::atomic<bool> &cancel) {
+  bool is_sock = true;
+  while (n > 0) {
+    ssize_t w = is_sock ? send(fd, p, n, MSG_NOSIGNAL | MSG_DONTWAIT) : write(fd, p, n);
+    if (w < 0) {
+      if (is_sock && errno == ENOTSOCK) {
+        is_sock = false;
+        const int fl = fcntl(fd, F_GETFL);
+        if (fl >= 0 && !(fl & O_NONBLOCK)) (void)fcntl(fd, F_SETFL, fl | O_NONBLOCK);  // pipes / files: same rule
+        continue;
+      }
+      if (errno == EINTR) continue;
+      if (errno == EAGAIN || errno == EWOULDBLOCK) {
+        if (cancel.load()) return false;
+        struct pollfd pfd = {fd, POLLOUT, 0};
+        (void)poll(&pfd, 1, 50);
+        continue;
+      }
+      return false;
+    }
+    p += w;
+    n -= (size_t)w;
+  }
+  return true;
+}
+
+bool xl_sink_emit(Sink *s, const uint8_t *p, size_t n) {
+  switch (s->kind) {
+    case K_FD: return xl_write_all_fd(s->fd, p, n, s->cancel);
+    case K_FILE: return fwrite(p, 1, n, s->file) == n;  // short write (disk full) ends the client (dsp_worker.c:20-24)
+    case K_GZ: {
+      while (n > 0) {
+        const unsigned part = (unsigned)std::min<size_t>(n, 1u << 30);
+        if (gzwrite(s->gz, p, part) != (int)part) return false;
+        p += part;
+        n -= part;
+      }
+      return true;
+    }
+  }
+  return false;
+}
+
+void xl_sink_close(Sink *s) {
+  if (s->file) fclose(s->file);
+  if (s->gz) gzclose(s->gz);
+  if (s->kind == K_FD && s->close_fd && s->fd >= 0) close(s->fd);
+  s->file = nullptr;
+  s->gz = nullptr;
+  s->fd = -1;
+}
+
+void xl_worker_main(xlating_sinks *S, Worker *w) {
+  // a peer that went away must surface as EPIPE from write(), not as a signal (sockets use MSG_NOSIGNAL anyway)
+  sigset_t set;
+  sigemptyset(&set);
+  sigaddset(&set, SIGPIPE);
+  (void)pthread_sigmask(SIG_BLOCK, &set, nullptr);
+  std::vector<uint8_t> buf;
+  std::unique_lock<std::mutex> lk(w->m);
+  for (;;) {
+    Sink *pick = nullptr;
+    if (!w->sinks.empty()) {
+      // round-robin over the sinks with queued bytes
+      auto it = w->sinks.lower_bound(w->rr);
+      for (size_t k = 0; k < w->sinks.size(); ++k, ++it) {
+        if (it == w->sinks.end()) it = w->sinks.begin();
+        Sink *s = it->second.get();
+        if (s->used > 0 && !s->busy && !s->failed) {
+          pick = s;
+          w->rr = s->id + 1;
+          break;
+        }
+      }
+    }
+    if (pick == nullptr) {
+      if (w->stop) return;
+      w->cv_work.wait(lk);
+      continue;
+    }
+    const size_t n = std::min(pick->used, kChunk);
+    buf.resize(n);
+    const size_t cap = pick->ring.size();
+    const size_t first = std::min(n, cap - pick->head);
+    memcpy(buf.data(), pick->ring.data() + pick->head, first);
+    memcpy(buf.data() + first, pick->ring.data(), n - first);
+    pick->head = (pick->head + n) % cap;
+    pick->used -= n;
+    pick->busy = true;
+    lk.unlock();
+    const bool ok = xl_sink_emit(pick, buf.data(), n);
+    if (ok) {
+      std::lock_guard<std::mutex> g(S->stats_m);
+      S->bytes_written += n;
+    }
+    lk.lock();
+    pick->busy = false;
+    if (!ok) {
+      pick->failed = true;
+      pick->used = 0;
+    }
+    w->cv_done.notify_all();
+  }
+}
+
+Worker *xl_worker_of(xlating_sinks *S, int id) { return S->workers[(size_t)((unsigned)id % S->workers.size())].get(); }
+
+// takes ownership of `s` only on success
+int xl_attach(xlating_sinks *S, std::unique_ptr<Sink> &s) {
+  Worker *w = xl_worker_of(S, s->id);
+  try {
+    s->ring.resize(S->queue_bytes);
+    std::lock_guard<std::mutex> g(w->m);
+    if (w->sinks.count(s->id)) return -EEXIST;
+    const int id = s->id;
+    w->sinks[id] = std::move(s);
+  } catch (...) {
+    return -ENOMEM;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int xlating_sinks_create(unsigned writer_threads, size_t queue_bytes, xlating_sinks **out) {
+  if (out == nullptr || writer_threads == 0 || writer_threads > 256 || queue_bytes < 8) return -EINVAL;
+  xlating_sinks *S = new (std::nothrow) xlating_sinks_t();
+  if (S == nullptr) return -ENOMEM;
+  S->queue_bytes = queue_bytes;
+  try {
+    for (unsigned i = 0; i < writer_threads; ++i) S->workers.emplace_back(new Worker());
+    for (auto &w : S->workers) w->th = std::thread(xl_worker_main, S, w.get());
+  } catch (...) {
+    xlating_sinks_destroy(S);
+    return -ENOMEM;
+  }
+  *out = S;
+  return 0;
+}
+
+extern "C" int xlating_sinks_attach_fd(xlating_sinks *S, int client_id, int fd, int close_on_detach) {
+  if (S == nullptr || client_id < 0 || fd < 0) return -EINVAL;
+  std::unique_ptr<Sink> s(new (std::nothrow) Sink());
+  if (!s) return -ENOMEM;
+  s->id = client_id;
+  s->kind = K_FD;
+  s->fd = fd;
+  s->close_fd = false;  // (stays the caller's if attaching fails)
+  const int rc = xl_attach(S, s);
+  if (rc == 0 && close_on_detach) {
+    Worker *w = xl_worker_of(S, client_id);
+    std::lock_guard<std::mutex> g(w->m);
+    auto it = w->sinks.find(client_id);
+    if (it != w->sinks.end()) it->second->close_fd = true;
+  }
+  return rc;
+}
+
+extern "C" int xlating_sinks_attach_file(xlating_sinks *S, int client_id, const char *base_path, int use_gzip) {
+  if (S == nullptr || client_id < 0 || base_path == nullptr) return -EINVAL;
+  {
+    Worker *w = xl_worker_of(S, client_id);
+    std::lock_guard<std::mutex> g(w->m);
+    if (w->sinks.count(client_id)) return -EEXIST;
+  }
+  std::unique_ptr<Sink> s(new (std::nothrow) Sink());
+  if (!s) return -ENOMEM;
+  s->id = client_id;
+  const std::string path = std::string(base_path) + "/" + std::to_string(client_id) + (use_gzip ? ".cf32.gz" : ".cf32");
+  if (use_gzip) {
+    s->kind = K_GZ;
+    s->gz = gzopen(path.c_str(), "wb");
+    if (s->gz == nullptr) {
+      const int e = errno ? errno : EIO;
+      XL_LOG_ERR("unable to open gz file for output: %s", path.c_str());
+      return -e;
+    }
+  } else {
+    s->kind = K_FILE;
+    s->file = fopen(path.c_str(), "wb");
+    if (s->file == nullptr) {
+      const int e = errno ? errno : EIO;
+      XL_LOG_ERR("unable to open file for output: %s", path.c_str());
+      return -e;
+    }
+  }
+  const int rc = xl_attach(S, s);
+  if (rc != 0 && s) xl_sink_close(s.get());
+  return rc;
+}
+
+extern "C" int xlating_sinks_write(xlating_sinks *S, int client_id, const float *samples, size_t n_complex) {
+  if (S == nullptr || client_id < 0 || (samples == nullptr && n_complex > 0)) return -EINVAL;
+  Worker *w = xl_worker_of(S, client_id);
+  const size_t n = n_complex * 2 * sizeof(float);
+  std::unique_lock<std::mutex> lk(w->m);
+  auto it = w->sinks.find(client_id);
+  if (it == w->sinks.end()) return -ENOENT;
+  Sink *s = it->second.get();
+  if (!s->failed && n > s->ring.size() - s->used) {
+    // the peer does not keep up: the reference would block its dsp thread until the queue overruns and then drop the
+    // client's blocks; here the client is failed at once
+    s->failed = true;
+    s->used = 0;
+    s->cancel.store(true);
+  }
+  if (s->failed) {
+    lk.unlock();
+    std::lock_guard<std::mutex> g(S->stats_m);
+    S->blocks_dropped++;
+    return -EPIPE;
+  }
+  if (n == 0) return 0;
+  const size_t cap = s->ring.size();
+  const size_t tail = (s->head + s->used) % cap;
+  const size_t first = std::min(n, cap - tail);
+  const uint8_t *src = reinterpret_cast<const uint8_t *>(samples);
+  memcpy(s->ring.data() + tail, src, first);
+  memcpy(s->ring.data(), src + first, n - first);
+  s->used += n;
+  w->cv_work.notify_one();
+  return 0;
+}
+
+extern "C" int xlating_sinks_submit(xlating_sinks *S, struct xlating_batch_t *engine) {
+  if (S == nullptr || engine == nullptr) return -EINVAL;
+  int queued = 0;
+  for (auto &w : S->workers) {
+    std::vector<int> ids;
+    {
+      std::lock_guard<std::mutex> g(w->m);
+      for (auto &kv : w->sinks) ids.push_back(kv.first);
+    }
+    for (int id : ids) {
+      const float *out = nullptr;
+      size_t n = 0;
+      if (xlating_batch_output_host(engine, id, &out, &n) != 0) continue;  // not a live client / nothing fetched
+      if (xlating_sinks_write(S, id, out, n) == 0) ++queued;
+    }
+  }
+  return queued;
+}
+
+extern "C" size_t xlating_sinks_failed(xlating_sinks *S, int *ids, size_t cap) {
+  if (S == nullptr || (ids == nullptr && cap > 0)) return 0;
+  size_t n = 0;
+  for (auto &w : S->workers) {
+    std::lock_guard<std::mutex> g(w->m);
+    for (auto &kv : w->sinks) {
+      Sink *s = kv.second.get();
+      if (s->failed && !s->reported && n < cap) {
+        ids[n++] = s->id;
+        s->reported = true;
+      }
+    }
+  }
+  return n;
+}
+
+extern "C" int xlating_sinks_flush(xlating_sinks *S) {
+  if (S == nullptr) return -EINVAL;
+  for (auto &w : S->workers) {
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv_done.wait(lk, [&] {
+      for (auto &kv : w->sinks) {
+        Sink *s = kv.second.get();
+        if (s->busy || (s->used > 0 && !s->failed)) return false;
+      }
+      return true;
+    });
+    for (auto &kv : w->sinks)
+      if (kv.second->file && !kv.second->failed) (void)fflush(kv.second->file);
+  }
+  return 0;
+}
+
+extern "C" int xlating_sinks_detach(xlating_sinks *S, int client_id) {
+  if (S == nullptr || client_id < 0) return -EINVAL;
+  Worker *w = xl_worker_of(S, client_id);
+  std::unique_ptr<Sink> s;
+  {
+    std::unique_lock<std::mutex> lk(w->m);
+    auto it = w->sinks.find(client_id);
+    if (it == w->sinks.end()) return -ENOENT;
+    Sink *p = it->second.get();
+    if (p->failed) p->cancel.store(true);
+    w->cv_done.wait(lk, [&] { return !p->busy && (p->used == 0 || p->failed); });
+    s = std::move(it->second);
+    w->sinks.erase(it);
+  }
+  xl_sink_close(s.get());
+  return 0;
+}
+
+extern "C" void xlating_sinks_stats(xlating_sinks *S, uint64_t *bytes_written, uint64_t *blocks_dropped) {
+  if (S == nullptr) return;
+  std::lock_guard<std::mutex> g(S->stats_m);
+  if (bytes_written) *bytes_written = S->bytes_written;
+  if (blocks_dropped) *blocks_dropped = S->blocks_dropped;
+}
+
+extern "C" void xlating_sinks_destroy(xlating_sinks *S) {
+  if (S == nullptr) return;
+  for (auto &w : S->workers) {
+    {
+      // give queued bytes two seconds to drain, then abandon whatever a stuck peer still holds up
+      std::unique_lock<std::mutex> lk(w->m);
+      (void)w->cv_done.wait_for(lk, std::chrono::seconds(2), [&] {
+        for (auto &kv : w->sinks) {
+          Sink *s = kv.second.get();
+          if (s->busy || (s->used > 0 && !s->failed)) return false;
+        }
+        return true;
+      });
+      for (auto &kv : w->sinks) {
+        kv.second->cancel.store(true);
+        kv.second->failed = true;
+        kv.second->used = 0;
+      }
+      w->stop = true;
+    }
+    w->cv_work.notify_all();
+    if (w->th.joinable()) w->th.join();
+    for (auto &kv : w->sinks) xl_sink_close(kv.second.get());
+    w->sinks.clear();
+  }
+  delete S;
+}

@@ -484,3 +484,35 @@ def test_bench_block_feeder_stream_plumbing():
                 assert rel_err(eng.output(cid), want[cid]) <= REL_TOL, (k, cid)
     torch.cuda.synchronize()
     eng.close()
+
+
+def test_sinks_submit_delivers_every_clients_stream(tmp_path):
+    """xlating_sinks_submit after xlating_batch_fetch: the files hold exactly each client's output stream over the
+    blocks (what dsp_worker.c's write_to_file would have written), for raw and gzip sinks; a removed client is skipped."""
+    import gzip
+
+    taps = lpf(FS, 24000, 48000)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    ids = [eng.add_client(42, taps, -400000 + 90000 * c) for c in range(9)]
+    sinks = xl.Sinks(writer_threads=2, queue_bytes=16 * 25600)
+    for cid in ids:
+        assert sinks.attach_file(cid, tmp_path, use_gzip=(cid % 3 == 0)) == 0
+    want = {cid: b"" for cid in ids}
+    for k in range(4):
+        if k == 2:
+            eng.remove_client(ids[4])
+        eng.process_host(siggen.xs_u8(siggen.XS_SEED + 200 + k, 262144 if k != 1 else 99998), "native")
+        eng.fetch()
+        live = [cid for cid in ids if not (k >= 2 and cid == ids[4])]
+        assert sinks.submit(eng) == len(live)
+        for cid in live:
+            want[cid] += eng.output(cid).tobytes()
+    sinks.flush()
+    assert sinks.failed() == []
+    for cid in ids:
+        assert sinks.detach(cid) == 0
+        path = tmp_path / (f"{cid}.cf32.gz" if cid % 3 == 0 else f"{cid}.cf32")
+        raw = gzip.open(path, "rb").read() if cid % 3 == 0 else path.read_bytes()
+        assert raw == want[cid], cid
+    sinks.close()
+    eng.close()
