@@ -20,6 +20,16 @@ import numpy as np
 
 from .build import build_library, library_path
 
+
+class WireRequest(C.Structure):
+    """include/xlating_wire.h xlating_wire_request"""
+    _fields_ = [("center_freq", C.c_uint32), ("sampling_rate", C.c_uint32), ("band_freq", C.c_uint32), ("destination", C.c_uint8)]
+
+
+class WireAdmission(C.Structure):
+    """include/xlating_wire.h xlating_wire_admission"""
+    _fields_ = [("decimation", C.c_uint32), ("center_offset", C.c_int32), ("lpf_cutoff", C.c_uint32), ("lpf_transition", C.c_uint32)]
+
 _c_float_p = C.POINTER(C.c_float)
 _c_i16_p = C.POINTER(C.c_int16)
 
@@ -41,6 +51,8 @@ EXPORTED_SYMBOLS = (
     + ["xlating_sinks_create", "xlating_sinks_attach_fd", "xlating_sinks_attach_file", "xlating_sinks_write",
        "xlating_sinks_submit", "xlating_sinks_failed", "xlating_sinks_flush", "xlating_sinks_detach", "xlating_sinks_stats",
        "xlating_sinks_destroy"]
+    + ["xlating_wire_parse_header", "xlating_wire_parse_request", "xlating_wire_build_request", "xlating_wire_build_response",
+       "xlating_wire_build_header", "xlating_wire_parse_response", "xlating_wire_admit", "xlating_wire_add_client"]
 )
 
 _lib = None
@@ -119,6 +131,23 @@ def lib():
     L.xlating_sinks_stats.restype = None
     L.xlating_sinks_destroy.argtypes = [C.c_void_p]
     L.xlating_sinks_destroy.restype = None
+    L.xlating_wire_parse_header.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint8)]
+    L.xlating_wire_parse_header.restype = C.c_int
+    L.xlating_wire_parse_request.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(WireRequest)]
+    L.xlating_wire_parse_request.restype = C.c_int
+    L.xlating_wire_build_request.argtypes = [C.POINTER(WireRequest), C.c_char_p]
+    L.xlating_wire_build_request.restype = C.c_size_t
+    L.xlating_wire_build_response.argtypes = [C.c_uint8, C.c_uint32, C.c_char_p]
+    L.xlating_wire_build_response.restype = C.c_size_t
+    L.xlating_wire_build_header.argtypes = [C.c_uint8, C.c_char_p]
+    L.xlating_wire_build_header.restype = C.c_size_t
+    L.xlating_wire_parse_response.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)]
+    L.xlating_wire_parse_response.restype = C.c_int
+    L.xlating_wire_admit.argtypes = [C.POINTER(WireRequest), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(WireAdmission),
+                                     C.POINTER(C.c_uint32)]
+    L.xlating_wire_admit.restype = C.c_int
+    L.xlating_wire_add_client.argtypes = [C.c_void_p, C.POINTER(WireAdmission), C.c_uint32]
+    L.xlating_wire_add_client.restype = C.c_int
     L.xlating_batch_timing_stride.argtypes = [C.c_void_p, C.c_uint]
     L.xlating_batch_timing_stride.restype = C.c_int
     L.xlating_batch_timing_polyphase.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
@@ -385,3 +414,51 @@ class Sinks:
             self.close()
         except Exception:
             pass
+
+
+# ---- include/xlating_wire.h (client wire format + admission rules; host-only)
+def wire_build_request(center_freq, sampling_rate, band_freq, destination):
+    req = WireRequest(center_freq & 0xFFFFFFFF, sampling_rate, band_freq, destination)
+    buf = C.create_string_buffer(15)
+    n = lib().xlating_wire_build_request(C.byref(req), buf)
+    return buf.raw[:n]
+
+
+def wire_build_response(status, details):
+    buf = C.create_string_buffer(7)
+    n = lib().xlating_wire_build_response(status, details, buf)
+    return buf.raw[:n]
+
+
+def wire_build_header(mtype):
+    buf = C.create_string_buffer(2)
+    n = lib().xlating_wire_build_header(mtype, buf)
+    return buf.raw[:n]
+
+
+def wire_parse_header(data):
+    t = C.c_uint8(0)
+    return lib().xlating_wire_parse_header(bytes(data), len(data), C.byref(t)), t.value
+
+
+def wire_parse_request(data):
+    req = WireRequest()
+    code = lib().xlating_wire_parse_request(bytes(data), len(data), C.byref(req))
+    return code, req
+
+
+def wire_parse_response(data):
+    st, det = C.c_uint8(0), C.c_uint32(0)
+    code = lib().xlating_wire_parse_response(bytes(data), len(data), C.byref(st), C.byref(det))
+    return code, st.value, det.value
+
+
+def wire_admit(req, band_sampling_rate, current_band_freq=0, lpf_cutoff_rate=5):
+    """-> (code, WireAdmission, failure_details)"""
+    adm, why = WireAdmission(), C.c_uint32(0)
+    code = lib().xlating_wire_admit(C.byref(req), band_sampling_rate, current_band_freq, lpf_cutoff_rate, C.byref(adm), C.byref(why))
+    return code, adm, why.value
+
+
+def wire_add_client(engine, adm, band_sampling_rate):
+    return lib().xlating_wire_add_client(engine.h, C.byref(adm), band_sampling_rate)

@@ -516,3 +516,34 @@ def test_sinks_submit_delivers_every_clients_stream(tmp_path):
         assert raw == want[cid], cid
     sinks.close()
     eng.close()
+
+
+@pytest.mark.parametrize("fmt", ["cu8", "cs16"])
+def test_replay_iq_file_end_to_end(fmt, tmp_path):
+    """Ingest -> wire admission -> engine -> sinks (tools/replay_iq.py): a raw IQ capture file replayed in device-sized
+    blocks; each admitted client's <id>.cf32 must be the stream the reference would have written for that request
+    (dsp_worker.c:96-104 parameters), one bad request is rejected the way tcp_server.c answers it."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("replay_iq", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "replay_iq.py"))
+    replay_iq = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(replay_iq)
+    band_rate, band_freq, buffer_size = 2016000, 460100000, 262144
+    nbytes = 3 * buffer_size + 50000  # a short last block
+    if fmt == "cu8":
+        raw = siggen.xs_u8(31337, nbytes)
+    else:
+        raw = siggen.xs_s16(31337, nbytes // 2)
+    path = tmp_path / f"capture.{fmt}"
+    raw.tofile(path)
+    reqs = [(460112000, 48000), (460050000, 96000), (460100000 + 2000000, 48000), (459900000, 48000)]
+    adm, rej, st = replay_iq.replay(str(path), fmt, band_rate, band_freq, reqs, str(tmp_path / "out"), buffer_size, 5, "native")
+    assert sorted(adm.values()) == sorted([reqs[0], reqs[1], reqs[3]]) and rej == [(reqs[2][0], reqs[2][1], 1)]
+    assert st["blocks"] == 4 and st["blocks_dropped"] == 0
+    per_block = buffer_size // raw.dtype.itemsize
+    for cid, (center, rate) in adm.items():
+        code, taps = xl.create_low_pass_filter(1.0, band_rate, rate // 2, rate // 5)
+        o = Oracle(band_rate // rate, taps, center - band_freq, band_rate, buffer_size)
+        want = b"".join(o.process(fmt, raw[off:off + per_block]).tobytes() for off in range(0, raw.size, per_block))
+        assert (tmp_path / "out" / f"{cid}.cf32").read_bytes() == want, cid
