@@ -111,6 +111,8 @@ struct xlating_batch_t {
   size_t phase_run_cap = 0;
   int poly_mode = -1;        // XL_EXP_POLY: 0 never, 1 whenever the shape allows, -1 (default) by the size rule
   uint32_t poly_min_clients = 192;  // measured crossover at 505 taps, D = 42: ~190 clients (profiles/r01_polyphase_crossover.txt)
+  const char *poly_trace = nullptr;  // XL_EXP_POLY_TRACE=<file>: timeline of the latest mix launch (tuning)
+  unsigned long long *d_ptrace = nullptr;
   uint32_t poly_exp = 0;     // XL_EXP_POLY_EXP: tuning switches of the mix kernel (wrong results)
   uint32_t poly_slice1 = 6000, poly_slice2 = 42000;  // NCO slice boundaries in 1/65536 of the block (forward | mix | inverse)
   std::vector<XlNcoClient> nco;
@@ -205,7 +207,7 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   xl_batch_free_plan(b);
   void *dev[] = {b->d_hist[0],  b->d_hist[1],  b->d_block,  b->d_phase[0], b->d_phase[1],
                  b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_trace,
-                 b->d_W,        b->d_phase_run};
+                 b->d_W,        b->d_phase_run, b->d_ptrace};
   for (void *p : dev)
     if (p) (void)hipFree(p);
   if (b->h_block) (void)hipHostFree(b->h_block);
@@ -261,6 +263,7 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   if (getenv("XL_EXP_RIDERS_MIN")) b->riders_min_wgs = atoi(getenv("XL_EXP_RIDERS_MIN"));
   if (getenv("XL_TIMING_EVERY")) b->timing_every = std::max(1, atoi(getenv("XL_TIMING_EVERY")));
   if (getenv("XL_EXP_POLY")) b->poly_mode = atoi(getenv("XL_EXP_POLY"));
+  b->poly_trace = getenv("XL_EXP_POLY_TRACE");
   if (getenv("XL_EXP_POLY_EXP")) b->poly_exp = (uint32_t)atoi(getenv("XL_EXP_POLY_EXP"));
   if (getenv("XL_EXP_POLY_MIN")) b->poly_min_clients = (uint32_t)atoi(getenv("XL_EXP_POLY_MIN"));
   if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
@@ -391,8 +394,8 @@ static int xl_batch_plan(xlating_batch *b) {
     c.cls = it->second;
     members[c.cls].push_back((int)i);
     c.out_off = off;
-    off += xl_roundup(c.out_cap, 8);  // rows start at multiples of 8: the NCO role stores pairs of table entries
-                                      // (every 4th phase) as 16 bytes
+    off += xl_roundup(c.out_cap, 2 * XL_PH_STRIDE);  // rows start at multiples of 2 strides: the NCO role stores
+                                                      // pairs of table entries as 16 bytes
     XlNcoClient nc;
     memset(&nc, 0, sizeof(nc));
     nc.incr = make_float2(c.incr[0], c.incr[1]);
@@ -672,7 +675,7 @@ static int xl_batch_plan(xlating_batch *b) {
     b->out_alloc = 0;
     for (int i = 0; i < 2; ++i) {
       XL_TRY(hipMalloc((void **)&b->d_out[i], b->out_total * sizeof(float2)));
-      XL_TRY(hipMalloc((void **)&b->d_phtab[i], (b->out_total / XL_PH_STRIDE + 8) * sizeof(float2)));  // every 4th phase
+      XL_TRY(hipMalloc((void **)&b->d_phtab[i], (b->out_total / XL_PH_STRIDE + 8) * sizeof(float2)));  // every XL_PH_STRIDE-th phase
     }
     b->out_alloc = b->out_total;
   }
@@ -919,7 +922,26 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_k1 = b->poly_slice2;
             pa.nco_state_src = b->d_phase_run;
           }
+          if (b->poly_trace) {  // tuning: timeline of the mix launch (work waves' span + each NCO wave)
+            if (!b->d_ptrace) XL_TRY(hipMalloc((void **)&b->d_ptrace, 4096 * sizeof(unsigned long long)));
+            XL_TRY(hipMemsetAsync(b->d_ptrace, 0, 4096 * sizeof(unsigned long long), s));
+            XL_TRY(hipMemsetAsync(b->d_ptrace, 0xFF, sizeof(unsigned long long), s));
+            pa.trace = b->d_ptrace;
+          }
           XL_TRY(xlp_launch_mix(pa, next, s));
+          if (b->poly_trace) {
+            pa.trace = nullptr;
+            std::vector<unsigned long long> h(4096);
+            XL_TRY(hipStreamSynchronize(s));
+            XL_TRY(hipMemcpy(h.data(), b->d_ptrace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(b->poly_trace, "w")) {
+              fprintf(f, "work waves: span %.2f us\n", (double)(h[1] - h[0]) * 0.01);
+              for (uint32_t i = 0; i < pa.nco_blocks && i < 1000; ++i)
+                fprintf(f, "nco wave %u: start %+.2f us, end %+.2f us (%.2f us for %llu steps)\n", i, ((double)h[8 + 4 * i] - (double)h[0]) * 0.01,
+                        ((double)h[8 + 4 * i + 1] - (double)h[0]) * 0.01, (double)(h[8 + 4 * i + 1] - h[8 + 4 * i]) * 0.01, h[8 + 4 * i + 2]);
+              fclose(f);
+            }
+          }
           if (pe[2]) XL_TRY(hipEventRecord(pe[2], s));
           if (carry) {
             pa.nco_k0 = b->poly_slice2;

@@ -128,8 +128,8 @@ XL_DEV v2f xl_nco_next(const v2f p, const v2f inc) {
 }
 
 // The work of one lane = one client: advance the recurrence over the outputs [kb, ke) of a block of K (kb a multiple
-// of 8 unless kb == ke), tabulating every XL_PH_STRIDE-th phase (entry (out_off + m) / 4 for m = 0 mod 4), reading the
-// running phase from state_src[slot]; the slice that ends the block (`final`) renormalises and stores the
+// of 2 * XL_PH_STRIDE unless kb == ke), tabulating every XL_PH_STRIDE-th phase (entry (out_off + m) / XL_PH_STRIDE), reading
+// the running phase from state_src[slot]; the slice that ends the block (`final`) renormalises and stores the
 // post-block phase to state_dst[slot], any other slice stores the running phase there.
 XL_DEV void xl_nco_client_slice(const XlNcoClient k, const uint32_t K, const uint32_t kb, const uint32_t ke,
                                 const bool final, const float2 *state_src, float2 *state_dst,
@@ -140,24 +140,25 @@ XL_DEV void xl_nco_client_slice(const XlNcoClient k, const uint32_t K, const uin
     return;
   }
   const v2f inc = {k.incr.x, k.incr.y};
-  v2f *__restrict__ o = reinterpret_cast<v2f *>(tab) + (k.out_off >> 2);  // out_off = 0 mod 8 -> 16-byte entry pairs
+  v2f *__restrict__ o = reinterpret_cast<v2f *>(tab) + (k.out_off >> XL_PH_SHIFT);  // out_off = 0 mod 2 * XL_PH_STRIDE: 16-byte pairs
   v4f *__restrict__ o4 = reinterpret_cast<v4f *>(o);
   uint32_t m = kb;
-  // 16 steps per trip; the 4 phases that are stored sit in distinct register pairs (a store reads its data registers
-  // asynchronously; a step that overwrote them right away would wait for that read)
-  for (; m + 16 <= ke; m += 16) {
-    v2f q[4];
+  // 2 * XL_PH_STRIDE steps and ONE store (two entries) per trip
+  for (; m + 2u * XL_PH_STRIDE <= ke; m += 2u * XL_PH_STRIDE) {
+    const v2f q0 = p;
+    for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      q[j] = p;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) p = xl_nco_next(p, inc);
+      for (int j = 0; j < 16; ++j) p = xl_nco_next(p, inc);
     }
-    o4[m >> 3] = (v4f){q[0].x, q[0].y, q[1].x, q[1].y};
-    o4[(m >> 3) + 1] = (v4f){q[2].x, q[2].y, q[3].x, q[3].y};
+    const v2f q1 = p;
+    for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) p = xl_nco_next(p, inc);
+    }
+    o4[m >> (XL_PH_SHIFT + 1u)] = (v4f){q0.x, q0.y, q1.x, q1.y};
   }
   for (; m < ke; ++m) {
-    if ((m & 3u) == 0u) o[m >> 2] = p;
+    if ((m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
     p = xl_nco_next(p, inc);
   }
   if (!final) {
@@ -170,19 +171,17 @@ XL_DEV void xl_nco_client_slice(const XlNcoClient k, const uint32_t K, const uin
   state_dst[k.slot] = make_float2(pr / mag, pi / mag);
 }
 
-// Consumer side: the phase of output m of the client whose table row starts at entry (out_off / 4) = `row`:
-// the tabulated phase of output m - m % 4 advanced by m % 4 exact recurrence steps (same three IEEE operations as the
-// producer: bit-identical to a table of every phase).
-XL_DEV v2f xl_phase_advance(v2f p, const uint32_t r, const v2f inc) {  // r <= 3 steps
-#pragma unroll
-  for (uint32_t j = 0; j < 3u; ++j) {
-    const v2f n = xl_nco_next(p, inc);
-    p = j < r ? n : p;
+// Consumer side, one lane: the `count` phases of outputs m0 .. m0 + count - 1 of the client whose table row is `row`
+// (entry pointer = table + out_off / XL_PH_STRIDE), written to dst[0 .. count) (LDS).  m0 need not be a multiple of the
+// stride: the tabulated phase of the entry below m0 is first advanced m0 % XL_PH_STRIDE steps.  Same three IEEE operations as the producer.
+XL_DEV void xl_phase_expand(const v2f *__restrict__ row, const uint32_t m0, const v2f inc, v2f *__restrict__ dst,
+                            const uint32_t count) {
+  v2f p = row[m0 >> XL_PH_SHIFT];
+  for (uint32_t j = m0 & (XL_PH_STRIDE - 1u); j > 0u; --j) p = xl_nco_next(p, inc);
+  for (uint32_t i = 0; i < count; ++i) {
+    dst[i] = p;
+    p = xl_nco_next(p, inc);
   }
-  return p;
-}
-XL_DEV v2f xl_phase_at(const v2f *__restrict__ row, const uint32_t m, const v2f inc) {
-  return xl_phase_advance(row[m >> 2], m & 3u, inc);
 }
 
 // whole block

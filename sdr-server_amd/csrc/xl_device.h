@@ -26,14 +26,19 @@
 
 enum { XLF_CU8 = 0, XLF_CS8 = 1, XLF_CS16 = 2, XLF_CF32 = 3 };
 
-#define XL_PH_STRIDE 4u  // the NCO phase table holds every 4th phase: entry (out_off + m) / 4 = phase of output m,
-                         // m = 0 mod 4; consumers take the remaining <= 3 recurrence steps themselves (bit-identical,
-                         // xl_phase_at).  Every 8 bytes of table store cost the dependent chain ~6-10 ns of issue time
-                         // on top of ~9 ns per step (tools/ubench_chain2.hip), whatever the layout.
+#define XL_PH_STRIDE 16u  // the NCO phase table holds every 16th phase: entry (out_off + m) / 16 = phase of output m,
+#define XL_PH_SHIFT 4u    // m = 0 mod 16; the consumers expand the phases in between themselves with the same three IEEE
+                          // operations (bit-identical), cooperatively through LDS.  Why: the recurrence is a dependent
+                          // chain that caps the block rate, and on a memory-saturated chip every table store blocks
+                          // the chain wave ~350 ns, while the bare chain is indifferent to VALU/LDS work sharing its
+                          // SIMD (tools/ubench_chain2/3/4.hip: 7.3 ns per step without stores, 54 ns with a store per
+                          // 8 steps next to HBM-bound waves).  Measured strides: 4 -> 16: 1024-client polyphase block
+                          // 59.5 -> 53.5 us, 4096 clients 189 -> 162 us; 64 is slower again (the consumers' expansion is
+                          // a dependent chain too: 6 us more in the inverse kernel, 5 us in the direct kernel).
 struct XlTile {
   uint32_t tap_off;              // float2 index into the tap image; layout [Tpad][ct]
   uint32_t nclients;             // 1..ct real clients (the rest of the tile has zero taps)
-  uint32_t out_off[XL_CT_MAX];   // per client: float2 index into the output image; / XL_PH_STRIDE into the phase table
+  uint32_t out_off[XL_CT_MAX];   // per client: float2 index into the output image (a multiple of 2 * XL_PH_STRIDE); / XL_PH_STRIDE into the phase table
   float2 incr[XL_CT_MAX];        // per client: NCO phase increment (xlating.c:544)
 };
 #define XL_TILE_DWORDS (2u + 3u * XL_CT_MAX)
@@ -111,7 +116,7 @@ hipError_t xl_launch_fir(int ct, int mode, int nw, const XlFirArgs &a, const XlD
 #define XL_NCO_LANES 64u  // clients per wave in the NCO table kernel / NCO role (with every 4th phase stored the
                           // stores are rare enough that a full wave costs the chain nothing: 8.8 vs 10.6 ns per step)
 // reads the running phases from state_in[slot], writes the post-block phases to state_out[slot] (may alias).
-// Every client's out_off must be a multiple of 8 (16-byte stores of table entry pairs).  prio: wave priority 0..3 of the kernel.
+// Every client's out_off must be a multiple of 2 * XL_PH_STRIDE (16-byte stores of table entry pairs).  prio: wave priority 0..3 of the kernel.
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
                                float2 *state_out, float2 *phtab, const XlDynArgs &dyn, uint32_t prio, hipStream_t s);
 // raw -> converted sample images of the single-filter path (xlating.c:352-433)

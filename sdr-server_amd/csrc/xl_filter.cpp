@@ -125,7 +125,7 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XL_TRY(hipMalloc((void **)&f->d_work_q, work_n * sizeof(short2)));
   XL_TRY(hipMalloc((void **)&f->d_out_f, f->out_cap * sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_out_q, f->out_cap * sizeof(short2)));
-  XL_TRY(hipMalloc((void **)&f->d_phtab, (f->out_cap / XL_PH_STRIDE + 8) * sizeof(float2)));  // every 4th phase
+  XL_TRY(hipMalloc((void **)&f->d_phtab, (f->out_cap / XL_PH_STRIDE + 8) * sizeof(float2)));  // every XL_PH_STRIDE-th phase
   XL_TRY(hipMalloc((void **)&f->d_qphtab, f->out_cap * sizeof(short2)));
   XL_TRY(hipMalloc((void **)&f->d_phase, sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_qphase, sizeof(short2)));

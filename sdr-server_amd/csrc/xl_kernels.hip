@@ -159,8 +159,37 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   const bool live = x * OT < K;
   if (!live && a.nco_lanes == 0u) return;
 
-  // ---- stage the window image: samples [win0, win0 + (OT-1)*D + Tpad) of the stream [in0 | in1], as cf32
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // ---- NCO phases of this wave's outputs, before the window image takes the LDS.  The table holds every
+  // XL_PH_STRIDE-th phase; lane (c, e) = (lane / G, lane % G), G = 64 / XL_PH_STRIDE, expands the phases of outputs
+  // x*OT + e*XL_PH_STRIDE .. of client c of the tile into this wave's [client][64] slice of the LDS, then every lane
+  // picks its own output's phase of each client into registers.  One dependent table load per lane at the START of
+  // the kernel instead of CT of them in the epilogue.
+  v2f phs[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) phs[c] = (v2f){1.0f, 0.0f};
   if (live) {
+    if (w < ntiles) {
+      constexpr uint32_t G = 64u / XL_PH_STRIDE;
+      const uint32_t lane = threadIdx.x & 63u;
+      v2f *__restrict__ pl = xl_win + w * (CT * 64u);
+      const uint32_t *__restrict__ tg = reinterpret_cast<const uint32_t *>(a.groups + y) + 8u + w * XL_TILE_DWORDS;
+      const uint32_t c = lane / G, e = lane % G;
+      const uint32_t m0 = x * OT + e * XL_PH_STRIDE;
+      if (c < tg[1] && e * XL_PH_STRIDE < OT && m0 < K) {
+        const uint32_t off = tg[2 + c];
+        const float2 ci = reinterpret_cast<const float2 *>(tg + 2 + XL_CT_MAX)[c];
+        const uint32_t left = K - m0, span = OT < XL_PH_STRIDE ? OT : XL_PH_STRIDE;
+        xl_phase_expand(reinterpret_cast<const v2f *>(a.phtab) + (off >> XL_PH_SHIFT), m0, (v2f){ci.x, ci.y},
+                        pl + c * 64u + e * XL_PH_STRIDE, left < span ? left : span);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) phs[cc] = pl[cc * 64u + lane];
+    }
+    __syncthreads();  // the phases are in registers: the LDS is free for the window image
+
+    // ---- stage the window image: samples [win0, win0 + (OT-1)*D + Tpad) of the stream [in0 | in1], as cf32
     const uint32_t win0 = d.base + x * OT * D;
     const uint32_t wlen = (OT - 1u) * D + Tpad;
     if (a.fmt == XLF_CU8) xl_stage_window<XLF_CU8>(a, d.zero_below, win0, wlen, xl_win);
@@ -170,7 +199,6 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   }
   __syncthreads();
 
-  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (w >= ntiles) {
     // ---- NCO rider: a wave this group has no tile for tabulates the NEXT block's phases of nco_lanes clients.
     // It shares its SIMD with one FIR wave fewer than the others do, which is about what the chain costs the SIMD
@@ -275,20 +303,14 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
 #undef XL_TAP_LOOP
 
   if (tr && lane == 0) tr[2] = wall_clock64();
-  // ---- epilogue: derotate with the tabulated NCO phase and store (coalesced: lanes = consecutive outputs)
-  const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
+  // ---- epilogue: derotate with the NCO phase (expanded in the prologue) and store (coalesced: lanes = consecutive outputs)
   v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
   {
     const uint32_t m = x * OT + lane;
     if (m < K && lane < OT) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        if ((uint32_t)c < ncl) {
-          const uint32_t off = t[2 + c];
-          const cfloat_p ti = (cfloat_p)(t + 2 + XL_CT_MAX);  // XlTile::incr
-          const v2f inc = {ti[2 * c], ti[2 * c + 1]};
-          out[off + m] = xl_rotate<MODE>(acc[c].value(), xl_phase_at(ph + (off >> 2), m, inc));
-        }
+        if ((uint32_t)c < ncl) out[t[2 + c] + m] = xl_rotate<MODE>(acc[c].value(), phs[c]);
       }
     }
   }
@@ -320,6 +342,9 @@ static hipError_t xl_fir_go2(int nw, const XlFirArgs &a, const XlDynArgs &dyn, c
   }
   const uint32_t nblocks = a.nco_blocks + 8u * ((a.ngroups * a.xtiles + 7u) / 8u);
   if (nblocks == 0) return hipSuccess;
+  // the prologue expands the NCO phases through the LDS: [wave][client][64] before the window image is staged
+  const size_t need = (size_t)nw * CT * 64u * sizeof(float2);
+  if (lds < need) lds = need;
   hipLaunchKernelGGL((xl_fir_kernel<CT, MODE, WIDE>), dim3(nblocks), dim3(64 * nw), lds, s, a, dyn, dyn_next);
   return hipGetLastError();
 }

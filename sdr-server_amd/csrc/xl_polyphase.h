@@ -39,6 +39,7 @@ struct XlpArgs {
   uint32_t nseg_cap;   // segment capacity of the Y image
   uint32_t ncg;        // column groups of XLP_COLS client columns
   uint32_t exp;        // tuning switches (0 in production)
+  unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
   const float2 *R;     // branch spectra   [cg][M][Dpad][XLP_COLS] (+ XLP_BSTEP rows of tail padding)

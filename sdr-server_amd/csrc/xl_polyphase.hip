@@ -98,14 +98,28 @@ XL_DEV void xlp_dft256(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, 
 XL_DEV void xlp_nco_role(const XlpArgs &a, const XlDynArgs &dyn_next) {
   __builtin_amdgcn_s_setprio(3);
   if (threadIdx.x >= XL_NCO_LANES) return;
+  const unsigned long long t0 = a.trace ? wall_clock64() : 0ull;
   const uint32_t c = blockIdx.x * XL_NCO_LANES + threadIdx.x;
   if (c >= a.nco_nclients) return;
   const XlNcoClient k = a.nco_clients[c];
   const uint32_t K = dyn_next.d[k.cls].K;
-  const uint32_t kb = a.nco_k0 == 0u ? 0u : (uint32_t)(((uint64_t)K * a.nco_k0) >> 16) & ~7u;
+  const uint32_t kb = a.nco_k0 == 0u ? 0u : (uint32_t)(((uint64_t)K * a.nco_k0) >> 16) & ~(2u * XL_PH_STRIDE - 1u);
   const bool final = a.nco_k1 >= 65536u;
-  const uint32_t ke = final ? K : (uint32_t)(((uint64_t)K * a.nco_k1) >> 16) & ~7u;
+  const uint32_t ke = final ? K : (uint32_t)(((uint64_t)K * a.nco_k1) >> 16) & ~(2u * XL_PH_STRIDE - 1u);
   xl_nco_client_slice(k, K, kb, ke, final, a.nco_state_src, a.nco_state_dst, a.nco_tab);
+  if (a.trace && threadIdx.x == 0) {
+    a.trace[8 + 4 * blockIdx.x] = t0;
+    a.trace[8 + 4 * blockIdx.x + 1] = wall_clock64();
+    a.trace[8 + 4 * blockIdx.x + 2] = ke - kb;
+  }
+}
+
+// tuning: time span of the work (non-NCO) waves of a launch
+XL_DEV void xlp_trace_work(const XlpArgs &a, const unsigned long long t0) {
+  if (a.trace && (threadIdx.x & 63u) == 0u) {
+    atomicMin(a.trace + 0, t0);
+    atomicMax(a.trace + 1, (unsigned long long)wall_clock64());
+  }
 }
 
 // ------------------------------------------------------------------------------------------- forward transforms
@@ -180,6 +194,7 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDy
     xlp_nco_role(a, dyn_next);
     return;
   }
+  const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;
   const uint32_t bid = blockIdx.x - a.nco_blocks;
   const uint32_t lane = threadIdx.x;
   const uint32_t m = bid % XLP_M;
@@ -241,6 +256,7 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDy
 #pragma unroll
   for (int i = 0; i < (int)XLP_SEG; ++i)
     if (s0 + i < a.nseg) Yp[(size_t)i * XLP_M * (XLP_COLS / 2)] = (v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y};
+  xlp_trace_work(a, t_begin);
 }
 
 // ------------------------------------------------------------------------------------------- inverse + epilogue
@@ -278,31 +294,25 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
       tile[2 * part + 1][XLP_POS(m)] = (v2f){v[i].z, v[i].w};
     }
   }
-  // the epilogue's operands, requested before the transforms: row offsets, increments and the tabulated NCO phases
-  // (every 4th output) of this wave's 4 columns -- all 16 loads in flight together, the <= 3 recurrence steps that
-  // complete a phase come after the transforms
+  // the epilogue's operands.  NCO phases: the table holds every XL_PH_STRIDE-th phase; after the transforms lane
+  // (n, gq) = (j / GQ, j % GQ), GQ = 256 / XL_PH_STRIDE, expands the phases of outputs gq*XL_PH_STRIDE .. of the wave's
+  // column n into that column's tile row (free by then), and every lane picks the phases of its own outputs j + 64 r
+  // from there.  The one table entry a lane needs is requested here, before the transforms.
+  constexpr uint32_t GQ = XLP_M / XL_PH_STRIDE;
+  static_assert(4u * GQ <= 64u, "one expansion duty per lane");
   const uint32_t K = dyn.d[a.cls].K;
   const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
   v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
+  const uint32_t colbase = cg * XLP_COLS + sub * 16u + 4u * w;
   uint32_t off[4];
-  v2f inc[4];
-  v2f pz[4][4];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const uint32_t col = cg * XLP_COLS + sub * 16u + 4u * w + n;
-    off[n] = a.col_out[col];
-    const float2 ci = a.col_incr[col];
-    inc[n] = (v2f){ci.x, ci.y};
-  }
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t qo = j + 64u * r, k = s * a.V + qo;
-      const bool ok = off[n] != 0xFFFFFFFFu && qo < a.V && k < K;
-      pz[n][r] = ph[ok ? (off[n] >> 2) + (k >> 2) : 0u];
-    }
-  }
+  for (int n = 0; n < 4; ++n) off[n] = a.col_out[colbase + n];
+  const uint32_t en = (j / GQ) & 3u, gq = j % GQ;  // expansion duty: column en, outputs gq*XL_PH_STRIDE ..
+  const uint32_t eoff = a.col_out[colbase + en];
+  const float2 eci = a.col_incr[colbase + en];
+  const uint32_t k0 = s * a.V + gq * XL_PH_STRIDE;
+  const bool eok = j < 4u * GQ && eoff != 0xFFFFFFFFu && gq * XL_PH_STRIDE < a.V && k0 < K;
+  v2f pe = ph[eok ? (eoff >> XL_PH_SHIFT) + (k0 >> XL_PH_SHIFT) : 0u];
   __syncthreads();
   v2f u[4][4];
   v2f *const rows[4] = {tile[4 * w], tile[4 * w + 1], tile[4 * w + 2], tile[4 * w + 3]};
@@ -312,6 +322,18 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
     for (int r = 0; r < 4; ++r) u[n][r] = rows[n][XLP_POS(j + 64u * r)];
   __builtin_amdgcn_wave_barrier();
   xlp_dft256<+1, 4>(u, rows, tw, j);
+  __builtin_amdgcn_wave_barrier();
+  if (eok) {
+    const v2f einc = {eci.x, eci.y};
+    for (uint32_t i = k0 & (XL_PH_STRIDE - 1u); i > 0u; --i) pe = xl_nco_next(pe, einc);  // (segments start anywhere)
+    v2f *__restrict__ row = tile[4 * w + en];
+    const uint32_t count = K - k0 < XL_PH_STRIDE ? K - k0 : XL_PH_STRIDE;
+    for (uint32_t i = 0; i < count; ++i) {
+      row[XLP_POS(gq * XL_PH_STRIDE + i)] = pe;
+      pe = xl_nco_next(pe, einc);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
 #pragma unroll
@@ -319,7 +341,7 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
       const uint32_t qo = j + 64u * r, k = s * a.V + qo;
       if (off[n] != 0xFFFFFFFFu && qo < a.V && k < K) {
         const v2f y = u[n][r] * (1.0f / (float)XLP_M);  // exact scaling by 2^-8
-        out[off[n] + k] = xl_rotate<1>(y, xl_phase_advance(pz[n][r], k & 3u, inc[n]));
+        out[off[n] + k] = xl_rotate<1>(y, rows[n][XLP_POS(qo)]);
       }
     }
   }
