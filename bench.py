@@ -257,16 +257,16 @@ def run_workload(xl, torch, dist, args, rank, world, ntaps_rate, steps, warmup, 
 def polyphase_traffic_model(nclients, K, ntaps):
     """HBM bytes one block moves by design on the polyphase path (xl_polyphase.h), per GPU: branch spectra R read
     once (8 D M bytes per client), mixed spectra Y written and read back (8 M bytes per client and segment), outputs
-    written, NCO phase table (every 4th phase) written and read; the shared spectra X and the raw block are noise."""
+    written, NCO phase table (every 16th phase) written and read; the shared spectra X and the raw block are noise."""
     M = 256
     A = -(-ntaps // D)
     V = M - A + 1
     nseg = -(-K // V)
     dpad = -(-D // 6) * 6
-    per_client = 8 * dpad * M + 2 * 8 * M * nseg + 8 * K + 2 * 8 * (K // 4)
+    per_client = 8 * dpad * M + 2 * 8 * M * nseg + 8 * K + 2 * 8 * (K // 16)
     return {"bytes_per_block": int(nclients * per_client), "bytes_per_client": int(per_client),
             "R_branch_spectra": 8 * dpad * M, "Y_mixed_spectra_write_plus_read": 2 * 8 * M * nseg,
-            "out": 8 * K, "phase_table_write_plus_read": 2 * 8 * (K // 4)}
+            "out": 8 * K, "phase_table_write_plus_read": 2 * 8 * (K // 16)}
 
 
 def summarize(m, steps, world):

@@ -111,14 +111,24 @@ XL_DEV void xlp_nco_role(const XlpArgs &a, const XlDynArgs &dyn_next) {
     a.trace[8 + 4 * blockIdx.x] = t0;
     a.trace[8 + 4 * blockIdx.x + 1] = wall_clock64();
     a.trace[8 + 4 * blockIdx.x + 2] = ke - kb;
+    a.trace[8 + 4 * blockIdx.x + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                      __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
   }
 }
 
 // tuning: time span of the work (non-NCO) waves of a launch
 XL_DEV void xlp_trace_work(const XlpArgs &a, const unsigned long long t0) {
   if (a.trace && (threadIdx.x & 63u) == 0u) {
+    const unsigned long long t1 = wall_clock64();
     atomicMin(a.trace + 0, t0);
-    atomicMax(a.trace + 1, (unsigned long long)wall_clock64());
+    atomicMax(a.trace + 1, t1);
+    // per (XCC, CU, SIMD): number of work waves and the sum of their durations, at 2048 + 2 * slot
+    const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 7u;
+    const uint32_t simd = (hw >> 4) & 3u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+    const uint32_t slot = (((xcc * 8u + se) * 2u + sh) * 16u + cu) * 4u + simd;  // < 8192
+    atomicAdd(a.trace + 8192 + 2 * slot, 1ull);
+    atomicAdd(a.trace + 8192 + 2 * slot + 1, t1 - t0);
   }
 }
 
