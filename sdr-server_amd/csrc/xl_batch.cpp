@@ -901,6 +901,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_nclients = (uint32_t)b->nco.size();
             pa.nco_blocks = (pa.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
             pa.nco_tab = b->d_phtab[tab ^ 1];
+            pa.nco_prio = b->nco_prio;
             pa.nco_k0 = 0;
             pa.nco_k1 = b->poly_slice1;
             pa.nco_state_src = b->d_phase[b->pcur];
@@ -921,11 +922,12 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_k0 = b->poly_slice1;
             pa.nco_k1 = b->poly_slice2;
             pa.nco_state_src = b->d_phase_run;
+            if (b->poly_exp & 4u) pa.nco_tab = nullptr;  // tuning: the mix launch's slice stores nothing (WRONG results)
+            if (b->poly_exp & 8u) pa.nco_blocks = 0;     // tuning: the mix launch carries no slice at all (WRONG results)
           }
           if (b->poly_trace) {  // tuning: timeline of the mix launch (work waves' span + each NCO wave)
             if (!b->d_ptrace) XL_TRY(hipMalloc((void **)&b->d_ptrace, 32768 * sizeof(unsigned long long)));
             XL_TRY(hipMemsetAsync(b->d_ptrace, 0, 32768 * sizeof(unsigned long long), s));
-            XL_TRY(hipMemsetAsync(b->d_ptrace, 0xFF, sizeof(unsigned long long), s));
             pa.trace = b->d_ptrace;
           }
           XL_TRY(xlp_launch_mix(pa, next, s));
@@ -934,25 +936,15 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             std::vector<unsigned long long> h(32768);
             XL_TRY(hipStreamSynchronize(s));
             XL_TRY(hipMemcpy(h.data(), b->d_ptrace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            if (FILE *f = fopen(b->poly_trace, "w")) {
-              fprintf(f, "work waves: span %.2f us\n", (double)(h[1] - h[0]) * 0.01);
-              for (uint32_t i = 0; i < pa.nco_blocks && i < 1000; ++i)
-              {
-                const uint32_t hw = (uint32_t)h[8 + 4 * i + 3], xcc = (uint32_t)(h[8 + 4 * i + 3] >> 32) & 7u;
-                const uint32_t simd = (hw >> 4) & 3u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
-                const uint32_t slot = (((xcc * 8u + se) * 2u + sh) * 16u + cu) * 4u + simd;
-                fprintf(f, "nco wave %u: start %+.2f us, end %+.2f us (%.2f us for %llu steps) xcc %u se %u cu %u simd %u: %llu work waves on its SIMD (mean %.1f us), on its CU:", i,
-                        ((double)h[8 + 4 * i] - (double)h[0]) * 0.01, ((double)h[8 + 4 * i + 1] - (double)h[0]) * 0.01,
-                        (double)(h[8 + 4 * i + 1] - h[8 + 4 * i]) * 0.01, h[8 + 4 * i + 2], xcc, se, cu, simd, h[8192 + 2 * slot],
-                        h[8192 + 2 * slot] ? (double)h[8192 + 2 * slot + 1] * 0.01 / (double)h[8192 + 2 * slot] : 0.0);
-                for (uint32_t q = 0; q < 4; ++q) fprintf(f, " %llu", h[8192 + 2 * ((slot & ~3u) + q)]);
-                fprintf(f, "\n");
-              }
+            if (FILE *f = fopen(b->poly_trace, "wb")) {  // raw dump; tools/poly_trace.py reads it
+              fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
               fclose(f);
             }
           }
           if (pe[2]) XL_TRY(hipEventRecord(pe[2], s));
           if (carry) {
+            pa.nco_tab = b->d_phtab[tab ^ 1];
+            pa.nco_blocks = (pa.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
             pa.nco_k0 = b->poly_slice2;
             pa.nco_k1 = 65536;
             pa.nco_state_dst = b->d_phase[b->pcur ^ 1];

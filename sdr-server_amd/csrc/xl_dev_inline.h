@@ -133,8 +133,12 @@ XL_DEV v2f xl_nco_next(const v2f p, const v2f inc) {
 // post-block phase to state_dst[slot], any other slice stores the running phase there.
 XL_DEV void xl_nco_client_slice(const XlNcoClient k, const uint32_t K, const uint32_t kb, const uint32_t ke,
                                 const bool final, const float2 *state_src, float2 *state_dst,
-                                float2 *__restrict__ tab) {
+                                float2 *__restrict__ tab, unsigned long long *stamp = nullptr) {
   v2f p = {state_src[k.slot].x, state_src[k.slot].y};
+  if (stamp) {  // tuning: when did the running phase arrive, when did the recurrence end
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[0] = wall_clock64();
+  }
   if (K == 0) {  // no output possible in this block: the reference leaves the phase untouched (xlating.c:58)
     state_dst[k.slot] = make_float2(p.x, p.y);
     return;
@@ -155,12 +159,13 @@ XL_DEV void xl_nco_client_slice(const XlNcoClient k, const uint32_t K, const uin
 #pragma unroll
       for (int j = 0; j < 16; ++j) p = xl_nco_next(p, inc);
     }
-    o4[m >> (XL_PH_SHIFT + 1u)] = (v4f){q0.x, q0.y, q1.x, q1.y};
+    if (tab != nullptr) o4[m >> (XL_PH_SHIFT + 1u)] = (v4f){q0.x, q0.y, q1.x, q1.y};  // (null: tuning experiment)
   }
   for (; m < ke; ++m) {
-    if ((m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
+    if (tab != nullptr && (m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
     p = xl_nco_next(p, inc);
   }
+  if (stamp) stamp[1] = wall_clock64();
   if (!final) {
     state_dst[k.slot] = make_float2(p.x, p.y);
     return;

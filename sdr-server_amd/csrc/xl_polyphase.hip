@@ -96,7 +96,9 @@ XL_DEV void xlp_dft256(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, 
 
 // NCO role of a launch: the first a.nco_blocks workgroups carry XL_NCO_LANES clients each (first wave only).
 XL_DEV void xlp_nco_role(const XlpArgs &a, const XlDynArgs &dyn_next) {
-  __builtin_amdgcn_s_setprio(3);
+  if (a.nco_prio == 3u) __builtin_amdgcn_s_setprio(3);
+  else if (a.nco_prio == 2u) __builtin_amdgcn_s_setprio(2);
+  else if (a.nco_prio == 1u) __builtin_amdgcn_s_setprio(1);
   if (threadIdx.x >= XL_NCO_LANES) return;
   const unsigned long long t0 = a.trace ? wall_clock64() : 0ull;
   const uint32_t c = blockIdx.x * XL_NCO_LANES + threadIdx.x;
@@ -106,29 +108,31 @@ XL_DEV void xlp_nco_role(const XlpArgs &a, const XlDynArgs &dyn_next) {
   const uint32_t kb = a.nco_k0 == 0u ? 0u : (uint32_t)(((uint64_t)K * a.nco_k0) >> 16) & ~(2u * XL_PH_STRIDE - 1u);
   const bool final = a.nco_k1 >= 65536u;
   const uint32_t ke = final ? K : (uint32_t)(((uint64_t)K * a.nco_k1) >> 16) & ~(2u * XL_PH_STRIDE - 1u);
-  xl_nco_client_slice(k, K, kb, ke, final, a.nco_state_src, a.nco_state_dst, a.nco_tab);
+  unsigned long long st[2] = {0ull, 0ull};
+  xl_nco_client_slice(k, K, kb, ke, final, a.nco_state_src, a.nco_state_dst, a.nco_tab, a.trace ? st : nullptr);
   if (a.trace && threadIdx.x == 0) {
-    a.trace[8 + 4 * blockIdx.x] = t0;
-    a.trace[8 + 4 * blockIdx.x + 1] = wall_clock64();
-    a.trace[8 + 4 * blockIdx.x + 2] = ke - kb;
-    a.trace[8 + 4 * blockIdx.x + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
-                                      __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    unsigned long long *t = a.trace + 8 + 8 * blockIdx.x;
+    t[0] = t0;
+    t[1] = st[0];
+    t[2] = st[1];
+    t[3] = wall_clock64();
+    t[4] = ke - kb;
+    t[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+           __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
   }
 }
 
 // tuning: time span of the work (non-NCO) waves of a launch
 XL_DEV void xlp_trace_work(const XlpArgs &a, const unsigned long long t0) {
-  if (a.trace && (threadIdx.x & 63u) == 0u) {
-    const unsigned long long t1 = wall_clock64();
-    atomicMin(a.trace + 0, t0);
-    atomicMax(a.trace + 1, t1);
-    // per (XCC, CU, SIMD): number of work waves and the sum of their durations, at 2048 + 2 * slot
-    const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 7u;
-    const uint32_t simd = (hw >> 4) & 3u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
-    const uint32_t slot = (((xcc * 8u + se) * 2u + sh) * 16u + cu) * 4u + simd;  // < 8192
-    atomicAdd(a.trace + 8192 + 2 * slot, 1ull);
-    atomicAdd(a.trace + 8192 + 2 * slot + 1, t1 - t0);
+  if (a.trace && (threadIdx.x & 63u) == 0u) {  // per work workgroup: start, end, placement (own slot: no atomics)
+    const uint32_t bid = blockIdx.x - a.nco_blocks;
+    if (bid < 6000u) {
+      unsigned long long *t = a.trace + 4096 + 4 * (size_t)bid;
+      t[0] = t0;
+      t[1] = wall_clock64();
+      t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+             __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
   }
 }
 

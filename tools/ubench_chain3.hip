@@ -17,7 +17,7 @@ __device__ __forceinline__ v2f nxt(v2f p, v2f q) {
 
 // HOG: 0 none, 1 pk_fma stream (16 independent accumulators), 2 LDS broadcast b128 + 8 FMAs, 3 global load + 8 FMAs
 template <int HOG>
-__global__ __launch_bounds__(1024) void k(float *tab, const v4f *gsrc, int steps, int prio_chain, long long *cyc, volatile int *stopflag) {
+__global__ __launch_bounds__(1024) void k(float *tab, const v4f *gsrc, int steps, int prio_chain, long long *cyc, volatile int *stopflag, int idle_chain) {
   __shared__ v4f lds[512];
   __shared__ unsigned simd_of_chain, nhogs;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -34,6 +34,9 @@ __global__ __launch_bounds__(1024) void k(float *tab, const v4f *gsrc, int steps
     v2f p = {1.0f, 1e-3f * l}, q = {0.9999f, 0.01f};
     v4f *o4 = (v4f *)(tab + (size_t)l * 6400);
     const long long t0 = wall_clock64();
+    if (idle_chain) {  // no VALU work: just let the same wall time pass
+      while (wall_clock64() - t0 < (long long)idle_chain) __builtin_amdgcn_s_sleep(8);
+    } else
     for (int m = 0; m + 16 <= steps; m += 16) {
       v2f s[4];
 #pragma unroll
@@ -85,31 +88,36 @@ __global__ __launch_bounds__(1024) void k(float *tab, const v4f *gsrc, int steps
   float r = 0;
   for (int i = 0; i < 16; ++i) r += acc[i].x + acc[i].y;
   tab[64 * 6400 + threadIdx.x] = r;
+  if (l == 0) atomicAdd((unsigned long long *)&cyc[2], (unsigned long long)n);
 }
 
 int main() {
-  float *tab; v4f *g; long long *cyc, h[2]; int *flag;
-  (void)hipMalloc(&tab, 64 * 6400 * 4 * 4 + 8192); (void)hipMalloc(&g, (1 << 20) * 16); (void)hipMalloc(&cyc, 16); (void)hipMalloc(&flag, 4);
+  float *tab; v4f *g; long long *cyc, h[3]; int *flag;
+  (void)hipMalloc(&tab, 64 * 6400 * 4 * 4 + 8192); (void)hipMalloc(&g, (1 << 20) * 16); (void)hipMalloc(&cyc, 32); (void)hipMalloc(&flag, 4);
   (void)hipMemset(g, 0, (1 << 20) * 16);
   const int steps = 3120;
   const char *names[] = {"alone", "pk_fma stream", "LDS broadcast + FMA", "global load + FMA"};
   for (int prio : {3, 0})
-    for (int nw : {8, 12, 16})     // waves in the workgroup
-      for (int hog = 0; hog < 4; ++hog) {
-        if (hog == 0 && nw != 8) continue;
-        for (int rep = 0; rep < 2; ++rep) {
-          (void)hipMemset(flag, 0, 4);
-          switch (hog) {
-            case 0: hipLaunchKernelGGL(k<0>, dim3(1), dim3(64 * nw), 0, 0, tab, g, steps, prio, cyc, flag); break;
-            case 1: hipLaunchKernelGGL(k<1>, dim3(1), dim3(64 * nw), 0, 0, tab, g, steps, prio, cyc, flag); break;
-            case 2: hipLaunchKernelGGL(k<2>, dim3(1), dim3(64 * nw), 0, 0, tab, g, steps, prio, cyc, flag); break;
-            case 3: hipLaunchKernelGGL(k<3>, dim3(1), dim3(64 * nw), 0, 0, tab, g, steps, prio, cyc, flag); break;
+    for (int nw : {8, 12, 16})
+      for (int hog = 1; hog < 4; ++hog) {
+        long long chain_ticks = 0, hog_with = 0, hog_alone = 0, nh = 0;
+        for (int idle = 0; idle < 2; ++idle) {
+          for (int rep = 0; rep < 2; ++rep) {
+            (void)hipMemset(flag, 0, 4);
+            (void)hipMemset(cyc, 0, 32);
+            const int idle_ticks = idle ? (int)chain_ticks : 0;
+            switch (hog) {
+              case 1: hipLaunchKernelGGL(k<1>, dim3(1), dim3(64 * nw), 0, 0, tab, g, steps, prio, cyc, flag, idle_ticks); break;
+              case 2: hipLaunchKernelGGL(k<2>, dim3(1), dim3(64 * nw), 0, 0, tab, g, steps, prio, cyc, flag, idle_ticks); break;
+              case 3: hipLaunchKernelGGL(k<3>, dim3(1), dim3(64 * nw), 0, 0, tab, g, steps, prio, cyc, flag, idle_ticks); break;
+            }
+            (void)hipDeviceSynchronize();
           }
-          (void)hipDeviceSynchronize();
+          (void)hipMemcpy(h, cyc, 24, hipMemcpyDeviceToHost);
+          if (!idle) { chain_ticks = h[0]; hog_with = h[2]; nh = h[1]; } else hog_alone = h[2];
         }
-        (void)hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
-        printf("chain prio %d, %lld other wave(s) on its SIMD (%d in the workgroup), hog = %-22s %6.2f ns / step  (%5.1f us per block)\n", prio, h[1], nw,
-               names[hog], (double)h[0] * 10.0 / steps, (double)h[0] * 10.0 / 1000.0);
+        printf("chain prio %d, %lld hog wave(s) on its SIMD, hog = %-22s chain %6.2f ns/step; hog iterations next to the chain / next to an idle wave: %lld / %lld = %.2f\n",
+               prio, nh, names[hog], (double)chain_ticks * 10.0 / steps, hog_with, hog_alone, hog_alone ? (double)hog_with / (double)hog_alone : 0.0);
       }
   return 0;
 }
