@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/xlating.h"
@@ -39,7 +40,14 @@ struct xlating_t {
   short2 *d_work_q = nullptr;
   float2 *d_out_f = nullptr;
   short2 *d_out_q = nullptr;
-  float2 *d_phtab = nullptr;
+  float2 *d_phtab = nullptr;      // phase table of the current call (every XL_PH_STRIDE-th phase)
+  float2 *d_phtab_next = nullptr; // look-ahead: table of the NEXT call, tabulated on stream_nco while the host is busy
+  float2 *d_phase_next = nullptr; // look-ahead: the phase after the next call
+  hipStream_t stream_nco = nullptr;
+  hipEvent_t ev_nco = nullptr;    // the look-ahead tabulation has finished
+  bool spec_valid = false;        // d_phtab_next / d_phase_next hold a call of spec_K outputs
+  bool lookahead = true;          // XL_EXP_NOLOOKAHEAD disables (tuning)
+  size_t spec_K = 0;
   short2 *d_qphtab = nullptr;
   float2 *d_phase = nullptr;
   short2 *d_qphase = nullptr;
@@ -57,13 +65,17 @@ static void xl_filter_free(xlating *f) {
   if (f == nullptr) return;
   if (f->device >= 0) (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
-  void *dev[] = {f->d_raw,   f->d_work_f, f->d_work_q, f->d_out_f, f->d_out_q, f->d_phtab, f->d_qphtab,
+  if (f->stream_nco) (void)hipStreamSynchronize(f->stream_nco);
+  void *dev[] = {f->d_phtab_next, f->d_phase_next,
+                 f->d_raw,   f->d_work_f, f->d_work_q, f->d_out_f, f->d_out_q, f->d_phtab, f->d_qphtab,
                  f->d_phase, f->d_qphase, f->d_taps,   f->d_qtaps, f->d_group, f->d_nco};
   for (void *p : dev)
     if (p) (void)hipFree(p);
   void *host[] = {f->h_in, f->h_out_f, f->h_out_q};
   for (void *p : host)
     if (p) (void)hipHostFree(p);
+  if (f->ev_nco) (void)hipEventDestroy(f->ev_nco);
+  if (f->stream_nco) (void)hipStreamDestroy(f->stream_nco);
   if (f->stream) (void)hipStreamDestroy(f->stream);
   if (f->original_taps) free(f->original_taps);  // xlating.c:600-602
   delete f;
@@ -120,6 +132,9 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
 
   XL_TRY(hipSetDevice(dev));
   XL_TRY(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  XL_TRY(hipStreamCreateWithFlags(&f->stream_nco, hipStreamNonBlocking));
+  XL_TRY(hipEventCreateWithFlags(&f->ev_nco, hipEventDisableTiming));
+  f->lookahead = getenv("XL_EXP_NOLOOKAHEAD") == nullptr;
   XL_TRY(hipMalloc(&f->d_raw, f->max_samples * 8 + 16));
   XL_TRY(hipMalloc((void **)&f->d_work_f, work_n * sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_work_q, work_n * sizeof(short2)));
@@ -128,6 +143,8 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XL_TRY(hipMalloc((void **)&f->d_phtab, (f->out_cap / XL_PH_STRIDE + 8) * sizeof(float2)));  // every XL_PH_STRIDE-th phase
   XL_TRY(hipMalloc((void **)&f->d_qphtab, f->out_cap * sizeof(short2)));
   XL_TRY(hipMalloc((void **)&f->d_phase, sizeof(float2)));
+  XL_TRY(hipMalloc((void **)&f->d_phtab_next, (f->out_cap / XL_PH_STRIDE + 8) * sizeof(float2)));
+  XL_TRY(hipMalloc((void **)&f->d_phase_next, sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_qphase, sizeof(short2)));
   XL_TRY(hipMalloc((void **)&f->d_taps, rt.size() * sizeof(float)));
   XL_TRY(hipMalloc((void **)&f->d_qtaps, rtq.size() * sizeof(int16_t)));
@@ -204,7 +221,18 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     dyn.d[0].K = (uint32_t)K;
     dyn.d[0].zero_below = 0;
     dyn.d[0].pad = 0;
-    XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase, f->d_phtab, dyn, 0, f->stream));
+    // The phases of this call: tabulated ahead on stream_nco after the previous call if that call guessed this one's
+    // output count (the recurrence is data independent: xlating.c:70-73), else now.  The chain is ~30 us of pure
+    // latency; ahead of time it overlaps the host's work between calls, the upload and the convert kernel.
+    if (f->spec_valid && f->spec_K == K) {
+      XL_TRY(hipStreamWaitEvent(f->stream, f->ev_nco, 0));
+      std::swap(f->d_phtab, f->d_phtab_next);
+      std::swap(f->d_phase, f->d_phase_next);
+    } else {
+      if (f->spec_valid) XL_TRY(hipStreamWaitEvent(f->stream, f->ev_nco, 0));  // (its buffers are reused below)
+      XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase, f->d_phtab, dyn, 0, f->stream));
+    }
+    f->spec_valid = false;
     XlFirArgs a;
     memset(&a, 0, sizeof(a));
     a.in0 = f->d_work_f;
@@ -230,6 +258,24 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     f->hist = keep;
   }
   XL_TRY(hipStreamSynchronize(f->stream));
+  if (K > 0 && f->lookahead) {
+    // look-ahead: if the next call brings the same number of samples (and no cs16-family call moves the shared
+    // history in between) it produces Knext outputs; tabulate them now, off the caller's critical path.
+    // d_phase (the committed post-call phase) is only read; nothing in flight on `stream` after the sync above.
+    size_t Wn, Kn, posn;
+    xl_counts(f, n, &Wn, &Kn, &posn);
+    if (Kn > 0) {
+      XlDynArgs dn;
+      dn.d[0].base = 0;
+      dn.d[0].K = (uint32_t)Kn;
+      dn.d[0].zero_below = 0;
+      dn.d[0].pad = 0;
+      XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase_next, f->d_phtab_next, dn, 0, f->stream_nco));
+      XL_TRY(hipEventRecord(f->ev_nco, f->stream_nco));
+      f->spec_valid = true;
+      f->spec_K = Kn;
+    }
+  }
   *output_len = K;
   return;
 fail:
