@@ -15,7 +15,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 import siggen  # noqa: E402
 import sdr_server_amd as xl  # noqa: E402
@@ -45,6 +44,9 @@ for rate, name in ((5, "505 taps"), (1, "101 taps")):
         f.close()
         res[f"{name} {variant}"] = {"us_per_block": round(dt * 1e6, 1), "Msps": round(131072 / dt / 1e6, 1)}
 out["config1_single_client_dropin_process_cu8_cf32"] = res
+
+import torch  # noqa: E402  (after the single-filter timings: with torch's runtime threads alive the host-bound drop-in loop
+#                            showed one 2x outlier -- 101 taps native -- that a torch-free run never shows)
 
 
 def run_batch(fs, fmt, nbytes_per_block, clients, blocks, steps=60, variant="optimized", host=False):
