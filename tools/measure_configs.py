@@ -27,26 +27,11 @@ def lpf(fs, cut, tw):
     return xl.create_low_pass_filter(1.0, fs, cut, tw)[1]
 
 
-# ---- [1] drop-in single filter
-x = siggen.xs_u8(1, 262144)
-res = {}
-for rate, name in ((5, "505 taps"), (1, "101 taps")):
-    taps = lpf(FS, 24000, 48000 // rate)
-    for variant in ("native", "optimized"):
-        f = xl.XlatingFilter(42, taps, -12000, FS, 262144)
-        for _ in range(20):
-            f.process(variant, "cu8", "cf32", x)
-        t0 = time.perf_counter()
-        n = 300
-        for _ in range(n):
-            f.process(variant, "cu8", "cf32", x)
-        dt = (time.perf_counter() - t0) / n
-        f.close()
-        res[f"{name} {variant}"] = {"us_per_block": round(dt * 1e6, 1), "Msps": round(131072 / dt / 1e6, 1)}
-out["config1_single_client_dropin_process_cu8_cf32"] = res
+# ---- [1] drop-in single filter: measured by a torch-free child process (tools/measure_dropin.py says why)
+import subprocess  # noqa: E402
 
-import torch  # noqa: E402  (after the single-filter timings: with torch's runtime threads alive the host-bound drop-in loop
-#                            showed one 2x outlier -- 101 taps native -- that a torch-free run never shows)
+_r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "measure_dropin.py")], capture_output=True, text=True, timeout=300)
+out["config1_single_client_dropin_process_cu8_cf32"] = json.loads(_r.stdout.strip().splitlines()[-1]) if _r.returncode == 0 else {"error": _r.stderr[-300:]}
 
 
 def run_batch(fs, fmt, nbytes_per_block, clients, blocks, steps=60, variant="optimized", host=False):

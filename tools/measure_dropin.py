@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""tools/measure_dropin.py -- latency of the drop-in process_* API (BASELINE config 2: 1 GPU, 1 client, latency-bound):
+microseconds per 262144-byte cu8 block, 505 and 101 taps, both variants.  Torch-free on purpose: with torch's runtime
+threads alive in the process the host-bound loop showed a 2x outlier (101 taps native) that a torch-free run never shows.
+Prints one JSON object."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import siggen  # noqa: E402
+import sdr_server_amd as xl  # noqa: E402
+
+FS = 2016000
+x = siggen.xs_u8(1, 262144)
+res = {}
+for rate, name in ((5, "505 taps"), (1, "101 taps")):
+    taps = xl.create_low_pass_filter(1.0, FS, 24000, 48000 // rate)[1]
+    for variant in ("native", "optimized"):
+        f = xl.XlatingFilter(42, taps, -12000, FS, 262144)
+        for _ in range(20):
+            f.process(variant, "cu8", "cf32", x)
+        ts = []
+        for _ in range(300):
+            t0 = time.perf_counter()
+            f.process(variant, "cu8", "cf32", x)
+            ts.append(time.perf_counter() - t0)
+        f.close()
+        ts.sort()
+        mean = sum(ts) / len(ts)
+        res[f"{name} {variant}"] = {"us_per_block": round(mean * 1e6, 1), "median_us": round(ts[len(ts) // 2] * 1e6, 1),
+                                    "Msps": round(131072 / mean / 1e6, 1)}
+print(json.dumps(res))
