@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 import siggen  # noqa: E402
 import sdr_server_amd as xl  # noqa: E402
