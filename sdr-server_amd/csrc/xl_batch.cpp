@@ -922,6 +922,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_k0 = b->poly_slice1;
             pa.nco_k1 = b->poly_slice2;
             pa.nco_state_src = b->d_phase_run;
+            if (!(b->poly_exp & 16u)) {  // keep the second wave slot of the chain SIMDs empty (1024 SIMDs, round-robin deal)
+              pa.nco_skip_at = 1024;
+              pa.nco_skip = pa.nco_blocks;
+            }
             if (b->poly_exp & 4u) pa.nco_tab = nullptr;  // tuning: the mix launch's slice stores nothing (WRONG results)
             if (b->poly_exp & 8u) pa.nco_blocks = 0;     // tuning: the mix launch carries no slice at all (WRONG results)
           }
@@ -931,6 +935,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.trace = b->d_ptrace;
           }
           XL_TRY(xlp_launch_mix(pa, next, s));
+          pa.nco_skip = 0;
           if (b->poly_trace) {
             pa.trace = nullptr;
             std::vector<unsigned long long> h(32768);

@@ -57,6 +57,7 @@ struct XlpArgs {
   uint32_t nco_nclients;
   uint32_t nco_blocks;
   uint32_t nco_prio;        // wave priority of the role (0..3)
+  uint32_t nco_skip_at, nco_skip;  // mix launch: workgroups [nco_skip_at, nco_skip_at + nco_skip) exit at once (see the kernel)
   uint32_t nco_k0, nco_k1;  // in 1/65536 of the block's outputs: slice = [K*k0 >> 16, K*k1 >> 16)
   const float2 *nco_state_src;  // phases at the start of the slice (committed phases for the first slice)
   float2 *nco_state_dst;        // phases after the slice (renormalised post-block phases for the last slice)

@@ -125,7 +125,7 @@ XL_DEV void xlp_nco_role(const XlpArgs &a, const XlDynArgs &dyn_next) {
 // tuning: time span of the work (non-NCO) waves of a launch
 XL_DEV void xlp_trace_work(const XlpArgs &a, const unsigned long long t0) {
   if (a.trace && (threadIdx.x & 63u) == 0u) {  // per work workgroup: start, end, placement (own slot: no atomics)
-    const uint32_t bid = blockIdx.x - a.nco_blocks;
+    const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
     if (bid < 6000u) {
       unsigned long long *t = a.trace + 4096 + 4 * (size_t)bid;
       t[0] = t0;
@@ -208,8 +208,14 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDy
     xlp_nco_role(a, dyn_next);
     return;
   }
+  // Workgroups are dealt to the SIMDs round-robin in blockIdx order (measured: the work waves that shared a SIMD with
+  // chain wave i were blocks i + 1024 and i + 2048), and a chain wave next to TWO memory-bound work waves oversubscribes
+  // the SIMD's VALU issue (both slow down, the launch ends 6-10 us late).  a.nco_skip workgroups right after position
+  // a.nco_skip_at exit at once, so that the chain SIMDs' second slot stays empty and they host one work wave only.
+  // (emptying the third slot as well gained nothing: the launch then ends with the SIMDs that got a third work wave)
+  if (blockIdx.x >= a.nco_skip_at && blockIdx.x < a.nco_skip_at + a.nco_skip) return;
   const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;
-  const uint32_t bid = blockIdx.x - a.nco_blocks;
+  const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
   const uint32_t lane = threadIdx.x;
   const uint32_t m = bid % XLP_M;
   const uint32_t q = bid / XLP_M;
@@ -405,7 +411,7 @@ hipError_t xlp_launch_mix(const XlpArgs &a, const XlDynArgs &dyn_next, hipStream
   const uint32_t passes = (a.nseg + XLP_SEG - 1) / XLP_SEG;
   const size_t lds = (size_t)a.Dpad * 8u * sizeof(v4f);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + XLP_M * a.ncg * passes), dim3(64), lds, s, a, dyn_next);
+  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + a.nco_skip + XLP_M * a.ncg * passes), dim3(64), lds, s, a, dyn_next);
   return hipGetLastError();
 }
 
