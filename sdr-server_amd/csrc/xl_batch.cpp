@@ -113,6 +113,7 @@ struct xlating_batch_t {
   uint32_t poly_min_clients = 192;  // measured crossover at 505 taps, D = 42: ~190 clients (profiles/r01_polyphase_crossover.txt)
   const char *poly_trace = nullptr;  // XL_EXP_POLY_TRACE=<file>: timeline of the latest mix launch (tuning)
   unsigned long long *d_ptrace = nullptr;
+  uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
   uint32_t poly_exp = 0;     // XL_EXP_POLY_EXP: tuning switches of the mix kernel (wrong results)
   uint32_t poly_slice1 = 6000, poly_slice2 = 42000;  // NCO slice boundaries in 1/65536 of the block (forward | mix | inverse)
   std::vector<XlNcoClient> nco;
@@ -264,6 +265,7 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   if (getenv("XL_TIMING_EVERY")) b->timing_every = std::max(1, atoi(getenv("XL_TIMING_EVERY")));
   if (getenv("XL_EXP_POLY")) b->poly_mode = atoi(getenv("XL_EXP_POLY"));
   b->poly_trace = getenv("XL_EXP_POLY_TRACE");
+  if (getenv("XL_EXP_INVSKIP")) b->inv_skip_at = (uint32_t)atoi(getenv("XL_EXP_INVSKIP"));
   if (getenv("XL_EXP_POLY_EXP")) b->poly_exp = (uint32_t)atoi(getenv("XL_EXP_POLY_EXP"));
   if (getenv("XL_EXP_POLY_MIN")) b->poly_min_clients = (uint32_t)atoi(getenv("XL_EXP_POLY_MIN"));
   if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
@@ -952,6 +954,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_blocks = (pa.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
             pa.nco_k0 = b->poly_slice2;
             pa.nco_k1 = 65536;
+            if (b->inv_skip_at > 0) {  // tuning: XL_EXP_INVSKIP=<position>
+              pa.nco_skip_at = b->inv_skip_at;
+              pa.nco_skip = pa.nco_blocks;
+            }
             pa.nco_state_dst = b->d_phase[b->pcur ^ 1];
             nco_fused = true;
           }

@@ -292,7 +292,8 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
     xlp_nco_role(a, dyn_next);
     return;
   }
-  const uint32_t bid = blockIdx.x - a.nco_blocks;
+  if (blockIdx.x >= a.nco_skip_at && blockIdx.x < a.nco_skip_at + a.nco_skip) return;  // (as in xlp_mix_kernel; 4-wave workgroups: per CU)
+  const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
   const uint32_t sub = bid & 7u;
   const uint32_t q = bid >> 3;
   const uint32_t cg = q % a.ncg, s = q / a.ncg;
@@ -416,6 +417,6 @@ hipError_t xlp_launch_mix(const XlpArgs &a, const XlDynArgs &dyn_next, hipStream
 }
 
 hipError_t xlp_launch_inverse(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s) {
-  hipLaunchKernelGGL(xlp_inverse_kernel, dim3(a.nco_blocks + a.nseg * a.ncg * 8u), dim3(256), 0, s, a, dyn, dyn_next);
+  hipLaunchKernelGGL(xlp_inverse_kernel, dim3(a.nco_blocks + a.nco_skip + a.nseg * a.ncg * 8u), dim3(256), 0, s, a, dyn, dyn_next);
   return hipGetLastError();
 }
