@@ -408,15 +408,29 @@ hipError_t xlp_launch_forward(const XlpArgs &a, const XlDynArgs &dyn, const XlDy
   return hipGetLastError();
 }
 
-hipError_t xlp_launch_mix(const XlpArgs &a, const XlDynArgs &dyn_next, hipStream_t s) {
-  const uint32_t passes = (a.nseg + XLP_SEG - 1) / XLP_SEG;
-  const size_t lds = (size_t)a.Dpad * 8u * sizeof(v4f);
+// The skipped positions must exist and lie behind the NCO-role workgroups, else the launch carries no skip.
+static XlpArgs xlp_checked_skip(const XlpArgs &a, uint32_t work_blocks) {
+  XlpArgs b = a;
+  if (b.nco_skip == 0u || b.nco_skip_at < b.nco_blocks || b.nco_skip_at + b.nco_skip > b.nco_blocks + work_blocks) {
+    b.nco_skip = 0u;
+    b.nco_skip_at = 0xFFFFFFFFu;
+  }
+  return b;
+}
+
+hipError_t xlp_launch_mix(const XlpArgs &a0, const XlDynArgs &dyn_next, hipStream_t s) {
+  const uint32_t passes = (a0.nseg + XLP_SEG - 1) / XLP_SEG;
+  const size_t lds = (size_t)a0.Dpad * 8u * sizeof(v4f);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + a.nco_skip + XLP_M * a.ncg * passes), dim3(64), lds, s, a, dyn_next);
+  const uint32_t work = XLP_M * a0.ncg * passes;
+  const XlpArgs a = xlp_checked_skip(a0, work);
+  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + a.nco_skip + work), dim3(64), lds, s, a, dyn_next);
   return hipGetLastError();
 }
 
-hipError_t xlp_launch_inverse(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s) {
-  hipLaunchKernelGGL(xlp_inverse_kernel, dim3(a.nco_blocks + a.nco_skip + a.nseg * a.ncg * 8u), dim3(256), 0, s, a, dyn, dyn_next);
+hipError_t xlp_launch_inverse(const XlpArgs &a0, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s) {
+  const uint32_t work = a0.nseg * a0.ncg * 8u;
+  const XlpArgs a = xlp_checked_skip(a0, work);
+  hipLaunchKernelGGL(xlp_inverse_kernel, dim3(a.nco_blocks + a.nco_skip + work), dim3(256), 0, s, a, dyn, dyn_next);
   return hipGetLastError();
 }
