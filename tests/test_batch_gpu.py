@@ -422,6 +422,32 @@ def test_polyphase_class_next_to_direct_classes():
     eng.close()
 
 
+def test_polyphase_100_block_drift(monkeypatch):
+    """100 consecutive blocks on the polyphase path (NCO recurrence cut into three slices per block, renormalised per
+    block, tabulated one block ahead): the float32 phase drift must stay the reference's own -- every 10th
+    block of 8 clients against the oracle, plus the committed phases at the end."""
+    taps = lpf(FS, 24000, 9600)
+    eng = _poly_engine(monkeypatch)
+    oracles = {}
+    for c in range(8):
+        fc = -800000 + c * 213000 + 17
+        oracles[eng.add_client(42, taps, fc)] = Oracle(42, taps, fc, FS, 262144)
+    worst = 0.0
+    for k in range(100):
+        x = siggen.xs_u8(20000 + k, 262144)
+        eng.process_host(x, "optimized")
+        want = {cid: o.process("cu8", x) for cid, o in oracles.items()}
+        if k % 10 == 9:
+            eng.fetch()
+            for cid in oracles:
+                worst = max(worst, rel_err(eng.output(cid), want[cid]))
+    assert worst <= REL_TOL, worst
+    for cid, o in oracles.items():
+        pr, pi = eng.phase(cid)
+        assert (np.float32(pr), np.float32(pi)) == tuple(np.float32(v) for v in o.phase), cid  # the recurrence is bit-exact
+    eng.close()
+
+
 def test_polyphase_default_rule_1024_clients():
     """The bench shape (1024 x 48 kHz, 505 taps): the size rule selects the path by itself.  Duplicated clients in
     different columns agree bit for bit, 16 sampled clients match the oracle within 1e-5 over three blocks, and a
