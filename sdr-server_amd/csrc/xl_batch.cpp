@@ -144,7 +144,6 @@ struct xlating_batch_t {
   bool exp_nofuse = false;    // XL_EXP_NOFUSE: keep the NCO tabulation a launch of its own (tuning)
 
   uint32_t exp_flags = 0;  // tuning knobs from XL_EXP_* environment variables
-  bool exp_same_taps = false;
   // Wave priority of the NCO role / NCO launch (3: a pure dependent chain must not queue behind the FIR waves;
   // 1..3 measured equal for 505 taps, 3 best for short filters).
   uint32_t nco_prio = 3;
@@ -155,7 +154,7 @@ struct xlating_batch_t {
   const char *exp_trace = nullptr;  // XL_EXP_TRACE=<file>: dump per-wave timestamps of the latest FIR launch
   unsigned long long *d_trace = nullptr;
   size_t trace_cap = 0;
-  uint32_t timing_every = 1;  // XL_TIMING_EVERY: bracket only every n-th block (each event pair costs a few us of stream time)
+  uint32_t timing_every = 1;  // xlating_batch_timing_stride: bracket only every n-th block (an event pair costs a few us of stream time)
   int timing = 0;  // 1: bracket every block's launches; 2: also time the three polyphase launches separately
   std::vector<hipEvent_t> ev;       // pairs: fir start, fir stop (on the FIR launch stream)
   std::vector<hipEvent_t> ev_ncot;  // pairs: start, stop of stand-alone NCO launches (rare)
@@ -252,9 +251,6 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
     XL_TRY(hipStreamSynchronize(b->own_stream));
   }
   if (getenv("XL_EXP_FLATPRIO")) b->exp_flags |= 2u;
-  if (getenv("XL_EXP_PRIOQUARTERS")) b->exp_flags |= 4u;
-  if (getenv("XL_EXP_PRIO4")) b->exp_flags |= 8u;  // default: segments end at 1/2, 3/4, 7/8
-  if (getenv("XL_EXP_SAME_TAPS")) b->exp_same_taps = true;
   if (getenv("XL_EXP_H")) b->exp_h = atoi(getenv("XL_EXP_H"));
   b->exp_trace = getenv("XL_EXP_TRACE");
   b->exp_nofuse = getenv("XL_EXP_NOFUSE") != nullptr;
@@ -262,7 +258,6 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   if (getenv("XL_EXP_NCOWPW")) b->nco_wpw = (uint32_t)atoi(getenv("XL_EXP_NCOWPW"));
   if (getenv("XL_EXP_RIDERS")) b->riders = atoi(getenv("XL_EXP_RIDERS")) != 0;
   if (getenv("XL_EXP_RIDERS_MIN")) b->riders_min_wgs = atoi(getenv("XL_EXP_RIDERS_MIN"));
-  if (getenv("XL_TIMING_EVERY")) b->timing_every = std::max(1, atoi(getenv("XL_TIMING_EVERY")));
   if (getenv("XL_EXP_POLY")) b->poly_mode = atoi(getenv("XL_EXP_POLY"));
   b->poly_trace = getenv("XL_EXP_POLY_TRACE");
   if (getenv("XL_EXP_INVSKIP")) b->inv_skip_at = (uint32_t)atoi(getenv("XL_EXP_INVSKIP"));
@@ -503,7 +498,6 @@ static int xl_batch_plan(xlating_batch *b) {
         t.nclients = (uint32_t)td.ids.size();  // a partial last tile keeps zero taps for the missing clients
         image.resize(image.size() + (size_t)2 * Tpad * ct, 0.0f);
         float *dst = image.data() + (size_t)2 * real_off;
-        if (b->exp_same_taps) t.tap_off = 0;  // tuning experiment: every tile streams the same taps (WRONG results)
         for (size_t j = 0; j < td.ids.size(); ++j) {
           const Client &c = b->clients[td.ids[j]];
           t.out_off[j] = c.out_off;
@@ -808,7 +802,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         const size_t wgs = (size_t)a.ngroups * a.xtiles;
         const size_t cap = 256 * std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(L.lds, 1), 7));
         const bool flat = (b->exp_flags & 2u) || wgs > 2 * cap;
-        a.flags = (L.all_wide ? 1u : 0u) | (flat ? 2u : 0u) | ((b->exp_flags & 4u) ? 0u : 4u) | ((b->nco_prio & 3u) << 4) | (b->exp_flags & 8u);
+        a.flags = (L.all_wide ? 1u : 0u) | (flat ? 2u : 0u) | 4u | ((b->nco_prio & 3u) << 4);
         a.taps = b->d_taps;
         a.phtab = b->d_phtab[tab];
         a.out = b->d_out[p];

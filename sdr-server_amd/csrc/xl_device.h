@@ -82,7 +82,7 @@ struct XlFirArgs {
   uint32_t xtiles;      // ceil(max K / outputs per tile)
   uint32_t ota;         // outputs per wave: 64, or 32/16/8 (upper lanes idle) when a 64-output window image would
                         // not fit the LDS (very large decimations)
-  uint32_t flags;       // bit 0: every group of the launch has even D (16-byte LDS reads); bit 1: flat wave priority; bit 2: priority segments end at 1/2, 3/4, 7/8
+  uint32_t flags;       // bit 0: every group of the launch has even D (16-byte LDS reads); bit 1: flat wave priority; bit 2: (set; historic) priority segments end at 1/2 and 7/8
   const float2 *taps;   // tap image
   const float2 *phtab;  // NCO phase table: every XL_PH_STRIDE-th phase, entry (out index) / XL_PH_STRIDE
   float2 *out;

@@ -274,30 +274,18 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
     // priority 3 is reserved for the short latency-bound phases (staging above, epilogue below, NCO role): a
     // workgroup that is still staging must outrank its neighbours' tap loops or it starves (measured: the last
     // dispatched workgroups of every XCD staged for 56 us instead of 4 us and then set the launch time).
-    // The tap loop itself runs at 2, 1, 0 over [0, 1/2), [1/2, 7/8), [7/8, 1] of the taps (bit 2 of flags;
-    // otherwise thirds): remaining-work priority, short last segment = tight finish.
+    // The tap loop itself runs at 2, 1, 0 over [0, 1/2), [1/2, 7/8), [7/8, 1] of the taps: remaining-work priority,
+    // short last segment = tight finish (equal thirds and a four-level variant measured slower).
     const uint32_t steps = Tpad / STEP;
-    if (a.flags & 8u) {  // tuning: four loop levels 3,2,1,0 over [0,1/2) [1/2,3/4) [3/4,7/8) [7/8,1]
-      const uint32_t e1 = (steps / 2) * STEP, e2 = ((3 * steps) / 4) * STEP, e3 = ((7 * steps) / 8) * STEP;
-      XL_TAP_LOOP(0u, e1)
-      __builtin_amdgcn_s_setprio(2);
-      XL_TAP_LOOP(e1, e2)
-      __builtin_amdgcn_s_setprio(1);
-      XL_TAP_LOOP(e2, e3)
-      __builtin_amdgcn_s_setprio(0);
-      XL_TAP_LOOP(e3, Tpad)
-    } else {
-      const uint32_t b1 = (a.flags & 4u) ? steps / 2 : (steps + 2) / 3;
-      const uint32_t b2 = (a.flags & 4u) ? (7 * steps) / 8 : 2 * ((steps + 2) / 3);
-      const uint32_t e1 = b1 * STEP < Tpad ? b1 * STEP : Tpad;
-      const uint32_t e2 = b2 * STEP < Tpad ? b2 * STEP : Tpad;
-      __builtin_amdgcn_s_setprio(2);
-      XL_TAP_LOOP(0u, e1)
-      __builtin_amdgcn_s_setprio(1);
-      XL_TAP_LOOP(e1, e2)
-      __builtin_amdgcn_s_setprio(0);
-      XL_TAP_LOOP(e2, Tpad)
-    }
+    const uint32_t b1 = steps / 2, b2 = (7 * steps) / 8;
+    const uint32_t e1 = b1 * STEP < Tpad ? b1 * STEP : Tpad;
+    const uint32_t e2 = b2 * STEP < Tpad ? b2 * STEP : Tpad;
+    __builtin_amdgcn_s_setprio(2);
+    XL_TAP_LOOP(0u, e1)
+    __builtin_amdgcn_s_setprio(1);
+    XL_TAP_LOOP(e1, e2)
+    __builtin_amdgcn_s_setprio(0);
+    XL_TAP_LOOP(e2, Tpad)
     __builtin_amdgcn_s_setprio(3);
   }
 #undef XL_TAP_LOOP
@@ -385,12 +373,7 @@ hipError_t xl_launch_fir(int ct, int mode, int nw, const XlFirArgs &a, const XlD
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
                                float2 *state_out, float2 *phtab, const XlDynArgs &dyn, uint32_t prio, hipStream_t s) {
   if (nclients == 0) return hipSuccess;
-  static uint32_t lanes = 0;
-  if (lanes == 0) {
-    const char *e = getenv("XL_EXP_NCOLANES");  // tuning
-    lanes = e ? (uint32_t)atoi(e) : XL_NCO_LANES;
-    if (lanes < 1 || lanes > 64) lanes = XL_NCO_LANES;
-  }
+  const uint32_t lanes = XL_NCO_LANES;
   hipLaunchKernelGGL(xl_nco_table_kernel, dim3((nclients + lanes - 1) / lanes), dim3(64), 0, s, clients, nclients,
                      state_in, state_out, phtab, dyn, prio, lanes);
   return hipGetLastError();
