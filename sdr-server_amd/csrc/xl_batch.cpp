@@ -255,7 +255,6 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   b->exp_trace = getenv("XL_EXP_TRACE");
   b->exp_nofuse = getenv("XL_EXP_NOFUSE") != nullptr;
   if (getenv("XL_EXP_NCOPRIO")) b->nco_prio = (uint32_t)atoi(getenv("XL_EXP_NCOPRIO")) & 3u;
-  if (getenv("XL_EXP_NCOWPW")) b->nco_wpw = (uint32_t)atoi(getenv("XL_EXP_NCOWPW"));
   if (getenv("XL_EXP_RIDERS")) b->riders = atoi(getenv("XL_EXP_RIDERS")) != 0;
   if (getenv("XL_EXP_RIDERS_MIN")) b->riders_min_wgs = atoi(getenv("XL_EXP_RIDERS_MIN"));
   if (getenv("XL_EXP_POLY")) b->poly_mode = atoi(getenv("XL_EXP_POLY"));
