@@ -110,7 +110,7 @@ struct xlating_batch_t {
   float2 *d_phase_run = nullptr;     // running phases between the NCO slices of a block
   size_t phase_run_cap = 0;
   int poly_mode = -1;        // XL_EXP_POLY: 0 never, 1 whenever the shape allows, -1 (default) by the size rule
-  uint32_t poly_min_clients = 192;  // measured crossover at 505 taps, D = 42: ~190 clients (profiles/r01_polyphase_crossover.txt)
+  uint32_t poly_min_clients = 128;  // measured at 505 taps, D = 42: x1.10 at 128 clients, x0.96 at 64 (profiles/r01_polyphase_vs_direct.txt)
   const char *poly_trace = nullptr;  // XL_EXP_POLY_TRACE=<file>: timeline of the latest mix launch (tuning)
   unsigned long long *d_ptrace = nullptr;
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
