@@ -573,3 +573,51 @@ def test_replay_iq_file_end_to_end(fmt, tmp_path):
         o = Oracle(band_rate // rate, taps, center - band_freq, band_rate, buffer_size)
         want = b"".join(o.process(fmt, raw[off:off + per_block]).tobytes() for off in range(0, raw.size, per_block))
         assert (tmp_path / "out" / f"{cid}.cf32").read_bytes() == want, cid
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("force_poly", [False, True])
+def test_randomised_engine_vs_oracle(seed, force_poly, monkeypatch):
+    """Randomised streams: mixed decimations / tap counts (even tap counts too: the reversal quirk), clients joining and
+    leaving, block lengths from a few samples to the maximum, native and optimized blocks in any order, with and
+    without the polyphase path forced on.  Every client, every block, against the oracle."""
+    if force_poly:
+        monkeypatch.setenv("XL_EXP_POLY", "1")
+    rng = np.random.default_rng(1000 + seed)
+    shapes = [(42, lpf(FS, 24000, 9600)), (21, lpf(FS, 48000, 19200)), (42, lpf(FS, 24000, 48000)),
+              (7, siggen.hamming_sinc(64, 0.05)), (100, siggen.hamming_sinc(301, 0.004))]
+    max_input = 131072
+    eng = xl.BatchEngine(FS, "cu8", max_input)
+    oracles = {}
+
+    def join():
+        D, taps = shapes[int(rng.integers(len(shapes)))]
+        fc = int(rng.integers(-900000, 900000))
+        oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, FS, max_input)
+
+    for _ in range(int(rng.integers(3, 14))):
+        join()
+    worst = 0.0
+    for k in range(14):
+        r = rng.random()
+        if r < 0.25:
+            join()
+        elif r < 0.4 and len(oracles) > 1:
+            gone = sorted(oracles)[int(rng.integers(len(oracles)))]
+            eng.remove_client(gone)
+            oracles.pop(gone).close()
+        n = int(rng.choice([max_input, max_input, 100000, 50002, 2 * int(rng.integers(1, 3000)), 8]))
+        x = siggen.xs_u8(int(rng.integers(1 << 30)), n)
+        variant = "native" if rng.random() < 0.3 else "optimized"
+        eng.process_host(x, variant)
+        eng.fetch()
+        for cid, o in oracles.items():
+            want = o.process("cu8", x)
+            got = eng.output(cid)
+            assert len(got) == len(want), (k, cid, len(got), len(want))
+            if variant == "native":
+                assert bits_equal(got, want), (k, cid)
+            else:
+                worst = max(worst, rel_err(got, want))
+    assert worst <= REL_TOL, worst
+    eng.close()
