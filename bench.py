@@ -254,17 +254,16 @@ def run_workload(xl, torch, dist, args, rank, world, ntaps_rate, steps, warmup, 
             "plan": plan, "polyphase": polyphase, "kernels_ms": kernels_ms}
 
 
-def polyphase_traffic_model(nclients, K, ntaps):
+def polyphase_traffic_model(nclients, K, ntaps, M=128):
     """HBM bytes one block moves by design on the polyphase path (xl_polyphase.h), per GPU: branch spectra R read
     once (8 D M bytes per client), mixed spectra Y written and read back (8 M bytes per client and segment), outputs
     written, NCO phase table (every 16th phase) written and read; the shared spectra X and the raw block are noise."""
-    M = 256
     A = -(-ntaps // D)
     V = M - A + 1
     nseg = -(-K // V)
-    dpad = -(-D // 6) * 6
+    dpad = -(-D // 7) * 7
     per_client = 8 * dpad * M + 2 * 8 * M * nseg + 8 * K + 2 * 8 * (K // 16)
-    return {"bytes_per_block": int(nclients * per_client), "bytes_per_client": int(per_client),
+    return {"transform_length_M": M, "bytes_per_block": int(nclients * per_client), "bytes_per_client": int(per_client),
             "R_branch_spectra": 8 * dpad * M, "Y_mixed_spectra_write_plus_read": 2 * 8 * M * nseg,
             "out": 8 * K, "phase_table_write_plus_read": 2 * 8 * (K // 16)}
 
@@ -387,7 +386,9 @@ def main():
                               "note": "the block is read once per GPU and shared through L2/LDS: 2/N + 8/D B per unit (SURVEY 8(d))"},
     }
     if m["polyphase"]:
-        tm = polyphase_traffic_model(nloc, m["K"], m["ntaps"])
+        import re
+        mm = re.search(r"polyphase: cls0 .*? M(\d+)", m["plan"])
+        tm = polyphase_traffic_model(nloc, m["K"], m["ntaps"], int(mm.group(1)) if mm else 256)
         roofline["kernel"] = ("xlp_forward_kernel + xlp_mix_kernel (dominant) + xlp_inverse_kernel: the three launches of one "
                               "block on the polyphase overlap-save path (each also carries a slice of the next block's NCO "
                               "phase recurrence; the forward launch rolls the raw history)")

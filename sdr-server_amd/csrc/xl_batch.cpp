@@ -80,6 +80,7 @@ struct Launch {
 // A class of clients evaluated by the polyphase overlap-save path (xl_polyphase.hip) in optimized mode.
 struct PolyClass {
   uint32_t cls = 0, D = 0, Dpad = 0, T = 0, A = 0, V = 0;
+  uint32_t M = 256;          // transform length (128 or 256), V = M - A + 1
   uint32_t ncols = 0, ncg = 0, nseg_cap = 0;
   float2 *d_R = nullptr;     // branch spectra [ncg][M][Dpad][128] (+ XLP_BSTEP rows of tail padding)
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
@@ -113,6 +114,8 @@ struct xlating_batch_t {
   uint32_t poly_min_clients = 128;  // measured at 505 taps, D = 42: x1.10 at 128 clients, x0.96 at 64 (profiles/r01_polyphase_vs_direct.txt)
   const char *poly_trace = nullptr;  // XL_EXP_POLY_TRACE=<file>: timeline of the latest mix launch (tuning)
   unsigned long long *d_ptrace = nullptr;
+  uint32_t poly_m = 0;        // XL_EXP_POLY_M: force the transform length (128 / 256); 0 = by the filter length
+  uint32_t mix_skip_at = 0;   // XL_EXP_MIXSKIP: position of the mix launch's skipped workgroups; 0 = 1024
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
   uint32_t poly_exp = 0;     // XL_EXP_POLY_EXP: tuning switches of the mix kernel (wrong results)
   uint32_t poly_slice1 = 8000, poly_slice2 = 50000;  // NCO slice boundaries in 1/65536 of the block (forward | mix | inverse)
@@ -259,6 +262,9 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   if (getenv("XL_EXP_RIDERS_MIN")) b->riders_min_wgs = atoi(getenv("XL_EXP_RIDERS_MIN"));
   if (getenv("XL_EXP_POLY")) b->poly_mode = atoi(getenv("XL_EXP_POLY"));
   b->poly_trace = getenv("XL_EXP_POLY_TRACE");
+  if (getenv("XL_EXP_POLY_M")) b->poly_m = (uint32_t)atoi(getenv("XL_EXP_POLY_M"));
+  if (b->poly_m != 0 && b->poly_m != 128 && b->poly_m != 256) b->poly_m = 0;
+  if (getenv("XL_EXP_MIXSKIP")) b->mix_skip_at = (uint32_t)atoi(getenv("XL_EXP_MIXSKIP"));
   if (getenv("XL_EXP_INVSKIP")) b->inv_skip_at = (uint32_t)atoi(getenv("XL_EXP_INVSKIP"));
   if (getenv("XL_EXP_POLY_EXP")) b->poly_exp = (uint32_t)atoi(getenv("XL_EXP_POLY_EXP"));
   if (getenv("XL_EXP_POLY_MIN")) b->poly_min_clients = (uint32_t)atoi(getenv("XL_EXP_POLY_MIN"));
@@ -565,7 +571,12 @@ static int xl_batch_plan(xlating_batch *b) {
   for (size_t k = 0; k < members.size(); ++k) {
     const ClassState &cs = b->classes[k];
     const uint32_t A = (cs.T + cs.D - 1) / cs.D;
-    const bool fits = A >= 2 && A <= XLP_M / 2 && cs.D <= 4096;
+    // transform length: the mix launch streams D x M branch-spectrum values per client and block from HBM, which is
+    // what bounds it with many clients; M = 128 halves that for ~5-10 % more arithmetic (valid outputs per segment
+    // M - A + 1) while the filter is short against the segment.  Measured at D = 42, 505 taps: x1.17 at 4096 clients,
+    // x1.08 at 2048, x1.015 at 1024, x0.99 at 512 and below (twice the forward transforms, nothing to save yet).
+    const uint32_t M = A > 64 ? 256u : (b->poly_m ? b->poly_m : (A <= 32 && members[k].size() >= 768 ? 128u : 256u));
+    const bool fits = A >= 2 && A <= M / 2 && cs.D <= 504;  // (the mix kernel stages D rows of 128 bytes in <= 64 KB of LDS)
     const bool pays = members[k].size() >= b->poly_min_clients && 2 * cs.T >= 9 * cs.D;  // crossover ~4.5 taps per branch
     if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
     PolyClass pc;
@@ -574,7 +585,8 @@ static int xl_batch_plan(xlating_batch *b) {
     pc.Dpad = xl_roundup(cs.D, XLP_BSTEP);
     pc.T = cs.T;
     pc.A = A;
-    pc.V = XLP_M - A + 1;
+    pc.M = M;
+    pc.V = M - A + 1;
     pc.ncols = (uint32_t)members[k].size();
     pc.ncg = (pc.ncols + XLP_COLS - 1) / XLP_COLS;
     pc.nseg_cap = (b->max_samples / cs.D + 1 + pc.V - 1) / pc.V;
@@ -606,9 +618,9 @@ static int xl_batch_plan(xlating_batch *b) {
   // ---- polyphase classes: images and the per-client branch spectra (device kernel, double arithmetic)
   if (!b->poly.empty()) {
     if (b->d_W == nullptr) {
-      std::vector<float> w(2 * XLP_M);
-      for (uint32_t n = 0; n < XLP_M; ++n) {
-        const double ang = -2.0 * M_PI * (double)n / (double)XLP_M;
+      std::vector<float> w(2 * 256);
+      for (uint32_t n = 0; n < 256; ++n) {
+        const double ang = -2.0 * M_PI * (double)n / 256.0;
         w[2 * n] = (float)cos(ang);
         w[2 * n + 1] = (float)sin(ang);
       }
@@ -616,8 +628,8 @@ static int xl_batch_plan(xlating_batch *b) {
       w[2 * 64] = 0.0f, w[2 * 64 + 1] = -1.0f;
       w[2 * 128] = -1.0f, w[2 * 128 + 1] = 0.0f;
       w[2 * 192] = 0.0f, w[2 * 192 + 1] = 1.0f;
-      XL_TRY(hipMalloc((void **)&b->d_W, XLP_M * sizeof(float2)));
-      XL_TRY(hipMemcpy(b->d_W, w.data(), XLP_M * sizeof(float2), hipMemcpyHostToDevice));
+      XL_TRY(hipMalloc((void **)&b->d_W, 256 * sizeof(float2)));
+      XL_TRY(hipMemcpy(b->d_W, w.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
     }
     if (b->phase_run_cap < b->phase_cap) {
       if (b->d_phase_run) (void)hipFree(b->d_phase_run);
@@ -630,11 +642,11 @@ static int xl_batch_plan(xlating_batch *b) {
       const std::vector<int> &m = members[pc.cls];
       const size_t rows = (size_t)pc.ncg * pc.Dpad + 1;  // (+1 x M rows: covers the XLP_BSTEP rows of tail padding)
       const uint32_t passes = (pc.nseg_cap + XLP_SEG - 1) / XLP_SEG;
-      XL_TRY(hipMalloc((void **)&pc.d_R, rows * XLP_M * XLP_COLS * sizeof(float2)));
-      XL_TRY(hipMemset(pc.d_R, 0, rows * XLP_M * XLP_COLS * sizeof(float2)));
-      XL_TRY(hipMalloc((void **)&pc.d_X, (size_t)passes * pc.Dpad * XLP_M * XLP_XS * sizeof(float2)));
-      XL_TRY(hipMemset(pc.d_X, 0, (size_t)passes * pc.Dpad * XLP_M * XLP_XS * sizeof(float2)));
-      XL_TRY(hipMalloc((void **)&pc.d_Y, (size_t)pc.ncg * pc.nseg_cap * XLP_M * XLP_COLS * sizeof(float2)));
+      XL_TRY(hipMalloc((void **)&pc.d_R, rows * pc.M * XLP_COLS * sizeof(float2)));
+      XL_TRY(hipMemset(pc.d_R, 0, rows * pc.M * XLP_COLS * sizeof(float2)));
+      XL_TRY(hipMalloc((void **)&pc.d_X, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2)));
+      XL_TRY(hipMemset(pc.d_X, 0, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2)));
+      XL_TRY(hipMalloc((void **)&pc.d_Y, (size_t)pc.ncg * pc.nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
       std::vector<uint32_t> col((size_t)pc.ncg * XLP_COLS, 0xFFFFFFFFu);
       std::vector<float> rt((size_t)pc.ncols * pc.T * 2);
       std::vector<float> colinc(2 * col.size(), 0.0f);
@@ -655,7 +667,7 @@ static int xl_batch_plan(xlating_batch *b) {
       float2 *d_rt = nullptr;
       XL_TRY(hipMalloc((void **)&d_rt, rt.size() * sizeof(float)));
       hipError_t e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = xlp_launch_tables(d_rt, pc.ncols, pc.T, pc.D, pc.Dpad, pc.A, pc.ncg, pc.d_R, b->own_stream);
+      if (e == hipSuccess) e = xlp_launch_tables(d_rt, pc.ncols, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.ncg, pc.d_R, b->own_stream);
       if (e == hipSuccess) e = hipStreamSynchronize(b->own_stream);
       (void)hipFree(d_rt);
       if (e != hipSuccess) goto fail;
@@ -778,7 +790,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
     bool rolled = false;
     // optimized mode: the polyphase classes leave the direct launches (tiny blocks stay direct: a segment is 256
     // branch samples whatever the block holds)
-    const bool use_poly = mode == XL_MODE_OPTIMIZED && !b->poly.empty() && maxK >= 2 * XLP_M;
+    const bool use_poly = mode == XL_MODE_OPTIMIZED && !b->poly.empty() && maxK >= 2 * XLP_M_MAX;
     Launch *const Ls = use_poly ? b->launches_rest : b->launches;
     if (maxK > 0) {
       if (f0) XL_TRY(hipEventRecord(f0, s));
@@ -876,6 +888,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
           pa.T = pc.T;
           pa.A = pc.A;
           pa.V = pc.V;
+          pa.M = pc.M;
           pa.nseg = (K + pc.V - 1) / pc.V;
           pa.nseg_cap = pc.nseg_cap;
           pa.ncg = pc.ncg;
@@ -918,7 +931,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_k1 = b->poly_slice2;
             pa.nco_state_src = b->d_phase_run;
             if (!(b->poly_exp & 16u)) {  // keep the second wave slot of the chain SIMDs empty (1024 SIMDs, round-robin deal)
-              pa.nco_skip_at = 1024;
+              pa.nco_skip_at = b->mix_skip_at ? b->mix_skip_at : 1024;
               pa.nco_skip = pa.nco_blocks;
             }
             if (b->poly_exp & 4u) pa.nco_tab = nullptr;  // tuning: the mix launch's slice stores nothing (WRONG results)
@@ -993,7 +1006,7 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
   if (b->poly.empty()) d += " none";
   for (const PolyClass &pc : b->poly)
     d += " cls" + std::to_string(pc.cls) + " D" + std::to_string(pc.D) + " T" + std::to_string(pc.T) + " cols" +
-         std::to_string(pc.ncols) + " V" + std::to_string(pc.V);
+         std::to_string(pc.ncols) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
   if (!b->poly.empty()) {
     d += " | optimized-mode direct:";
     bool any = false;

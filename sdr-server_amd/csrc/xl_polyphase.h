@@ -20,7 +20,7 @@
 #define XL_POLYPHASE_H_
 #include "xl_device.h"
 
-#define XLP_M 256u     // transform length (branch samples per segment)
+#define XLP_M_MAX 256u  // transform length M (branch samples per segment): 256 or 128, chosen per class
 #define XLP_SEG 14u    // segments accumulated per lane in one pass of the mix kernel
 #define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: XLP_SEG padded to 128 bytes
 #define XLP_COLS 128u  // client columns per column group (= one mix workgroup: a wave with two columns per lane)
@@ -34,7 +34,9 @@ struct XlpArgs {
   uint32_t fmt;
   uint32_t cls;        // index into XlDynArgs::d
   uint32_t D, Dpad;    // decimation = number of branches; padded to a multiple of XLP_BSTEP in the images
-  uint32_t T, A, V;    // taps, taps per branch, valid outputs per segment
+  uint32_t T, A, V;    // taps, taps per branch, valid outputs per segment = M - A + 1
+  uint32_t M;          // transform length: 256 or 128
+  uint32_t mix_passes; // (set by xlp_launch_mix) passes of 14 segments = ceil(nseg / 14)
   uint32_t nseg;       // segments of this block = ceil(K / V)
   uint32_t nseg_cap;   // segment capacity of the Y image
   uint32_t ncg;        // column groups of XLP_COLS client columns
@@ -67,7 +69,7 @@ struct XlpArgs {
 // reversed band-pass taps of every column -> branch spectra R (double arithmetic, rounded once to float)
 //   rt: [T][ncols] float2 (tap-major), ncols <= ncg * XLP_COLS; columns >= ncols and branches >= D get 0
 hipError_t xlp_launch_tables(const float2 *rt, uint32_t ncols, uint32_t T, uint32_t D, uint32_t Dpad, uint32_t A,
-                             uint32_t ncg, float2 *R, hipStream_t s);
+                             uint32_t M, uint32_t ncg, float2 *R, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, const XlDynArgs &dyn_next, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s);

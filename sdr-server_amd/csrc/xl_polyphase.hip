@@ -20,30 +20,34 @@ XL_DEV v2f xlp_cmul(const v2f a, const v2f b) {
   return (v2f){__builtin_fmaf(-a.y, b.y, a.x * b.x), __builtin_fmaf(a.y, b.x, a.x * b.y)};
 }
 
-// 256-point DFT by one wave: radix-4 Stockham autosort, passes p = 1, 4, 16, 64; lane j holds points j + 64 r.
-// In: u[r] = x[j + 64 r].  Out: u[r] = X[j + 64 r] (natural order).  SIGN -1 forward, +1 inverse (unnormalised).
-// The twiddles of a lane depend only on (pass, r, j): xlp_twiddles() fetches the nine of them once (one exposed
-// global latency instead of three), e^{-2 pi j n / 256} from the table W, conjugated for the inverse.
-// `lds` = XLP_ROW complex owned by this wave, addressed through XLP_POS (may be the input row itself); LDS operations of one wave execute in
-// order, so no barrier is needed between a pass's scatter and the next gather.
+// M-point DFT, M = 256 or 128, by M/4 lanes (a wave, or a half-wave: two 128-point transforms per wave): radix-4
+// Stockham autosort, passes p = 1, 4, 16 (and 64 for M = 256); lane l < M/4 holds points l + (M/4) r.  M = 128 ends with
+// a radix-2 pass that needs no exchange: after the third scatter a lane's four points are the operands of its two
+// radix-2 butterflies, (l, l + 64) and (l + 32, l + 96).
+// In: u[r] = x[l + (M/4) r].  Out: u[r] = X[l + (M/4) r] (natural order).  SIGN -1 forward, +1 inverse (unnormalised).
+// The twiddles of a lane depend only on (pass, r, l): xlp_twiddles() fetches them once (one exposed global latency
+// instead of three), e^{-2 pi j n / 256} from the table W, conjugated for the inverse.
+// `lds` = XLP_ROW(M) complex owned by this transform, addressed through XLP_POS (may be the input row itself); LDS
+// operations of one wave execute in order, so no barrier is needed between a pass's scatter and the next gather.
 struct XlpTw {
-  v2f w[3][3];  // [pass - 1][r - 1]
+  v2f w[3][3];  // [pass - 1][r - 1]; M = 128: w[2][0], w[2][1] are the radix-2 twiddles
 };
 // LDS position of transform element i: one pad element per four.  The scatter of pass p writes elements
-// jo + r p with jo = 4 (j - j % p) + j % p -- strides of 4, 16, 64 elements of 8 bytes across lanes, a 4- to 16-way
+// jo + r p with jo = 4 (l - l % p) + l % p -- strides of 4, 16, 64 elements of 8 bytes across lanes, a 4- to 16-way
 // bank conflict on a dense row (measured: the inverse kernel spent ~20 of its 28 us there); with the pad the 16
 // lanes of a quarter-wave hit 16 distinct bank pairs in passes 0 and 1 and at most 2-way conflicts elsewhere.
 #define XLP_POS(i) ((i) + ((i) >> 2))
-#define XLP_ROW (XLP_M + XLP_M / 4)  // padded row length in elements
+#define XLP_ROW(M) ((M) + (M) / 4)  // padded row length in elements
 
-template <int SIGN>
-XL_DEV XlpTw xlp_twiddles(const v2f *__restrict__ W, const uint32_t j) {
+template <int SIGN, int M>
+XL_DEV XlpTw xlp_twiddles(const v2f *__restrict__ W, const uint32_t l) {
   XlpTw t;
+  constexpr int NP4 = M == 256 ? 4 : 3;  // radix-4 passes
 #pragma unroll
-  for (int pass = 1; pass < 4; ++pass) {
+  for (int pass = 1; pass < NP4; ++pass) {
     const uint32_t p = 1u << (2 * pass);
-    const uint32_t k = j & (p - 1u);
-    const uint32_t step = 64u >> (2 * pass);  // 256 / (4 p)
+    const uint32_t k = l & (p - 1u);
+    const uint32_t step = 64u >> (2 * pass);  // W_{4p}^{r k} = W_256^{r k 64 / p}, whatever M
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
       v2f w = W[(r * k * step) & 255u];
@@ -51,12 +55,20 @@ XL_DEV XlpTw xlp_twiddles(const v2f *__restrict__ W, const uint32_t j) {
       t.w[pass - 1][r - 1] = w;
     }
   }
+  if (M == 128) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      v2f w = W[(2u * l + 64u * i) & 255u];  // W_128^{l + 32 i}
+      if (SIGN > 0) w.y = -w.y;
+      t.w[2][i] = w;
+    }
+  }
   return t;
 }
 
-// one pass (butterflies) on registers
+// one radix-4 pass (butterflies) on registers
 template <int SIGN>
-XL_DEV void xlp_dft256_butterfly(v2f (&u)[4], const XlpTw &tw, const int pass) {
+XL_DEV void xlp_dft_butterfly(v2f (&u)[4], const XlpTw &tw, const int pass) {
   if (pass > 0) {
 #pragma unroll
     for (int r = 1; r < 4; ++r) u[r] = xlp_cmul(u[r], tw.w[pass - 1][r - 1]);
@@ -69,17 +81,19 @@ XL_DEV void xlp_dft256_butterfly(v2f (&u)[4], const XlpTw &tw, const int pass) {
   u[3] = v1 - v3;
 }
 
-// NI independent transforms interleaved (instruction-level parallelism for a wave that runs almost alone)
-template <int SIGN, int NI>
-XL_DEV void xlp_dft256(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, const uint32_t j) {
+// NI independent transforms per lane interleaved (instruction-level parallelism for a wave that runs almost alone)
+template <int SIGN, int NI, int M>
+XL_DEV void xlp_dft(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, const uint32_t l) {
+  constexpr uint32_t L = M / 4;
+  constexpr int NP4 = M == 256 ? 4 : 3;
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int pass = 0; pass < NP4; ++pass) {
     const uint32_t p = 1u << (2 * pass);
-    const uint32_t k = j & (p - 1u);
+    const uint32_t k = l & (p - 1u);
 #pragma unroll
-    for (int n = 0; n < NI; ++n) xlp_dft256_butterfly<SIGN>(u[n], tw, pass);
+    for (int n = 0; n < NI; ++n) xlp_dft_butterfly<SIGN>(u[n], tw, pass);
     if (pass < 3) {
-      const uint32_t jo = ((j - k) << 2) + k;
+      const uint32_t jo = ((l - k) << 2) + k;
 #pragma unroll
       for (int n = 0; n < NI; ++n)
 #pragma unroll
@@ -88,8 +102,19 @@ XL_DEV void xlp_dft256(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, 
 #pragma unroll
       for (int n = 0; n < NI; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u[n][r] = lds[n][XLP_POS(j + 64u * r)];
+        for (int r = 0; r < 4; ++r) u[n][r] = lds[n][XLP_POS(l + L * r)];
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (M == 128) {
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const v2f a0 = u[n][0], a1 = xlp_cmul(u[n][2], tw.w[2][0]);
+      const v2f b0 = u[n][1], b1 = xlp_cmul(u[n][3], tw.w[2][1]);
+      u[n][0] = a0 + a1;
+      u[n][1] = b0 + b1;
+      u[n][2] = a0 - a1;
+      u[n][3] = b0 - b1;
     }
   }
 }
@@ -124,10 +149,11 @@ XL_DEV void xlp_nco_role(const XlpArgs &a, const XlDynArgs &dyn_next) {
 
 // tuning: time span of the work (non-NCO) waves of a launch
 XL_DEV void xlp_trace_work(const XlpArgs &a, const unsigned long long t0) {
-  if (a.trace && (threadIdx.x & 63u) == 0u) {  // per work workgroup: start, end, placement (own slot: no atomics)
+  if (a.trace && (threadIdx.x & 63u) == 0u) {  // per work wave: start, end, placement (own slot: no atomics)
     const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
-    if (bid < 6000u) {
-      unsigned long long *t = a.trace + 4096 + 4 * (size_t)bid;
+    const uint32_t slot = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (slot < 6000u) {
+      unsigned long long *t = a.trace + 4096 + 4 * (size_t)slot;
       t[0] = t0;
       t[1] = wall_clock64();
       t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
@@ -137,20 +163,25 @@ XL_DEV void xlp_trace_work(const XlpArgs &a, const unsigned long long t0) {
 }
 
 // ------------------------------------------------------------------------------------------- forward transforms
-// grid = nco_blocks + nseg * D transform workgroups (one wave each) + a.roll_blocks history-roll workgroups.
+// grid = nco_blocks + ceil(nseg * D / TPW) transform workgroups (one wave each: TPW = 256 / M transforms) +
+// a.roll_blocks history-roll workgroups.
+template <int M>
 __global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a, const XlDynArgs dyn,
                                                          const XlDynArgs dyn_next) {
-  __shared__ v2f lds[XLP_ROW];
+  constexpr uint32_t TPW = 256 / M, L = M / 4;
+  __shared__ v2f lds[TPW][XLP_ROW(M)];
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a, dyn_next);
     return;
   }
   const uint32_t bid = blockIdx.x - a.nco_blocks;
   const uint32_t j = threadIdx.x;
-  if (bid >= a.nseg * a.D) {
+  const uint32_t ntr = a.nseg * a.D;
+  const uint32_t nwg = (ntr + TPW - 1u) / TPW;
+  if (bid >= nwg) {
     // raw-history roll (as in xl_fir_kernel): hist_out = the last hist_units 2-byte units of [in0 | in1]; nothing in
     // this block's launches reads hist_out
-    const uint32_t rb = bid - a.nseg * a.D;
+    const uint32_t rb = bid - nwg;
     const uint16_t *__restrict__ h0 = reinterpret_cast<const uint16_t *>(a.in0);
     const uint16_t *__restrict__ h1 = reinterpret_cast<const uint16_t *>(a.in1);
     uint16_t *__restrict__ ho = reinterpret_cast<uint16_t *>(a.hist_out);
@@ -160,8 +191,11 @@ __global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a, const 
     }
     return;
   }
-  const XlpTw tw = xlp_twiddles<-1>(reinterpret_cast<const v2f *>(a.W), j);
-  const uint32_t s = bid / a.D, b = bid - s * a.D;
+  const uint32_t h = j / L, l = j % L;  // transform of this wave, lane within it
+  const XlpTw tw = xlp_twiddles<-1, M>(reinterpret_cast<const v2f *>(a.W), l);
+  const uint32_t tr = bid * TPW + h;
+  const bool live = tr < ntr;
+  const uint32_t s = (live ? tr : 0u) / a.D, b = (live ? tr : 0u) - s * a.D;
   const XlDyn d = dyn.d[a.cls];
   // branch sample n of segment s = stream sample base + (s V + n) D + b   (base: first tap of output 0)
   const uint32_t first = d.base + s * a.V * a.D + b;
@@ -169,25 +203,29 @@ __global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a, const 
   v2f u[1][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const uint32_t idx = first + (j + 64u * r) * a.D;
-    const bool ok = idx >= d.zero_below && idx < end;  // late joiner: zeros below; past the block: zeros (those
-                                                       // outputs lie beyond K and are never stored)
+    const uint32_t idx = first + (l + L * r) * a.D;
+    const bool ok = live && idx >= d.zero_below && idx < end;  // late joiner: zeros below; past the block: zeros
+                                                               // (those outputs lie beyond K and are never stored)
     const bool lo = idx < a.n0;
     const void *src = (lo || !ok) ? a.in0 : a.in1;
     const v2f v = xl_sample(src, (int)a.fmt, ok ? (lo ? idx : idx - a.n0) : 0u);
     u[0][r] = ok ? v : (v2f){0.0f, 0.0f};
   }
-  v2f *const bufs[1] = {lds};
-  xlp_dft256<-1, 1>(u, bufs, tw, j);
+  v2f *const bufs[1] = {lds[h]};
+  xlp_dft<-1, 1, M>(u, bufs, tw, l);
   const uint32_t pass = s / XLP_SEG, si = s - pass * XLP_SEG;
   v2f *__restrict__ X = reinterpret_cast<v2f *>(a.X);
+  if (live) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) X[(((size_t)pass * a.Dpad + b) * XLP_M + (j + 64u * r)) * XLP_XS + si] = u[0][r];
+    for (int r = 0; r < 4; ++r) X[(((size_t)pass * a.Dpad + b) * M + (l + L * r)) * XLP_XS + si] = u[0][r];
+  }
 }
 
 // ------------------------------------------------------------------------------------------- mix (the hot kernel)
 // acc += r * x with ONE accumulator pair: two v_pk_fma_f32, the second negates x.im in its low half (neg_lo) --
 //   acc.re += r.re*x.re;  acc.im += r.re*x.im;      acc.re += r.im*(-x.im);  acc.im += r.im*x.re
+// (running the first halves of four products before their second halves, to space the dependent pairs, changed nothing
+// at 1024 clients and cost 5 % at 4096: a lone wave issues a packed FMA every ~6.7 cycles whatever the spacing)
 XL_DEV void xlp_cmac(v2f &acc, const v2f r, const v2f x) {
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
       "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
@@ -195,13 +233,17 @@ XL_DEV void xlp_cmac(v2f &acc, const v2f r, const v2f x) {
       : "v"(r), "v"(x));
 }
 
-// grid = nco_blocks + M * ncg * passes workgroups of ONE wave; lane l = client columns cg*128 + 2l, 2l+1; the spectrum
-// bin m is workgroup-uniform.  The bin's column of the shared spectra (Dpad rows of 14 segments, 128 bytes each) is
-// staged in LDS once and read back row by row as broadcast reads (every lane the same address): a uniform operand with
-// short, in-order latency (scalar loads of the rows were latency-bound).  R is streamed from HBM exactly once, by
-// exactly one wave: 16 bytes per lane and branch through a ring of XLP_BSTEP register slots, XLP_BSTEP - 1 rows ahead
-// of the multiply (a stage-wise double buffer ran one short stage ahead and every stage waited out a memory latency;
-// a two-wave workgroup sharing the R rows through L1 was 15 % slower at 4096 clients).
+// grid = nco_blocks + M * ncg * passes workgroups of ONE wave = (bin m, column group, pass = 14 segments); lane l =
+// client columns cg*128 + 2l, 2l+1; the spectrum bin m is workgroup-uniform.  The bin's column of the shared spectra
+// (Dpad rows of 14 segments, 128 bytes each) is staged in LDS once and read back row by row as broadcast reads (every
+// lane the same address): a uniform operand with short, in-order latency (scalar loads of the rows were
+// latency-bound).  R is streamed through a ring of XLP_BSTEP register slots, 16 bytes per lane and branch,
+// XLP_BSTEP - 1 rows ahead of the multiply (a stage-wise double buffer ran one short stage ahead and every stage
+// waited out a memory latency; a ring of 14 changed nothing).  A block with more than 14 segments (M = 128 at the
+// server default: 27) takes several passes over the same R rows: the passes of one (m, cg) sit 8 positions apart in
+// the grid -- same XCD (workgroups are dealt to the XCDs round-robin), dispatched together -- so that R comes from HBM
+// once and the other passes hit that XCD's L2.  (The passes as waves of one workgroup gave the same traffic but an
+// uneven deal: two-wave workgroups left SIMDs with 1 to 3 waves, and the launch ends with the fullest.)
 __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDynArgs dyn_next) {
   extern __shared__ __attribute__((aligned(16))) v4f xlp_xcol[];  // [Dpad][8]
   if (blockIdx.x < a.nco_blocks) {
@@ -217,19 +259,20 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDy
   const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;
   const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
   const uint32_t lane = threadIdx.x;
-  const uint32_t m = bid % XLP_M;
-  const uint32_t q = bid / XLP_M;
-  const uint32_t cg = q % a.ncg, pass = q / a.ncg;
+  const uint32_t M = a.M;  // (a power of two >= 128: M * ncg is a multiple of 8)
+  const uint32_t grp = bid / (8u * a.mix_passes), rr = bid - grp * 8u * a.mix_passes;
+  const uint32_t pass = rr >> 3, pair = grp * 8u + (rr & 7u);
+  const uint32_t m = pair & (M - 1u), cg = pair / M;
   // R image [cg][m][Dpad][128 columns]: the Dpad rows of a workgroup are one contiguous run (42 KB at D = 42)
   const v4f *__restrict__ Rp =
-      reinterpret_cast<const v4f *>(a.R) + ((size_t)cg * XLP_M + m) * a.Dpad * (XLP_COLS / 2) + lane;
+      reinterpret_cast<const v4f *>(a.R) + ((size_t)cg * M + m) * a.Dpad * (XLP_COLS / 2) + lane;
   const size_t rstride = XLP_COLS / 2;
   v4f r[XLP_BSTEP];
 #pragma unroll
   for (int u = 0; u < (int)XLP_BSTEP - 1; ++u) r[u] = Rp[(size_t)u * rstride];
   {
     const v4f *__restrict__ Xc =
-        reinterpret_cast<const v4f *>(a.X + ((size_t)pass * a.Dpad * XLP_M + m) * XLP_XS);  // row stride M * 8 v4f
+        reinterpret_cast<const v4f *>(a.X + ((size_t)pass * a.Dpad * M + m) * XLP_XS);  // row stride M * 8 v4f
     const uint32_t n8 = a.Dpad * 8u;
     for (uint32_t base = 0; base < n8; base += 512u) {  // one trip for D <= 64; all loads of a trip in flight together
       v4f t[8];
@@ -237,7 +280,7 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDy
       for (int u = 0; u < 8; ++u) {
         const uint32_t i = base + lane + 64u * u;
         const uint32_t ic = i < n8 ? i : 0u;
-        t[u] = Xc[(size_t)(ic >> 3) * (XLP_M * 8u) + (ic & 7u)];
+        t[u] = Xc[(size_t)(ic >> 3) * (M * 8u) + (ic & 7u)];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -272,82 +315,91 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDy
   }
   const uint32_t s0 = pass * XLP_SEG;
   v4f *__restrict__ Yp =
-      reinterpret_cast<v4f *>(a.Y) + (((size_t)cg * a.nseg_cap + s0) * XLP_M + m) * (XLP_COLS / 2) + lane;
+      reinterpret_cast<v4f *>(a.Y) + (((size_t)cg * a.nseg_cap + s0) * M + m) * (XLP_COLS / 2) + lane;
 #pragma unroll
   for (int i = 0; i < (int)XLP_SEG; ++i)
-    if (s0 + i < a.nseg) Yp[(size_t)i * XLP_M * (XLP_COLS / 2)] = (v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y};
+    if (s0 + i < a.nseg) Yp[(size_t)i * M * (XLP_COLS / 2)] = (v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y};
   xlp_trace_work(a, t_begin);
 }
 
 // ------------------------------------------------------------------------------------------- inverse + epilogue
-// grid = nco_blocks + nseg * ncg * 8 workgroups of 256 threads; workgroup = (segment, 16 columns).  The tile rows
-// double as the transforms' scratch; each wave runs its four columns' transforms interleaved.
+// grid = nco_blocks + nseg * ncg * (128 / CW) workgroups of 256 threads; workgroup = (segment, CW columns), CW = 16
+// (M = 256: a wave runs its four columns' transforms interleaved) or 32 (M = 128: each half-wave runs four).  The tile
+// rows double as the transforms' scratch.
+template <int M>
 __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const XlDynArgs dyn,
                                                           const XlDynArgs dyn_next) {
-  // [column][padded bin position].  Row length 319 (= XLP_POS(255) + 1): 638 dwords = -2 banks per row, so the 8 lanes
-  // that fill 8 different rows of one bin hit distinct bank pairs; and 16 x 319 x 8 B = 40832 B lets a CU hold four
-  // workgroups (at 41.2 KB it held three: 768 slots for the 832 workgroups of a 1024-client block -> a second round)
-  __shared__ v2f tile[16][XLP_ROW - 1];
+  constexpr uint32_t L = M / 4;            // lanes per transform
+  constexpr uint32_t CW = 16u * (256 / M);  // columns per workgroup
+  constexpr uint32_t WPC = CW / 4;          // columns per wave
+  constexpr uint32_t NSUB = XLP_COLS / CW;  // workgroups per column group
+  // [column][padded bin position].  Row length XLP_POS(M - 1) + 1 (319 / 159): 2 banks short of a multiple of 32, so
+  // the lanes that fill different rows of one bin hit distinct bank pairs; and 16 x 319 x 8 B = 40832 B lets a CU hold
+  // four workgroups (at 41.2 KB it held three: 768 slots for the 832 workgroups of a 1024-client block -> a second round)
+  __shared__ v2f tile[CW][XLP_ROW(M) - 1];
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a, dyn_next);
     return;
   }
   if (blockIdx.x >= a.nco_skip_at && blockIdx.x < a.nco_skip_at + a.nco_skip) return;  // (as in xlp_mix_kernel; 4-wave workgroups: per CU)
   const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
-  const uint32_t sub = bid & 7u;
-  const uint32_t q = bid >> 3;
+  const uint32_t sub = bid % NSUB;
+  const uint32_t q = bid / NSUB;
   const uint32_t cg = q % a.ncg, s = q / a.ncg;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = threadIdx.x & 63u;
-  const XlpTw tw = xlp_twiddles<+1>(reinterpret_cast<const v2f *>(a.W), j);
+  const uint32_t h = j / L, l = j % L;  // (h = 0 for M = 256)
+  const XlpTw tw = xlp_twiddles<+1, M>(reinterpret_cast<const v2f *>(a.W), l);
   {
-    // Y tile: 256 bins x 16 columns = 256 chunks of 128 contiguous bytes, 2 KB apart.  Eight lanes share a chunk
-    // (16 bytes = 2 columns each), so a load instruction touches 8 full lines instead of 64 partial ones.
-    const uint32_t part = threadIdx.x & 7u, mrow = threadIdx.x >> 3;  // mrow 0..31
+    // Y tile: M bins x CW columns = M chunks of CW * 8 contiguous bytes, 1 KB apart.  CW / 2 lanes share a chunk
+    // (16 bytes = 2 columns each), so a load instruction touches full lines instead of 64 partial ones.
+    constexpr uint32_t PARTS = CW / 2, MR = 256 / PARTS;
+    const uint32_t part = threadIdx.x % PARTS, mrow = threadIdx.x / PARTS;
     const v4f *__restrict__ src = reinterpret_cast<const v4f *>(
-        a.Y + (((size_t)cg * a.nseg_cap + s) * XLP_M) * XLP_COLS + sub * 16u) + part;
+        a.Y + (((size_t)cg * a.nseg_cap + s) * M) * XLP_COLS + sub * CW) + part;
     v4f v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(mrow + 32u * i) * (XLP_COLS / 2)];
+    for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(mrow + MR * i) * (XLP_COLS / 2)];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const uint32_t m = mrow + 32u * i;
+      const uint32_t m = mrow + MR * i;
       tile[2 * part][XLP_POS(m)] = (v2f){v[i].x, v[i].y};
       tile[2 * part + 1][XLP_POS(m)] = (v2f){v[i].z, v[i].w};
     }
   }
   // the epilogue's operands.  NCO phases: the table holds every XL_PH_STRIDE-th phase; after the transforms lane
-  // (n, gq) = (j / GQ, j % GQ), GQ = 256 / XL_PH_STRIDE, expands the phases of outputs gq*XL_PH_STRIDE .. of the wave's
-  // column n into that column's tile row (free by then), and every lane picks the phases of its own outputs j + 64 r
+  // (en, gq) = (j / GQ, j % GQ), GQ = M / XL_PH_STRIDE, expands the phases of outputs gq*XL_PH_STRIDE .. of the wave's
+  // column en into that column's tile row (free by then), and every lane picks the phases of its own outputs l + L r
   // from there.  The one table entry a lane needs is requested here, before the transforms.
-  constexpr uint32_t GQ = XLP_M / XL_PH_STRIDE;
-  static_assert(4u * GQ <= 64u, "one expansion duty per lane");
+  constexpr uint32_t GQ = M / XL_PH_STRIDE;
+  static_assert(WPC * GQ == 64u, "one expansion duty per lane");
   const uint32_t K = dyn.d[a.cls].K;
   const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
   v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
-  const uint32_t colbase = cg * XLP_COLS + sub * 16u + 4u * w;
+  const uint32_t colbase = cg * XLP_COLS + sub * CW + WPC * w;
   uint32_t off[4];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) off[n] = a.col_out[colbase + n];
-  const uint32_t en = (j / GQ) & 3u, gq = j % GQ;  // expansion duty: column en, outputs gq*XL_PH_STRIDE ..
+  for (int n = 0; n < 4; ++n) off[n] = a.col_out[colbase + 4u * h + n];
+  const uint32_t en = j / GQ, gq = j % GQ;  // expansion duty: column en of the wave, outputs gq*XL_PH_STRIDE ..
   const uint32_t eoff = a.col_out[colbase + en];
   const float2 eci = a.col_incr[colbase + en];
   const uint32_t k0 = s * a.V + gq * XL_PH_STRIDE;
-  const bool eok = j < 4u * GQ && eoff != 0xFFFFFFFFu && gq * XL_PH_STRIDE < a.V && k0 < K;
+  const bool eok = eoff != 0xFFFFFFFFu && gq * XL_PH_STRIDE < a.V && k0 < K;
   v2f pe = ph[eok ? (eoff >> XL_PH_SHIFT) + (k0 >> XL_PH_SHIFT) : 0u];
   __syncthreads();
   v2f u[4][4];
-  v2f *const rows[4] = {tile[4 * w], tile[4 * w + 1], tile[4 * w + 2], tile[4 * w + 3]};
+  v2f *const rows[4] = {tile[WPC * w + 4u * h], tile[WPC * w + 4u * h + 1], tile[WPC * w + 4u * h + 2],
+                        tile[WPC * w + 4u * h + 3]};
 #pragma unroll
   for (int n = 0; n < 4; ++n)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) u[n][r] = rows[n][XLP_POS(j + 64u * r)];
+    for (int r = 0; r < 4; ++r) u[n][r] = rows[n][XLP_POS(l + L * r)];
   __builtin_amdgcn_wave_barrier();
-  xlp_dft256<+1, 4>(u, rows, tw, j);
+  xlp_dft<+1, 4, M>(u, rows, tw, l);
   __builtin_amdgcn_wave_barrier();
   if (eok) {
     const v2f einc = {eci.x, eci.y};
     for (uint32_t i = k0 & (XL_PH_STRIDE - 1u); i > 0u; --i) pe = xl_nco_next(pe, einc);  // (segments start anywhere)
-    v2f *__restrict__ row = tile[4 * w + en];
+    v2f *__restrict__ row = tile[WPC * w + en];
     const uint32_t count = K - k0 < XL_PH_STRIDE ? K - k0 : XL_PH_STRIDE;
     for (uint32_t i = 0; i < count; ++i) {
       row[XLP_POS(gq * XL_PH_STRIDE + i)] = pe;
@@ -359,9 +411,9 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
   for (int n = 0; n < 4; ++n) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const uint32_t qo = j + 64u * r, k = s * a.V + qo;
+      const uint32_t qo = l + L * r, k = s * a.V + qo;
       if (off[n] != 0xFFFFFFFFu && qo < a.V && k < K) {
-        const v2f y = u[n][r] * (1.0f / (float)XLP_M);  // exact scaling by 2^-8
+        const v2f y = u[n][r] * (1.0f / (float)M);  // exact scaling by 2^-8 / 2^-7
         out[off[n] + k] = xl_rotate<1>(y, rows[n][XLP_POS(qo)]);
       }
     }
@@ -371,12 +423,13 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
 // ------------------------------------------------------------------------------------------- branch spectra
 // R[cg][m][b][col] = sum_{a<A} r_col[D a + b] e^{+2 pi j a m / M}, in double, rounded once.  One-time per plan.
 __global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__restrict__ rt, uint32_t ncols, uint32_t T,
-                                                              uint32_t D, uint32_t Dpad, uint32_t A, float2 *__restrict__ R) {
-  __shared__ double wc[XLP_M], ws[XLP_M];  // e^{+2 pi j n / M} in double
-  for (uint32_t n = threadIdx.x; n < XLP_M; n += blockDim.x) sincospi(2.0 * (double)n / (double)XLP_M, &ws[n], &wc[n]);
+                                                              uint32_t D, uint32_t Dpad, uint32_t A, uint32_t M,
+                                                              float2 *__restrict__ R) {
+  __shared__ double wc[256], ws[256];  // e^{+2 pi j n / M} in double
+  for (uint32_t n = threadIdx.x; n < M; n += blockDim.x) sincospi(2.0 * (double)n / (double)M, &ws[n], &wc[n]);
   __syncthreads();
-  const uint32_t m = blockIdx.x % XLP_M;
-  const uint32_t q = blockIdx.x / XLP_M;
+  const uint32_t m = blockIdx.x % M;
+  const uint32_t q = blockIdx.x / M;
   const uint32_t b = q % Dpad, cg = q / Dpad;
   const uint32_t col = cg * XLP_COLS + threadIdx.x;
   double sr = 0.0, si = 0.0;
@@ -384,7 +437,7 @@ __global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__re
     for (uint32_t aa = 0; aa < A; ++aa) {
       const uint32_t i = D * aa + b;
       if (i >= T) break;
-      const uint32_t n = (aa * m) & (XLP_M - 1u);
+      const uint32_t n = (aa * m) & (M - 1u);
       const double cs = wc[n], sn = ws[n];
       const float2 tv = rt[(size_t)i * ncols + col];  // [tap][column]: coalesced across the columns of the block
       const double tr = tv.x, ti = tv.y;
@@ -392,19 +445,25 @@ __global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__re
       si += tr * sn + ti * cs;
     }
   }
-  R[(((size_t)cg * XLP_M + m) * Dpad + b) * XLP_COLS + threadIdx.x] = make_float2((float)sr, (float)si);
+  R[(((size_t)cg * M + m) * Dpad + b) * XLP_COLS + threadIdx.x] = make_float2((float)sr, (float)si);
 }
 
 // ------------------------------------------------------------------------------------------- launchers
+static bool xlp_valid_m(uint32_t M) { return M == 128u || M == 256u; }
+
 hipError_t xlp_launch_tables(const float2 *rt, uint32_t ncols, uint32_t T, uint32_t D, uint32_t Dpad, uint32_t A,
-                             uint32_t ncg, float2 *R, hipStream_t s) {
-  hipLaunchKernelGGL(xlp_tables_kernel, dim3(XLP_M * Dpad * ncg), dim3(XLP_COLS), 0, s, rt, ncols, T, D, Dpad, A, R);
+                             uint32_t M, uint32_t ncg, float2 *R, hipStream_t s) {
+  if (!xlp_valid_m(M)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(xlp_tables_kernel, dim3(M * Dpad * ncg), dim3(XLP_COLS), 0, s, rt, ncols, T, D, Dpad, A, M, R);
   return hipGetLastError();
 }
 
 hipError_t xlp_launch_forward(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s) {
-  hipLaunchKernelGGL(xlp_forward_kernel, dim3(a.nco_blocks + a.nseg * a.D + a.roll_blocks), dim3(64), 0, s, a, dyn,
-                     dyn_next);
+  if (!xlp_valid_m(a.M)) return hipErrorInvalidValue;
+  const uint32_t tpw = 256u / a.M;
+  const dim3 grid(a.nco_blocks + (a.nseg * a.D + tpw - 1u) / tpw + a.roll_blocks);
+  if (a.M == 256u) hipLaunchKernelGGL(xlp_forward_kernel<256>, grid, dim3(64), 0, s, a, dyn, dyn_next);
+  else hipLaunchKernelGGL(xlp_forward_kernel<128>, grid, dim3(64), 0, s, a, dyn, dyn_next);
   return hipGetLastError();
 }
 
@@ -419,18 +478,23 @@ static XlpArgs xlp_checked_skip(const XlpArgs &a, uint32_t work_blocks) {
 }
 
 hipError_t xlp_launch_mix(const XlpArgs &a0, const XlDynArgs &dyn_next, hipStream_t s) {
+  if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
   const uint32_t passes = (a0.nseg + XLP_SEG - 1) / XLP_SEG;
   const size_t lds = (size_t)a0.Dpad * 8u * sizeof(v4f);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  const uint32_t work = XLP_M * a0.ncg * passes;
-  const XlpArgs a = xlp_checked_skip(a0, work);
+  const uint32_t work = a0.M * a0.ncg * passes;
+  XlpArgs a = xlp_checked_skip(a0, work);
+  a.mix_passes = passes;
   hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + a.nco_skip + work), dim3(64), lds, s, a, dyn_next);
   return hipGetLastError();
 }
 
 hipError_t xlp_launch_inverse(const XlpArgs &a0, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s) {
-  const uint32_t work = a0.nseg * a0.ncg * 8u;
+  if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
+  const uint32_t work = a0.nseg * a0.ncg * (a0.M == 256u ? 8u : 4u);
   const XlpArgs a = xlp_checked_skip(a0, work);
-  hipLaunchKernelGGL(xlp_inverse_kernel, dim3(a.nco_blocks + a.nco_skip + work), dim3(256), 0, s, a, dyn, dyn_next);
+  const dim3 grid(a.nco_blocks + a.nco_skip + work);
+  if (a.M == 256u) hipLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, a, dyn, dyn_next);
+  else hipLaunchKernelGGL(xlp_inverse_kernel<128>, grid, dim3(256), 0, s, a, dyn, dyn_next);
   return hipGetLastError();
 }

@@ -289,12 +289,20 @@ def test_1000_clients_split_group_riders():
 # Polyphase overlap-save path (xl_polyphase.hip): the optimized arithmetic of big classes.  Same operator as the
 # direct kernels, so the same oracle and the same 1e-5 bar; XL_EXP_POLY=1 forces it for classes of any size so
 # that the oracle can check every client.
+# The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
+# the forced-path tests run with both.
+@pytest.fixture(params=[128, 256], ids=["M128", "M256"])
+def poly_m(request, monkeypatch):
+    monkeypatch.setenv("XL_EXP_POLY_M", str(request.param))
+    return request.param
+
+
 def _poly_engine(monkeypatch, fmt="cu8", max_input=262144, fs=FS):
     monkeypatch.setenv("XL_EXP_POLY", "1")
     return xl.BatchEngine(fs, fmt, max_input)
 
 
-def test_polyphase_forced_server_default_ragged_and_join(monkeypatch):
+def test_polyphase_forced_server_default_ragged_and_join(monkeypatch, poly_m):
     """D=42, 505 taps: ragged block lengths (output grid offset changes every block), a client joining mid-stream
     (zero history below its join point, phase 1), a native block in between (both paths share history and phases)."""
     taps = lpf(FS, 24000, 9600)
@@ -303,7 +311,7 @@ def test_polyphase_forced_server_default_ragged_and_join(monkeypatch):
     for c in range(20):
         fc = -900000 + c * 91000
         oracles[eng.add_client(42, taps, fc)] = Oracle(42, taps, fc, FS, 262144)
-    assert "polyphase: cls0 D42 T505 cols20 V244" in eng.describe(), eng.describe()
+    assert "polyphase: cls0 D42 T505 cols20 V%d M%d" % (poly_m - 12, poly_m) in eng.describe(), eng.describe()
     worst = 0.0
     # (blocks of 2000 and 30 bytes hold fewer than 512 outputs: those fall back to the direct kernel in between)
     for k, n in enumerate((262144, 262144, 100002, 100002, 262144, 50000, 262144, 2000, 262144, 30, 262144)):
@@ -329,7 +337,7 @@ def test_polyphase_forced_server_default_ragged_and_join(monkeypatch):
     eng.close()
 
 
-def test_polyphase_forced_mixed_rates_and_fixture_shape(monkeypatch):
+def test_polyphase_forced_mixed_rates_and_fixture_shape(monkeypatch, poly_m):
     """Two classes on the path at once (48 kHz: D=42/T=505, 96 kHz: D=21/T=253), then the reference's own test
     shape (test_xlating.c: 57 taps, D=5, fs 48000, fc -12000) on a long ramp input."""
     t48, t96 = lpf(FS, 24000, 9600), lpf(FS, 48000, 19200)
@@ -348,14 +356,14 @@ def test_polyphase_forced_mixed_rates_and_fixture_shape(monkeypatch):
     oracles = {}
     for fc in (-12000, 0, 7000):
         oracles[eng.add_client(5, t57, fc)] = Oracle(5, t57, fc, 48000, 100000)
-    assert "polyphase: cls0 D5 T57 cols3 V245" in eng.describe(), eng.describe()
+    assert "polyphase: cls0 D5 T57 cols3 V%d M%d" % (poly_m - 11, poly_m) in eng.describe(), eng.describe()
     for k in range(3):
         check_clients(eng, oracles, "cu8", siggen.ramp_u8(k * 31, 100000 - 2 * k), "optimized")
     eng.close()
 
 
 @pytest.mark.parametrize("fmt", ["cs8", "cs16", "cf32"])
-def test_polyphase_forced_other_formats(fmt, monkeypatch):
+def test_polyphase_forced_other_formats(fmt, monkeypatch, poly_m):
     taps = lpf(FS, 24000, 9600)
     n = 65536
     eng = _poly_engine(monkeypatch, fmt=fmt)
@@ -375,7 +383,7 @@ def test_polyphase_forced_other_formats(fmt, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", ["perf_2429_taps", "cf32_d100_257_taps", "d400_4819_taps"])
-def test_polyphase_forced_other_shapes(shape, monkeypatch):
+def test_polyphase_forced_other_shapes(shape, monkeypatch, poly_m):
     """Other branch counts / taps per branch on the path: the reference's perf shape (test/perf_xlating.c: 2429 taps,
     D=42 -> 58 taps per branch, 199 valid outputs per segment), BASELINE config 5 (cf32 in, D=100, 257 taps -> 3 taps
     per branch) and a huge decimation (20 Msps -> 50 kHz: D=400, 4819 taps)."""
@@ -422,7 +430,7 @@ def test_polyphase_class_next_to_direct_classes():
     eng.close()
 
 
-def test_polyphase_100_block_drift(monkeypatch):
+def test_polyphase_100_block_drift(monkeypatch, poly_m):
     """100 consecutive blocks on the polyphase path (NCO recurrence cut into three slices per block, renormalised per
     block, tabulated one block ahead): the float32 phase drift must stay the reference's own -- every 10th
     block of 8 clients against the oracle, plus the committed phases at the end."""
@@ -576,13 +584,14 @@ def test_replay_iq_file_end_to_end(fmt, tmp_path):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
-@pytest.mark.parametrize("force_poly", [False, True])
+@pytest.mark.parametrize("force_poly", [0, 128, 256])
 def test_randomised_engine_vs_oracle(seed, force_poly, monkeypatch):
     """Randomised streams: mixed decimations / tap counts (even tap counts too: the reversal quirk), clients joining and
     leaving, block lengths from a few samples to the maximum, native and optimized blocks in any order, with and
     without the polyphase path forced on.  Every client, every block, against the oracle."""
     if force_poly:
         monkeypatch.setenv("XL_EXP_POLY", "1")
+        monkeypatch.setenv("XL_EXP_POLY_M", str(force_poly))
     rng = np.random.default_rng(1000 + seed)
     shapes = [(42, lpf(FS, 24000, 9600)), (21, lpf(FS, 48000, 19200)), (42, lpf(FS, 24000, 48000)),
               (7, siggen.hamming_sinc(64, 0.05)), (100, siggen.hamming_sinc(301, 0.004))]

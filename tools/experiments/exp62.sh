@@ -1,0 +1,29 @@
+#!/bin/bash
+# transform length 128 vs 256 (XL_EXP_POLY_M), mix launch skip position for the two-wave workgroups, slice split
+OUT=$GRAFT_REPO_ROOT/gpurun_out/s62; mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_batch_gpu.py -m gpu -q -x -k "poly or random" 2>&1 | tail -5
+cd /tmp
+run() { # label, env...
+  L=$1; shift
+  env "$@" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python $GRAFT_REPO_ROOT/tools/sweep.py --clients $N --rates 5 --modes optimized --steps 100 > $OUT/prof.log 2>&1
+  echo "== clients $N $L: $(grep -v amdgpu $OUT/prof.log | grep optimized | awk '{print $5, $10}')"
+  python3 - $OUT/prof/p_kernel_stats.csv <<'PY'
+import csv, sys
+tot=0; o=[]
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'xlp' in r['Name'] and 'tables' not in r['Name']: o.append(r['Name'][4:8]+" "+str(round(float(r['AverageNs'])/1000,1))); tot+=float(r['AverageNs'])
+print("   ", ", ".join(o), " sum", round(tot/1000,1))
+PY
+}
+for N in 1024 4096; do
+run "M256" XL_EXP_POLY_M=256
+run "M128 skip512" XL_EXP_POLY_M=128
+run "M128 skip1024" XL_EXP_POLY_M=128 XL_EXP_MIXSKIP=1024
+run "M128 skip256" XL_EXP_POLY_M=128 XL_EXP_MIXSKIP=256
+run "M128 noskip" XL_EXP_POLY_M=128 XL_EXP_POLY_EXP=16
+run "M128 skip512 slices 8000,44000" XL_EXP_POLY_M=128 XL_EXP_POLY_SLICES=8000,44000
+run "M128 skip512 slices 8000,38000" XL_EXP_POLY_M=128 XL_EXP_POLY_SLICES=8000,38000
+done
+N=256; run "M256" XL_EXP_POLY_M=256; run "M128" XL_EXP_POLY_M=128
+N=128; run "M256" XL_EXP_POLY_M=256; run "M128" XL_EXP_POLY_M=128

@@ -1,0 +1,23 @@
+#!/bin/bash
+# mix kernel R ring 14 deep (exp62 had 7): M = 128 / 256 at 1024 and 4096 clients
+OUT=$GRAFT_REPO_ROOT/gpurun_out/s63; mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_batch_gpu.py -m gpu -q -x -k "poly or random" 2>&1 | tail -3
+cd /tmp
+run() { # label, env...
+  L=$1; shift
+  env "$@" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python $GRAFT_REPO_ROOT/tools/sweep.py --clients $N --rates 5 --modes optimized --steps 100 > $OUT/prof.log 2>&1
+  echo "== clients $N $L: $(grep -v amdgpu $OUT/prof.log | grep optimized | awk '{print $5, $10}')"
+  python3 - $OUT/prof/p_kernel_stats.csv <<'PY'
+import csv, sys
+tot=0; o=[]
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'xlp' in r['Name'] and 'tables' not in r['Name']: o.append(r['Name'][4:8]+" "+str(round(float(r['AverageNs'])/1000,1))); tot+=float(r['AverageNs'])
+print("   ", ", ".join(o), " sum", round(tot/1000,1))
+PY
+}
+for N in 1024 4096 2048 512; do
+run "M256" XL_EXP_POLY_M=256
+run "M128" XL_EXP_POLY_M=128
+run "M128 slices 8000,44000" XL_EXP_POLY_M=128 XL_EXP_POLY_SLICES=8000,44000
+done

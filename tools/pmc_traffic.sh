@@ -26,7 +26,8 @@ for path in ("poly", "direct"):
         for r in csv.DictReader(open(fs[0])):
             if r["Counter_Name"] != c: continue
             k = r["Kernel_Name"].split("(")[0]
-            if k.startswith("xlp_") and "tables" not in k or k.startswith("void xl_fir_kernel") or k.startswith("xl_fir_kernel"):
+            k = k[5:] if k.startswith("void ") else k
+            if k.startswith("xlp_") and "tables" not in k or k.startswith("xl_fir_kernel"):
                 agg[k].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             v = v[2:] if len(v) > 4 else v          # skip the first blocks (stand-alone NCO tabulation, cold caches)

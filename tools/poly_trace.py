@@ -21,6 +21,9 @@ we = (w[:, 1].astype(np.int64) - t0) * 0.01
 wp = [place(v) for v in w[:, 2]]
 print(f"work workgroups: {nw}; start min {ws.min():.1f} med {np.median(ws):.1f} max {ws.max():.1f}; end min {we.min():.1f} p10 {np.percentile(we,10):.1f} "
       f"med {np.median(we):.1f} p90 {np.percentile(we,90):.1f} max {we.max():.1f} us")
+dur = we - ws
+print(f"work workgroup durations: min {dur.min():.1f} p10 {np.percentile(dur,10):.1f} med {np.median(dur):.1f} p90 {np.percentile(dur,90):.1f} max {dur.max():.1f} us; "
+      f"started after 2 us: {(ws > 2).sum()} (their durations med {np.median(dur[ws > 2]) if (ws > 2).any() else 0:.1f})")
 nco = h[8:8 + 8 * nn].reshape(nn, 8)
 simd_of = {}
 for i in range(nn):
