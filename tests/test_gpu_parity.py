@@ -248,3 +248,48 @@ def test_rejects_shapes_that_cannot_fit():
         eng.add_client(42, taps, 0)
     assert e.value.code == -22
     eng.close()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(__import__("os").environ.get("XL_TEST_FUZZ_SEEDS", "6")))))
+def test_randomised_dropin_filter_vs_oracle(seed):
+    """Randomised call sequences on ONE drop-in filter: any input format, cf32 and cs16 outputs interleaved (they share
+    the history and the NCO phase, xlating.c:84-89), native and optimized calls in any order, block lengths from nothing
+    to the maximum, odd and even tap counts.  Every call against the oracle: bit-exact for native cf32 and for every
+    cs16 output, 1e-5 relative for optimized cf32."""
+    import siggen
+    rng = np.random.default_rng(7000 + seed)
+    fmt = ["cu8", "cs8", "cs16", "cf32"][int(rng.integers(4))]
+    D, taps = [(42, hip_lpf(1.0, 2016000, 24000, 9600)), (21, hip_lpf(1.0, 2016000, 48000, 19200)),
+               (7, siggen.hamming_sinc(64, 0.05)), (5, siggen.hamming_sinc(57, 0.08)), (100, siggen.hamming_sinc(301, 0.004)),
+               (1, siggen.hamming_sinc(33, 0.2))][int(rng.integers(6))]
+    fs = 2016000
+    fc = int(rng.integers(-900000, 900000))
+    max_input = int(rng.choice([4096, 65536, 262144]))
+    f = xl.XlatingFilter(D, taps, fc, fs, max_input)
+    o = Oracle(D, taps, fc, fs, max_input)
+    per = {"cu8": 1, "cs8": 1, "cs16": 1, "cf32": 1}[fmt]  # max_input counts elements of the input type
+    worst = 0.0
+    for k in range(int(rng.integers(6, 16))):
+        r = rng.random()
+        n = max_input if r < 0.2 else int(rng.integers(0, 40)) if r < 0.35 else int(rng.integers(0, max_input // per + 1))
+        n -= n % 2  # whole IQ pairs
+        if fmt == "cu8":
+            x = siggen.xs_u8(seed * 100 + k, n)
+        elif fmt == "cs8":
+            x = siggen.xs_u8(seed * 100 + k, n).view(np.int8)
+        elif fmt == "cs16":
+            x = siggen.xs_s16(seed * 100 + k, n)
+        else:
+            x = (siggen.xs_s16(seed * 100 + k, n).astype(np.float32) / np.float32(32768)).astype(np.float32)
+        out = "cs16" if (rng.random() < 0.3 and fmt != "cf32") else "cf32"
+        variant = "native" if rng.random() < 0.4 else "optimized"
+        got = f.process(variant, fmt, out, x)
+        want = o.process(fmt, x, out)
+        assert len(got) == len(want), (k, fmt, out, n)
+        if out == "cs16" or variant == "native":
+            assert bits_equal(got, want), (k, fmt, out, variant, n)
+        else:
+            worst = max(worst, rel_err(got, want))
+    assert worst <= REL_TOL, worst
+    f.close()
+    o.close()
