@@ -5,8 +5,8 @@
 //   y[k] = sum_{i<T} r[i] x[kD + i]                      (r = reversed band-pass taps, xlating.c:525-535)
 //        = sum_{b<D} sum_{a<A} r_b[a] x_b[k + a]         r_b[a] = r[D a + b], x_b[n] = x[D n + b], A = ceil(T/D)
 //
-// i.e. D short correlations at the OUTPUT rate.  Over a segment of M = 256 branch samples each correlation is a
-// circular one, exact for the first V = M - A + 1 outputs:
+// i.e. D short correlations at the OUTPUT rate.  Over a segment of M branch samples (256, or 128 for big classes of
+// short filters: half the R stream) each correlation is a circular one, exact for the first V = M - A + 1 outputs:
 //
 //   y_seg = IDFT_M( sum_b DFT_M(x_b) * R_b ),            R_b[m] = sum_a r_b[a] e^{+2 pi j a m / M}
 //

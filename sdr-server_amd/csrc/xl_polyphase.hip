@@ -2,16 +2,17 @@
 // algebra and why it is the same operator as /root/reference/src/xlating.c:52-72).  Hand-written for gfx950.
 //
 // Three launches per block and class (stream order is the only synchronisation):
-//   xlp_forward_kernel  one wave per (segment, branch): raw samples -> cf32 (xlating.c:357-378, exact) -> 256-point
-//                       DFT of the branch -> shared spectra X[pass][b][m][s].  D * nseg small transforms: ~1 MB.
+//   xlp_forward_kernel  one wave per (segment, branch) -- two per wave at M = 128: raw samples -> cf32
+//                       (xlating.c:357-378, exact) -> M-point DFT of the branch -> shared spectra X[pass][b][m][s].
+//                       D * nseg small transforms: ~1 MB.
 //   xlp_mix_kernel      Y[c][s][m] = sum_b X[s][b][m] * R[c][b][m].  lane = two client columns, the bin m is
 //                       workgroup-uniform: its column of X is staged in LDS once and broadcast-read row by row, R is
-//                       streamed exactly once, coalesced (16 bytes per lane and branch).  HBM-bound on R:
-//                       8 * D * M bytes per client and block.
-//   xlp_inverse_kernel  per (segment, 16 columns): Y tile -> LDS (transposed) -> 256-point inverse DFT per column ->
-//                       scale, NCO rotate (xlating.c:70) with the tabulated float32 phase -> out[k], k < K.
-// Each launch also carries a slice of the NEXT block's NCO phase recurrence (a ~57 us dependent chain per block
-// that would otherwise serialise with these short kernels).
+//                       streamed from HBM once, coalesced (16 bytes per lane and branch): 8 * D * M bytes per client
+//                       and block, which bounds the launch with many clients.
+//   xlp_inverse_kernel  per (segment, 16 or 32 columns): Y tile -> LDS (transposed) -> M-point inverse DFT per column
+//                       -> scale, NCO rotate (xlating.c:70) with the tabulated float32 phase -> out[k], k < K.
+// M = 256 or 128 per class (xl_polyphase.h).  Each launch also carries a slice of the NEXT block's NCO phase recurrence
+// (a ~23 us dependent chain per block that would otherwise serialise with these short kernels).
 #include "xl_polyphase.h"
 
 #include "xl_dev_inline.h"
