@@ -632,3 +632,15 @@ def test_randomised_engine_vs_oracle(seed, force_poly, monkeypatch):
                 worst = max(worst, rel_err(got, want))
     assert worst <= REL_TOL, worst
     eng.close()
+
+
+def test_bench_block_feed_over_real_rccl():
+    """bench.py's multi-GPU feed on the real RCCL backend (a world-size-1 process group on this one-GPU box, the feeder
+    driven as rank 0 of 2): init with device_id, broadcast on the side stream, event-ordered buffer reuse -- and the
+    engine's outputs identical to the directly-fed run.  In a child process: the process group is global state."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "feed_nccl_selftest.py")], capture_output=True, text=True,
+                       timeout=400, env=dict(os.environ, MASTER_PORT="29581"))
+    assert r.returncode == 0 and "outputs identical to the direct feed" in r.stdout, (r.stdout[-400:], r.stderr[-800:])
