@@ -937,14 +937,15 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             if (b->poly_exp & 4u) pa.nco_tab = nullptr;  // tuning: the mix launch's slice stores nothing (WRONG results)
             if (b->poly_exp & 8u) pa.nco_blocks = 0;     // tuning: the mix launch carries no slice at all (WRONG results)
           }
-          if (b->poly_trace) {  // tuning: timeline of the mix launch (work waves' span + each NCO wave)
+          const bool trace_inv = b->poly_trace && getenv("XL_EXP_POLY_TRACE_INV");  // (the inverse launch instead)
+          if (b->poly_trace && !trace_inv) {  // tuning: timeline of the mix launch (work waves' span + each NCO wave)
             if (!b->d_ptrace) XL_TRY(hipMalloc((void **)&b->d_ptrace, 32768 * sizeof(unsigned long long)));
             XL_TRY(hipMemsetAsync(b->d_ptrace, 0, 32768 * sizeof(unsigned long long), s));
             pa.trace = b->d_ptrace;
           }
           XL_TRY(xlp_launch_mix(pa, next, s));
           pa.nco_skip = 0;
-          if (b->poly_trace) {
+          if (b->poly_trace && !trace_inv) {
             pa.trace = nullptr;
             std::vector<unsigned long long> h(32768);
             XL_TRY(hipStreamSynchronize(s));
@@ -967,7 +968,22 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_state_dst = b->d_phase[b->pcur ^ 1];
             nco_fused = true;
           }
+          if (trace_inv) {
+            if (!b->d_ptrace) XL_TRY(hipMalloc((void **)&b->d_ptrace, 32768 * sizeof(unsigned long long)));
+            XL_TRY(hipMemsetAsync(b->d_ptrace, 0, 32768 * sizeof(unsigned long long), s));
+            pa.trace = b->d_ptrace;
+          }
           XL_TRY(xlp_launch_inverse(pa, dyn, next, s));
+          if (trace_inv) {
+            pa.trace = nullptr;
+            std::vector<unsigned long long> h(32768);
+            XL_TRY(hipStreamSynchronize(s));
+            XL_TRY(hipMemcpy(h.data(), b->d_ptrace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(b->poly_trace, "wb")) {
+              fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+              fclose(f);
+            }
+          }
           if (pe[3]) XL_TRY(hipEventRecord(pe[3], s));
         }
       }

@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
     return;
   }
   if (blockIdx.x >= a.nco_skip_at && blockIdx.x < a.nco_skip_at + a.nco_skip) return;  // (as in xlp_mix_kernel; 4-wave workgroups: per CU)
+  const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;
   const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
   const uint32_t sub = bid % NSUB;
   const uint32_t q = bid / NSUB;
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
   const bool eok = eoff != 0xFFFFFFFFu && gq * XL_PH_STRIDE < a.V && k0 < K;
   v2f pe = ph[eok ? (eoff >> XL_PH_SHIFT) + (k0 >> XL_PH_SHIFT) : 0u];
   __syncthreads();
+  const unsigned long long t_loaded = a.trace ? wall_clock64() : 0ull;
   v2f u[4][4];
   v2f *const rows[4] = {tile[WPC * w + 4u * h], tile[WPC * w + 4u * h + 1], tile[WPC * w + 4u * h + 2],
                         tile[WPC * w + 4u * h + 3]};
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
     }
   }
   __builtin_amdgcn_wave_barrier();
+  const unsigned long long t_xf = a.trace ? wall_clock64() : 0ull;
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
 #pragma unroll
@@ -418,6 +421,13 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
         out[off[n] + k] = xl_rotate<1>(y, rows[n][XLP_POS(qo)]);
       }
     }
+  }
+  if (a.trace && threadIdx.x == 0 && bid < 6000u) {  // tuning: start, tile loaded, transforms done, end
+    unsigned long long *t = a.trace + 4096 + 4 * (size_t)bid;
+    t[0] = t_begin;
+    t[1] = wall_clock64();
+    t[2] = t_loaded;
+    t[3] = t_xf;
   }
 }
 
