@@ -487,6 +487,50 @@ def test_polyphase_default_rule_1024_clients():
     eng.close()
 
 
+def test_polyphase_plan_switches_transform_length_mid_stream():
+    """A class growing past 768 clients moves from the 256-point to the 128-point plan, and back when clients leave:
+    new branch spectra, new segment grid, same stream -- the only state carried over is the raw history and the phases.
+    Late joiners start as a class of their own (their output grid and history differ); they join at a stream position
+    that is a multiple of D, so one block later their grid and history match the old clients' and the next re-plan
+    merges them.  Sampled old clients and the joiners are checked against the oracle across the switches."""
+    taps = lpf(FS, 24000, 9600)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    fcs = [-984000 + 2560 * c for c in range(767)]
+    ids = [eng.add_client(42, taps, fc) for fc in fcs]
+    assert "cols767 V244 M256" in eng.describe(), eng.describe()
+    sample = [0, 5, 300, 766]
+    oracles = {ids[c]: Oracle(42, taps, fcs[c], FS, 262144) for c in sample}
+
+    def block(k, n=262144):
+        x = siggen.xs_u8(9100 + k, n)
+        eng.process_host(x, "optimized")
+        eng.fetch()
+        for cid, o in oracles.items():
+            want = o.process("cu8", x)
+            got = eng.output(cid)
+            assert len(got) == len(want) and rel_err(got, want) <= REL_TOL, (k, cid, rel_err(got, want))
+
+    block(0)
+    block(1, 2 * 100012)  # 131072 + 100012 samples = 42 * 5502
+    joiners = []
+    for j in range(2):
+        cid = eng.add_client(42, taps, 111000 + 7000 * j)
+        oracles[cid] = Oracle(42, taps, 111000 + 7000 * j, FS, 262144)
+        joiners.append(cid)
+    assert "classes 2" in eng.describe() and "cols767 V244 M256" in eng.describe(), eng.describe()
+    block(2)
+    eng.remove_client(ids[1])  # (a re-plan: the joiners' class now equals the old one -> 768 clients -> 128-point plan)
+    assert "classes 1" in eng.describe() and "cols768 V116 M128" in eng.describe(), eng.describe()
+    block(3)
+    block(4, 131070)
+    for cid in joiners:  # 766 clients: back to the 256-point plan
+        eng.remove_client(cid)
+        oracles.pop(cid).close()
+    assert "cols766 V244 M256" in eng.describe(), eng.describe()
+    block(5)
+    eng.close()
+
+
 def test_bench_block_feeder_stream_plumbing():
     """bench.py's multi-GPU feed (broadcast of block k+1 on a side stream while block k is filtered, two receive
     buffers, event-ordered reuse) with a stand-in for torch.distributed whose broadcast is the identity (this box has
