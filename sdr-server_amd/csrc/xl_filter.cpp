@@ -56,6 +56,7 @@ struct xlating_t {
   XlGroup *d_group = nullptr;
   XlNcoClient *d_nco = nullptr;
 
+  bool zero_copy = true;  // kernels read the pinned input / write the pinned output over PCIe (XL_EXP_DROPIN_COPY=1: staged copies)
   void *h_in = nullptr;
   float2 *h_out_f = nullptr;
   short2 *h_out_q = nullptr;
@@ -135,6 +136,7 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XL_TRY(hipStreamCreateWithFlags(&f->stream_nco, hipStreamNonBlocking));
   XL_TRY(hipEventCreateWithFlags(&f->ev_nco, hipEventDisableTiming));
   f->lookahead = getenv("XL_EXP_NOLOOKAHEAD") == nullptr;
+  f->zero_copy = getenv("XL_EXP_DROPIN_COPY") == nullptr;
   XL_TRY(hipMalloc(&f->d_raw, f->max_samples * 8 + 16));
   XL_TRY(hipMalloc((void **)&f->d_work_f, work_n * sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_work_q, work_n * sizeof(short2)));
@@ -191,6 +193,14 @@ static inline void xl_counts(const xlating *f, size_t fresh, size_t *W, size_t *
   *pos = *K * (size_t)f->D;
 }
 
+// the same for the call AFTER one that leaves `hist_after` samples of history
+static inline void xl_counts_after(const xlating *f, size_t fresh, size_t hist_after, size_t *W, size_t *K, size_t *pos) {
+  *W = hist_after + fresh;
+  *K = 0;
+  if (*W > f->T - 1) *K = (*W - (f->T - 1) + f->D - 1) / f->D;
+  *pos = *K * (size_t)f->D;
+}
+
 static bool xl_check_len(xlating *f, size_t nsamples) {
   if (nsamples <= f->max_samples) return true;
   if (!f->warned) {
@@ -212,8 +222,9 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
   XL_TRY(hipSetDevice(f->device));
   if (n > 0) {
     memcpy(f->h_in, input, bytes);
-    XL_TRY(hipMemcpyAsync(f->d_raw, f->h_in, bytes, hipMemcpyHostToDevice, f->stream));
-    XL_TRY(xl_launch_convert_cf32(f->d_raw, fmt, (uint32_t)n, f->d_work_f + f->hist, f->stream));
+    // the convert kernel reads the pinned block over PCIe itself: one stream operation less than copy + convert
+    if (!f->zero_copy) XL_TRY(hipMemcpyAsync(f->d_raw, f->h_in, bytes, hipMemcpyHostToDevice, f->stream));
+    XL_TRY(xl_launch_convert_cf32(f->zero_copy ? f->h_in : f->d_raw, fmt, (uint32_t)n, f->d_work_f + f->hist, f->stream));
   }
   if (K > 0) {
     XlDynArgs dyn;
@@ -224,15 +235,35 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     // The phases of this call: tabulated ahead on stream_nco after the previous call if that call guessed this one's
     // output count (the recurrence is data independent: xlating.c:70-73), else now.  The chain is ~30 us of pure
     // latency; ahead of time it overlaps the host's work between calls, the upload and the convert kernel.
+    bool ahead = false;  // the next call's table has been requested already (else: below, after the sync)
     if (f->spec_valid && f->spec_K == K) {
       XL_TRY(hipStreamWaitEvent(f->stream, f->ev_nco, 0));
       std::swap(f->d_phtab, f->d_phtab_next);
       std::swap(f->d_phase, f->d_phase_next);
+      // d_phase now holds the committed phase AFTER this call (tabulated ahead together with this call's table), and
+      // the swapped-out buffers were last read by the previous call, which has been waited for: the NEXT call's table
+      // is requested right away, so that its launch overlaps this call's upload, convert and FIR instead of following
+      // the final sync on the caller's clock (measured: 69 -> 47 us per 262144-byte block).
+      if (f->lookahead) {
+        size_t Wn, Kn, posn;
+        xl_counts_after(f, n, pos <= W ? W - pos : 0, &Wn, &Kn, &posn);
+        if (Kn > 0) {
+          XlDynArgs dn;
+          dn.d[0].base = 0;
+          dn.d[0].K = (uint32_t)Kn;
+          dn.d[0].zero_below = 0;
+          dn.d[0].pad = 0;
+          XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase_next, f->d_phtab_next, dn, 0, f->stream_nco));
+          XL_TRY(hipEventRecord(f->ev_nco, f->stream_nco));
+          f->spec_K = Kn;
+          ahead = true;
+        }
+      }
     } else {
       if (f->spec_valid) XL_TRY(hipStreamWaitEvent(f->stream, f->ev_nco, 0));  // (its buffers are reused below)
       XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase, f->d_phtab, dyn, 0, f->stream));
     }
-    f->spec_valid = false;
+    f->spec_valid = ahead;
     XlFirArgs a;
     memset(&a, 0, sizeof(a));
     a.in0 = f->d_work_f;
@@ -247,9 +278,9 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     a.flags = ((f->D % 2 == 0) ? 1u : 0u) | 4u;
     a.taps = f->d_taps;
     a.phtab = f->d_phtab;
-    a.out = f->d_out_f;
+    a.out = f->zero_copy ? f->h_out_f : f->d_out_f;  // (the K outputs go straight to the pinned result buffer)
     XL_TRY(xl_launch_fir(1, mode, XL_NW_DEFAULT, a, dyn, dyn, xl_fir_lds_bytes_ota(f->D, f->Tpad, f->ota), f->stream));
-    XL_TRY(hipMemcpyAsync(f->h_out_f, f->d_out_f, K * sizeof(float2), hipMemcpyDeviceToHost, f->stream));
+    if (!f->zero_copy) XL_TRY(hipMemcpyAsync(f->h_out_f, f->d_out_f, K * sizeof(float2), hipMemcpyDeviceToHost, f->stream));
   }
   {
     // xlating.c:76-79.  pos can only exceed W when D > T (the reference underflows there); clamp.
@@ -258,7 +289,7 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     f->hist = keep;
   }
   XL_TRY(hipStreamSynchronize(f->stream));
-  if (K > 0 && f->lookahead) {
+  if (K > 0 && f->lookahead && !f->spec_valid) {
     // look-ahead: if the next call brings the same number of samples (and no cs16-family call moves the shared
     // history in between) it produces Knext outputs; tabulate them now, off the caller's critical path.
     // d_phase (the committed post-call phase) is only read; nothing in flight on `stream` after the sync above.
@@ -293,16 +324,16 @@ static void xl_run_q15(xlating *f, const void *input, size_t input_len, int fmt,
   XL_TRY(hipSetDevice(f->device));
   if (input_len > 0) {
     memcpy(f->h_in, input, bytes);
-    XL_TRY(hipMemcpyAsync(f->d_raw, f->h_in, bytes, hipMemcpyHostToDevice, f->stream));
+    if (!f->zero_copy) XL_TRY(hipMemcpyAsync(f->d_raw, f->h_in, bytes, hipMemcpyHostToDevice, f->stream));
     // xlating.c:417-419: every scalar element is converted (also a trailing odd one)
-    XL_TRY(xl_launch_convert_q15(f->d_raw, fmt, (uint32_t)input_len, reinterpret_cast<int16_t *>(f->d_work_q + f->hist),
+    XL_TRY(xl_launch_convert_q15(f->zero_copy ? f->h_in : f->d_raw, fmt, (uint32_t)input_len, reinterpret_cast<int16_t *>(f->d_work_q + f->hist),
                                  f->stream));
   }
   if (K > 0) {
     XL_TRY(xl_launch_nco_table_q15(f->qinc[0], f->qinc[1], f->d_qphase, f->d_qphtab, (uint32_t)K, f->stream));
-    XL_TRY(xl_launch_fir_q15(f->d_work_q, f->d_qtaps, (uint32_t)f->T, f->D, (uint32_t)K, f->d_qphtab, f->d_out_q,
-                             f->stream));
-    XL_TRY(hipMemcpyAsync(f->h_out_q, f->d_out_q, K * sizeof(short2), hipMemcpyDeviceToHost, f->stream));
+    XL_TRY(xl_launch_fir_q15(f->d_work_q, f->d_qtaps, (uint32_t)f->T, f->D, (uint32_t)K, f->d_qphtab,
+                             f->zero_copy ? f->h_out_q : f->d_out_q, f->stream));
+    if (!f->zero_copy) XL_TRY(hipMemcpyAsync(f->h_out_q, f->d_out_q, K * sizeof(short2), hipMemcpyDeviceToHost, f->stream));
   }
   {
     const size_t keep = pos <= W ? W - pos : 0;  // xlating.c:133-136
