@@ -193,14 +193,6 @@ static inline void xl_counts(const xlating *f, size_t fresh, size_t *W, size_t *
   *pos = *K * (size_t)f->D;
 }
 
-// the same for the call AFTER one that leaves `hist_after` samples of history
-static inline void xl_counts_after(const xlating *f, size_t fresh, size_t hist_after, size_t *W, size_t *K, size_t *pos) {
-  *W = hist_after + fresh;
-  *K = 0;
-  if (*W > f->T - 1) *K = (*W - (f->T - 1) + f->D - 1) / f->D;
-  *pos = *K * (size_t)f->D;
-}
-
 static bool xl_check_len(xlating *f, size_t nsamples) {
   if (nsamples <= f->max_samples) return true;
   if (!f->warned) {
@@ -218,6 +210,7 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
   if (!xl_check_len(f, n)) return;
   const size_t bytes = n * xl_bytes_per_sample(fmt);
   size_t W, K, pos;
+  bool ahead = false;  // the next call's table is requested during this call (else after the sync, if at all)
   xl_counts(f, n, &W, &K, &pos);
   XL_TRY(hipSetDevice(f->device));
   if (n > 0) {
@@ -235,35 +228,20 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     // The phases of this call: tabulated ahead on stream_nco after the previous call if that call guessed this one's
     // output count (the recurrence is data independent: xlating.c:70-73), else now.  The chain is ~30 us of pure
     // latency; ahead of time it overlaps the host's work between calls, the upload and the convert kernel.
-    bool ahead = false;  // the next call's table has been requested already (else: below, after the sync)
+    ahead = false;
     if (f->spec_valid && f->spec_K == K) {
       XL_TRY(hipStreamWaitEvent(f->stream, f->ev_nco, 0));
       std::swap(f->d_phtab, f->d_phtab_next);
       std::swap(f->d_phase, f->d_phase_next);
       // d_phase now holds the committed phase AFTER this call (tabulated ahead together with this call's table), and
       // the swapped-out buffers were last read by the previous call, which has been waited for: the NEXT call's table
-      // is requested right away, so that its launch overlaps this call's upload, convert and FIR instead of following
-      // the final sync on the caller's clock (measured: 69 -> 47 us per 262144-byte block).
-      if (f->lookahead) {
-        size_t Wn, Kn, posn;
-        xl_counts_after(f, n, pos <= W ? W - pos : 0, &Wn, &Kn, &posn);
-        if (Kn > 0) {
-          XlDynArgs dn;
-          dn.d[0].base = 0;
-          dn.d[0].K = (uint32_t)Kn;
-          dn.d[0].zero_below = 0;
-          dn.d[0].pad = 0;
-          XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase_next, f->d_phtab_next, dn, 0, f->stream_nco));
-          XL_TRY(hipEventRecord(f->ev_nco, f->stream_nco));
-          f->spec_K = Kn;
-          ahead = true;
-        }
-      }
+      // can be requested during this call (below, behind this call's own launches) instead of after its final sync.
+      ahead = f->lookahead;
     } else {
       if (f->spec_valid) XL_TRY(hipStreamWaitEvent(f->stream, f->ev_nco, 0));  // (its buffers are reused below)
       XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase, f->d_phtab, dyn, 0, f->stream));
     }
-    f->spec_valid = ahead;
+    f->spec_valid = false;
     XlFirArgs a;
     memset(&a, 0, sizeof(a));
     a.in0 = f->d_work_f;
@@ -287,6 +265,23 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     const size_t keep = pos <= W ? W - pos : 0;
     if (pos > 0) XL_TRY(xl_launch_move_down(f->d_work_f, (uint32_t)pos, (uint32_t)keep, 8, f->stream));
     f->hist = keep;
+  }
+  if (ahead) {
+    // the launch overlaps this call's convert / FIR / move kernels on the device and costs the caller no wait
+    // (measured per 262144-byte block, 505 taps: 69 us with the request after the sync, 47 us here)
+    size_t Wn, Kn, posn;
+    xl_counts(f, n, &Wn, &Kn, &posn);
+    if (Kn > 0) {
+      XlDynArgs dn;
+      dn.d[0].base = 0;
+      dn.d[0].K = (uint32_t)Kn;
+      dn.d[0].zero_below = 0;
+      dn.d[0].pad = 0;
+      XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase_next, f->d_phtab_next, dn, 0, f->stream_nco));
+      XL_TRY(hipEventRecord(f->ev_nco, f->stream_nco));
+      f->spec_valid = true;
+      f->spec_K = Kn;
+    }
   }
   XL_TRY(hipStreamSynchronize(f->stream));
   if (K > 0 && f->lookahead && !f->spec_valid) {
