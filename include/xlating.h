@@ -12,8 +12,10 @@
  * -ENODEV and logs a "<3>" line on stderr (the reference's logging convention).
  *
  * Semantics kept from the reference (file:line are into /root/reference/src/xlating.c):
- *  - create takes OWNERSHIP of `taps` on success and on -ENOMEM; returns -1 for taps_len == 0
- *    WITHOUT consuming taps (:496-498, :508, :600-602).
+ *  - create takes OWNERSHIP of `taps` on success and on EVERY failure (-ENOMEM like the reference, and this
+ *    library's -ENODEV no usable device / -EINVAL bad shape / -EIO HIP error: the caller, dsp_worker.c:98-107,
+ *    assumes the hand-over whenever taps_len != 0); returns -1 for taps_len == 0 WITHOUT consuming taps
+ *    (:496-498, :508, :600-602).
  *  - `input_len` counts scalar elements of the input type: bytes for cu8/cs8, int16 values for cs16
  *    (:355, :365, :375; caller at dsp_worker.c:65), i.e. 2 x complex samples.
  *  - `*output` points to filter-owned host memory, valid until the next call on the same filter;

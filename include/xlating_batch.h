@@ -39,6 +39,19 @@ enum { XL_MODE_NATIVE = 0, XL_MODE_OPTIMIZED = 1 };
  * Returns 0, -ENODEV (no usable HIP device), -EINVAL, -ENOMEM. */
 int xlating_batch_create(uint32_t sampling_freq, int input_format, uint32_t max_input_buffer_length, int device,
                          xlating_batch **batch);
+/* The same, for an engine whose process calls may cover up to `max_group_blocks` (1..64) consecutive blocks of up to
+ * max_input_buffer_length each ("group"; see xlating_batch_process_device_group). */
+int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint32_t max_input_buffer_length,
+                                 unsigned max_group_blocks, int device, xlating_batch **batch);
+
+/* Plan options (result-neutral: every setting passes the same parity tests).  name / value:
+ *   "polyphase"             -1 by the size rule (default), 0 never, 1 whenever the shape allows: which classes take the
+ *                           polyphase overlap-save path in XL_MODE_OPTIMIZED
+ *   "polyphase_m"           0 by the size rule, 128, 256: its transform length
+ *   "polyphase_min_clients" smallest class that takes it under the size rule (default 128)
+ *   "riders" 0/1, "riders_min_workgroups" n, "tile_height" 0/8/9/10/12, "nco_slices" (a << 16 | b): launch shaping
+ * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call. */
+int xlating_batch_set_option(xlating_batch *batch, const char *name, long value);
 
 /* Add a client whose stream starts with the NEXT block (like dsp_worker_start, dsp_worker.c:90-108).
  * `taps` is the real low-pass prototype (lpf.h); it is COPIED (unlike create_frequency_xlating_filter
@@ -61,9 +74,25 @@ int xlating_batch_num_clients(const xlating_batch *batch);
 int xlating_batch_process_host(xlating_batch *batch, const void *input, size_t input_len, int mode);
 int xlating_batch_process_device(xlating_batch *batch, const void *d_input, size_t input_len, int mode,
                                  void *hip_stream);
+/* Consecutive calls may use different streams: a call on another stream than the previous one is ordered behind the
+ * previous call's work (the engine's device state -- history, phases -- chains the calls). */
 
-/* Number of complex output samples client produced in the last processed block (host-side integer state). */
+/* Process `nblocks` consecutive blocks of `input_len` scalar elements each, stored back to back, in ONE call: the
+ * results are exactly those of nblocks successive process calls (every client's NCO phase is renormalised at each
+ * block end like xlating.c:73 does per call; per-client outputs of the blocks are concatenated), from one set of
+ * launches.  What sdr_callback would do with a super-block of several device buffers; it is
+ * also what makes the launches big enough to fill the chip and streams the per-client filter images once per call
+ * instead of once per block.  nblocks <= the engine's max_group_blocks; for nblocks > 1 every block must hold at least
+ * one output of every client (input_len / 2 >= the largest decimation).  Same return codes as above. */
+int xlating_batch_process_host_group(xlating_batch *batch, const void *input, size_t input_len, unsigned nblocks,
+                                     int mode);
+int xlating_batch_process_device_group(xlating_batch *batch, const void *d_input, size_t input_len, unsigned nblocks,
+                                       int mode, void *hip_stream);
+
+/* Number of complex output samples client produced in the last processed call (host-side integer state), and in
+ * block `block` of that call (the client's output row holds the blocks' outputs back to back). */
 size_t xlating_batch_output_len(const xlating_batch *batch, int client_id);
+size_t xlating_batch_output_len_block(const xlating_batch *batch, int client_id, unsigned block);
 
 /* Copy every client's last-block output D2H into engine-owned pinned memory (one copy) and wait for it. */
 int xlating_batch_fetch(xlating_batch *batch);

@@ -43,7 +43,8 @@ EXPORTED_SYMBOLS = (
     ["SIMD_STATUS", "create_frequency_xlating_filter", "destroy_xlating", "create_low_pass_filter"]
     + [f"process_{v}_{i}_{o}" for v in ("native", "optimized") for i in ("cu8", "cs8", "cs16") for o in ("cf32", "cs16")]
     + ["process_native_cf32_cf32", "process_optimized_cf32_cf32"]
-    + ["xlating_batch_create", "xlating_batch_add_client", "xlating_batch_remove_client", "xlating_batch_num_clients",
+    + ["xlating_batch_create", "xlating_batch_create_grouped", "xlating_batch_set_option", "xlating_batch_process_host_group",
+       "xlating_batch_process_device_group", "xlating_batch_output_len_block", "xlating_batch_add_client", "xlating_batch_remove_client", "xlating_batch_num_clients",
        "xlating_batch_process_host", "xlating_batch_process_device", "xlating_batch_output_len", "xlating_batch_fetch",
        "xlating_batch_output_host", "xlating_batch_output_device", "xlating_batch_client_phase", "xlating_batch_sync",
        "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_timing_polyphase", "xlating_batch_timing_stride", "xlating_batch_describe", "xlating_batch_destroy",
@@ -85,6 +86,16 @@ def lib():
                 fn.restype = None
     L.xlating_batch_create.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
     L.xlating_batch_create.restype = C.c_int
+    L.xlating_batch_create_grouped.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_uint, C.c_int, C.POINTER(C.c_void_p)]
+    L.xlating_batch_create_grouped.restype = C.c_int
+    L.xlating_batch_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+    L.xlating_batch_set_option.restype = C.c_int
+    L.xlating_batch_process_host_group.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_int]
+    L.xlating_batch_process_host_group.restype = C.c_int
+    L.xlating_batch_process_device_group.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_int, C.c_void_p]
+    L.xlating_batch_process_device_group.restype = C.c_int
+    L.xlating_batch_output_len_block.argtypes = [C.c_void_p, C.c_int, C.c_uint]
+    L.xlating_batch_output_len_block.restype = C.c_size_t
     L.xlating_batch_add_client.argtypes = [C.c_void_p, C.c_uint32, _c_float_p, C.c_size_t, C.c_int32]
     L.xlating_batch_add_client.restype = C.c_int
     L.xlating_batch_remove_client.argtypes = [C.c_void_p, C.c_int]
@@ -247,13 +258,36 @@ class XlatingFilter:
 class BatchEngine:
     """`xlating_batch *` (include/xlating_batch.h): one IQ stream, many clients, one GPU."""
 
-    def __init__(self, sampling_freq, in_fmt, max_input_buffer_length, device=-1):
+    def __init__(self, sampling_freq, in_fmt, max_input_buffer_length, device=-1, group_blocks=1):
         h = C.c_void_p()
-        code = lib().xlating_batch_create(sampling_freq, FMT[in_fmt], max_input_buffer_length, device, C.byref(h))
+        code = lib().xlating_batch_create_grouped(sampling_freq, FMT[in_fmt], max_input_buffer_length, group_blocks, device,
+                                                  C.byref(h))
         if code != 0:
             raise XlatingError("xlating_batch_create", code)
         self.h = h
         self.in_fmt = in_fmt
+
+    def set_option(self, name, value):
+        code = lib().xlating_batch_set_option(self.h, name.encode(), int(value))
+        if code != 0:
+            raise XlatingError(f"xlating_batch_set_option({name})", code)
+
+    def process_host_group(self, x, nblocks, variant="native"):
+        """x holds nblocks equal blocks back to back; results == nblocks successive process_host calls."""
+        x = np.ascontiguousarray(x, dtype=_NP[self.in_fmt])
+        assert x.size % nblocks == 0
+        code = lib().xlating_batch_process_host_group(self.h, x.ctypes.data, x.size // nblocks, nblocks, MODE[variant])
+        if code != 0:
+            raise XlatingError("xlating_batch_process_host_group", code)
+
+    def process_device_group(self, d_ptr, input_len, nblocks, variant="native", stream=0):
+        code = lib().xlating_batch_process_device_group(self.h, C.c_void_p(d_ptr), input_len, nblocks, MODE[variant],
+                                                        C.c_void_p(stream) if stream else None)
+        if code != 0:
+            raise XlatingError("xlating_batch_process_device_group", code)
+
+    def output_len_block(self, cid, block):
+        return lib().xlating_batch_output_len_block(self.h, cid, block)
 
     def add_client(self, decimation, taps, center_freq):
         taps = np.ascontiguousarray(taps, dtype=np.float32)

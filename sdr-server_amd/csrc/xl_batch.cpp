@@ -2,31 +2,31 @@
 //
 // What the reference does per IQ block with N clients (src/tcp_server.c:257-271 -> src/dsp_worker.c:202-204 ->
 // src/queue.c:87-119 -> dsp_worker.c:57-65): N memcpy's of the block and N process_* calls on N threads.
-// Here: the block lives ONCE in HBM, one NCO-table launch and one fused FIR launch (per register-tile height)
-// serve every client of this GPU, outputs stay in HBM until fetched.
+// Here: the block lives ONCE in HBM, one to three launches serve every client of this GPU, outputs stay in HBM until
+// fetched.  A CALL covers G >= 1 consecutive blocks ("group"): the results are those of G successive reference calls
+// (the NCO phase is renormalised at every block end, xlating.c:73) from one set of launches -- the branch spectra of
+// the polyphase path are streamed once per call instead of once per block, the launches are G times bigger, and the
+// NCO recurrence (a dependent chain of ~23 us per block whatever the client count) has G times more work to hide in.
 //
-// HBM layout (all resident across blocks; only XlDynArgs -- 16 B per class -- travels per block, as kernargs):
+// HBM layout (all resident across calls; a call's only per-call data is XlPos, 16 bytes of kernel arguments):
 //   hist[2]      raw history (ping-pong): the last XL_HCAP samples of the stream in the INPUT format
-//   block        engine-owned copy of the current block (host path) -- or the caller's device buffer, in place
+//   block        engine-owned copy of the current blocks (host path) -- or the caller's device buffer, in place
 //   taps         [tile][Tpad][ct] float2, tap i of the ct clients of a tile contiguous (one s_load_dwordx16)
-//   groups[ct]   XlGroup descriptors (<= 4 tiles of one class each)
+//   groups[ct]   XlGroup descriptors (<= 4 tiles of one class each) incl. the class's plan-time stream record
 //   nco          XlNcoClient per client; phase[2][slot] running NCO phases (committed / next)
-//   phtab[2]     [client][K_cap] float2 phase tables (ping-pong), out[2] outputs (ping-pong), same indexing
+//   phtab[2]     [client][K_cap / 16] float2 phase tables (ping-pong), out[2] outputs (ping-pong), same indexing
 //
-// Streaming rule: a client's outputs lie on the global grid n = k*D of ITS stream; output k's
-// newest sample is stream sample k*D.  With `consumed` = samples this client has seen before the block,
-// j0 = (-consumed) mod D is the block-local index of the first output's newest sample, K = ceil((S - j0)/D),
-// and in [hist | block] coordinates the first window starts at XL_HCAP - (T-1) + j0.  Samples older than the
-// client (it joined mid-stream) must read as zero: zero_below = XL_HCAP - min(consumed, XL_HCAP).
+// Streaming rule (xl_grid.h): a client's outputs lie on the global grid n = k*D of ITS stream; output
+// k's newest sample is stream sample k*D.  Samples older than the client (it joined mid-stream) must read as zero.
+// Classes: clients sharing (D, T, stream offset mod D, valid history) share tiles of the direct kernel; their number is
+// unlimited (the per-call numbers of a class are computed on the device from its record and XlPos).  In optimized mode
+// all "mature" clients (every window inside their own stream) of one (D, T) form ONE polyphase class whatever their
+// grid offsets (xl_polyphase.h).
 //
-// Streams.  A block's outputs depend on (raw history, block, phase table) only.  The phase table is data
-// independent (float32 recurrence p <- p * incr, xlating.c:70-73), so block b+1's table is tabulated by the leading
-// workgroups of block b's FIR launch (the "NCO role"), guessing that b+1 has the same length; the running phases are
-// double-buffered (committed / next) so that a wrong guess is simply redone by a small launch of its own.  A block
-// is therefore ONE kernel launch on the caller's stream -- history roll, FIR, next block's phase table -- and its
-// results are stream-ordered behind the call.
-// (Measured and dropped: the phase table on a side stream fenced by events -- a steady 24 us gap between consecutive
-// FIR launches; consecutive blocks' FIR launches concurrently on two streams -- no gain.  See DESIGN.md.)
+// Streams.  A call's outputs depend on (raw history, blocks, phase table) only.  The phase table is data independent
+// (float32 recurrence p <- p * incr, xlating.c:70-73), so call c+1's table is tabulated inside call c's launches (the
+// "NCO role"), guessing that c+1 has the same shape; the running phases are double-buffered (committed / next) so that
+// a wrong guess is simply redone by a small launch of its own.  Everything runs on the caller's stream in stream order.
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,7 +45,7 @@
 #include "xl_taps.h"
 
 #define XL_NLAUNCH 7
-#define XL_HCAP 16384u  // raw history kept on the device, in samples; needs T - 1 <= XL_HCAP
+#define XL_GROUP_MAX 64u  // most blocks per call
 
 namespace {
 
@@ -57,13 +57,16 @@ struct Client {
   uint64_t consumed = 0;
   uint32_t out_off = 0, out_cap = 0;
   uint32_t last_K = 0;
-  uint32_t cls = 0;
+  std::vector<uint32_t> last_Kg;  // outputs per block of the latest call
+  bool planned_mature = false;
 };
 
-struct ClassState {
-  uint32_t D, T;
-  uint32_t rem;  // consumed mod D
-  uint32_t hv;   // min(consumed, XL_HCAP)
+// every window of the client's next outputs lies inside its own stream (no zeros below its join point are needed)
+static inline bool xl_mature(const Client &c) { return c.consumed >= (uint64_t)c.T - 1u; }
+
+struct DirectClass {
+  uint32_t D, T, rem0, hv0;
+  std::vector<int> members;
 };
 
 struct Launch {
@@ -75,18 +78,24 @@ struct Launch {
   size_t lds = 0;  // window image bytes of the launch (max over its groups)
   uint32_t idle_waves = 0;  // spare waves over all groups (NCO rider slots per output tile)
   bool all_wide = true;  // every group has an even decimation
+  uint32_t maxD = 1, minD = 0xFFFFFFFFu;
 };
 
-// A class of clients evaluated by the polyphase overlap-save path (xl_polyphase.hip) in optimized mode.
+// A class of clients evaluated by the polyphase overlap-save path (xl_polyphase.hip) in optimized mode: all mature
+// clients of one (D, T), whatever their grid offsets -- or clients of one (D, T) that joined together and are still
+// inside their zero history (one grid, one zero_below).
 struct PolyClass {
-  uint32_t cls = 0, D = 0, Dpad = 0, T = 0, A = 0, V = 0;
+  uint32_t D = 0, Dpad = 0, T = 0, A = 0, V = 0;
   uint32_t M = 256;          // transform length (128 or 256), V = M - A + 1
   uint32_t ncols = 0, ncg = 0, nseg_cap = 0;
+  uint32_t rem_ref0 = 0;     // plan-time record of the shared grid's reference client (xl_grid.h)
+  uint32_t hv0 = XL_HCAP;    // plan-time valid history of the members (XL_HCAP: mature)
+  uint32_t dmax = 0;         // largest grid offset of a member
+  std::vector<int> members;
   float2 *d_R = nullptr;     // branch spectra [ncg][M][Dpad][128] (+ XLP_BSTEP rows of tail padding)
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
   float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
-  uint32_t *d_col = nullptr; // column -> output row offset
-  float2 *d_colinc = nullptr; // column -> NCO phase increment
+  XlpCol *d_cols = nullptr;  // per column: output row, grid offset, NCO increment
 };
 
 }  // namespace
@@ -95,36 +104,41 @@ struct xlating_batch_t {
   uint32_t fs = 0;
   int fmt = 0;
   uint32_t bps = 2;
-  uint32_t max_samples = 0;
+  uint32_t max_samples = 0;  // per block
+  uint32_t gcap = 1;         // most blocks per call
   int device = -1;
   hipStream_t own_stream = nullptr;   // used when the caller passes no stream / host path
-  hipStream_t last_stream = nullptr;  // caller stream of the latest block
+  hipStream_t last_stream = nullptr;  // caller stream of the latest call
+  hipEvent_t dep_ev = nullptr;        // orders a call on a new stream behind the previous call's stream
+  bool poisoned = false;              // a launch failed mid-call: device state is undefined, every later call fails
 
   std::vector<Client> clients;
   int nalive = 0;
   bool dirty = true;
-  std::vector<ClassState> classes;
-  Launch launches[XL_NLAUNCH];  // one per register-tile height 12, 10, 9, 8, 4, 2, 1: ALL clients (native mode)
-  Launch launches_rest[XL_NLAUNCH];  // same, over the classes that are not in `poly` (optimized mode)
+  int planned_immature = 0;  // clients that were not mature when the plan was built (they merge once they are)
+  uint32_t trel = 0;         // samples consumed since the plan was built (XlPos::trel)
+  uint32_t plan_maxD = 1;
+  std::vector<DirectClass> classes;       // direct classes over ALL clients (native mode)
+  std::vector<DirectClass> classes_rest;  // direct classes over the clients outside `poly` (optimized mode)
+  Launch launches[XL_NLAUNCH];       // one per register-tile height 12, 10, 9, 8, 4, 2, 1: ALL clients (native mode)
+  Launch launches_rest[XL_NLAUNCH];  // same, over classes_rest (optimized mode)
   std::vector<PolyClass> poly;       // classes on the polyphase overlap-save path in optimized mode
   float2 *d_W = nullptr;             // e^{-2 pi j n/256}
-  float2 *d_phase_run = nullptr;     // running phases between the NCO slices of a block
+  float2 *d_phase_run = nullptr;     // running phases between the NCO slices of a call
   size_t phase_run_cap = 0;
-  int poly_mode = -1;        // XL_EXP_POLY: 0 never, 1 whenever the shape allows, -1 (default) by the size rule
+  int poly_mode = -1;        // option "polyphase": 0 never, 1 whenever the shape allows, -1 (default) by the size rule
   uint32_t poly_min_clients = 128;  // measured at 505 taps, D = 42: x1.10 at 128 clients, x0.96 at 64 (profiles/r01_polyphase_vs_direct.txt)
-  const char *poly_trace = nullptr;  // XL_EXP_POLY_TRACE=<file>: timeline of the latest mix launch (tuning)
-  unsigned long long *d_ptrace = nullptr;
-  uint32_t poly_m = 0;        // XL_EXP_POLY_M: force the transform length (128 / 256); 0 = by the filter length
-  uint32_t mix_skip_at = 0;   // XL_EXP_MIXSKIP: position of the mix launch's skipped workgroups; 0 = 1024
+  uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
+  uint32_t mix_skip_at = 0;   // position of the mix launch's skipped workgroups; 0 = 1024
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
-  uint32_t poly_exp = 0;     // XL_EXP_POLY_EXP: tuning switches of the mix kernel (wrong results)
-  uint32_t poly_slice1 = 8000, poly_slice2 = 50000;  // NCO slice boundaries in 1/65536 of the block (forward | mix | inverse)
+  uint32_t poly_exp = 0;     // XL_TUNING builds: tuning switches of the mix kernel
+  uint32_t poly_slice1 = 8000, poly_slice2 = 50000;  // NCO slice boundaries in 1/65536 of the call (forward | mix | inverse)
   std::vector<XlNcoClient> nco;
   size_t out_total = 0;
-  uint64_t nblk = 0;  // blocks processed
+  uint64_t ncalls = 0;  // calls processed
 
   void *d_hist[2] = {nullptr, nullptr};
-  int hcur = 0;  // d_hist[hcur] = history in front of the next block
+  int hcur = 0;  // d_hist[hcur] = history in front of the next call
   void *d_block = nullptr;
   void *h_block = nullptr;  // pinned staging
   float2 *d_taps = nullptr;
@@ -134,37 +148,41 @@ struct xlating_batch_t {
   size_t phase_cap = 0;
   float2 *d_phtab[2] = {nullptr, nullptr};
   float2 *d_out[2] = {nullptr, nullptr};
-  int ocur = 0;  // d_out[ocur] holds the latest block's outputs
+  int ocur = 0;  // d_out[ocur] holds the latest call's outputs
   size_t out_alloc = 0;
   float2 *h_out = nullptr;
   size_t h_out_alloc = 0;
   bool fetched = false;
 
-  int tab = 0;              // table used by the latest block
-  bool spec_valid = false;  // table[spec_tab] holds the phases of the NEXT block assuming spec_S samples
-  size_t spec_S = 0;
+  int tab = 0;              // table used by the latest call
+  bool spec_valid = false;  // table[spec_tab] holds the phases of the NEXT call assuming spec_S samples x spec_G blocks
+  uint32_t spec_S = 0, spec_G = 0;
   int spec_tab = 0;
-  bool exp_nofuse = false;    // XL_EXP_NOFUSE: keep the NCO tabulation a launch of its own (tuning)
+  bool exp_nofuse = false;  // XL_TUNING: keep the NCO tabulation a launch of its own
 
-  uint32_t exp_flags = 0;  // tuning knobs from XL_EXP_* environment variables
+  uint32_t exp_flags = 0;  // tuning knobs
   // Wave priority of the NCO role / NCO launch (3: a pure dependent chain must not queue behind the FIR waves;
   // 1..3 measured equal for 505 taps, 3 best for short filters).
   uint32_t nco_prio = 3;
   uint32_t nco_wpw = 1;   // waves per NCO-role workgroup that carry clients
   bool riders = true;     // NCO role rides in spare waves of the FIR workgroups when the plan has some
   int riders_min_wgs = 512;
-  int exp_h = 0;   // XL_EXP_H=8|9|10|12 forces the tile height of the large classes
+  int exp_h = 0;   // forces the tile height of the large classes (8 | 9 | 10 | 12)
+#ifdef XL_TUNING
+  const char *poly_trace = nullptr;  // XL_EXP_POLY_TRACE=<file>: timeline of the latest mix launch
+  unsigned long long *d_ptrace = nullptr;
   const char *exp_trace = nullptr;  // XL_EXP_TRACE=<file>: dump per-wave timestamps of the latest FIR launch
   unsigned long long *d_trace = nullptr;
   size_t trace_cap = 0;
-  uint32_t timing_every = 1;  // xlating_batch_timing_stride: bracket only every n-th block (an event pair costs a few us of stream time)
-  int timing = 0;  // 1: bracket every block's launches; 2: also time the three polyphase launches separately
-  std::vector<hipEvent_t> ev;       // pairs: fir start, fir stop (on the FIR launch stream)
+#endif
+  uint32_t timing_every = 1;  // xlating_batch_timing_stride: bracket only every n-th call (an event pair costs a few us of stream time)
+  int timing = 0;  // 1: bracket every call's launches; 2: also time the three polyphase launches separately
+  std::vector<hipEvent_t> ev;       // pairs: start, stop of a call's launches (on the launch stream)
   std::vector<hipEvent_t> ev_ncot;  // pairs: start, stop of stand-alone NCO launches (rare)
   std::vector<hipEvent_t> ev_poly;  // quadruples: before forward, after forward, after mix, after inverse (timing == 2)
   double poly_ms[3] = {0.0, 0.0, 0.0};
   int timed_poly = 0;
-  std::vector<hipEvent_t> ev_pool;  // recycled timing events (hipEventCreate per block would bound the host)
+  std::vector<hipEvent_t> ev_pool;  // recycled timing events (hipEventCreate per call would bound the host)
   double fir_ms = 0.0, nco_ms = 0.0;
   int timed_launches = 0, timed_nco = 0;
 };
@@ -192,7 +210,7 @@ static void xl_batch_free_plan(xlating_batch *b) {
       l.groups.clear();
     }
   for (PolyClass &pc : b->poly) {
-    void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_col, pc.d_colinc};
+    void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_cols};
     for (void *q : dev)
       if (q) (void)hipFree(q);
   }
@@ -209,24 +227,59 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   xl_batch_sync_all(b);
   xl_batch_free_plan(b);
   void *dev[] = {b->d_hist[0],  b->d_hist[1],  b->d_block,  b->d_phase[0], b->d_phase[1],
-                 b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_trace,
-                 b->d_W,        b->d_phase_run, b->d_ptrace};
+                 b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_W,        b->d_phase_run};
   for (void *p : dev)
     if (p) (void)hipFree(p);
+#ifdef XL_TUNING
+  if (b->d_trace) (void)hipFree(b->d_trace);
+  if (b->d_ptrace) (void)hipFree(b->d_ptrace);
+#endif
   if (b->h_block) (void)hipHostFree(b->h_block);
   if (b->h_out) (void)hipHostFree(b->h_out);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_ncot) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_poly) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
+  if (b->dep_ev) (void)hipEventDestroy(b->dep_ev);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
 }
 
-extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, uint32_t max_input_buffer_length,
-                                    int device, xlating_batch **batch) {
+extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long value) {
+  if (b == nullptr || name == nullptr) return -EINVAL;
+  const std::string n(name);
+  if (n == "polyphase") {
+    if (value < -1 || value > 1) return -EINVAL;
+    b->poly_mode = (int)value;
+  } else if (n == "polyphase_m") {
+    if (value != 0 && value != 128 && value != 256) return -EINVAL;
+    b->poly_m = (uint32_t)value;
+  } else if (n == "polyphase_min_clients") {
+    if (value < 1) return -EINVAL;
+    b->poly_min_clients = (uint32_t)value;
+  } else if (n == "riders") {
+    b->riders = value != 0;
+  } else if (n == "riders_min_workgroups") {
+    b->riders_min_wgs = (int)value;
+  } else if (n == "tile_height") {
+    if (value != 0 && value != 8 && value != 9 && value != 10 && value != 12) return -EINVAL;
+    b->exp_h = (int)value;
+  } else if (n == "nco_slices") {  // value = slice1 * 65536 + slice2, both in 1/65536 of a call
+    b->poly_slice1 = (uint32_t)((value >> 16) & 0xFFFF);
+    b->poly_slice2 = (uint32_t)(value & 0xFFFF);
+    if (b->poly_slice1 > b->poly_slice2) return -EINVAL;
+  } else {
+    return -ENOENT;
+  }
+  b->dirty = true;
+  return 0;
+}
+
+extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint32_t max_input_buffer_length,
+                                            unsigned max_group_blocks, int device, xlating_batch **batch) {
   if (batch == nullptr || input_format < XL_FMT_CU8 || input_format > XL_FMT_CF32 || sampling_freq == 0 ||
-      max_input_buffer_length < 2)
+      max_input_buffer_length < 2 || max_group_blocks < 1 || max_group_blocks > XL_GROUP_MAX ||
+      (uint64_t)(max_input_buffer_length / 2) * max_group_blocks > (1u << 28))
     return -EINVAL;
   const int dev = xl_hip_select_device(device);
   if (dev < 0) {
@@ -239,12 +292,14 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
   b->fmt = input_format;
   b->bps = xl_bytes_per_sample(input_format);
   b->max_samples = max_input_buffer_length / 2;
+  b->gcap = max_group_blocks;
   b->device = dev;
   {
     const size_t hbytes = (size_t)XL_HCAP * b->bps;
-    const size_t bbytes = (size_t)b->max_samples * b->bps + 16;
+    const size_t bbytes = (size_t)b->max_samples * b->gcap * b->bps + 16;
     XL_TRY(hipSetDevice(dev));
     XL_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+    XL_TRY(hipEventCreateWithFlags(&b->dep_ev, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
       XL_TRY(hipMalloc(&b->d_hist[i], hbytes));
       XL_TRY(hipMemsetAsync(b->d_hist[i], 0, hbytes, b->own_stream));
@@ -253,28 +308,37 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
     XL_TRY(hipHostMalloc(&b->h_block, bbytes, hipHostMallocDefault));
     XL_TRY(hipStreamSynchronize(b->own_stream));
   }
-  if (getenv("XL_EXP_FLATPRIO")) b->exp_flags |= 2u;
-  if (getenv("XL_EXP_H")) b->exp_h = atoi(getenv("XL_EXP_H"));
-  b->exp_trace = getenv("XL_EXP_TRACE");
-  b->exp_nofuse = getenv("XL_EXP_NOFUSE") != nullptr;
-  if (getenv("XL_EXP_NCOPRIO")) b->nco_prio = (uint32_t)atoi(getenv("XL_EXP_NCOPRIO")) & 3u;
-  if (getenv("XL_EXP_RIDERS")) b->riders = atoi(getenv("XL_EXP_RIDERS")) != 0;
-  if (getenv("XL_EXP_RIDERS_MIN")) b->riders_min_wgs = atoi(getenv("XL_EXP_RIDERS_MIN"));
-  if (getenv("XL_EXP_POLY")) b->poly_mode = atoi(getenv("XL_EXP_POLY"));
-  b->poly_trace = getenv("XL_EXP_POLY_TRACE");
-  if (getenv("XL_EXP_POLY_M")) b->poly_m = (uint32_t)atoi(getenv("XL_EXP_POLY_M"));
-  if (b->poly_m != 0 && b->poly_m != 128 && b->poly_m != 256) b->poly_m = 0;
+  // Result-neutral plan options may also come from the environment (tests and tools force a path this way); the
+  // switches that trace launches or break results exist in -DXL_TUNING builds only (tools/experiments/).
+  if (getenv("XL_EXP_H")) (void)xlating_batch_set_option(b, "tile_height", atol(getenv("XL_EXP_H")));
+  if (getenv("XL_EXP_RIDERS")) (void)xlating_batch_set_option(b, "riders", atol(getenv("XL_EXP_RIDERS")));
+  if (getenv("XL_EXP_RIDERS_MIN")) (void)xlating_batch_set_option(b, "riders_min_workgroups", atol(getenv("XL_EXP_RIDERS_MIN")));
+  if (getenv("XL_EXP_POLY")) (void)xlating_batch_set_option(b, "polyphase", atol(getenv("XL_EXP_POLY")));
+  if (getenv("XL_EXP_POLY_M")) (void)xlating_batch_set_option(b, "polyphase_m", atol(getenv("XL_EXP_POLY_M")));
+  if (getenv("XL_EXP_POLY_MIN")) (void)xlating_batch_set_option(b, "polyphase_min_clients", atol(getenv("XL_EXP_POLY_MIN")));
+  if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
   if (getenv("XL_EXP_MIXSKIP")) b->mix_skip_at = (uint32_t)atoi(getenv("XL_EXP_MIXSKIP"));
   if (getenv("XL_EXP_INVSKIP")) b->inv_skip_at = (uint32_t)atoi(getenv("XL_EXP_INVSKIP"));
+  if (getenv("XL_EXP_NCOPRIO")) b->nco_prio = (uint32_t)atoi(getenv("XL_EXP_NCOPRIO")) & 3u;
+  if (getenv("XL_EXP_FLATPRIO")) b->exp_flags |= 2u;
+#ifdef XL_TUNING
+  b->exp_trace = getenv("XL_EXP_TRACE");
+  b->exp_nofuse = getenv("XL_EXP_NOFUSE") != nullptr;
+  b->poly_trace = getenv("XL_EXP_POLY_TRACE");
   if (getenv("XL_EXP_POLY_EXP")) b->poly_exp = (uint32_t)atoi(getenv("XL_EXP_POLY_EXP"));
-  if (getenv("XL_EXP_POLY_MIN")) b->poly_min_clients = (uint32_t)atoi(getenv("XL_EXP_POLY_MIN"));
-  if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
+#endif
   b->last_stream = b->own_stream;
+  b->dirty = true;
   *batch = b;
   return 0;
 fail:
   xlating_batch_destroy(b);
-  return -ENOMEM;
+  return xl_errno_of_last_hip_error();
+}
+
+extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, uint32_t max_input_buffer_length,
+                                    int device, xlating_batch **batch) {
+  return xlating_batch_create_grouped(sampling_freq, input_format, max_input_buffer_length, 1, device, batch);
 }
 
 extern "C" int xlating_batch_num_clients(const xlating_batch *b) { return b ? b->nalive : 0; }
@@ -283,8 +347,8 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
                                         int32_t center_freq) {
   if (taps_len == 0) return -1;  // like create_frequency_xlating_filter (xlating.c:496-498)
   if (b == nullptr || taps == nullptr || decimation == 0) return -EINVAL;
-  if (taps_len - 1 > XL_HCAP) {
-    XL_LOG_ERR("%zu taps exceed the engine's history capacity (%u samples)", taps_len, XL_HCAP);
+  if (taps_len - 1 + decimation > XL_HCAP) {
+    XL_LOG_ERR("%zu taps at decimation %u exceed the engine's history capacity (%u samples)", taps_len, decimation, XL_HCAP);
     return -EINVAL;
   }
   const uint32_t Tpad = xl_roundup((uint32_t)taps_len, XL_TAP_UNROLL);
@@ -313,7 +377,7 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
   std::vector<int16_t> q15(2 * taps_len);
   int16_t qinc[2];
   xl_prepare_taps(taps, taps_len, center_freq, b->fs, decimation, c.rt.data(), q15.data(), c.incr, qinc);
-  c.out_cap = b->max_samples / decimation + 1;  // xlating.c:568
+  c.out_cap = b->gcap * (b->max_samples / decimation + 1);  // xlating.c:568 per block
   b->nalive++;
   b->dirty = true;
   // The running phase of a new client starts at 1 + 0j (xlating.c:543); slot = client id.  Any phase table
@@ -368,33 +432,169 @@ static bool xl_riders_window(size_t wgs, int nw, uint32_t Tpad, int ct, uint32_t
   return min_wgs <= 1 || (wgs >= (size_t)min_wgs && wgs <= cap && fir_us >= 1.3 * chain_us);
 }
 
+static const int kHeights[XL_NLAUNCH] = {12, 10, 9, 8, 4, 2, 1};
+
+// Direct classes over the clients selected by `use`: key (D, T, consumed mod D, valid history).  A mature client's
+// windows never reach below its join point, so all mature clients of one grid share a class whatever their age.
+static void xl_direct_classes(const xlating_batch *b, const std::vector<bool> &use, std::vector<DirectClass> *out) {
+  out->clear();
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, size_t> cls_of;
+  for (size_t i = 0; i < b->clients.size(); ++i) {
+    const Client &c = b->clients[i];
+    if (!c.alive || !use[i]) continue;
+    const uint32_t rem = (uint32_t)(c.consumed % c.D);
+    const uint32_t hv = xl_mature(c) ? XL_HCAP : (uint32_t)c.consumed;
+    auto key = std::make_tuple(c.D, c.T, rem, hv);
+    auto it = cls_of.find(key);
+    if (it == cls_of.end()) {
+      it = cls_of.emplace(key, out->size()).first;
+      out->push_back(DirectClass{c.D, c.T, rem, hv, {}});
+    }
+    (*out)[it->second].members.push_back((int)i);
+  }
+}
+
+// Builds one set of direct-FIR launches over `classes`: tiles, groups, tap image rows (appended to `image`).
+static int xl_build_launches(xlating_batch *b, Launch *Ls, const std::vector<DirectClass> &classes, int big_h,
+                             std::vector<float> *image) {
+  struct TileDesc {
+    size_t cls;
+    std::vector<int> ids;
+  };
+  std::vector<TileDesc> tiles_of[XL_NLAUNCH];
+  const uint32_t cap_samples = b->max_samples * b->gcap;
+  for (int li = 0; li < XL_NLAUNCH; ++li) {
+    Ls[li].ct = kHeights[li];
+    Ls[li].lds = 0;
+    Ls[li].nw = XL_NW_DEFAULT;
+    Ls[li].all_wide = true;
+    Ls[li].maxD = 1;
+    Ls[li].minD = 0xFFFFFFFFu;
+  }
+  for (size_t k = 0; k < classes.size(); ++k) {
+    const std::vector<int> &m = classes[k].members;
+    int h = big_h;
+    if (m.size() < 8) h = m.size() > 4 ? 8 : (m.size() > 2 ? 4 : (m.size() > 1 ? 2 : 1));
+    int li = 0;
+    while (kHeights[li] != h) ++li;
+    for (size_t next = 0; next < m.size(); next += (size_t)h) {
+      const size_t cnt = std::min<size_t>((size_t)h, m.size() - next);
+      tiles_of[li].push_back(TileDesc{k, std::vector<int>(m.begin() + next, m.begin() + next + cnt)});
+    }
+  }
+
+  for (int li = 0; li < XL_NLAUNCH; ++li) {
+    Launch &L = Ls[li];
+    if (tiles_of[li].empty()) continue;
+    const int ct = L.ct;
+    int gi = -1;
+    size_t gcls = 0;
+    for (const TileDesc &td : tiles_of[li]) {
+      const DirectClass &cs = classes[td.cls];
+      const uint32_t Tpad = xl_roundup(cs.T, xl_tap_step(ct));
+      if (gi < 0 || gcls != td.cls || L.groups[gi].ntiles == (uint32_t)L.nw) {
+        L.groups.emplace_back();
+        gi = (int)L.groups.size() - 1;
+        gcls = td.cls;
+        XlGroup *g = &L.groups[gi];
+        memset(g, 0, sizeof(*g));
+        g->D = cs.D;
+        g->T = cs.T;
+        g->Tpad = Tpad;
+        g->rem0 = cs.rem0;
+        g->hv0 = cs.hv0;
+        g->wide = (cs.D % 2 == 0) ? 1u : 0u;
+        if (!g->wide) L.all_wide = false;
+        L.lds = std::max(L.lds, xl_fir_lds_bytes_ota(cs.D, Tpad, 64));
+        L.maxD = std::max(L.maxD, cs.D);
+        L.minD = std::min(L.minD, cs.D);
+      }
+      XlGroup *g = &L.groups[gi];
+      XlTile &t = g->tiles[g->ntiles++];
+      const uint32_t real_off = (uint32_t)(image->size() / 2);
+      t.tap_off = real_off;
+      t.nclients = (uint32_t)td.ids.size();  // a partial last tile keeps zero taps for the missing clients
+      image->resize(image->size() + (size_t)2 * Tpad * ct, 0.0f);
+      float *dst = image->data() + (size_t)2 * real_off;
+      for (size_t j = 0; j < td.ids.size(); ++j) {
+        const Client &c = b->clients[td.ids[j]];
+        t.out_off[j] = c.out_off;
+        t.incr[j] = make_float2(c.incr[0], c.incr[1]);
+        for (uint32_t i = 0; i < cs.T; ++i) {
+          dst[((size_t)i * ct + j) * 2] = c.rt[2 * i];
+          dst[((size_t)i * ct + j) * 2 + 1] = c.rt[2 * i + 1];
+        }
+      }
+    }
+  }
+  // ---- spare waves for the NCO riders (xl_kernels.hip): groups with fewer tiles than the launch has waves.  The
+  // launch that carries the role (the first one with groups) gets a spare wave by splitting its last full group
+  // into 3 + 1 tiles when it has none and the engine is big enough for the balance to matter.
+  {
+    bool first = true;
+    for (int lq = 0; lq < XL_NLAUNCH; ++lq) {
+      Launch &L = Ls[lq];
+      if (L.groups.empty()) continue;
+      uint32_t idle = 0;
+      for (const XlGroup &g : L.groups) idle += (uint32_t)L.nw - g.ntiles;
+      const uint32_t kest = cap_samples / L.groups[0].D + 1;
+      if (first && idle == 0 && b->riders && L.nw == XL_NW_MAX &&
+          xl_riders_window((L.groups.size() + 1) * ((kest + 63) / 64), L.nw, L.groups[0].Tpad, L.ct, kest, L.lds,
+                           b->riders_min_wgs)) {
+        XlGroup &last = L.groups.back();
+        XlGroup extra = last;
+        extra.ntiles = 1;
+        extra.tiles[0] = last.tiles[XL_NW_MAX - 1];
+        last.ntiles = XL_NW_MAX - 1;
+        L.groups.push_back(extra);
+      }
+      // (riders are only used in one-round launches -- xl_riders_window -- where every workgroup is dispatched within
+      // ~10 us of the start, so the groups with spare waves can stay where they are: last, which suits the tail)
+      idle = 0;
+      for (XlGroup &g : L.groups) {
+        g.idle_before = idle;
+        idle += (uint32_t)L.nw - g.ntiles;
+      }
+      L.idle_waves = idle;
+      first = false;
+    }
+  }
+  for (int lq = 0; lq < XL_NLAUNCH; ++lq) {
+    Launch &L = Ls[lq];
+    L.ota = 64;
+    if (L.lds > 160 * 1024) {  // huge decimation: fewer active lanes per wave so that the window image fits
+      for (L.ota = 32; L.ota >= 8; L.ota >>= 1) {
+        size_t need = 0;
+        for (const XlGroup &g : L.groups) need = std::max(need, xl_fir_lds_bytes_ota(g.D, g.Tpad, L.ota));
+        if (need <= 160 * 1024) {
+          L.lds = need;
+          break;
+        }
+      }
+      if (L.ota < 8) return -EINVAL;  // (add_client already refused such a shape)
+    }
+  }
+  return 0;
+}
+
 static int xl_batch_plan(xlating_batch *b) {
   xl_batch_sync_all(b);
   b->spec_valid = false;
   xl_batch_free_plan(b);
   b->classes.clear();
+  b->classes_rest.clear();
   b->nco.clear();
-  std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> cls_of;
-  std::vector<std::vector<int>> members;
+  b->trel = 0;
+  b->planned_immature = 0;
+  b->plan_maxD = 1;
+  const uint32_t cap_samples = b->max_samples * b->gcap;
   uint32_t off = 0;
   for (size_t i = 0; i < b->clients.size(); ++i) {
     Client &c = b->clients[i];
     if (!c.alive) continue;
-    const uint32_t rem = (uint32_t)(c.consumed % c.D);
-    const uint32_t hv = (uint32_t)std::min<uint64_t>(c.consumed, XL_HCAP);
-    auto key = std::make_tuple(c.D, c.T, rem, hv);
-    auto it = cls_of.find(key);
-    if (it == cls_of.end()) {
-      if (b->classes.size() >= XL_MAX_CLASSES) {
-        XL_LOG_ERR("more than %d distinct (decimation, taps, stream offset) classes in one engine", XL_MAX_CLASSES);
-        return -E2BIG;
-      }
-      it = cls_of.emplace(key, (uint32_t)b->classes.size()).first;
-      b->classes.push_back(ClassState{c.D, c.T, rem, hv});
-      members.emplace_back();
-    }
-    c.cls = it->second;
-    members[c.cls].push_back((int)i);
+    c.planned_mature = xl_mature(c);
+    if (!c.planned_mature) b->planned_immature++;
+    b->plan_maxD = std::max(b->plan_maxD, c.D);
     c.out_off = off;
     off += xl_roundup(c.out_cap, 2 * XL_PH_STRIDE);  // rows start at multiples of 2 strides: the NCO role stores
                                                       // pairs of table entries as 16 bytes
@@ -402,11 +602,66 @@ static int xl_batch_plan(xlating_batch *b) {
     memset(&nc, 0, sizeof(nc));
     nc.incr = make_float2(c.incr[0], c.incr[1]);
     nc.out_off = c.out_off;
-    nc.cls = c.cls;
     nc.slot = (uint32_t)i;
+    nc.D = c.D;
+    nc.rem0 = (uint32_t)(c.consumed % c.D);
     b->nco.push_back(nc);
   }
   b->out_total = off;
+
+  // ---- polyphase classes (optimized mode): all mature clients of one (D, T) -- many clients (its lanes are client
+  // columns and its cost per client does not depend on the tap count) with a filter long enough to be worth it
+  std::vector<bool> all_use(b->clients.size(), true), rest_use(b->clients.size(), true);
+  {
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<int>> by_shape;
+    for (size_t i = 0; i < b->clients.size(); ++i) {
+      const Client &c = b->clients[i];
+      if (c.alive) by_shape[std::make_tuple(c.D, c.T, c.planned_mature ? XL_HCAP : (uint32_t)c.consumed)].push_back((int)i);
+    }
+    for (auto &kv : by_shape) {
+      const uint32_t D = std::get<0>(kv.first), T = std::get<1>(kv.first), hv0 = std::get<2>(kv.first);
+      const std::vector<int> &m = kv.second;
+      // the shared grid's reference: the member offset that keeps the largest delay of a member smallest
+      std::vector<uint32_t> rems;
+      for (int id : m) rems.push_back((uint32_t)(b->clients[id].consumed % D));
+      std::vector<uint32_t> distinct(rems);
+      std::sort(distinct.begin(), distinct.end());
+      distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+      uint32_t best_ref = distinct[0], best_dmax = 0xFFFFFFFFu;
+      for (uint32_t ref : distinct) {
+        uint32_t dm = 0;
+        for (uint32_t r : distinct) dm = std::max(dm, (ref + D - r) % D);  // delta = (j0_c - j0_ref) mod D = (rem_ref - rem_c) mod D
+        if (dm < best_dmax) best_dmax = dm, best_ref = ref;
+      }
+      const uint32_t A = (T + best_dmax + D - 1) / D;
+      // transform length: the mix launch streams D x M branch-spectrum values per client and call from HBM, which is
+      // what bounds it with many clients and one block per call; M = 128 halves that for ~5-10 % more arithmetic
+      // (valid outputs per segment M - A + 1) while the filter is short against the segment.  Measured at D = 42,
+      // 505 taps, one block per call: x1.17 at 4096 clients, x1.08 at 2048, x1.015 at 1024, x0.99 at 512 and below.
+      const uint32_t M = A > 64 ? 256u : (b->poly_m ? b->poly_m : (A <= 32 && m.size() >= 768 ? 128u : 256u));
+      const bool fits = A >= 2 && A <= M / 2 && D <= 504;  // (the mix kernel stages D rows of 128 bytes in <= 64 KB of LDS)
+      const bool pays = m.size() >= b->poly_min_clients && 2 * T >= 9 * D;  // crossover ~4.5 taps per branch
+      if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
+      PolyClass pc;
+      pc.D = D;
+      pc.Dpad = xl_roundup(D, XLP_BSTEP);
+      pc.T = T;
+      pc.A = A;
+      pc.M = M;
+      pc.V = M - A + 1;
+      pc.rem_ref0 = best_ref;
+      pc.hv0 = hv0;
+      pc.dmax = best_dmax;
+      pc.members = m;
+      pc.ncols = (uint32_t)m.size();
+      pc.ncg = (pc.ncols + XLP_COLS - 1) / XLP_COLS;
+      pc.nseg_cap = (cap_samples / D + 2 + pc.V - 1) / pc.V + 1;
+      b->poly.push_back(pc);
+      for (int id : m) rest_use[id] = false;
+    }
+  }
+  xl_direct_classes(b, all_use, &b->classes);
+  if (!b->poly.empty()) xl_direct_classes(b, rest_use, &b->classes_rest);
 
   // ---- register-tile height.  Every wave does the same work (64 outputs x H clients x T taps) and a CU holds
   // floor(160 KiB / window image) workgroups of 4 waves (6 at the server-default shape).  A launch whose workgroups
@@ -415,13 +670,11 @@ static int xl_batch_plan(xlating_batch *b) {
   // slots).  Taller tiles trade a little per-wave time for fewer workgroups: pick the height whose launch costs
   // least in (waves on the busiest SIMD) x (work per wave).  Classes with fewer than 8 clients use one small
   // tile.
-  static const int kHeights[XL_NLAUNCH] = {12, 10, 9, 8, 4, 2, 1};
   int big_h = 8;
   {
     size_t lds1 = 0;
-    for (size_t k = 0; k < members.size(); ++k)
-      if (members[k].size() >= 8)
-        lds1 = std::max(lds1, xl_fir_lds_bytes_ota(b->classes[k].D, xl_roundup(b->classes[k].T, 12), 64));
+    for (const DirectClass &cs : b->classes)
+      if (cs.members.size() >= 8) lds1 = std::max(lds1, xl_fir_lds_bytes_ota(cs.D, xl_roundup(cs.T, 12), 64));
     if (lds1 > 0) {
       const long slots = std::max<long>(1, std::min<long>((long)(160 * 1024 / lds1), 7));
       const long cap = slots * 256;
@@ -429,10 +682,10 @@ static int xl_batch_plan(xlating_batch *b) {
       static const int cand[4] = {8, 9, 10, 12};
       for (int h : cand) {
         long wgs = 0;
-        for (size_t k = 0; k < members.size(); ++k) {
-          const long n = (long)members[k].size();
+        for (const DirectClass &cs : b->classes) {
+          const long n = (long)cs.members.size();
           if (n < 8) continue;
-          const long kest = b->max_samples / b->classes[k].D + 1;
+          const long kest = b->max_samples / cs.D + 1;
           wgs += (((n + h - 1) / h + XL_NW_MAX - 1) / XL_NW_MAX) * ((kest + 63) / 64);
         }
         const long full = wgs / cap, rem = wgs % cap;
@@ -447,155 +700,9 @@ static int xl_batch_plan(xlating_batch *b) {
     if (b->exp_h == 8 || b->exp_h == 9 || b->exp_h == 10 || b->exp_h == 12) big_h = b->exp_h;
   }
   std::vector<float> image;  // tap image, floats (shared by both launch sets)
-  // Builds one set of direct-FIR launches over the classes selected by use_cls: tiles, groups, tap image rows.
-  auto build_launches = [&](Launch *Ls, const std::vector<bool> &use_cls) -> int {
-    struct TileDesc {
-      uint32_t cls;
-      std::vector<int> ids;
-    };
-    std::vector<TileDesc> tiles_of[XL_NLAUNCH];
-    for (int li = 0; li < XL_NLAUNCH; ++li) {
-      Ls[li].ct = kHeights[li];
-      Ls[li].lds = 0;
-      Ls[li].nw = XL_NW_DEFAULT;
-      Ls[li].all_wide = true;
-    }
-    for (size_t k = 0; k < members.size(); ++k) {
-      if (!use_cls[k]) continue;
-      const std::vector<int> &m = members[k];
-      int h = big_h;
-      if (m.size() < 8) h = m.size() > 4 ? 8 : (m.size() > 2 ? 4 : (m.size() > 1 ? 2 : 1));
-      int li = 0;
-      while (kHeights[li] != h) ++li;
-      for (size_t next = 0; next < m.size(); next += (size_t)h) {
-        const size_t cnt = std::min<size_t>((size_t)h, m.size() - next);
-        tiles_of[li].push_back(TileDesc{(uint32_t)k, std::vector<int>(m.begin() + next, m.begin() + next + cnt)});
-      }
-    }
-
-    for (int li = 0; li < XL_NLAUNCH; ++li) {
-      Launch &L = Ls[li];
-      if (tiles_of[li].empty()) continue;
-      const int ct = L.ct;
-      int gi = -1;
-      uint32_t gcls = 0;
-      for (const TileDesc &td : tiles_of[li]) {
-        const ClassState &cs = b->classes[td.cls];
-        const uint32_t Tpad = xl_roundup(cs.T, xl_tap_step(ct));
-        if (gi < 0 || gcls != td.cls || L.groups[gi].ntiles == (uint32_t)L.nw) {
-          L.groups.emplace_back();
-          gi = (int)L.groups.size() - 1;
-          gcls = td.cls;
-          XlGroup *g = &L.groups[gi];
-          memset(g, 0, sizeof(*g));
-          g->D = cs.D;
-          g->T = cs.T;
-          g->Tpad = Tpad;
-          g->cls = td.cls;
-          g->wide = (cs.D % 2 == 0) ? 1u : 0u;
-          if (!g->wide) L.all_wide = false;
-          L.lds = std::max(L.lds, xl_fir_lds_bytes_ota(cs.D, Tpad, 64));
-        }
-        XlGroup *g = &L.groups[gi];
-        XlTile &t = g->tiles[g->ntiles++];
-        const uint32_t real_off = (uint32_t)(image.size() / 2);
-        t.tap_off = real_off;
-        t.nclients = (uint32_t)td.ids.size();  // a partial last tile keeps zero taps for the missing clients
-        image.resize(image.size() + (size_t)2 * Tpad * ct, 0.0f);
-        float *dst = image.data() + (size_t)2 * real_off;
-        for (size_t j = 0; j < td.ids.size(); ++j) {
-          const Client &c = b->clients[td.ids[j]];
-          t.out_off[j] = c.out_off;
-          t.incr[j] = make_float2(c.incr[0], c.incr[1]);
-          for (uint32_t i = 0; i < cs.T; ++i) {
-            dst[((size_t)i * ct + j) * 2] = c.rt[2 * i];
-            dst[((size_t)i * ct + j) * 2 + 1] = c.rt[2 * i + 1];
-          }
-        }
-      }
-    }
-    // ---- spare waves for the NCO riders (xl_kernels.hip): groups with fewer tiles than the launch has waves.  The
-    // launch that carries the role (the first one with groups) gets a spare wave by splitting its last full group
-    // into 3 + 1 tiles when it has none and the engine is big enough for the balance to matter.
-    {
-      bool first = true;
-      for (int lq = 0; lq < XL_NLAUNCH; ++lq) {
-        Launch &L = Ls[lq];
-        if (L.groups.empty()) continue;
-        uint32_t idle = 0;
-        for (const XlGroup &g : L.groups) idle += (uint32_t)L.nw - g.ntiles;
-        const uint32_t kest = b->max_samples / L.groups[0].D + 1;
-        if (first && idle == 0 && b->riders && L.nw == XL_NW_MAX &&
-            xl_riders_window((L.groups.size() + 1) * ((kest + 63) / 64), L.nw, L.groups[0].Tpad, L.ct, kest, L.lds,
-                             b->riders_min_wgs)) {
-          XlGroup &last = L.groups.back();
-          XlGroup extra = last;
-          extra.ntiles = 1;
-          extra.tiles[0] = last.tiles[XL_NW_MAX - 1];
-          last.ntiles = XL_NW_MAX - 1;
-          L.groups.push_back(extra);
-        }
-        // (riders are only used in one-round launches -- xl_riders_window -- where every workgroup is dispatched within
-        // ~10 us of the start, so the groups with spare waves can stay where they are: last, which suits the tail)
-        idle = 0;
-        for (XlGroup &g : L.groups) {
-          g.idle_before = idle;
-          idle += (uint32_t)L.nw - g.ntiles;
-        }
-        L.idle_waves = idle;
-        first = false;
-      }
-    }
-    for (int lq = 0; lq < XL_NLAUNCH; ++lq) {
-        Launch &L = Ls[lq];
-      L.ota = 64;
-      if (L.lds > 160 * 1024) {  // huge decimation: fewer active lanes per wave so that the window image fits
-        for (L.ota = 32; L.ota >= 8; L.ota >>= 1) {
-          size_t need = 0;
-          for (const XlGroup &g : L.groups) need = std::max(need, xl_fir_lds_bytes_ota(g.D, g.Tpad, L.ota));
-          if (need <= 160 * 1024) {
-            L.lds = need;
-            break;
-          }
-        }
-        if (L.ota < 8) return -EINVAL;  // (add_client already refused such a shape)
-      }
-    }
-
-    return 0;
-  };
-
-  // ---- classes that take the polyphase overlap-save path in optimized mode: many clients (its lanes are client
-  // columns and its cost per client does not depend on the tap count) with a filter long enough to be worth it
-  std::vector<bool> all_cls(members.size(), true), rest_cls(members.size(), true);
-  for (size_t k = 0; k < members.size(); ++k) {
-    const ClassState &cs = b->classes[k];
-    const uint32_t A = (cs.T + cs.D - 1) / cs.D;
-    // transform length: the mix launch streams D x M branch-spectrum values per client and block from HBM, which is
-    // what bounds it with many clients; M = 128 halves that for ~5-10 % more arithmetic (valid outputs per segment
-    // M - A + 1) while the filter is short against the segment.  Measured at D = 42, 505 taps: x1.17 at 4096 clients,
-    // x1.08 at 2048, x1.015 at 1024, x0.99 at 512 and below (twice the forward transforms, nothing to save yet).
-    const uint32_t M = A > 64 ? 256u : (b->poly_m ? b->poly_m : (A <= 32 && members[k].size() >= 768 ? 128u : 256u));
-    const bool fits = A >= 2 && A <= M / 2 && cs.D <= 504;  // (the mix kernel stages D rows of 128 bytes in <= 64 KB of LDS)
-    const bool pays = members[k].size() >= b->poly_min_clients && 2 * cs.T >= 9 * cs.D;  // crossover ~4.5 taps per branch
-    if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
-    PolyClass pc;
-    pc.cls = (uint32_t)k;
-    pc.D = cs.D;
-    pc.Dpad = xl_roundup(cs.D, XLP_BSTEP);
-    pc.T = cs.T;
-    pc.A = A;
-    pc.M = M;
-    pc.V = M - A + 1;
-    pc.ncols = (uint32_t)members[k].size();
-    pc.ncg = (pc.ncols + XLP_COLS - 1) / XLP_COLS;
-    pc.nseg_cap = (b->max_samples / cs.D + 1 + pc.V - 1) / pc.V;
-    b->poly.push_back(pc);
-    rest_cls[k] = false;
-  }
   {
-    int rc = build_launches(b->launches, all_cls);
-    if (rc == 0 && !b->poly.empty()) rc = build_launches(b->launches_rest, rest_cls);
+    int rc = xl_build_launches(b, b->launches, b->classes, big_h, &image);
+    if (rc == 0 && !b->poly.empty()) rc = xl_build_launches(b, b->launches_rest, b->classes_rest, big_h, &image);
     if (rc != 0) return rc;
   }
 
@@ -639,7 +746,7 @@ static int xl_batch_plan(xlating_batch *b) {
       b->phase_run_cap = b->phase_cap;
     }
     for (PolyClass &pc : b->poly) {
-      const std::vector<int> &m = members[pc.cls];
+      const std::vector<int> &m = pc.members;
       const size_t rows = (size_t)pc.ncg * pc.Dpad + 1;  // (+1 x M rows: covers the XLP_BSTEP rows of tail padding)
       const uint32_t passes = (pc.nseg_cap + XLP_SEG - 1) / XLP_SEG;
       XL_TRY(hipMalloc((void **)&pc.d_R, rows * pc.M * XLP_COLS * sizeof(float2)));
@@ -647,30 +754,42 @@ static int xl_batch_plan(xlating_batch *b) {
       XL_TRY(hipMalloc((void **)&pc.d_X, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2)));
       XL_TRY(hipMemset(pc.d_X, 0, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2)));
       XL_TRY(hipMalloc((void **)&pc.d_Y, (size_t)pc.ncg * pc.nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
-      std::vector<uint32_t> col((size_t)pc.ncg * XLP_COLS, 0xFFFFFFFFu);
+      std::vector<XlpCol> cols((size_t)pc.ncg * XLP_COLS);
+      for (XlpCol &cc : cols) {
+        cc.out_off = 0xFFFFFFFFu;
+        cc.delta = 0;
+        cc.incr = make_float2(0.0f, 0.0f);
+      }
       std::vector<float> rt((size_t)pc.ncols * pc.T * 2);
-      std::vector<float> colinc(2 * col.size(), 0.0f);
+      std::vector<uint32_t> delta(pc.ncols);
       for (size_t j = 0; j < m.size(); ++j) {
         const Client &c = b->clients[m[j]];
-        col[j] = c.out_off;
-        colinc[2 * j] = c.incr[0];
-        colinc[2 * j + 1] = c.incr[1];
+        const uint32_t rem = (uint32_t)(c.consumed % pc.D);
+        cols[j].out_off = c.out_off;
+        cols[j].delta = delta[j] = (pc.rem_ref0 + pc.D - rem) % pc.D;
+        cols[j].incr = make_float2(c.incr[0], c.incr[1]);
         for (uint32_t i = 0; i < pc.T; ++i) {  // [tap][column]
           rt[((size_t)i * pc.ncols + j) * 2] = c.rt[2 * i];
           rt[((size_t)i * pc.ncols + j) * 2 + 1] = c.rt[2 * i + 1];
         }
       }
-      XL_TRY(hipMalloc((void **)&pc.d_col, col.size() * sizeof(uint32_t)));
-      XL_TRY(hipMemcpy(pc.d_col, col.data(), col.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      XL_TRY(hipMalloc((void **)&pc.d_colinc, colinc.size() * sizeof(float)));
-      XL_TRY(hipMemcpy(pc.d_colinc, colinc.data(), colinc.size() * sizeof(float), hipMemcpyHostToDevice));
+      XL_TRY(hipMalloc((void **)&pc.d_cols, cols.size() * sizeof(XlpCol)));
+      XL_TRY(hipMemcpy(pc.d_cols, cols.data(), cols.size() * sizeof(XlpCol), hipMemcpyHostToDevice));
       float2 *d_rt = nullptr;
+      uint32_t *d_delta = nullptr;
       XL_TRY(hipMalloc((void **)&d_rt, rt.size() * sizeof(float)));
-      hipError_t e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = xlp_launch_tables(d_rt, pc.ncols, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.ncg, pc.d_R, b->own_stream);
+      hipError_t e = hipMalloc((void **)&d_delta, delta.size() * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(d_delta, delta.data(), delta.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+      if (e == hipSuccess)
+        e = xlp_launch_tables(d_rt, d_delta, pc.ncols, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.ncg, pc.d_R, b->own_stream);
       if (e == hipSuccess) e = hipStreamSynchronize(b->own_stream);
       (void)hipFree(d_rt);
-      if (e != hipSuccess) goto fail;
+      if (d_delta) (void)hipFree(d_delta);
+      if (e != hipSuccess) {
+        xl_last_hip_error = e;
+        goto fail;
+      }
     }
   }
   if (b->out_total > b->out_alloc) {
@@ -689,28 +808,15 @@ static int xl_batch_plan(xlating_batch *b) {
   b->dirty = false;
   return 0;
 fail:
-  return -ENOMEM;
+  // a half-built plan must not be used: drop it and stay dirty, the next call plans again (or fails again)
+  xl_batch_free_plan(b);
+  b->dirty = true;
+  return xl_errno_of_last_hip_error();
 }
 
-// Per-class numbers of a block of S samples, from the classes' current stream positions.
-static uint32_t xl_batch_dyn(const xlating_batch *b, size_t S, XlDynArgs *dyn) {
-  memset(dyn, 0, sizeof(*dyn));
-  uint32_t maxK = 0;
-  for (size_t k = 0; k < b->classes.size(); ++k) {
-    const ClassState &cs = b->classes[k];
-    const uint32_t j0 = (cs.D - cs.rem) % cs.D;
-    const uint32_t K = S > j0 ? (uint32_t)((S - j0 + cs.D - 1) / cs.D) : 0u;
-    dyn->d[k].base = XL_HCAP - (cs.T - 1) + j0;
-    dyn->d[k].K = K;
-    dyn->d[k].zero_below = XL_HCAP - cs.hv;
-    maxK = std::max(maxK, K);
-  }
-  return maxK;
-}
-
-// Tabulate the phases of a block as a launch of its own on stream `st`: committed phases -> table[tab] + next
-// phases.  Only needed when no table was tabulated ahead (first block, changed block length, changed client set).
-static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab, hipStream_t st) {
+// Tabulate the phases of a call as a launch of its own on stream `st`: committed phases -> table[tab] + next
+// phases.  Only needed when no table was tabulated ahead (first call, changed call shape, changed client set).
+static hipError_t xl_batch_nco(xlating_batch *b, const XlPos pos, int tab, hipStream_t st) {
   hipError_t e;
   hipEvent_t n0 = nullptr, n1 = nullptr;
   if (b->timing) {
@@ -726,59 +832,95 @@ static hipError_t xl_batch_nco(xlating_batch *b, const XlDynArgs &dyn, int tab, 
     if (e != hipSuccess) return e;
   }
   e = xl_launch_nco_table(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[b->pcur], b->d_phase[b->pcur ^ 1],
-                          b->d_phtab[tab], dyn, b->nco_prio, st);
+                          b->d_phtab[tab], pos, 0xFFFFFFFFu, b->nco_prio, st);
   if (e != hipSuccess) return e;
   return n1 ? hipEventRecord(n1, st) : hipSuccess;
 }
 
-static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len, int mode, hipStream_t s) {
+#ifdef XL_TUNING
+static hipError_t xl_dump_trace(const char *path, const unsigned long long *d, size_t n, hipStream_t s) {
+  std::vector<unsigned long long> h(n);
+  hipError_t e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  e = hipMemcpy(h.data(), d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return e;
+  if (FILE *f = fopen(path, "wb")) {
+    fwrite(h.data(), sizeof(unsigned long long), n, f);
+    fclose(f);
+  }
+  return hipSuccess;
+}
+#endif
+
+// One call: G blocks of S samples each, contiguous at d_blocks.
+static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len, unsigned G, int mode, hipStream_t s) {
   const size_t S = input_len / 2;
-  if (S > b->max_samples || (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED)) return -EINVAL;
+  if (S > b->max_samples || G < 1 || G > b->gcap || (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED)) return -EINVAL;
+  if (b->poisoned) return -EIO;
+  // a client that was still inside its zero-history when the plan was built may be mature by now: it then joins
+  // the class of its grid (direct kernel) / its (D, T) class (polyphase) -- re-plan
+  if (!b->dirty && b->planned_immature > 0)
+    for (const Client &c : b->clients)
+      if (c.alive && !c.planned_mature && xl_mature(c)) {
+        b->dirty = true;
+        break;
+      }
+  if (!b->dirty && (uint64_t)b->trel + (uint64_t)S * G >= (1ull << 31)) b->dirty = true;  // re-base the classes' stream records
   if (b->dirty) {
     int rc = xl_batch_plan(b);
     if (rc != 0) return rc;
+  }
+  if (G > 1 && S < b->plan_maxD && !b->nco.empty()) {
+    XL_LOG_ERR("a call of %u blocks needs blocks of at least the largest decimation (%u samples); got %zu", G, b->plan_maxD, S);
+    return -EINVAL;
+  }
+  // Calls depend on each other through the engine's device state (history, phases, tables): a call on another
+  // stream than the previous one is ordered behind it.
+  if (s != b->last_stream) {
+    XL_TRY(hipEventRecord(b->dep_ev, b->last_stream));
+    XL_TRY(hipStreamWaitEvent(s, b->dep_ev, 0));
   }
   b->last_stream = s;
   b->fetched = false;
   if (b->nco.empty()) return 0;
 
-  const int p = (int)(b->nblk & 1);  // parity of this block: output buffer
-  const int hb = b->hcur, hn = b->hcur ^ 1;
-
-  const bool fuse = !b->exp_nofuse;  // tuning: XL_EXP_NOFUSE tabulates by a launch of its own before every block
-  bool nco_fused = false;
-  XlDynArgs dyn, next;
-  const uint32_t maxK = xl_batch_dyn(b, S, &dyn);
-  for (ClassState &cs : b->classes) {  // advance the stream positions past this block
-    cs.rem = (uint32_t)((cs.rem + S) % cs.D);
-    cs.hv = (uint32_t)std::min<uint64_t>((uint64_t)cs.hv + S, XL_HCAP);
-  }
-  for (Client &c : b->clients) {
-    if (!c.alive) continue;
-    c.last_K = dyn.d[c.cls].K;
-    c.consumed += S;
-  }
-
-  // ---- this block's phase table: tabulated ahead by the previous block's launch if the length guess was right
-  int tab;
-  if (b->spec_valid && b->spec_S == S) {
-    tab = b->spec_tab;
-  } else {
-    tab = b->spec_valid ? b->spec_tab : (b->tab ^ 1);
-    XL_TRY(xl_batch_nco(b, dyn, tab, s));
-  }
-  b->spec_valid = false;
-  b->pcur ^= 1;  // the phases written by that tabulation are now the committed ones
-  b->tab = tab;
-
-  (void)xl_batch_dyn(b, S, &next);  // per-class numbers of the NEXT block if it has the same length (the guess)
-
-  // ---- the fused FIR launch(es) on the caller's stream: window images from [d_hist[hb] | block], phases from
-  // table[tab] -> d_out[p]; the first launch also rolls the raw history into d_hist[hn] and tabulates
-  // table[tab ^ 1] for the next block
   {
+    const int p = (int)(b->ncalls & 1);  // parity of this call: output buffer
+    const int hb = b->hcur, hn = b->hcur ^ 1;
+    const uint32_t N = (uint32_t)(S * G);
+    XlPos pos;
+    pos.trel = b->trel;
+    pos.S = (uint32_t)S;
+    pos.G = G;
+    pos.pad = 0;
+#ifdef XL_TUNING
+    const bool fuse = !b->exp_nofuse;  // tuning: tabulate by a launch of its own before every call
+#else
+    const bool fuse = true;
+#endif
+    bool nco_fused = false;
+    // the most outputs any client produces in this call
+    uint32_t maxK = 0;
+    for (const DirectClass &cs : b->classes) maxK = std::max(maxK, xl_grid_dyn(cs.D, cs.T, cs.rem0, cs.hv0, pos).K);
+
+    // ---- this call's phase table: tabulated ahead by the previous call's launches if the shape guess was right
+    int tab;
+    int pcur = b->pcur;
+    if (b->spec_valid && b->spec_S == S && b->spec_G == G) {
+      tab = b->spec_tab;
+    } else {
+      tab = b->spec_valid ? b->spec_tab : (b->tab ^ 1);
+      XL_TRY(xl_batch_nco(b, pos, tab, s));
+    }
+    pcur ^= 1;  // the phases written by that tabulation are now the committed ones
+    b->spec_valid = false;  // (from here on a failure poisons the engine)
+    b->poisoned = true;
+
+    // ---- the launches on the caller's stream: window images from [d_hist[hb] | blocks], phases from table[tab] ->
+    // d_out[p]; the first launch also rolls the raw history into d_hist[hn], and the launches tabulate table[tab ^ 1]
+    // for the next call
     hipEvent_t f0 = nullptr, f1 = nullptr;
-    if (b->timing && maxK > 0 && b->nblk % b->timing_every == 0) {
+    if (b->timing && maxK > 0 && b->ncalls % b->timing_every == 0) {
       for (int i = 0; i < 2; ++i) {
         hipEvent_t ev;
         XL_TRY(xl_batch_timing_event(b, &ev));
@@ -788,8 +930,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
       f1 = b->ev[b->ev.size() - 1];
     }
     bool rolled = false;
-    // optimized mode: the polyphase classes leave the direct launches (tiny blocks stay direct: a segment is 256
-    // branch samples whatever the block holds)
+    // optimized mode: the polyphase classes leave the direct launches (tiny calls stay direct: a segment is 128 or 256
+    // branch samples whatever the call holds)
     const bool use_poly = mode == XL_MODE_OPTIMIZED && !b->poly.empty() && maxK >= 2 * XLP_M_MAX;
     Launch *const Ls = use_poly ? b->launches_rest : b->launches;
     if (maxK > 0) {
@@ -801,13 +943,15 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         memset(&a, 0, sizeof(a));
         a.in0 = b->d_hist[hb];
         a.n0 = XL_HCAP;
-        a.in1 = d_block;
-        a.n1 = (uint32_t)S;
+        a.in1 = d_blocks;
+        a.n1 = N;
         a.fmt = b->fmt;
+        a.pos = pos;
         a.groups = L.d_groups;
         a.ngroups = (uint32_t)L.groups.size();
         a.ota = L.ota;
-        a.xtiles = (maxK + L.ota - 1) / L.ota;
+        const uint32_t Kl = (N + L.minD - 1) / L.minD;  // (an upper bound of the launch's largest output count)
+        a.xtiles = (std::min(Kl, maxK) + L.ota - 1) / L.ota;
         // wave-priority segments pay when the launch is about one round of workgroups, and cost when new
         // workgroups keep arriving (they would outrank nearly finished ones): enable up to two rounds
         const size_t wgs = (size_t)a.ngroups * a.xtiles;
@@ -820,7 +964,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
         if (!rolled) {
           a.hist_out = b->d_hist[hn];
           a.hist_units = XL_HCAP * (b->bps / 2);
-          a.block_units = (uint32_t)S * (b->bps / 2);
+          a.block_units = N * (b->bps / 2);
           rolled = true;
           if (fuse) {
             a.nco_clients = b->d_nco;
@@ -835,14 +979,15 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
               a.nco_wpw = std::max<uint32_t>(1, std::min<uint32_t>(b->nco_wpw, (uint32_t)L.nw));
               a.nco_blocks = (a.nco_nclients + XL_NCO_LANES * a.nco_wpw - 1) / (XL_NCO_LANES * a.nco_wpw);
             }
-            a.nco_state_in = b->d_phase[b->pcur];
-            a.nco_state_out = b->d_phase[b->pcur ^ 1];
+            a.nco_state_in = b->d_phase[pcur];
+            a.nco_state_out = b->d_phase[pcur ^ 1];
             a.nco_tab = b->d_phtab[tab ^ 1];
             nco_fused = true;
           }
         }
+#ifdef XL_TUNING
         size_t trace_n = 0;
-        if (b->exp_trace) {  // tuning only
+        if (b->exp_trace) {
           trace_n = ((size_t)a.nco_blocks + (size_t)8 * ((a.ngroups * a.xtiles + 7) / 8)) * XL_NW_MAX * 6;
           if (trace_n > b->trace_cap) {
             if (b->d_trace) (void)hipFree(b->d_trace);
@@ -853,55 +998,57 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
           XL_TRY(hipMemsetAsync(b->d_trace, 0, trace_n * sizeof(unsigned long long), s));
           a.trace = b->d_trace;
         }
-        XL_TRY(xl_launch_fir(L.ct, mode, L.nw, a, dyn, next, L.lds, s));
-        if (b->exp_trace) {
-          std::vector<unsigned long long> h(trace_n);
-          XL_TRY(hipStreamSynchronize(s));
-          XL_TRY(hipMemcpy(h.data(), b->d_trace, trace_n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-          if (FILE *f = fopen(b->exp_trace, "wb")) {
-            fwrite(h.data(), sizeof(unsigned long long), trace_n, f);
-            fclose(f);
-          }
-        }
+#endif
+        XL_TRY(xl_launch_fir(L.ct, mode, L.nw, a, L.lds, s));
+#ifdef XL_TUNING
+        if (b->exp_trace) XL_TRY(xl_dump_trace(b->exp_trace, b->d_trace, trace_n, s));
+#endif
       }
       if (use_poly) {
         for (PolyClass &pc : b->poly) {
-          const uint32_t K = dyn.d[pc.cls].K;
-          if (K == 0) continue;
           XlpArgs pa;
           memset(&pa, 0, sizeof(pa));
           if (!rolled) {  // the forward launch also rolls the raw history
             pa.hist_out = b->d_hist[hn];
             pa.hist_units = XL_HCAP * (b->bps / 2);
-            pa.block_units = (uint32_t)S * (b->bps / 2);
+            pa.block_units = N * (b->bps / 2);
             pa.roll_blocks = 32;
             rolled = true;
           }
           pa.in0 = b->d_hist[hb];
           pa.n0 = XL_HCAP;
-          pa.in1 = d_block;
-          pa.n1 = (uint32_t)S;
+          pa.in1 = d_blocks;
+          pa.n1 = N;
           pa.fmt = (uint32_t)b->fmt;
-          pa.cls = pc.cls;
+          pa.pos = pos;
+          // the class's shared grid in this call (xl_grid.h): one D-step ahead of the reference client's output 0
+          const XlDyn dref = xl_grid_dyn(pc.D, pc.T, pc.rem_ref0, pc.hv0, pos);
+          pa.j0_ref = dref.j0;
+          pa.base = dref.base - pc.D;
+          pa.Kq = xl_merge_points(pc.D, pos);
+          pa.zero_below = dref.zero_below;  // (0 for mature members: nothing below their join points is weighted)
           pa.D = pc.D;
           pa.Dpad = pc.Dpad;
           pa.T = pc.T;
           pa.A = pc.A;
           pa.V = pc.V;
           pa.M = pc.M;
-          pa.nseg = (K + pc.V - 1) / pc.V;
+          pa.nseg = (pa.Kq + pc.V - 1) / pc.V;
           pa.nseg_cap = pc.nseg_cap;
+          if (pa.nseg > pa.nseg_cap) {
+            XL_LOG_ERR("internal: %u segments exceed the plan's capacity %u", pa.nseg, pa.nseg_cap);
+            goto fail;
+          }
           pa.ncg = pc.ncg;
           pa.exp = b->poly_exp;
           pa.W = b->d_W;
           pa.X = pc.d_X;
           pa.R = pc.d_R;
           pa.Y = pc.d_Y;
-          pa.col_out = pc.d_col;
-          pa.col_incr = pc.d_colinc;
+          pa.cols = pc.d_cols;
           pa.phtab = b->d_phtab[tab];
           pa.out = b->d_out[p];
-          // the NEXT block's phase recurrence rides in these three launches as three slices (a direct launch
+          // the NEXT call's phase recurrence rides in these three launches as three slices (a direct launch
           // above carries all of it if there is one)
           const bool carry = fuse && !nco_fused;
           if (carry) {
@@ -912,7 +1059,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             pa.nco_prio = b->nco_prio;
             pa.nco_k0 = 0;
             pa.nco_k1 = b->poly_slice1;
-            pa.nco_state_src = b->d_phase[b->pcur];
+            pa.nco_state_src = b->d_phase[pcur];
             pa.nco_state_dst = b->d_phase_run;
           }
           hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -923,7 +1070,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
             }
             XL_TRY(hipEventRecord(pe[0], s));
           }
-          XL_TRY(xlp_launch_forward(pa, dyn, next, s));
+          XL_TRY(xlp_launch_forward(pa, s));
           if (pe[1]) XL_TRY(hipEventRecord(pe[1], s));
           pa.roll_blocks = 0;
           if (carry) {
@@ -934,78 +1081,95 @@ static int xl_batch_run(xlating_batch *b, const void *d_block, size_t input_len,
               pa.nco_skip_at = b->mix_skip_at ? b->mix_skip_at : 1024;
               pa.nco_skip = pa.nco_blocks;
             }
+#ifdef XL_TUNING
             if (b->poly_exp & 4u) pa.nco_tab = nullptr;  // tuning: the mix launch's slice stores nothing (WRONG results)
             if (b->poly_exp & 8u) pa.nco_blocks = 0;     // tuning: the mix launch carries no slice at all (WRONG results)
+#endif
           }
+#ifdef XL_TUNING
           const bool trace_inv = b->poly_trace && getenv("XL_EXP_POLY_TRACE_INV");  // (the inverse launch instead)
-          if (b->poly_trace && !trace_inv) {  // tuning: timeline of the mix launch (work waves' span + each NCO wave)
+          if (b->poly_trace && !trace_inv) {  // timeline of the mix launch (work waves' span + each NCO wave)
             if (!b->d_ptrace) XL_TRY(hipMalloc((void **)&b->d_ptrace, 32768 * sizeof(unsigned long long)));
             XL_TRY(hipMemsetAsync(b->d_ptrace, 0, 32768 * sizeof(unsigned long long), s));
             pa.trace = b->d_ptrace;
           }
-          XL_TRY(xlp_launch_mix(pa, next, s));
+#endif
+          XL_TRY(xlp_launch_mix(pa, s));
           pa.nco_skip = 0;
+#ifdef XL_TUNING
           if (b->poly_trace && !trace_inv) {
             pa.trace = nullptr;
-            std::vector<unsigned long long> h(32768);
-            XL_TRY(hipStreamSynchronize(s));
-            XL_TRY(hipMemcpy(h.data(), b->d_ptrace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            if (FILE *f = fopen(b->poly_trace, "wb")) {  // raw dump; tools/poly_trace.py reads it
-              fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
-              fclose(f);
-            }
+            XL_TRY(xl_dump_trace(b->poly_trace, b->d_ptrace, 32768, s));
           }
+#endif
           if (pe[2]) XL_TRY(hipEventRecord(pe[2], s));
           if (carry) {
             pa.nco_tab = b->d_phtab[tab ^ 1];
             pa.nco_blocks = (pa.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
             pa.nco_k0 = b->poly_slice2;
             pa.nco_k1 = 65536;
-            if (b->inv_skip_at > 0) {  // tuning: XL_EXP_INVSKIP=<position>
+            if (b->inv_skip_at > 0) {
               pa.nco_skip_at = b->inv_skip_at;
               pa.nco_skip = pa.nco_blocks;
             }
-            pa.nco_state_dst = b->d_phase[b->pcur ^ 1];
+            pa.nco_state_dst = b->d_phase[pcur ^ 1];
             nco_fused = true;
           }
+#ifdef XL_TUNING
           if (trace_inv) {
             if (!b->d_ptrace) XL_TRY(hipMalloc((void **)&b->d_ptrace, 32768 * sizeof(unsigned long long)));
             XL_TRY(hipMemsetAsync(b->d_ptrace, 0, 32768 * sizeof(unsigned long long), s));
             pa.trace = b->d_ptrace;
           }
-          XL_TRY(xlp_launch_inverse(pa, dyn, next, s));
+#endif
+          XL_TRY(xlp_launch_inverse(pa, s));
+#ifdef XL_TUNING
           if (trace_inv) {
             pa.trace = nullptr;
-            std::vector<unsigned long long> h(32768);
-            XL_TRY(hipStreamSynchronize(s));
-            XL_TRY(hipMemcpy(h.data(), b->d_ptrace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            if (FILE *f = fopen(b->poly_trace, "wb")) {
-              fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
-              fclose(f);
-            }
+            XL_TRY(xl_dump_trace(b->poly_trace, b->d_ptrace, 32768, s));
           }
+#endif
           if (pe[3]) XL_TRY(hipEventRecord(pe[3], s));
         }
       }
       if (f1) XL_TRY(hipEventRecord(f1, s));
     }
-    if (!rolled)  // no client produced output in this block (tiny block): roll the history on its own
-      XL_TRY(xl_launch_update_history(b->d_hist[hb], d_block, XL_HCAP, (uint32_t)S, b->bps, b->d_hist[hn], s));
-  }
-  b->ocur = p;
-  b->hcur = hn;
-  b->nblk++;
+    if (!rolled)  // no client produced output in this call (tiny block): roll the history on its own
+      XL_TRY(xl_launch_update_history(b->d_hist[hb], d_blocks, XL_HCAP, N, b->bps, b->d_hist[hn], s));
 
-  // ---- the NEXT block's phases, guessing it has the same length, were tabulated inside the FIR launch above;
-  // without one (tiny block, or the tuning switch) the next call tabulates for itself
-  if (nco_fused) {
-    b->spec_valid = true;
-    b->spec_S = S;
-    b->spec_tab = tab ^ 1;
+    // ---- everything is enqueued: commit the host-side state of the call
+    b->poisoned = false;
+    for (Client &c : b->clients) {
+      if (!c.alive) continue;
+      const uint32_t j0 = (uint32_t)((c.D - c.consumed % c.D) % c.D);
+      c.last_Kg.resize(G);
+      uint32_t prev = 0;
+      for (uint32_t g = 1; g <= G; ++g) {
+        const uint32_t ms = xl_grid_mstart(j0, c.D, (uint32_t)S, g);
+        c.last_Kg[g - 1] = ms - prev;
+        prev = ms;
+      }
+      c.last_K = prev;
+      c.consumed += N;
+    }
+    b->trel += N;
+    b->pcur = pcur;
+    b->tab = tab;
+    b->ocur = p;
+    b->hcur = hn;
+    b->ncalls++;
+    // ---- the NEXT call's phases, guessing it has the same shape, were tabulated inside the launches above;
+    // without them (tiny call, or the tuning switch) the next call tabulates for itself
+    if (nco_fused) {
+      b->spec_valid = true;
+      b->spec_S = (uint32_t)S;
+      b->spec_G = G;
+      b->spec_tab = tab ^ 1;
+    }
   }
   return 0;
 fail:
-  return -EIO;
+  return b->poisoned ? -EIO : xl_errno_of_last_hip_error();
 }
 
 extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
@@ -1020,9 +1184,12 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
     if (!L.groups.empty()) d += " h" + std::to_string(L.ct) + " x " + std::to_string(L.groups.size()) + " groups";
   d += " | polyphase:";
   if (b->poly.empty()) d += " none";
-  for (const PolyClass &pc : b->poly)
-    d += " cls" + std::to_string(pc.cls) + " D" + std::to_string(pc.D) + " T" + std::to_string(pc.T) + " cols" +
+  for (size_t k = 0; k < b->poly.size(); ++k) {
+    const PolyClass &pc = b->poly[k];
+    d += " cls" + std::to_string(k) + " D" + std::to_string(pc.D) + " T" + std::to_string(pc.T) + " cols" +
          std::to_string(pc.ncols) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
+    if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
+  }
   if (!b->poly.empty()) {
     d += " | optimized-mode direct:";
     bool any = false;
@@ -1039,34 +1206,51 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
   return (int)len;
 }
 
-extern "C" int xlating_batch_process_device(xlating_batch *b, const void *d_input, size_t input_len, int mode,
-                                            void *hip_stream) {
+extern "C" int xlating_batch_process_device_group(xlating_batch *b, const void *d_input, size_t input_len,
+                                                  unsigned nblocks, int mode, void *hip_stream) {
   if (b == nullptr || (d_input == nullptr && input_len > 0)) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
   // NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is by default): pass it through
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-  return xl_batch_run(b, d_input, input_len, mode, s);
+  return xl_batch_run(b, d_input, input_len, nblocks, mode, s);
 }
 
-extern "C" int xlating_batch_process_host(xlating_batch *b, const void *input, size_t input_len, int mode) {
+extern "C" int xlating_batch_process_device(xlating_batch *b, const void *d_input, size_t input_len, int mode,
+                                            void *hip_stream) {
+  return xlating_batch_process_device_group(b, d_input, input_len, 1, mode, hip_stream);
+}
+
+extern "C" int xlating_batch_process_host_group(xlating_batch *b, const void *input, size_t input_len, unsigned nblocks,
+                                                int mode) {
   if (b == nullptr || (input == nullptr && input_len > 0)) return -EINVAL;
   const size_t S = input_len / 2;
-  if (S > b->max_samples) return -EINVAL;
+  if (S > b->max_samples || nblocks < 1 || nblocks > b->gcap) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
   hipStream_t s = b->own_stream;
-  // the pinned staging buffer and the device block buffer are reused: wait until the previous block is consumed
+  // the pinned staging buffer and the device block buffer are reused: wait until the previous call is consumed
   xl_batch_sync_all(b);
-  const size_t bytes = S * b->bps;
+  const size_t bytes = S * nblocks * b->bps;
   if (bytes) {
     memcpy(b->h_block, input, bytes);
     if (hipMemcpyAsync(b->d_block, b->h_block, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
   }
-  return xl_batch_run(b, b->d_block, input_len, mode, s);
+  return xl_batch_run(b, b->d_block, input_len, nblocks, mode, s);
+}
+
+extern "C" int xlating_batch_process_host(xlating_batch *b, const void *input, size_t input_len, int mode) {
+  return xlating_batch_process_host_group(b, input, input_len, 1, mode);
 }
 
 extern "C" size_t xlating_batch_output_len(const xlating_batch *b, int id) {
   if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive) return 0;
   return b->clients[id].last_K;
+}
+
+extern "C" size_t xlating_batch_output_len_block(const xlating_batch *b, int id, unsigned block) {
+  if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive ||
+      block >= b->clients[id].last_Kg.size())
+    return 0;
+  return b->clients[id].last_Kg[block];
 }
 
 extern "C" int xlating_batch_sync(xlating_batch *b) {
@@ -1123,8 +1307,8 @@ extern "C" int xlating_batch_client_phase(xlating_batch *b, int id, float *re, f
   if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
   xl_batch_sync_all(b);
-  // the look-ahead NCO launch has already produced the phases AFTER the next block into d_phase[pcur^1];
-  // the committed ones (after the latest processed block) are d_phase[pcur]
+  // the look-ahead NCO role has already produced the phases AFTER the next call into d_phase[pcur^1];
+  // the committed ones (after the latest processed call) are d_phase[pcur]
   float2 ph;
   if (hipMemcpy(&ph, b->d_phase[b->pcur] + id, sizeof(ph), hipMemcpyDeviceToHost) != hipSuccess) return -EIO;
   *re = ph.x;
@@ -1204,7 +1388,7 @@ extern "C" int xlating_batch_timing_read(xlating_batch *b, double *fir_ms_total,
   int rc = xl_batch_drain_events(b);
   if (rc != 0) return rc;
   if (fir_ms_total) *fir_ms_total = b->fir_ms;
-  // the NCO launches are not one-to-one with blocks (one extra look-ahead): report the per-block equivalent
+  // the NCO launches are not one-to-one with calls (one extra look-ahead): report the per-call equivalent
   if (nco_ms_total) *nco_ms_total = b->timed_nco ? b->nco_ms / b->timed_nco * b->timed_launches : 0.0;
   const int n = b->timed_launches;
   if (reset) {

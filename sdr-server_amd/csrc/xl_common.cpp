@@ -1,6 +1,7 @@
 // xl_common.cpp -- HIP device probing and the exported identification strings.
 #include "xl_common.h"
 
+#include <errno.h>
 #include <mutex>
 #include <string.h>
 
@@ -10,6 +11,23 @@
 // Reference: src/xlating.c:145,148,156,268 export one of "AVX" / "ARM NEON" / "Not detected" /
 // "Manually turned off"; src/main.c:23 and test/perf_xlating.c:15 print it.
 extern "C" const char *SIMD_STATUS = "HIP gfx950";
+
+thread_local hipError_t xl_last_hip_error = hipSuccess;
+
+int xl_errno_of_last_hip_error(void) {
+  switch (xl_last_hip_error) {
+    case hipErrorOutOfMemory:
+      return -ENOMEM;
+    case hipErrorNoDevice:
+    case hipErrorInvalidDevice:
+    case hipErrorNoBinaryForGpu:
+    case hipErrorInvalidDeviceFunction:
+    case hipErrorSharedObjectInitFailed:
+      return -ENODEV;
+    default:
+      return -EIO;
+  }
+}
 
 static std::once_flag g_probe_once;
 static int g_device_count = 0;

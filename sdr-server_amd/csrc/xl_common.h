@@ -14,10 +14,16 @@
     fprintf(stderr, "\n");              \
   } while (0)
 
+// The HIP error of the latest failed XL_TRY of this thread, and its errno: allocation failures -> -ENOMEM, no
+// usable device / no gfx950 code object -> -ENODEV, anything else -> -EIO.
+extern thread_local hipError_t xl_last_hip_error;
+int xl_errno_of_last_hip_error(void);
+
 #define XL_TRY(expr)                                                                       \
   do {                                                                                     \
     hipError_t xl_e_ = (expr);                                                             \
     if (xl_e_ != hipSuccess) {                                                             \
+      xl_last_hip_error = xl_e_;                                                           \
       XL_LOG_ERR("%s failed: %s (%s:%d)", #expr, hipGetErrorString(xl_e_), __FILE__, __LINE__); \
       goto fail;                                                                           \
     }                                                                                      \

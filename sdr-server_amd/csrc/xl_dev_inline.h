@@ -127,19 +127,28 @@ XL_DEV v2f xl_nco_next(const v2f p, const v2f inc) {
   return r;
 }
 
-// The work of one lane = one client: advance the recurrence over the outputs [kb, ke) of a block of K (kb a multiple
-// of 2 * XL_PH_STRIDE unless kb == ke), tabulating every XL_PH_STRIDE-th phase (entry (out_off + m) / XL_PH_STRIDE), reading
-// the running phase from state_src[slot]; the slice that ends the block (`final`) renormalises and stores the
-// post-block phase to state_dst[slot], any other slice stores the running phase there.
-XL_DEV void xl_nco_client_slice(const XlNcoClient k, const uint32_t K, const uint32_t kb, const uint32_t ke,
-                                const bool final, const float2 *state_src, float2 *state_dst,
-                                float2 *__restrict__ tab, unsigned long long *stamp = nullptr) {
+// xlating.c:73 `phase /= hypotf(re, im)`: glibc's hypotf evaluates sqrt(x*x + y*y) in double and narrows; restated with
+// IEEE double operations (equal to libm on 2e8 inputs, tests/test_oracle.py) and correctly rounded float divisions.
+XL_DEV v2f xl_nco_renorm(const v2f p) {
+  const double mag2 = (double)p.x * (double)p.x + (double)p.y * (double)p.y;
+  const float mag = (float)__dsqrt_rn(mag2);
+  return (v2f){p.x / mag, p.y / mag};
+}
+
+// The work of one lane = one client: advance the recurrence over the outputs [kb, ke) of a call of bnd.K outputs in
+// bnd.G blocks, tabulating every XL_PH_STRIDE-th phase (entry (out_off + m) / XL_PH_STRIDE = phase of output m, m on
+// the call's output index) and renormalising at every block end inside the range (xlating.c:73; the table entry of a
+// block's first output is the renormalised phase).  The running phase comes from state_src[slot] and goes to
+// state_dst[slot]: a slice that ends the call (ke == bnd.K) leaves the committed post-call phase there.
+XL_DEV void xl_nco_client_chain(const XlNcoClient k, const XlBnd bnd, const uint32_t kb, const uint32_t ke,
+                                const float2 *state_src, float2 *state_dst, float2 *__restrict__ tab,
+                                unsigned long long *stamp = nullptr) {
   v2f p = {state_src[k.slot].x, state_src[k.slot].y};
   if (stamp) {  // tuning: when did the running phase arrive, when did the recurrence end
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp[0] = wall_clock64();
   }
-  if (K == 0) {  // no output possible in this block: the reference leaves the phase untouched (xlating.c:58)
+  if (bnd.K == 0u) {  // no output possible in this call: the reference leaves the phase untouched (xlating.c:58)
     state_dst[k.slot] = make_float2(p.x, p.y);
     return;
   }
@@ -147,52 +156,67 @@ XL_DEV void xl_nco_client_slice(const XlNcoClient k, const uint32_t K, const uin
   v2f *__restrict__ o = reinterpret_cast<v2f *>(tab) + (k.out_off >> XL_PH_SHIFT);  // out_off = 0 mod 2 * XL_PH_STRIDE: 16-byte pairs
   v4f *__restrict__ o4 = reinterpret_cast<v4f *>(o);
   uint32_t m = kb;
-  // 2 * XL_PH_STRIDE steps and ONE store (two entries) per trip
-  for (; m + 2u * XL_PH_STRIDE <= ke; m += 2u * XL_PH_STRIDE) {
-    const v2f q0 = p;
-    for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) p = xl_nco_next(p, inc);
+  while (m < ke) {
+    const uint32_t nb = xl_bnd_next(bnd, m);  // end of the block output m lies in
+    const uint32_t me = nb < ke ? nb : ke;
+    for (; m < me && (m & (2u * XL_PH_STRIDE - 1u)) != 0u; ++m) {  // head: up to the next pair boundary
+      if (tab != nullptr && (m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
+      p = xl_nco_next(p, inc);
     }
-    const v2f q1 = p;
-    for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
+    // 2 * XL_PH_STRIDE steps and ONE store (two entries) per trip
+    for (; m + 2u * XL_PH_STRIDE <= me; m += 2u * XL_PH_STRIDE) {
+      const v2f q0 = p;
+      for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) p = xl_nco_next(p, inc);
+        for (int j = 0; j < 16; ++j) p = xl_nco_next(p, inc);
+      }
+      const v2f q1 = p;
+      for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) p = xl_nco_next(p, inc);
+      }
+      if (tab != nullptr) o4[m >> (XL_PH_SHIFT + 1u)] = (v4f){q0.x, q0.y, q1.x, q1.y};
     }
-    if (tab != nullptr) o4[m >> (XL_PH_SHIFT + 1u)] = (v4f){q0.x, q0.y, q1.x, q1.y};  // (null: tuning experiment)
-  }
-  for (; m < ke; ++m) {
-    if (tab != nullptr && (m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
-    p = xl_nco_next(p, inc);
+    for (; m < me; ++m) {
+      if (tab != nullptr && (m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
+      p = xl_nco_next(p, inc);
+    }
+    if (me == nb) p = xl_nco_renorm(p);  // a block of the call ends here
   }
   if (stamp) stamp[1] = wall_clock64();
-  if (!final) {
-    state_dst[k.slot] = make_float2(p.x, p.y);
-    return;
-  }
-  const float pr = p.x, pi = p.y;
-  const double mag2 = (double)pr * (double)pr + (double)pi * (double)pi;
-  const float mag = (float)__dsqrt_rn(mag2);
-  state_dst[k.slot] = make_float2(pr / mag, pi / mag);
+  state_dst[k.slot] = make_float2(p.x, p.y);
 }
 
-// Consumer side, one lane: the `count` phases of outputs m0 .. m0 + count - 1 of the client whose table row is `row`
-// (entry pointer = table + out_off / XL_PH_STRIDE), written to dst[0 .. count) (LDS).  m0 need not be a multiple of the
-// stride: the tabulated phase of the entry below m0 is first advanced m0 % XL_PH_STRIDE steps.  Same three IEEE operations as the producer.
-XL_DEV void xl_phase_expand(const v2f *__restrict__ row, const uint32_t m0, const v2f inc, v2f *__restrict__ dst,
-                            const uint32_t count) {
-  v2f p = row[m0 >> XL_PH_SHIFT];
-  for (uint32_t j = m0 & (XL_PH_STRIDE - 1u); j > 0u; --j) p = xl_nco_next(p, inc);
-  for (uint32_t i = 0; i < count; ++i) {
-    dst[i] = p;
+// Block boundaries of client k in a call at stream position pos (xl_grid.h); explicit_K != 0xFFFFFFFF: the
+// single-filter path's one-block call of explicit_K outputs.
+XL_DEV XlBnd xl_nco_bnd(const XlNcoClient k, const XlPos pos, const uint32_t explicit_K) {
+  XlBnd b;
+  if (explicit_K != 0xFFFFFFFFu) {
+    b.j0 = 0u, b.D = k.D, b.S = 0xFFFFFFFFu, b.G = 1u, b.K = explicit_K;
+  } else {
+    const XlDyn d = xl_grid_dyn(k.D, 1u, k.rem0, 0u, pos);
+    b.j0 = d.j0, b.D = k.D, b.S = pos.S, b.G = pos.G, b.K = d.K;
+  }
+  return b;
+}
+
+// Consumer side, one lane: the phases of outputs m0 .. m0 + count - 1 of a client, handed to store(i, phase), i < count.
+// `p` is the tabulated phase of output mt = m0 rounded down to the table stride (the caller loaded it, early); the
+// phases in between follow with the producer's own three IEEE operations, renormalised where a block of the call
+// ends (bit-identical to the producer's chain).
+template <class Store>
+XL_DEV void xl_phase_walk(v2f p, const uint32_t m0, const uint32_t count, const v2f inc, const XlBnd bnd, Store store) {
+  uint32_t m = m0 & ~(XL_PH_STRIDE - 1u);
+  uint32_t nb = xl_bnd_next(bnd, m);
+  const uint32_t end = m0 + count;
+  for (; m < end; ++m) {
+    if (m >= m0) store(m - m0, p);
     p = xl_nco_next(p, inc);
+    if (m + 1u == nb) {
+      p = xl_nco_renorm(p);
+      nb = xl_bnd_next(bnd, m + 1u);
+    }
   }
-}
-
-// whole block
-XL_DEV void xl_nco_client(const XlNcoClient k, const uint32_t K, const float2 *state_in, float2 *state_out,
-                          float2 *__restrict__ tab) {
-  xl_nco_client_slice(k, K, 0u, K, true, state_in, state_out, tab);
 }
 
 #endif  // XL_DEV_INLINE_H_

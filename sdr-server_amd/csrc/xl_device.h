@@ -8,20 +8,23 @@
 //   tile     up to CT clients that share (D, T, window grid) -> one wavefront's work, taps interleaved
 //            [tap i][client c] so that one scalar load fetches tap i of every client of the tile
 //   group    up to NW (<= XL_NW_MAX) tiles of the same class -> one workgroup; its waves share one LDS window image
-//   class    all groups sharing (D, T, stream offset mod D, valid-history length); only the per-block
-//            numbers of a class (window origin, output count) change from block to block and travel
-//            as kernel arguments, everything else is resident in HBM.
+//   class    all groups sharing (D, T, stream offset mod D, valid-history length).  A class's per-call numbers
+//            (window origin, output count) follow from its plan-time record and the stream position of the call
+//            (XlPos, 16 bytes of kernel arguments): any number of classes, nothing uploaded per call (xl_grid.h).
+//   call     G >= 1 consecutive blocks of S samples handled by one set of launches ("group" of blocks); the NCO
+//            phase is renormalised at every block end exactly as G successive reference calls would.
 #ifndef XL_DEVICE_H_
 #define XL_DEVICE_H_
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "xl_grid.h"
+
 #define XL_NW_MAX 4      // waves (tiles) per workgroup: one per SIMD (5..7 measured slower: unbalanced SIMDs; 8 ties)
 #define XL_NW_DEFAULT 4
 #define XL_CT_MAX 12     // most clients per tile (register-tile height: 1, 2, 4, 8, 9, 10 or 12)
 #define XL_TAP_UNROLL 4  // taps per inner-loop step for heights <= 8 and 12; heights 9, 10 step by 6 (xl_tap_step)
-#define XL_MAX_CLASSES 48
 #define XL_ROLL_BLOCKS 16  // workgroups of a FIR launch that also roll the raw history
 
 enum { XLF_CU8 = 0, XLF_CS8 = 1, XLF_CS16 = 2, XLF_CF32 = 3 };
@@ -45,31 +48,21 @@ struct XlTile {
 
 struct XlGroup {
   uint32_t D, T, Tpad;
-  uint32_t cls;                  // index into XlDynArgs::d
+  uint32_t rem0;                 // class record at plan time: consumed mod D (xl_grid_dyn)
   uint32_t ntiles;               // 1..XL_NW_MAX (<= waves of the launch)
   uint32_t wide;                 // 1: D even (informational; the launch-level flag selects the 16-byte read kernel)
   uint32_t idle_before;          // spare waves (launch waves - ntiles) of the groups before this one: rider slot base
-  uint32_t pad1;
+  uint32_t hv0;                  // class record at plan time: min(consumed, XL_HCAP); XL_HCAP once every window lies inside the client's own stream
   XlTile tiles[XL_NW_MAX];
 };
 
-struct XlDyn {
-  uint32_t base;        // sample index (in [in0|in1] coordinates) of the first tap of output 0
-  uint32_t K;           // outputs produced by every client of the class in this block
-  uint32_t zero_below;  // samples with index < zero_below read as 0 (client joined mid-stream)
-  uint32_t pad;
-};
-
-struct XlDynArgs {
-  XlDyn d[XL_MAX_CLASSES];
-};
 
 struct XlNcoClient {
   float2 incr;          // phase increment cexpf(-j*w0*D) (xlating.c:544)
   uint32_t out_off;     // float2 index of the client's row in the phase-table image
-  uint32_t cls;         // index into XlDynArgs::d (K of this block)
   uint32_t slot;        // index of the client's running phase in the phase-state array
-  uint32_t pad;
+  uint32_t D;           // decimation
+  uint32_t rem0;        // plan-time record: consumed mod D (its K and block boundaries follow from XlPos, xl_grid.h)
 };
 
 struct XlFirArgs {
@@ -77,6 +70,9 @@ struct XlFirArgs {
   const void *in1;      // second part (the new block), n1 samples; may be null when n1 == 0
   uint32_t n0, n1;
   int fmt;              // XLF_*
+  XlPos pos;            // stream position of this call (the groups' per-call numbers follow from it: xl_grid_dyn)
+  uint32_t explicit_dyn;  // 1: single-filter path -- every group uses dyn1 as given (a one-block call, G = 1)
+  XlDyn dyn1;
   const XlGroup *groups;
   uint32_t ngroups;
   uint32_t xtiles;      // ceil(max K / outputs per tile)
@@ -89,8 +85,9 @@ struct XlFirArgs {
   void *hist_out;       // batch engine: where to write the rolled raw history (null: no roll)
   uint32_t hist_units;  // history length in 2-byte units (= n0 * bytes-per-sample / 2)
   uint32_t block_units; // block length in 2-byte units (= n1 * bytes-per-sample / 2)
-  // "NCO role": the first nco_blocks workgroups of the launch tabulate the NEXT block's phase table instead of
-  // filtering (xl_batch.cpp).  All null/0 when the launch carries no NCO role.
+  // "NCO role": the first nco_blocks workgroups of the launch tabulate the NEXT call's phase table (stream position
+  // xl_grid_next(pos): same shape assumed) instead of filtering (xl_batch.cpp).  All null/0 when the launch carries
+  // no NCO role.
   const XlNcoClient *nco_clients;
   uint32_t nco_nclients;
   uint32_t nco_blocks;   // = ceil(nco_nclients / (XL_NCO_LANES * nco_wpw))
@@ -110,15 +107,15 @@ struct XlFirArgs {
 // mode: 0 native (bit-exact scalar order, unfused), 1 optimized (fma).  ct: 1, 2, 4, 8, 9, 10 or 12 clients per tile.
 // a.xtiles = ceil(max K / a.ota); lds_bytes = xl_fir_lds_bytes_ota(D, Tpad, a.ota) maximised over the groups.
 // nw: waves per workgroup (>= the largest ntiles of the groups).
-// dyn_next: per-class numbers of the NEXT block, used only by the NCO role (a.nco_blocks > 0); may alias dyn.
-hipError_t xl_launch_fir(int ct, int mode, int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next,
-                         size_t lds_bytes, hipStream_t s);
+hipError_t xl_launch_fir(int ct, int mode, int nw, const XlFirArgs &a, size_t lds_bytes, hipStream_t s);
 #define XL_NCO_LANES 64u  // clients per wave in the NCO table kernel / NCO role (with every 4th phase stored the
                           // stores are rare enough that a full wave costs the chain nothing: 8.8 vs 10.6 ns per step)
 // reads the running phases from state_in[slot], writes the post-block phases to state_out[slot] (may alias).
 // Every client's out_off must be a multiple of 2 * XL_PH_STRIDE (16-byte stores of table entry pairs).  prio: wave priority 0..3 of the kernel.
+// pos: stream position of the call to tabulate; explicit_K != 0xFFFFFFFF: single-filter path, one block of explicit_K outputs.
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
-                               float2 *state_out, float2 *phtab, const XlDynArgs &dyn, uint32_t prio, hipStream_t s);
+                               float2 *state_out, float2 *phtab, XlPos pos, uint32_t explicit_K, uint32_t prio,
+                               hipStream_t s);
 // raw -> converted sample images of the single-filter path (xlating.c:352-433)
 hipError_t xl_launch_convert_cf32(const void *raw, int fmt, uint32_t nsamples, float2 *dst, hipStream_t s);
 hipError_t xl_launch_convert_q15(const void *raw, int fmt, uint32_t nelems, int16_t *dst, hipStream_t s);

@@ -86,10 +86,18 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
                                                uint32_t sampling_freq, uint32_t max_input_buffer_length,
                                                xlating **filter) {
   if (taps_len == 0) return -1;  // xlating.c:496-498 (taps NOT consumed)
-  if (decimation == 0 || filter == nullptr || taps == nullptr) return -EINVAL;
+  if (filter == nullptr || taps == nullptr) return -EINVAL;
+  // From here on the taps are CONSUMED on every path, failures included: the caller (dsp_worker_start,
+  // dsp_worker.c:98-107) treats them as handed over once taps_len != 0, like the reference's own error paths
+  // (xlating.c:521,556).
+  if (decimation == 0) {
+    free(taps);
+    return -EINVAL;
+  }
   const int dev = xl_hip_select_device(-1);
   if (dev < 0) {
     XL_LOG_ERR("no usable HIP device (%s); this build has no CPU arithmetic path", xlating_hip_device_info());
+    free(taps);
     return -ENODEV;
   }
   xlating *f = new (std::nothrow) xlating_t();
@@ -117,7 +125,8 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   g.D = decimation;
   g.T = (uint32_t)taps_len;
   g.Tpad = f->Tpad;
-  g.cls = 0;
+  g.rem0 = 0;
+  g.hv0 = 0;
   g.ntiles = 1;
   g.wide = (decimation % 2 == 0) ? 1u : 0u;
   g.tiles[0].tap_off = 0;
@@ -126,6 +135,7 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XlNcoClient nc;
   memset(&nc, 0, sizeof(nc));
   nc.incr = make_float2(incr[0], incr[1]);
+  nc.D = decimation;
   const float2 one = make_float2(1.0f, 0.0f);          // xlating.c:543
   const short2 qone = make_short2(INT16_MAX, 0);        // xlating.c:546-547
   // work images hold a few samples past `cap`: the FIR kernel's window image is padded to the unroll width
@@ -176,7 +186,7 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   return 0;
 fail:
   xl_filter_free(f);  // frees taps too, like the reference's -ENOMEM paths (xlating.c:521,556,...)
-  return -ENOMEM;
+  return xl_errno_of_last_hip_error();  // -ENOMEM (allocation), -ENODEV (no gfx950 code object / device), -EIO
 }
 
 extern "C" void destroy_xlating(xlating *filter) { xl_filter_free(filter); }
@@ -220,11 +230,10 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     XL_TRY(xl_launch_convert_cf32(f->zero_copy ? f->h_in : f->d_raw, fmt, (uint32_t)n, f->d_work_f + f->hist, f->stream));
   }
   if (K > 0) {
-    XlDynArgs dyn;
-    dyn.d[0].base = 0;
-    dyn.d[0].K = (uint32_t)K;
-    dyn.d[0].zero_below = 0;
-    dyn.d[0].pad = 0;
+    XlPos pos;
+    memset(&pos, 0, sizeof(pos));
+    pos.S = (uint32_t)n;
+    pos.G = 1;
     // The phases of this call: tabulated ahead on stream_nco after the previous call if that call guessed this one's
     // output count (the recurrence is data independent: xlating.c:70-73), else now.  The chain is ~30 us of pure
     // latency; ahead of time it overlaps the host's work between calls, the upload and the convert kernel.
@@ -239,7 +248,7 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
       ahead = f->lookahead;
     } else {
       if (f->spec_valid) XL_TRY(hipStreamWaitEvent(f->stream, f->ev_nco, 0));  // (its buffers are reused below)
-      XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase, f->d_phtab, dyn, 0, f->stream));
+      XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase, f->d_phtab, pos, (uint32_t)K, 0, f->stream));
     }
     f->spec_valid = false;
     XlFirArgs a;
@@ -249,6 +258,12 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     a.in1 = nullptr;
     a.n1 = 0;
     a.fmt = XLF_CF32;
+    a.pos = pos;
+    a.explicit_dyn = 1;  // the work image carries its own history: window of output 0 starts at sample 0 (xlating.c:61)
+    a.dyn1.base = 0;
+    a.dyn1.K = (uint32_t)K;
+    a.dyn1.zero_below = 0;
+    a.dyn1.j0 = 0;
     a.groups = f->d_group;
     a.ngroups = 1;
     a.ota = f->ota;
@@ -257,7 +272,7 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     a.taps = f->d_taps;
     a.phtab = f->d_phtab;
     a.out = f->zero_copy ? f->h_out_f : f->d_out_f;  // (the K outputs go straight to the pinned result buffer)
-    XL_TRY(xl_launch_fir(1, mode, XL_NW_DEFAULT, a, dyn, dyn, xl_fir_lds_bytes_ota(f->D, f->Tpad, f->ota), f->stream));
+    XL_TRY(xl_launch_fir(1, mode, XL_NW_DEFAULT, a, xl_fir_lds_bytes_ota(f->D, f->Tpad, f->ota), f->stream));
     if (!f->zero_copy) XL_TRY(hipMemcpyAsync(f->h_out_f, f->d_out_f, K * sizeof(float2), hipMemcpyDeviceToHost, f->stream));
   }
   {
@@ -272,12 +287,11 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     size_t Wn, Kn, posn;
     xl_counts(f, n, &Wn, &Kn, &posn);
     if (Kn > 0) {
-      XlDynArgs dn;
-      dn.d[0].base = 0;
-      dn.d[0].K = (uint32_t)Kn;
-      dn.d[0].zero_below = 0;
-      dn.d[0].pad = 0;
-      XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase_next, f->d_phtab_next, dn, 0, f->stream_nco));
+      XlPos pn;
+      memset(&pn, 0, sizeof(pn));
+      pn.S = (uint32_t)n;
+      pn.G = 1;
+      XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase_next, f->d_phtab_next, pn, (uint32_t)Kn, 0, f->stream_nco));
       XL_TRY(hipEventRecord(f->ev_nco, f->stream_nco));
       f->spec_valid = true;
       f->spec_K = Kn;
@@ -291,12 +305,11 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     size_t Wn, Kn, posn;
     xl_counts(f, n, &Wn, &Kn, &posn);
     if (Kn > 0) {
-      XlDynArgs dn;
-      dn.d[0].base = 0;
-      dn.d[0].K = (uint32_t)Kn;
-      dn.d[0].zero_below = 0;
-      dn.d[0].pad = 0;
-      XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase_next, f->d_phtab_next, dn, 0, f->stream_nco));
+      XlPos pn;
+      memset(&pn, 0, sizeof(pn));
+      pn.S = (uint32_t)n;
+      pn.G = 1;
+      XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase_next, f->d_phtab_next, pn, (uint32_t)Kn, 0, f->stream_nco));
       XL_TRY(hipEventRecord(f->ev_nco, f->stream_nco));
       f->spec_valid = true;
       f->spec_K = Kn;

@@ -39,8 +39,9 @@
 // operations) plus the store issue time, which is why only every 4th phase is tabulated (tools/ubench_chain2.hip).
 __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
                                                           const float2 *state_in, float2 *state_out,
-                                                          float2 *__restrict__ tab, const XlDynArgs dyn,
-                                                          const uint32_t prio, const uint32_t lanes) {
+                                                          float2 *__restrict__ tab, const XlPos pos,
+                                                          const uint32_t explicit_K, const uint32_t prio,
+                                                          const uint32_t lanes) {
   if (prio == 3) __builtin_amdgcn_s_setprio(3);
   else if (prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__r
   const uint32_t c = blockIdx.x * lanes + threadIdx.x;
   if (c >= n) return;
   const XlNcoClient k = cl[c];
-  xl_nco_client(k, dyn.d[k.cls].K, state_in, state_out, tab);
+  const XlBnd bnd = xl_nco_bnd(k, pos, explicit_K);
+  xl_nco_client_chain(k, bnd, 0u, bnd.K, state_in, state_out, tab);
 }
 
 // Window staging: raw samples -> cf32 image in LDS.  Four independent loads per thread are issued before any is
@@ -85,8 +87,7 @@ XL_DEV void xl_stage_window(const XlFirArgs &a, const uint32_t zero_below, const
 // SGPR cap 96: 64 hold one batch of taps; at <= 96 the CU admits 7 waves per SIMD instead of 6 (the allocation
 // granule is 16 and 800 SGPRs serve a SIMD), which lets a 5-wave-per-workgroup launch keep 25 waves per CU.
 template <int CT, int MODE, bool WIDE>
-__global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))) void xl_fir_kernel(
-    const XlFirArgs a, const XlDynArgs dyn, const XlDynArgs dyn_next) {
+__global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))) void xl_fir_kernel(const XlFirArgs a) {
   extern __shared__ __attribute__((aligned(16))) v2f xl_win[];
   // outputs per tile: 64 (one per lane), or fewer active lanes (a.ota = 32/16/8) for huge decimations
   const uint32_t OT = a.ota;
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
       const uint32_t c = (blockIdx.x * a.nco_wpw + nwave) * XL_NCO_LANES + nlane;
       if (c < a.nco_nclients) {
         const XlNcoClient k = a.nco_clients[c];
-        xl_nco_client(k, dyn_next.d[k.cls].K, a.nco_state_in, a.nco_state_out, a.nco_tab);
+        const XlBnd bnd = xl_nco_bnd(k, xl_grid_next(a.pos), 0xFFFFFFFFu);
+        xl_nco_client_chain(k, bnd, 0u, bnd.K, a.nco_state_in, a.nco_state_out, a.nco_tab);
       }
       if (a.trace && nlane == 0) {  // tuning: stamp the NCO-role wave (stamps 1, 2 stay 0 = "NCO role")
         unsigned long long *tn = a.trace + ((size_t)blockIdx.x * XL_NW_MAX + nwave) * 6;
@@ -153,8 +155,9 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
   if (y >= a.ngroups) return;
 
   const cu32_p g = (cu32_p)(uintptr_t)(a.groups + y);  // XlGroup as dwords, scalar-loaded
-  const uint32_t D = g[0], Tpad = g[2], cls = g[3], ntiles = g[4];
-  const XlDyn d = dyn.d[cls];
+  const uint32_t D = g[0], Tpad = g[2], ntiles = g[4];
+  // per-call numbers of the group's class from its plan-time record and the stream position (xl_grid.h)
+  const XlDyn d = a.explicit_dyn ? a.dyn1 : xl_grid_dyn(D, g[1], g[3], g[7], a.pos);
   const uint32_t K = d.K;
   const bool live = x * OT < K;
   if (!live && a.nco_lanes == 0u) return;
@@ -180,8 +183,11 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
         const uint32_t off = tg[2 + c];
         const float2 ci = reinterpret_cast<const float2 *>(tg + 2 + XL_CT_MAX)[c];
         const uint32_t left = K - m0, span = OT < XL_PH_STRIDE ? OT : XL_PH_STRIDE;
-        xl_phase_expand(reinterpret_cast<const v2f *>(a.phtab) + (off >> XL_PH_SHIFT), m0, (v2f){ci.x, ci.y},
-                        pl + c * 64u + e * XL_PH_STRIDE, left < span ? left : span);
+        XlBnd bnd;
+        bnd.j0 = d.j0, bnd.D = D, bnd.S = a.pos.S, bnd.G = a.explicit_dyn ? 1u : a.pos.G, bnd.K = K;
+        v2f *__restrict__ dst = pl + c * 64u + e * XL_PH_STRIDE;
+        xl_phase_walk((reinterpret_cast<const v2f *>(a.phtab) + (off >> XL_PH_SHIFT))[m0 >> XL_PH_SHIFT], m0,
+                      left < span ? left : span, (v2f){ci.x, ci.y}, bnd, [&](uint32_t i, v2f ph) { dst[i] = ph; });
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -212,7 +218,8 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
       const uint32_t c = slot * a.nco_lanes + nlane;
       if (c < a.nco_nclients) {
         const XlNcoClient k = a.nco_clients[c];
-        xl_nco_client(k, dyn_next.d[k.cls].K, a.nco_state_in, a.nco_state_out, a.nco_tab);
+        const XlBnd bnd = xl_nco_bnd(k, xl_grid_next(a.pos), 0xFFFFFFFFu);
+        xl_nco_client_chain(k, bnd, 0u, bnd.K, a.nco_state_in, a.nco_state_out, a.nco_tab);
       }
       if (a.trace && nlane == 0) {
         unsigned long long *tn = a.trace + ((size_t)blockIdx.x * XL_NW_MAX + w) * 6;
@@ -319,8 +326,7 @@ uint32_t xl_fir_pick_ota(uint32_t D, uint32_t Tpad, size_t budget) {
 }
 
 template <int CT, int MODE, bool WIDE>
-static hipError_t xl_fir_go2(int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, size_t lds,
-                             hipStream_t s) {
+static hipError_t xl_fir_go2(int nw, const XlFirArgs &a, size_t lds, hipStream_t s) {
   static bool attr_done = false;  // per instantiation; benign race (idempotent)
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&xl_fir_kernel<CT, MODE, WIDE>),
@@ -333,49 +339,47 @@ static hipError_t xl_fir_go2(int nw, const XlFirArgs &a, const XlDynArgs &dyn, c
   // the prologue expands the NCO phases through the LDS: [wave][client][64] before the window image is staged
   const size_t need = (size_t)nw * CT * 64u * sizeof(float2);
   if (lds < need) lds = need;
-  hipLaunchKernelGGL((xl_fir_kernel<CT, MODE, WIDE>), dim3(nblocks), dim3(64 * nw), lds, s, a, dyn, dyn_next);
+  hipLaunchKernelGGL((xl_fir_kernel<CT, MODE, WIDE>), dim3(nblocks), dim3(64 * nw), lds, s, a);
   return hipGetLastError();
 }
 
 // a.flags bit 0 set by the caller = every group of the launch has an even decimation -> 16-byte LDS reads
 template <int CT, int MODE>
-static hipError_t xl_fir_go(int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, size_t lds,
-                            hipStream_t s) {
-  return (a.flags & 1u) ? xl_fir_go2<CT, MODE, true>(nw, a, dyn, dyn_next, lds, s)
-                        : xl_fir_go2<CT, MODE, false>(nw, a, dyn, dyn_next, lds, s);
+static hipError_t xl_fir_go(int nw, const XlFirArgs &a, size_t lds, hipStream_t s) {
+  return (a.flags & 1u) ? xl_fir_go2<CT, MODE, true>(nw, a, lds, s) : xl_fir_go2<CT, MODE, false>(nw, a, lds, s);
 }
 
 // a.xtiles must be ceil(max K / a.ota)
-hipError_t xl_launch_fir(int ct, int mode, int nw, const XlFirArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next,
-                         size_t lds, hipStream_t s) {
+hipError_t xl_launch_fir(int ct, int mode, int nw, const XlFirArgs &a, size_t lds, hipStream_t s) {
   if (lds > 160 * 1024 || nw < 1 || nw > XL_NW_MAX) return hipErrorInvalidValue;
   if (a.ota != 64 && a.ota != 32 && a.ota != 16 && a.ota != 8) return hipErrorInvalidValue;
   switch (ct * 2 + (mode ? 1 : 0)) {
-    case 2: return xl_fir_go<1, 0>(nw, a, dyn, dyn_next, lds, s);
-    case 3: return xl_fir_go<1, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 4: return xl_fir_go<2, 0>(nw, a, dyn, dyn_next, lds, s);
-    case 5: return xl_fir_go<2, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 8: return xl_fir_go<4, 0>(nw, a, dyn, dyn_next, lds, s);
-    case 9: return xl_fir_go<4, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 16: return xl_fir_go<8, 0>(nw, a, dyn, dyn_next, lds, s);
-    case 17: return xl_fir_go<8, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 18: return xl_fir_go<9, 0>(nw, a, dyn, dyn_next, lds, s);
-    case 19: return xl_fir_go<9, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 20: return xl_fir_go<10, 0>(nw, a, dyn, dyn_next, lds, s);
-    case 21: return xl_fir_go<10, 1>(nw, a, dyn, dyn_next, lds, s);
-    case 24: return xl_fir_go<12, 0>(nw, a, dyn, dyn_next, lds, s);
-    case 25: return xl_fir_go<12, 1>(nw, a, dyn, dyn_next, lds, s);
+    case 2: return xl_fir_go<1, 0>(nw, a, lds, s);
+    case 3: return xl_fir_go<1, 1>(nw, a, lds, s);
+    case 4: return xl_fir_go<2, 0>(nw, a, lds, s);
+    case 5: return xl_fir_go<2, 1>(nw, a, lds, s);
+    case 8: return xl_fir_go<4, 0>(nw, a, lds, s);
+    case 9: return xl_fir_go<4, 1>(nw, a, lds, s);
+    case 16: return xl_fir_go<8, 0>(nw, a, lds, s);
+    case 17: return xl_fir_go<8, 1>(nw, a, lds, s);
+    case 18: return xl_fir_go<9, 0>(nw, a, lds, s);
+    case 19: return xl_fir_go<9, 1>(nw, a, lds, s);
+    case 20: return xl_fir_go<10, 0>(nw, a, lds, s);
+    case 21: return xl_fir_go<10, 1>(nw, a, lds, s);
+    case 24: return xl_fir_go<12, 0>(nw, a, lds, s);
+    case 25: return xl_fir_go<12, 1>(nw, a, lds, s);
     default: return hipErrorInvalidValue;
   }
 }
 
 // (NCO phase-table code: see above the FIR kernel)
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
-                               float2 *state_out, float2 *phtab, const XlDynArgs &dyn, uint32_t prio, hipStream_t s) {
+                               float2 *state_out, float2 *phtab, XlPos pos, uint32_t explicit_K, uint32_t prio,
+                               hipStream_t s) {
   if (nclients == 0) return hipSuccess;
   const uint32_t lanes = XL_NCO_LANES;
   hipLaunchKernelGGL(xl_nco_table_kernel, dim3((nclients + lanes - 1) / lanes), dim3(64), 0, s, clients, nclients,
-                     state_in, state_out, phtab, dyn, prio, lanes);
+                     state_in, state_out, phtab, pos, explicit_K, prio, lanes);
   return hipGetLastError();
 }
 

@@ -10,6 +10,11 @@
 //
 //   y_seg = IDFT_M( sum_b DFT_M(x_b) * R_b ),            R_b[m] = sum_a r_b[a] e^{+2 pi j a m / M}
 //
+// Clients of one (D, T) whose output grids are offset against each other (they joined at different stream positions:
+// dsp_worker.c:98-104, xlating.c:552) still form ONE class: a client whose grid lies delta samples behind the class's
+// shared grid is evaluated with its taps delayed by delta samples -- delta leading zeros, at most one more tap per
+// branch -- which is the same sum (xl_grid.h, XlpCol::delta).
+//
 // DFT_M(x_b) is shared by ALL clients of the class (D transforms per segment, whatever the client count) and the
 // per-client work is D complex MACs per spectrum bin plus one inverse transform per segment: ~45 complex MACs per
 // output instead of T (= 505 at the server default).  The NCO derotation (exact float32 recurrence table) and the
@@ -26,52 +31,65 @@
 #define XLP_COLS 128u  // client columns per column group (= one mix workgroup: a wave with two columns per lane)
 #define XLP_BSTEP 7u   // slots of the mix kernel's R-row register ring (branch count is padded to a multiple in the images)
 
+// One client column of a class: 16 bytes, one load.
+struct XlpCol {
+  uint32_t out_off;  // float2 index of the client's row in out (/ XL_PH_STRIDE in the phase table); 0xFFFFFFFF = empty column
+  uint32_t delta;    // offset of the client's output grid against the class's shared grid, 0 .. D-1 (xl_grid.h); its
+                     // branch spectra are those of its taps delayed by delta samples
+  float2 incr;       // NCO phase increment
+};
+
 struct XlpArgs {
-  // input stream [in0 | in1] as in XlFirArgs
+  // input stream [in0 | in1] as in XlFirArgs (in1 = the G blocks of the call, contiguous)
   const void *in0;
   const void *in1;
   uint32_t n0, n1;
   uint32_t fmt;
-  uint32_t cls;        // index into XlDynArgs::d
+  XlPos pos;           // stream position of the call (per-column output counts, block boundaries, the NCO role)
+  uint32_t j0_ref;     // shared grid of the class in this call: j0 of its virtual reference client (xl_grid.h)
+  uint32_t base;       // sample index in [in0 | in1] coordinates of the first tap of shared point q = 0
+  uint32_t Kq;         // shared points evaluated, q < Kq
+  uint32_t zero_below; // samples below read as 0
   uint32_t D, Dpad;    // decimation = number of branches; padded to a multiple of XLP_BSTEP in the images
-  uint32_t T, A, V;    // taps, taps per branch, valid outputs per segment = M - A + 1
+  uint32_t T, A, V;    // taps, taps per branch of the delayed filters, valid outputs per segment = M - A + 1
   uint32_t M;          // transform length: 256 or 128
   uint32_t mix_passes; // (set by xlp_launch_mix) passes of 14 segments = ceil(nseg / 14)
-  uint32_t nseg;       // segments of this block = ceil(K / V)
+  uint32_t nseg;       // segments of this call = ceil(Kq / V)
   uint32_t nseg_cap;   // segment capacity of the Y image
   uint32_t ncg;        // column groups of XLP_COLS client columns
-  uint32_t exp;        // tuning switches (0 in production)
+  uint32_t exp;        // tuning switches (XL_TUNING builds only; 0 otherwise)
   unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
   const float2 *R;     // branch spectra   [cg][M][Dpad][XLP_COLS] (+ XLP_BSTEP rows of tail padding)
   float2 *Y;           // mixed spectra    [cg][nseg_cap][M][XLP_COLS]
-  const uint32_t *col_out;  // per column: float2 index of the client's row in out (/ 4 in phtab), 0xFFFFFFFF = empty
-  const float2 *col_incr;   // per column: NCO phase increment
+  const XlpCol *cols;  // per column
   const float2 *phtab;
   float2 *out;
   // raw-history roll, carried by the forward launch (as XlFirArgs): null / 0 = none
   void *hist_out;
   uint32_t hist_units, block_units, roll_blocks;
-  // NCO role pieces (see XlFirArgs): each of the three launches of a block carries a slice [nco_k0, nco_k1) of the
-  // NEXT block's phase recurrence; the slice that ends the block renormalises (xlating.c:73).
+  // NCO role pieces (see XlFirArgs): each of the three launches of a call carries a slice [nco_k0, nco_k1) of the
+  // NEXT call's phase recurrence (stream position xl_grid_next(pos)); block ends inside a slice renormalise
+  // (xlating.c:73).
   const XlNcoClient *nco_clients;
   uint32_t nco_nclients;
   uint32_t nco_blocks;
   uint32_t nco_prio;        // wave priority of the role (0..3)
   uint32_t nco_skip_at, nco_skip;  // mix launch: workgroups [nco_skip_at, nco_skip_at + nco_skip) exit at once (see the kernel)
-  uint32_t nco_k0, nco_k1;  // in 1/65536 of the block's outputs: slice = [K*k0 >> 16, K*k1 >> 16)
+  uint32_t nco_k0, nco_k1;  // in 1/65536 of the call's outputs: slice = [K*k0 >> 16, K*k1 >> 16) rounded down to pairs of table entries
   const float2 *nco_state_src;  // phases at the start of the slice (committed phases for the first slice)
-  float2 *nco_state_dst;        // phases after the slice (renormalised post-block phases for the last slice)
+  float2 *nco_state_dst;        // phases after the slice (committed post-call phases for the last slice)
   float2 *nco_tab;
 };
 
 // reversed band-pass taps of every column -> branch spectra R (double arithmetic, rounded once to float)
 //   rt: [T][ncols] float2 (tap-major), ncols <= ncg * XLP_COLS; columns >= ncols and branches >= D get 0
-hipError_t xlp_launch_tables(const float2 *rt, uint32_t ncols, uint32_t T, uint32_t D, uint32_t Dpad, uint32_t A,
-                             uint32_t M, uint32_t ncg, float2 *R, hipStream_t s);
-hipError_t xlp_launch_forward(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s);
-hipError_t xlp_launch_mix(const XlpArgs &a, const XlDynArgs &dyn_next, hipStream_t s);
-hipError_t xlp_launch_inverse(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s);
+//   delta: [ncols] delay of every column's taps in samples (xl_grid.h: merged classes); A = ceil((T + max delta) / D)
+hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, uint32_t ncols, uint32_t T, uint32_t D,
+                             uint32_t Dpad, uint32_t A, uint32_t M, uint32_t ncg, float2 *R, hipStream_t s);
+hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
+hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
+hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s);
 
 #endif  // XL_POLYPHASE_H_

@@ -120,8 +120,9 @@ XL_DEV void xlp_dft(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, con
   }
 }
 
-// NCO role of a launch: the first a.nco_blocks workgroups carry XL_NCO_LANES clients each (first wave only).
-XL_DEV void xlp_nco_role(const XlpArgs &a, const XlDynArgs &dyn_next) {
+// NCO role of a launch: the first a.nco_blocks workgroups carry XL_NCO_LANES clients each (first wave only) through
+// this launch's slice of the NEXT call's phase recurrence.
+XL_DEV void xlp_nco_role(const XlpArgs &a) {
   if (a.nco_prio == 3u) __builtin_amdgcn_s_setprio(3);
   else if (a.nco_prio == 2u) __builtin_amdgcn_s_setprio(2);
   else if (a.nco_prio == 1u) __builtin_amdgcn_s_setprio(1);
@@ -130,12 +131,12 @@ XL_DEV void xlp_nco_role(const XlpArgs &a, const XlDynArgs &dyn_next) {
   const uint32_t c = blockIdx.x * XL_NCO_LANES + threadIdx.x;
   if (c >= a.nco_nclients) return;
   const XlNcoClient k = a.nco_clients[c];
-  const uint32_t K = dyn_next.d[k.cls].K;
+  const XlBnd bnd = xl_nco_bnd(k, xl_grid_next(a.pos), 0xFFFFFFFFu);
+  const uint32_t K = bnd.K;
   const uint32_t kb = a.nco_k0 == 0u ? 0u : (uint32_t)(((uint64_t)K * a.nco_k0) >> 16) & ~(2u * XL_PH_STRIDE - 1u);
-  const bool final = a.nco_k1 >= 65536u;
-  const uint32_t ke = final ? K : (uint32_t)(((uint64_t)K * a.nco_k1) >> 16) & ~(2u * XL_PH_STRIDE - 1u);
+  const uint32_t ke = a.nco_k1 >= 65536u ? K : (uint32_t)(((uint64_t)K * a.nco_k1) >> 16) & ~(2u * XL_PH_STRIDE - 1u);
   unsigned long long st[2] = {0ull, 0ull};
-  xl_nco_client_slice(k, K, kb, ke, final, a.nco_state_src, a.nco_state_dst, a.nco_tab, a.trace ? st : nullptr);
+  xl_nco_client_chain(k, bnd, kb, ke, a.nco_state_src, a.nco_state_dst, a.nco_tab, a.trace ? st : nullptr);
   if (a.trace && threadIdx.x == 0) {
     unsigned long long *t = a.trace + 8 + 8 * blockIdx.x;
     t[0] = t0;
@@ -167,12 +168,11 @@ XL_DEV void xlp_trace_work(const XlpArgs &a, const unsigned long long t0) {
 // grid = nco_blocks + ceil(nseg * D / TPW) transform workgroups (one wave each: TPW = 256 / M transforms) +
 // a.roll_blocks history-roll workgroups.
 template <int M>
-__global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a, const XlDynArgs dyn,
-                                                         const XlDynArgs dyn_next) {
+__global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a) {
   constexpr uint32_t TPW = 256 / M, L = M / 4;
   __shared__ v2f lds[TPW][XLP_ROW(M)];
   if (blockIdx.x < a.nco_blocks) {
-    xlp_nco_role(a, dyn_next);
+    xlp_nco_role(a);
     return;
   }
   const uint32_t bid = blockIdx.x - a.nco_blocks;
@@ -197,15 +197,14 @@ __global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a, const 
   const uint32_t tr = bid * TPW + h;
   const bool live = tr < ntr;
   const uint32_t s = (live ? tr : 0u) / a.D, b = (live ? tr : 0u) - s * a.D;
-  const XlDyn d = dyn.d[a.cls];
-  // branch sample n of segment s = stream sample base + (s V + n) D + b   (base: first tap of output 0)
-  const uint32_t first = d.base + s * a.V * a.D + b;
+  // branch sample n of segment s = stream sample base + (s V + n) D + b   (base: first tap of shared point 0)
+  const uint32_t first = a.base + s * a.V * a.D + b;
   const uint32_t end = a.n0 + a.n1;
   v2f u[1][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint32_t idx = first + (l + L * r) * a.D;
-    const bool ok = live && idx >= d.zero_below && idx < end;  // late joiner: zeros below; past the block: zeros
+    const bool ok = live && idx >= a.zero_below && idx < end;  // late joiner: zeros below; past the block: zeros
                                                                // (those outputs lie beyond K and are never stored)
     const bool lo = idx < a.n0;
     const void *src = (lo || !ok) ? a.in0 : a.in1;
@@ -245,10 +244,10 @@ XL_DEV void xlp_cmac(v2f &acc, const v2f r, const v2f x) {
 // the grid -- same XCD (workgroups are dealt to the XCDs round-robin), dispatched together -- so that R comes from HBM
 // once and the other passes hit that XCD's L2.  (The passes as waves of one workgroup gave the same traffic but an
 // uneven deal: two-wave workgroups left SIMDs with 1 to 3 waves, and the launch ends with the fullest.)
-__global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDynArgs dyn_next) {
+__global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) v4f xlp_xcol[];  // [Dpad][8]
   if (blockIdx.x < a.nco_blocks) {
-    xlp_nco_role(a, dyn_next);
+    xlp_nco_role(a);
     return;
   }
   // Workgroups are dealt to the SIMDs round-robin in blockIdx order (measured: the work waves that shared a SIMD with
@@ -328,8 +327,7 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a, const XlDy
 // (M = 256: a wave runs its four columns' transforms interleaved) or 32 (M = 128: each half-wave runs four).  The tile
 // rows double as the transforms' scratch.
 template <int M>
-__global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const XlDynArgs dyn,
-                                                          const XlDynArgs dyn_next) {
+__global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
   constexpr uint32_t L = M / 4;            // lanes per transform
   constexpr uint32_t CW = 16u * (256 / M);  // columns per workgroup
   constexpr uint32_t WPC = CW / 4;          // columns per wave
@@ -339,7 +337,7 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
   // four workgroups (at 41.2 KB it held three: 768 slots for the 832 workgroups of a 1024-client block -> a second round)
   __shared__ v2f tile[CW][XLP_ROW(M) - 1];
   if (blockIdx.x < a.nco_blocks) {
-    xlp_nco_role(a, dyn_next);
+    xlp_nco_role(a);
     return;
   }
   if (blockIdx.x >= a.nco_skip_at && blockIdx.x < a.nco_skip_at + a.nco_skip) return;  // (as in xlp_mix_kernel; 4-wave workgroups: per CU)
@@ -368,25 +366,39 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
       tile[2 * part + 1][XLP_POS(m)] = (v2f){v[i].z, v[i].w};
     }
   }
-  // the epilogue's operands.  NCO phases: the table holds every XL_PH_STRIDE-th phase; after the transforms lane
-  // (en, gq) = (j / GQ, j % GQ), GQ = M / XL_PH_STRIDE, expands the phases of outputs gq*XL_PH_STRIDE .. of the wave's
-  // column en into that column's tile row (free by then), and every lane picks the phases of its own outputs l + L r
-  // from there.  The one table entry a lane needs is requested here, before the transforms.
+  // the epilogue's operands.  A column's client lies on the class's shared grid with its own offset (xl_grid.h):
+  // its output k is the shared point q = k + shift, shift in {0, 1}, and it owns K_c outputs in this call.
+  // NCO phases: the table holds every XL_PH_STRIDE-th phase; after the transforms lane (en, gq) = (j / GQ, j % GQ),
+  // GQ = M / XL_PH_STRIDE, expands the phases of the shared points gq*XL_PH_STRIDE .. of the segment for the wave's
+  // column en into that column's tile row (free by then), and every lane picks the phases of its own points
+  // l + L r from there.  The one table entry a lane needs is requested here, before the transforms.
   constexpr uint32_t GQ = M / XL_PH_STRIDE;
   static_assert(WPC * GQ == 64u, "one expansion duty per lane");
-  const uint32_t K = dyn.d[a.cls].K;
+  const uint32_t N = a.pos.S * a.pos.G;
+  const uint32_t Ka = N / a.D, Nr = N - Ka * a.D;  // a column with j0 < Nr owns Ka + 1 outputs, else Ka
   const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
   v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
   const uint32_t colbase = cg * XLP_COLS + sub * CW + WPC * w;
-  uint32_t off[4];
+  uint32_t off[4], ksh[4], kc[4];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) off[n] = a.col_out[colbase + 4u * h + n];
-  const uint32_t en = j / GQ, gq = j % GQ;  // expansion duty: column en of the wave, outputs gq*XL_PH_STRIDE ..
-  const uint32_t eoff = a.col_out[colbase + en];
-  const float2 eci = a.col_incr[colbase + en];
-  const uint32_t k0 = s * a.V + gq * XL_PH_STRIDE;
-  const bool eok = eoff != 0xFFFFFFFFu && gq * XL_PH_STRIDE < a.V && k0 < K;
-  v2f pe = ph[eok ? (eoff >> XL_PH_SHIFT) + (k0 >> XL_PH_SHIFT) : 0u];
+  for (int n = 0; n < 4; ++n) {
+    const XlpCol c = a.cols[colbase + 4u * h + n];
+    const uint32_t j0c = xl_merge_j0(a.j0_ref, c.delta, a.D);
+    off[n] = c.out_off;
+    ksh[n] = xl_merge_shift(a.j0_ref, c.delta, a.D);
+    kc[n] = Ka + (j0c < Nr ? 1u : 0u);
+  }
+  const uint32_t en = j / GQ, gq = j % GQ;  // expansion duty: column en of the wave, shared points s V + gq*XL_PH_STRIDE ..
+  const XlpCol ce = a.cols[colbase + en];
+  XlBnd ebnd;
+  ebnd.j0 = xl_merge_j0(a.j0_ref, ce.delta, a.D), ebnd.D = a.D, ebnd.S = a.pos.S, ebnd.G = a.pos.G;
+  ebnd.K = Ka + (ebnd.j0 < Nr ? 1u : 0u);
+  const uint32_t esh = xl_merge_shift(a.j0_ref, ce.delta, a.D);
+  const uint32_t q0 = s * a.V + gq * XL_PH_STRIDE;
+  const uint32_t ibeg = q0 < esh ? 1u : 0u;     // (shared point 0 of a column with shift 1 is nobody's output)
+  const uint32_t m0 = q0 + ibeg - esh;          // the column's output index of the first phase to expand
+  const bool eok = ce.out_off != 0xFFFFFFFFu && gq * XL_PH_STRIDE < a.V && m0 < ebnd.K;
+  const v2f pe = ph[eok ? (ce.out_off >> XL_PH_SHIFT) + (m0 >> XL_PH_SHIFT) : 0u];
   __syncthreads();
   const unsigned long long t_loaded = a.trace ? wall_clock64() : 0ull;
   v2f u[4][4];
@@ -400,14 +412,11 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
   xlp_dft<+1, 4, M>(u, rows, tw, l);
   __builtin_amdgcn_wave_barrier();
   if (eok) {
-    const v2f einc = {eci.x, eci.y};
-    for (uint32_t i = k0 & (XL_PH_STRIDE - 1u); i > 0u; --i) pe = xl_nco_next(pe, einc);  // (segments start anywhere)
     v2f *__restrict__ row = tile[WPC * w + en];
-    const uint32_t count = K - k0 < XL_PH_STRIDE ? K - k0 : XL_PH_STRIDE;
-    for (uint32_t i = 0; i < count; ++i) {
-      row[XLP_POS(gq * XL_PH_STRIDE + i)] = pe;
-      pe = xl_nco_next(pe, einc);
-    }
+    const uint32_t left = ebnd.K - m0, span = XL_PH_STRIDE - ibeg;
+    const uint32_t p0 = gq * XL_PH_STRIDE + ibeg;
+    xl_phase_walk(pe, m0, left < span ? left : span, (v2f){ce.incr.x, ce.incr.y}, ebnd,
+                  [&](uint32_t i, v2f phs) { row[XLP_POS(p0 + i)] = phs; });
   }
   __builtin_amdgcn_wave_barrier();
   const unsigned long long t_xf = a.trace ? wall_clock64() : 0ull;
@@ -415,10 +424,10 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
   for (int n = 0; n < 4; ++n) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const uint32_t qo = l + L * r, k = s * a.V + qo;
-      if (off[n] != 0xFFFFFFFFu && qo < a.V && k < K) {
+      const uint32_t qo = l + L * r, qs = s * a.V + qo;  // shared point of this value
+      if (off[n] != 0xFFFFFFFFu && qo < a.V && qs >= ksh[n] && qs - ksh[n] < kc[n]) {
         const v2f y = u[n][r] * (1.0f / (float)M);  // exact scaling by 2^-8 / 2^-7
-        out[off[n] + k] = xl_rotate<1>(y, rows[n][XLP_POS(qo)]);
+        out[off[n] + (qs - ksh[n])] = xl_rotate<1>(y, rows[n][XLP_POS(qo)]);
       }
     }
   }
@@ -432,10 +441,12 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a, const
 }
 
 // ------------------------------------------------------------------------------------------- branch spectra
-// R[cg][m][b][col] = sum_{a<A} r_col[D a + b] e^{+2 pi j a m / M}, in double, rounded once.  One-time per plan.
-__global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__restrict__ rt, uint32_t ncols, uint32_t T,
-                                                              uint32_t D, uint32_t Dpad, uint32_t A, uint32_t M,
-                                                              float2 *__restrict__ R) {
+// R[cg][m][b][col] = sum_{a<A} r'_col[D a + b] e^{+2 pi j a m / M}, r' = the column's taps delayed by its grid offset
+// (xl_grid.h), in double, rounded once.  One-time per plan.
+__global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__restrict__ rt,
+                                                              const uint32_t *__restrict__ delta, uint32_t ncols,
+                                                              uint32_t T, uint32_t D, uint32_t Dpad, uint32_t A,
+                                                              uint32_t M, float2 *__restrict__ R) {
   __shared__ double wc[256], ws[256];  // e^{+2 pi j n / M} in double
   for (uint32_t n = threadIdx.x; n < M; n += blockDim.x) sincospi(2.0 * (double)n / (double)M, &ws[n], &wc[n]);
   __syncthreads();
@@ -445,8 +456,10 @@ __global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__re
   const uint32_t col = cg * XLP_COLS + threadIdx.x;
   double sr = 0.0, si = 0.0;
   if (col < ncols && b < D) {
+    const uint32_t dl = delta[col];  // the column's taps are delayed by dl samples: r'[i] = r[i - dl]
     for (uint32_t aa = 0; aa < A; ++aa) {
-      const uint32_t i = D * aa + b;
+      if (D * aa + b < dl) continue;
+      const uint32_t i = D * aa + b - dl;
       if (i >= T) break;
       const uint32_t n = (aa * m) & (M - 1u);
       const double cs = wc[n], sn = ws[n];
@@ -462,19 +475,20 @@ __global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__re
 // ------------------------------------------------------------------------------------------- launchers
 static bool xlp_valid_m(uint32_t M) { return M == 128u || M == 256u; }
 
-hipError_t xlp_launch_tables(const float2 *rt, uint32_t ncols, uint32_t T, uint32_t D, uint32_t Dpad, uint32_t A,
-                             uint32_t M, uint32_t ncg, float2 *R, hipStream_t s) {
+hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, uint32_t ncols, uint32_t T, uint32_t D,
+                             uint32_t Dpad, uint32_t A, uint32_t M, uint32_t ncg, float2 *R, hipStream_t s) {
   if (!xlp_valid_m(M)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(xlp_tables_kernel, dim3(M * Dpad * ncg), dim3(XLP_COLS), 0, s, rt, ncols, T, D, Dpad, A, M, R);
+  hipLaunchKernelGGL(xlp_tables_kernel, dim3(M * Dpad * ncg), dim3(XLP_COLS), 0, s, rt, delta, ncols, T, D, Dpad, A, M,
+                     R);
   return hipGetLastError();
 }
 
-hipError_t xlp_launch_forward(const XlpArgs &a, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s) {
+hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s) {
   if (!xlp_valid_m(a.M)) return hipErrorInvalidValue;
   const uint32_t tpw = 256u / a.M;
   const dim3 grid(a.nco_blocks + (a.nseg * a.D + tpw - 1u) / tpw + a.roll_blocks);
-  if (a.M == 256u) hipLaunchKernelGGL(xlp_forward_kernel<256>, grid, dim3(64), 0, s, a, dyn, dyn_next);
-  else hipLaunchKernelGGL(xlp_forward_kernel<128>, grid, dim3(64), 0, s, a, dyn, dyn_next);
+  if (a.M == 256u) hipLaunchKernelGGL(xlp_forward_kernel<256>, grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(xlp_forward_kernel<128>, grid, dim3(64), 0, s, a);
   return hipGetLastError();
 }
 
@@ -488,7 +502,7 @@ static XlpArgs xlp_checked_skip(const XlpArgs &a, uint32_t work_blocks) {
   return b;
 }
 
-hipError_t xlp_launch_mix(const XlpArgs &a0, const XlDynArgs &dyn_next, hipStream_t s) {
+hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
   const uint32_t passes = (a0.nseg + XLP_SEG - 1) / XLP_SEG;
   const size_t lds = (size_t)a0.Dpad * 8u * sizeof(v4f);
@@ -496,16 +510,16 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, const XlDynArgs &dyn_next, hipStrea
   const uint32_t work = a0.M * a0.ncg * passes;
   XlpArgs a = xlp_checked_skip(a0, work);
   a.mix_passes = passes;
-  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + a.nco_skip + work), dim3(64), lds, s, a, dyn_next);
+  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + a.nco_skip + work), dim3(64), lds, s, a);
   return hipGetLastError();
 }
 
-hipError_t xlp_launch_inverse(const XlpArgs &a0, const XlDynArgs &dyn, const XlDynArgs &dyn_next, hipStream_t s) {
+hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s) {
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
   const uint32_t work = a0.nseg * a0.ncg * (a0.M == 256u ? 8u : 4u);
   const XlpArgs a = xlp_checked_skip(a0, work);
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
-  if (a.M == 256u) hipLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, a, dyn, dyn_next);
-  else hipLaunchKernelGGL(xlp_inverse_kernel<128>, grid, dim3(256), 0, s, a, dyn, dyn_next);
+  if (a.M == 256u) hipLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(xlp_inverse_kernel<128>, grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }

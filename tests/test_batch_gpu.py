@@ -688,3 +688,187 @@ def test_bench_block_feed_over_real_rccl():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "feed_nccl_selftest.py")], capture_output=True, text=True,
                        timeout=400, env=dict(os.environ, MASTER_PORT="29581"))
     assert r.returncode == 0 and "outputs identical to the direct feed" in r.stdout, (r.stdout[-400:], r.stderr[-800:])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Calls of several blocks ("groups", xlating_batch_process_*_group): the results of G successive reference calls from
+# one set of launches -- every client's phase is renormalised at each block end (xlating.c:73).
+def _group_engine(fmt, max_input, gcap, clients, poly=None, m=None):
+    eng = xl.BatchEngine(FS, fmt, max_input, group_blocks=gcap)
+    if poly is not None:
+        eng.set_option("polyphase", poly)
+    if m is not None:
+        eng.set_option("polyphase_m", m)
+    oracles = {}
+    for D, taps, fc in clients:
+        oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, FS, max_input)
+    return eng, oracles
+
+
+def _check_group(eng, oracles, fmt, x, G, variant, ids=None):
+    eng.process_host_group(x, G, variant)
+    eng.fetch()
+    blocks = np.split(np.asarray(x), G)
+    for cid, o in oracles.items():
+        parts = [o.process(fmt, bl) for bl in blocks]
+        if ids is not None and cid not in ids:
+            continue
+        want = np.concatenate(parts) if parts else np.zeros(0, np.complex64)
+        got = eng.output(cid)
+        assert eng.output_len(cid) == len(want), (cid, eng.output_len(cid), len(want))
+        assert [eng.output_len_block(cid, g) for g in range(G)] == [len(p) for p in parts], cid
+        if variant == "native":
+            assert bits_equal(got, want), f"client {cid}"
+        else:
+            assert rel_err(got, want) <= REL_TOL, (cid, rel_err(got, want))
+
+
+@pytest.mark.parametrize("variant", ["native", "optimized"])
+def test_group_of_blocks_equals_successive_calls_direct(variant):
+    """Direct kernels: mixed rates, G = 3 then 1 then 2 (the call shape changes: the look-ahead phase table is redone),
+    block lengths that move the output grid, phases bit-exact at the end."""
+    t48, t96, t101 = lpf(FS, 24000, 9600), lpf(FS, 48000, 19200), lpf(FS, 24000, 48000)
+    clients = [(42, t48, -900000 + 91000 * c) for c in range(11)] + [(21, t96, 5000 * c) for c in range(5)] + \
+              [(42, t101, -77777)]
+    eng, oracles = _group_engine("cu8", 100002, 4, clients, poly=0)
+    for k, (G, n) in enumerate(((3, 100002), (1, 100002), (2, 65536), (3, 100002), (3, 100002), (4, 2000))):
+        x = siggen.xs_u8(4400 + k, G * n)
+        _check_group(eng, oracles, "cu8", x, G, variant)
+    if variant == "native":
+        for cid, o in oracles.items():
+            assert tuple(np.float32(v).tobytes() for v in eng.phase(cid)) == tuple(np.float32(v).tobytes() for v in o.phase)
+    eng.close()
+
+
+@pytest.mark.parametrize("m", [128, 256])
+def test_group_of_blocks_polyphase(m):
+    """Forced polyphase path, G = 4 server-default blocks per call (108 segments at M = 128): every client vs the
+    oracle's four successive calls; a native group in between (shared history and phases); ragged group."""
+    t48 = lpf(FS, 24000, 9600)
+    clients = [(42, t48, -900000 + 61000 * c) for c in range(30)]
+    eng, oracles = _group_engine("cu8", 262144, 4, clients, poly=1, m=m)
+    for k, (G, n, variant) in enumerate(((4, 262144, "optimized"), (4, 262144, "optimized"), (2, 262144, "native"),
+                                        (3, 100002, "optimized"), (4, 262144, "optimized"), (1, 262144, "optimized"))):
+        x = siggen.xs_u8(4500 + k, G * n)
+        _check_group(eng, oracles, "cu8", x, G, variant)
+    assert "polyphase: cls0 D42 T505 cols30" in eng.describe(), eng.describe()
+    eng.close()
+
+
+def test_group_bench_shape_1024_clients_sampled():
+    """The bench workload: 1024 x 48 kHz clients, 8 blocks per call, engine's own plan; 16 sampled clients."""
+    t48 = lpf(FS, 24000, 9600)
+    eng = xl.BatchEngine(FS, "cu8", 262144, group_blocks=8)
+    fcs = [-984000 + 1920 * c for c in range(1024)]
+    ids = [eng.add_client(42, t48, fc) for fc in fcs]
+    sample = [0, 1, 63, 64, 127, 128, 255, 256, 500, 511, 512, 777, 1000, 1021, 1022, 1023]
+    oracles = {ids[c]: Oracle(42, t48, fcs[c], FS, 262144) for c in sample}
+    for k in range(3):
+        x = siggen.xs_u8(4600 + k, 8 * 262144)
+        _check_group(eng, oracles, "cu8", x, 8, "optimized")
+    assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
+    _check_group(eng, oracles, "cu8", siggen.xs_u8(4610, 8 * 262144), 8, "native")
+    eng.close()
+
+
+def test_group_rejects_blocks_without_output():
+    t48 = lpf(FS, 24000, 9600)
+    eng = xl.BatchEngine(FS, "cu8", 262144, group_blocks=4)
+    eng.add_client(42, t48, 1000)
+    with pytest.raises(xl.XlatingError) as e:
+        eng.process_host_group(np.zeros(4 * 40, np.uint8), 4, "native")  # 20 samples per block < D = 42
+    assert e.value.code == -22
+    with pytest.raises(xl.XlatingError):
+        eng.process_host_group(np.zeros(5 * 1000, np.uint8), 5, "native")  # more blocks than the engine was built for
+    eng.process_host_group(np.zeros(40, np.uint8), 1, "native")  # a single tiny block is fine
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Clients that joined at different stream positions (dsp_worker.c:98-104: every client starts its own output grid).
+def test_staggered_joins_merge_into_one_polyphase_class():
+    """1024 x 48 kHz clients joining over 21 consecutive blocks (S mod D = 32: every join lands on another grid
+    offset).  Once inside their own stream they all share ONE polyphase class (taps delayed by the grid offset, baked
+    into the branch spectra); 16 sampled clients <= 1e-5 vs the oracle throughout, native bit-exact afterwards."""
+    t48 = lpf(FS, 24000, 9600)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    fcs = [-984000 + 1920 * c for c in range(1024)]
+    per = [49] * 20 + [44]
+    sample_pos = {0, 48, 49, 100, 500, 979, 980, 1023}
+    oracles = {}
+    nxt = 0
+    for k in range(24):
+        if k < 21:
+            for _ in range(per[k]):
+                cid = eng.add_client(42, t48, fcs[nxt])
+                if nxt in sample_pos or nxt % 128 == 5:
+                    oracles[cid] = Oracle(42, t48, fcs[nxt], FS, 262144)
+                nxt += 1
+        x = siggen.xs_u8(4700 + k, 262144)
+        check_clients(eng, oracles, "cu8", x, "optimized")
+    assert nxt == 1024 and len(oracles) == 16
+    d = eng.describe()
+    assert "clients 1024 classes 21 " in d and "polyphase: cls0 D42 T505 cols1024 " in d and "cls1" not in d, d
+    assert "optimized-mode direct: none" in d, d
+    check_clients(eng, oracles, "cu8", siggen.xs_u8(4790, 262144), "native")
+    check_clients(eng, oracles, "cu8", siggen.xs_u8(4791, 100002), "optimized")
+    eng.close()
+
+
+def test_many_classes_no_limit():
+    """More than 48 distinct (D, T, grid offset) classes in one engine: blocks of 1009 samples (= 1 mod 42), a 48 kHz
+    client joining before each of 42 blocks and a 96 kHz client before each of the first 21 -> 63 classes, every one
+    with its own output grid.  (Round 1 failed every client with -E2BIG at the 49th class.)"""
+    t48, t96 = lpf(FS, 24000, 9600), lpf(FS, 48000, 19200)
+    eng = xl.BatchEngine(FS, "cu8", 20000)
+    oracles = {}
+    for k in range(44):
+        if k < 42:
+            fc = -500000 + 17000 * k
+            oracles[eng.add_client(42, t48, fc)] = Oracle(42, t48, fc, FS, 20000)
+        if k < 21:
+            fc = 300000 + 9000 * k
+            oracles[eng.add_client(21, t96, fc)] = Oracle(21, t96, fc, FS, 20000)
+        check_clients(eng, oracles, "cu8", siggen.xs_u8(4800 + k, 2 * 1009), "native" if k % 2 else "optimized")
+    d = eng.describe()
+    assert "clients 63 classes 63 " in d, d
+    eng.close()
+
+
+def test_calls_on_different_streams_are_ordered():
+    """Consecutive calls on different HIP streams (advice r1): the engine orders them itself."""
+    import torch
+
+    t48 = lpf(FS, 24000, 9600)
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    fcs = [-900000 + 28000 * c for c in range(40)]
+    oracles = {eng.add_client(42, t48, fc): Oracle(42, t48, fc, FS, 262144) for fc in fcs}
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    blocks = [siggen.xs_u8(4900 + k, 262144) for k in range(6)]
+    dev = [torch.from_numpy(b).cuda() for b in blocks]
+    torch.cuda.synchronize()
+    wants = {cid: [o.process("cu8", b) for b in blocks] for cid, o in oracles.items()}
+    for k in range(6):
+        st = streams[k % 3]
+        eng.process_device(dev[k].data_ptr(), 262144, "native", st.cuda_stream)
+        if k in (2, 5):
+            eng.fetch()
+            for cid in oracles:
+                assert bits_equal(eng.output(cid), wants[cid][k]), (k, cid)
+    eng.close()
+
+
+def test_set_option_and_unknown_option():
+    eng = xl.BatchEngine(FS, "cu8", 262144)
+    with pytest.raises(xl.XlatingError) as e:
+        eng.set_option("no_such_option", 1)
+    assert e.value.code == -2
+    with pytest.raises(xl.XlatingError):
+        eng.set_option("polyphase_m", 100)
+    eng.set_option("polyphase", 1)
+    eng.set_option("polyphase_m", 256)
+    t48 = lpf(FS, 24000, 9600)
+    for c in range(5):
+        eng.add_client(42, t48, 1000 * c)
+    assert "polyphase: cls0 D42 T505 cols5 V244 M256" in eng.describe()
+    eng.close()

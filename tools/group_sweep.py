@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""tools/group_sweep.py -- GPU: time per BLOCK vs blocks per call (G), client count, variant, transform length.
+Run on the GPU box:  python tools/group_sweep.py [--clients 128,1024] [--groups 1,2,4,8] [--modes optimized,native] [--m 0,128,256]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import siggen  # noqa: E402
+import sdr_server_amd as xl  # noqa: E402
+
+FS, D, BLOCK = 2016000, 42, 262144
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clients", default="128,256,1024,4096")
+    ap.add_argument("--groups", default="1,2,4,8")
+    ap.add_argument("--modes", default="optimized")
+    ap.add_argument("--m", default="0")
+    ap.add_argument("--rate", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=320, help="blocks in the timed region")
+    ap.add_argument("--poly3", action="store_true", help="also time the three polyphase launches separately")
+    ap.add_argument("--slices", default="")
+    args = ap.parse_args()
+    code, taps = xl.create_low_pass_filter(1.0, FS, 24000, 48000 // args.rate)
+    gmax = max(int(g) for g in args.groups.split(","))
+    data = torch.from_numpy(siggen.xs_u8(99, gmax * BLOCK)).cuda()
+    st = torch.cuda.current_stream()
+    print(f"{'mode':10s} {'M':>4s} {'clients':>7s} {'G':>2s} {'us/block':>9s} {'kern us/blk':>11s} {'Msps':>10s}   plan / launches us per block")
+    for mode in args.modes.split(","):
+        for m in [int(v) for v in args.m.split(",")]:
+            for n in [int(c) for c in args.clients.split(",")]:
+                for G in [int(g) for g in args.groups.split(",")]:
+                    eng = xl.BatchEngine(FS, "cu8", BLOCK, group_blocks=G)
+                    if m:
+                        eng.set_option("polyphase_m", m)
+                    if args.slices:
+                        a, b = (int(v) for v in args.slices.split(","))
+                        eng.set_option("nco_slices", (a << 16) | b)
+                    for c in range(n):
+                        eng.add_client(D, taps, -984000 + 1920 * (c % 1024) + 240 * (c // 1024))
+                    calls = max(4, args.blocks // G)
+                    for k in range(4):
+                        eng.process_device_group(data.data_ptr(), BLOCK, G, mode, st.cuda_stream)
+                    torch.cuda.synchronize()
+                    eng.timing_stride(2)
+                    eng.timing(1)
+                    t0 = time.perf_counter()
+                    for k in range(calls):
+                        eng.process_device_group(data.data_ptr(), BLOCK, G, mode, st.cuda_stream)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / (calls * G)
+                    nt, fir, nco = eng.timing_read()
+                    eng.timing(0)
+                    extra = ""
+                    if args.poly3 and "polyphase: none" not in eng.describe() and mode == "optimized":
+                        eng.timing_stride(1)
+                        eng.timing(2)
+                        for k in range(8):
+                            eng.process_device_group(data.data_ptr(), BLOCK, G, mode, st.cuda_stream)
+                        torch.cuda.synchronize()
+                        n3, ms3 = eng.timing_polyphase()
+                        eng.timing(0)
+                        if n3:
+                            extra = "fwd %.1f mix %.1f inv %.1f" % tuple(v / n3 / G * 1e3 for v in ms3)
+                    plan = eng.describe()
+                    eng.close()
+                    kern = fir / max(nt, 1) / G * 1e3
+                    print(f"{mode:10s} {m:4d} {n:7d} {G:2d} {dt*1e6:9.2f} {kern:11.2f} {n*131072/dt/1e6:10.0f}   {plan.split('|')[2].strip()[:60]} {extra}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
