@@ -1,32 +1,41 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the xlating-FIR hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
 
-A "step" = one pass of the hot path over one IQ block for every client of every GPU:
-    N > 1: rank 0's block is broadcast over RCCL/xGMI (the path's only exchange step), then each rank runs its
-    own clients on it -- no further communication (clients are embarrassingly parallel).
-Workload (config.workload): 1024 concurrent 48 kHz clients PER GPU off one 2.016 Msps cu8 stream, server-default
-262144-byte blocks (131072 complex samples), D=42, low-pass designed with the server default lpf_cutoff_rate=5
--> 505 taps (the BASELINE "~84-tap" figure is not reachable with the reference's designer; the
-lpf_cutoff_rate=1 -> 101-tap variant is measured too and reported under "variants").  Weak scaling: per-GPU work
-is fixed as N grows.  Inputs are synthetic (xorshift bytes), already resident in HBM when the timed region starts.
+N > 1 without a torch.distributed environment re-launches itself under `python -m torch.distributed.run` (one rank per
+GPU, rendezvous on 127.0.0.1); inside such a launch (RANK / WORLD_SIZE set, e.g. by the driver) it just runs its rank.
+
+Workload (config.workload) = BASELINE.json configs[3] / the 1-GPU target: 1024 concurrent 48 kHz clients IN TOTAL
+(`--scaling strong`, the default: client c -> GPU c mod N; `--scaling weak`: 1024 per GPU) off one 2.016 Msps cu8
+stream, server-default 262144-byte blocks (131072 complex samples), D = 42, low-pass designed with the server default
+lpf_cutoff_rate=5 -> 505 taps (the BASELINE "~84-tap" figure is not reachable with the reference's designer,
+SURVEY D3).  The engine is driven as sdr_callback would drive it with a super-block: calls
+of 8 consecutive blocks (xlating_batch_process_device_group) -- results identical to 8 successive process calls.
+
+A "step" = one pass of the hot path over one batch of synthetic input = BLOCKS_PER_STEP consecutive blocks (40 calls of
+8 blocks, 41.9 M samples of the stream) for every client of every GPU; ms_per_step x steps = the timed seconds.
+    N > 1: rank 0's blocks are broadcast over RCCL/xGMI, 8 blocks per broadcast, on a side stream (the path's only
+    exchange step), then each rank runs its own clients on them -- no further communication.
+Inputs are synthetic (xorshift bytes), already resident in HBM when the timed region starts.
 
 Prints ONE JSON line (rank 0): value = input IQ Msamples/s summed over all clients and GPUs.
-"roofline":     HBM-read roofline of the block's launches, per-client-read model of SURVEY 8(d): algorithmic bytes per
-                block = clients x samples x (2 B in + 8/D B out), divided by the mean duration of the block's
-                launches measured with HIP events on the launch stream inside the timed region.  The optimized
-                variant of this workload runs the polyphase overlap-save kernels (three launches per block:
-                forward / mix / inverse, xl_polyphase.hip) -- HBM-bound; their separate durations come from a
-                short extra pass after the timed region ("kernels_ms").  The direct FIR kernel (what the native
-                variant and short filters use; 96 flop per (client, sample) at 505 taps: FP32-bound) is reported
-                under "variants" with its FP32 fraction.
+"roofline":     per-client-read model of SURVEY 8(d): algorithmic bytes per call = clients x samples x (2 B in + 8/D B
+                out), divided by the mean duration of a call's launches measured with HIP events on the launch stream
+                inside the timed region ("frac").  "traffic" = HBM bytes per call from the PMC counters (separate
+                rocprofv3 passes; "traffic_source" says where they were measured) and "hbm_counter_frac" = traffic /
+                that duration / peak: what the launches really move.
+"parity_spot":  after the timed region 16 sampled clients are fetched and compared with the oracle (whose stream state
+                is fast-forwarded over the run: phase recurrence only, then real blocks).
+"native":       the same workload with the reference's default arithmetic (cpu_optimization NATIVE_CF32,
+                src/config.c:252-264): bit-exact scalar order, direct FIR kernel.
 "cpu_baseline": the reference itself (oracle/_ref, unmodified sources, -O3 -ffast-math AVX2) -- or the repo's CPU
                 restatement when that build is absent -- timed on this box's host cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -42,10 +51,12 @@ RATE = 48000
 D = FS // RATE
 BLOCK_BYTES = 262144            # server default buffer_size (src/resources/config.conf:13)
 S = BLOCK_BYTES // 2            # complex samples per block
+GROUP = 8                       # blocks per engine call and per RCCL broadcast (8-block super-block)
+BLOCKS_PER_STEP = 320           # blocks per bench step (40 calls): 20 steps ~ 0.2 s of GPU time at 1024 clients
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
-TIMING_STRIDE = 4               # HIP events bracket every 4th block of the timed region (an event pair costs ~6 us of
-                                # stream time: measured 65.7 us per block with a pair per block, 59.9 us with one per 4)
+TIMING_STRIDE = 4               # HIP events bracket every 4th call of the timed region (an event pair costs ~6 us of stream time)
+SPOT_CLIENTS = 16
 
 
 def shard_clients(total_clients, world_size, rank):
@@ -69,8 +80,8 @@ def flops_per_unit(ntaps, decim):
 
 
 def broadcast_block(dist, recv, src_block, rank):
-    """The path's only exchange step: rank 0's raw IQ block -> every rank (RCCL over xGMI on GPUs, gloo in the
-    CPU tests).  `recv` is each rank's receive buffer; returns the tensor holding the block on this rank."""
+    """The path's only exchange step: rank 0's raw IQ blocks -> every rank (RCCL over xGMI on GPUs, gloo in the
+    CPU tests).  `recv` is each rank's receive buffer; returns the tensor holding the blocks on this rank."""
     if rank == 0:
         recv.copy_(src_block, non_blocking=True)
     dist.broadcast(recv, src=0)
@@ -84,19 +95,262 @@ def reduce_max_seconds(dist, torch, dt, device):
     return float(t.item())
 
 
-def make_blocks(nblocks, seed):
+NSRC_GROUPS = 4  # distinct 8-block super-blocks the synthetic stream cycles through
+
+
+def make_group(g, seed=0x5DEECE66D):
+    """Super-block g of the synthetic stream: GROUP blocks back to back (uint8)."""
     import siggen
 
-    return [siggen.xs_u8(seed + k, BLOCK_BYTES) for k in range(nblocks)]
+    return siggen.xs_u8(seed + g, GROUP * BLOCK_BYTES)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside a torch.distributed environment: start N ranks of this script on this node
+    (what the driver's own `python -m torch.distributed.run ... bench.py` command does) and pass their output through."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------- engines
+class PlumbingEngine:
+    """CPU stand-in for the HIP engine, used ONLY by `--plumbing-test` (tests/test_bench_launch.py: the launcher,
+    sharding, feed and reduce code paths on a GPU-less box).  It filters nothing and its numbers are never reported as
+    a measurement ("data": "cpu-plumbing-test")."""
+
+    def __init__(self):
+        self.n = 0
+        self.calls = 0
+
+    def add_client(self, *a):
+        self.n += 1
+        return self.n - 1
+
+    def process_device_group(self, ptr, input_len, nblocks, mode, stream=0):
+        self.calls += 1
+
+    def describe(self):
+        return f"clients {self.n} classes 1 | direct: none | polyphase: none"
+
+    def timing(self, *a):
+        pass
+
+    timing_stride = sync = close = timing
+
+    def timing_read(self, reset=True):
+        return 0, 0.0, 0.0
+
+    def output_len(self, cid):
+        return 0
+
+
+class GroupFeeder:
+    """Delivers super-block k (GROUP blocks) to this rank: N = 1 -> a resident device buffer; N > 1 -> rank 0's
+    super-blocks broadcast over RCCL/xGMI into one of two alternating receive buffers ON A SEPARATE STREAM, so that
+    the broadcast of super-block k+1 overlaps the filtering of k (events order buffer reuse: the broadcast into a
+    buffer waits until the launches that read it two calls ago have been passed by the compute stream)."""
+
+    def __init__(self, torch, dist, rank, world, dev_groups, cuda=True):
+        self.torch, self.dist, self.rank, self.world, self.groups, self.cuda = torch, dist, rank, world, dev_groups, cuda
+        self.issued = 0
+        if world > 1:
+            dev = "cuda" if cuda else "cpu"
+            self.recv = [torch.empty(GROUP * BLOCK_BYTES, dtype=torch.uint8, device=dev) for _ in range(2)]
+            if cuda:
+                self.comm = torch.cuda.Stream()
+                self.ready = [torch.cuda.Event() for _ in range(2)]
+                self.free = [torch.cuda.Event() for _ in range(2)]
+            self.free_valid = [False, False]
+
+    def _issue(self, g):
+        torch = self.torch
+        i = g % 2
+        if not self.cuda:
+            broadcast_block(self.dist, self.recv[i], self.groups[g % len(self.groups)] if self.rank == 0 else None, self.rank)
+            self.issued = g + 1
+            return
+        if self.free_valid[i]:
+            self.comm.wait_event(self.free[i])
+        with torch.cuda.stream(self.comm):
+            broadcast_block(self.dist, self.recv[i], self.groups[g % len(self.groups)] if self.rank == 0 else None, self.rank)
+            self.ready[i].record(self.comm)
+        self.issued = g + 1
+
+    def get(self, k, stream):
+        """Device pointer of super-block k, valid on `stream`; call consumed(k, stream) after enqueuing its consumer."""
+        if self.world == 1:
+            return self.groups[k % len(self.groups)].data_ptr()
+        while self.issued <= k + 1:  # keep one broadcast in flight ahead of the consumer
+            self._issue(self.issued)
+        if self.cuda:
+            stream.wait_event(self.ready[k % 2])
+        return self.recv[k % 2].data_ptr()
+
+    def consumed(self, k, stream):
+        if self.world > 1 and self.cuda:
+            self.free[k % 2].record(stream)
+            self.free_valid[k % 2] = True
+
+
+def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROUP, options=None, staggered=False,
+                 spot=False, poly3=True):
+    """Build this rank's engine with its shard of clients and time `steps` steps.  Returns dict of measurements.
+    options: engine plan options (xlating_batch_set_option); staggered: the clients join over 21 consecutive blocks
+    before the warm-up (every join lands on another output grid) instead of all before block 0."""
+    xl, torch, dist, rank, world = ctx["xl"], ctx["torch"], ctx["dist"], ctx["rank"], ctx["world"]
+    cuda = ctx["cuda"]
+    code, taps = ctx["lpf"](1.0, FS, RATE // 2, RATE // ntaps_rate)
+    assert code == 0
+    mine = shard_clients(total_clients, world, rank)
+    if cuda:
+        eng = xl.BatchEngine(FS, "cu8", BLOCK_BYTES, device=torch.cuda.current_device(), group_blocks=group)
+        for k, v in (options or {}).items():
+            eng.set_option(k, v)
+        stream = torch.cuda.current_stream()
+        sptr = stream.cuda_stream
+    else:
+        eng, stream, sptr = PlumbingEngine(), None, 0
+    feeder = GroupFeeder(torch, dist, rank, world, ctx["dev_groups"], cuda)
+    calls_per_step = BLOCKS_PER_STEP // GROUP
+    state = {"k": 0}
+    ids = {}
+
+    def call(nblocks=group):
+        # (a call of fewer than GROUP blocks reads the head of the super-block)
+        k = state["k"]
+        ptr = feeder.get(k, stream)
+        for j in range(0, GROUP, nblocks):
+            eng.process_device_group(ptr + j * BLOCK_BYTES, BLOCK_BYTES, nblocks, mode, sptr)
+        feeder.consumed(k, stream)
+        state["k"] = k + 1
+
+    if staggered and cuda:  # one block per call while the clients trickle in (21 joins, then 3 blocks to mature + merge)
+        per = -(-len(mine) // 21)
+        ptr0 = ctx["dev_groups"][0].data_ptr() if world == 1 else None
+        for j in range(24):
+            for c in mine[j * per:(j + 1) * per]:
+                ids[c] = eng.add_client(D, taps, client_center_freq(c))
+            if world > 1:
+                ptr0 = feeder.get(state["k"], stream)
+            eng.process_device_group(ptr0 + (j % GROUP) * BLOCK_BYTES, BLOCK_BYTES, 1, mode, sptr)
+            if world > 1:
+                feeder.consumed(state["k"], stream)
+                state["k"] += 1
+    else:
+        for c in mine:
+            ids[c] = eng.add_client(D, taps, client_center_freq(c))
+    blocks_before = (24 if staggered and cuda else 0)
+
+    for _ in range(warmup * calls_per_step if warmup else 2):
+        call()
+    warm_calls = state["k"] - (blocks_before if world > 1 else 0)
+    if cuda:
+        eng.sync()
+        torch.cuda.synchronize()
+    eng.timing_stride(TIMING_STRIDE)
+    eng.timing(True)
+    if world > 1:
+        dist.barrier()
+    if cuda:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps * calls_per_step):
+        call()
+    if cuda:
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if cuda:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nt, fir_ms, nco_ms = eng.timing_read(reset=True)
+    eng.timing(False)
+    if world > 1:
+        dt = reduce_max_seconds(dist, torch, dt, "cuda" if cuda else "cpu")
+    plan = eng.describe()
+    polyphase = mode == "optimized" and "polyphase: none" not in plan
+    klen = eng.output_len(ids[mine[0]]) if mine else 0
+
+    spot_res = None
+    if spot and cuda and mine and group == GROUP and not staggered and world == 1:
+        spot_res = parity_spot(ctx, eng, ids, mine, taps, mode, state["k"], call)
+
+    kernels_ms = None
+    if polyphase and poly3 and cuda:  # separate durations of the three launches: a short extra pass, OUTSIDE the timed region
+        eng.timing_stride(1)
+        eng.timing(2)
+        for _ in range(8):
+            call()
+        torch.cuda.synchronize()
+        n3, ms3 = eng.timing_polyphase(reset=True)
+        eng.timing(False)
+        if n3 > 0:
+            kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), "xlp_mix_kernel": round(ms3[1] / n3, 4),
+                          "xlp_inverse_kernel": round(ms3[2] / n3, 4)}
+    eng.close()
+    return {"ntaps": int(taps.size), "seconds": dt, "call_ms_avg": fir_ms / max(nt, 1), "nco_ms_avg": nco_ms / max(nt, 1),
+            "timed_calls": nt, "clients_this_rank": len(mine), "total_clients": total_clients, "K_call": int(klen),
+            "plan": plan, "polyphase": polyphase, "kernels_ms": kernels_ms, "group": group, "steps": steps,
+            "warm_calls": warm_calls, "parity_spot": spot_res}
+
+
+def parity_spot(ctx, eng, ids, mine, taps, mode, calls_done, call):
+    """16 sampled clients of the engine the timed region just ran, vs the oracle.  The oracle's stream state (phase
+    recurrence with per-block renormalisation, history counter) is fast-forwarded over the blocks processed so far
+    without filtering, then it filters the next super-block for real to load its sample history, and the one after is
+    compared (native: bit-exact; optimized: max|d| / max|y| <= 1e-5)."""
+    odir = os.path.join(ROOT, "oracle")  # the checker (test infrastructure): never on the timed path
+    if odir not in sys.path:
+        sys.path.insert(0, odir)
+    from pyoracle import Oracle
+
+    t0 = time.perf_counter()
+    n = len(mine)
+    sample = sorted({mine[(i * (n - 1)) // (SPOT_CLIENTS - 1)] for i in range(SPOT_CLIENTS)}) if n > 1 else list(mine)
+    ors = {}
+    for c in sample:
+        o = Oracle(D, taps, client_center_freq(c), FS, BLOCK_BYTES)
+        o.skip_calls(S, calls_done * GROUP)
+        ors[c] = o
+    worst, exact, want_len = 0.0, True, 0
+    for rnd in range(2):
+        g = make_group((calls_done + rnd) % NSRC_GROUPS)
+        call()
+        if rnd == 1:
+            eng.fetch()
+        for c, o in ors.items():
+            want = np.concatenate([o.process("cu8", bl) for bl in np.split(g, GROUP)])
+            if rnd == 0:
+                continue
+            got = eng.output(ids[c])
+            if got.shape != want.shape:
+                worst, exact = float("inf"), False
+                continue
+            want_len = len(want)
+            worst = max(worst, float(np.abs(got.astype(np.complex128) - want).max() / np.abs(want).max()))
+            exact = exact and np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    for o in ors.values():
+        o.close()
+    return {"clients": len(sample), "blocks_before": calls_done * GROUP, "outputs_compared_per_client": want_len,
+            "max_rel": worst, "bit_exact": bool(exact), "tolerance": 0.0 if mode == "native" else 1e-5,
+            "ok": bool(exact if mode == "native" else worst <= 1e-5), "seconds": round(time.perf_counter() - t0, 2),
+            "how": "oracle fast-forwarded over the run's blocks (phase recurrence + per-block renormalisation only), one "
+                   "super-block filtered to load its history, the next one compared"}
 
 
 def cpu_baseline(ntaps_rate, seconds=12.0):
     """Reference (oracle/_ref/libref_fast.so) -- or the repo's CPU restatement when that build is absent -- on the
     host cores, via the native pthread driver oracle/cpu_bench: one thread per client, each with its own filter
     over the same block (the reference's dsp_worker model, src/dsp_worker.c:41-88).  Bounded sample: `seconds` of
-    wall time split between a 1-thread and an all-cores run."""
-    import subprocess
-
+    wall time split between a 1-thread and an all-threads run."""
     odir = os.path.join(ROOT, "oracle")
     drv = os.path.join(odir, "cpu_bench")
     flags = open("/proc/cpuinfo").read()
@@ -105,194 +359,102 @@ def cpu_baseline(ntaps_rate, seconds=12.0):
     ref = os.path.join(odir, "_ref", "libref_fast.so")
     if os.path.exists(ref) and " avx2 " in flat and " fma " in flat:
         lib, api, variant, kind = ref, "ref", "optimized", "reference"
-        what = "unmodified src/xlating.c process_optimized_cu8_cf32 (hand-written AVX path; gcc -O3 -ffast-math -mavx2 -mfma)"
+        what = "unmodified src/xlating.c process_optimized_cu8_cf32 (hand-written AVX path, no phase renormalisation; gcc -O3 -ffast-math -mavx2 -mfma)"
     else:
         lib, api, variant, kind = os.path.join(odir, "liboracle.so"), "orc", "native", "port"
         what = "oracle/xlating_oracle.c scalar restatement (gcc -O2, canonical order)"
-    cores = os.cpu_count() or 1
+    threads = os.cpu_count() or 1
+    phys = set()
+    pid = cid = None
+    for line in flags.splitlines():
+        if line.startswith("physical id"):
+            pid = line.split(":")[1].strip()
+        elif line.startswith("core id"):
+            cid = line.split(":")[1].strip()
+        elif not line.strip() and pid is not None and cid is not None:
+            phys.add((pid, cid))
+            pid = cid = None
+    cores = len(phys) or threads
 
-    def run(threads, secs):
-        r = subprocess.run([drv, lib, api, variant, str(threads), str(secs), str(FS), str(RATE), str(RATE // ntaps_rate),
+    def run(nthreads, secs):
+        r = subprocess.run([drv, lib, api, variant, str(nthreads), str(secs), str(FS), str(RATE), str(RATE // ntaps_rate),
                             str(BLOCK_BYTES)], capture_output=True, text=True, timeout=secs * 3 + 60)
         if r.returncode != 0:
             raise RuntimeError(f"cpu_bench failed: {r.stderr[-500:]}")
         return json.loads(r.stdout.strip().splitlines()[-1])
 
     one = run(1, max(2.0, seconds * 0.3))
-    allc = run(cores, max(3.0, seconds * 0.7))
+    allc = run(threads, max(3.0, seconds * 0.7))
     return {
-        "value": round(allc["msps"], 1), "unit": "Msamples/s", "cores": cores, "kind": kind,
+        "value": round(allc["msps"], 1), "unit": "Msamples/s", "cores": cores, "threads": threads, "kind": kind,
         "single_thread_value": round(one["msps"], 1),
         "sample": f"{what}; lpf_cutoff_rate={ntaps_rate} -> {allc['ntaps']} taps, D={D}, {BLOCK_BYTES}-byte cu8 blocks, one "
-                  f"filter per thread over a shared block; {allc['calls']} calls on {cores} threads in {allc['seconds']:.1f} s "
-                  f"wall (+ {one['calls']} calls on 1 thread in {one['seconds']:.1f} s); host CPU: {model}",
+                  f"filter per thread over a shared block; {allc['calls']} calls on {threads} threads ({cores} physical cores) in "
+                  f"{allc['seconds']:.1f} s wall (+ {one['calls']} calls on 1 thread in {one['seconds']:.1f} s); host CPU: {model}",
     }
 
 
-FEED_GROUP = 8  # blocks per RCCL broadcast (SURVEY 8(d) config 4 names the 8-block super-block): the cross-stream event
-                # pair that orders a broadcast against the filtering costs ~10 us of stream time (tools/feed_overhead.py:
-                # 58.7 -> 68.8 us per block with one pair per block), a sixth of a block's launches
-
-
-class BlockFeeder:
-    """Delivers block k to this rank: N = 1 -> a resident device buffer; N > 1 -> rank 0's blocks broadcast over
-    RCCL/xGMI, FEED_GROUP blocks per broadcast, into one of two alternating receive buffers ON A SEPARATE STREAM, so
-    that the broadcast of group g+1 overlaps the filtering of group g (events order buffer reuse: the broadcast into a
-    buffer waits until the launches that read it two groups ago have been passed by the compute stream)."""
-
-    def __init__(self, torch, dist, rank, world, dev_blocks, group=FEED_GROUP):
-        self.torch, self.dist, self.rank, self.world, self.blocks = torch, dist, rank, world, dev_blocks
-        self.group = group
-        self.issued = 0  # groups issued
-        if world > 1:
-            self.recv = [torch.empty(group * BLOCK_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)]
-            self.comm = torch.cuda.Stream()
-            self.ready = [torch.cuda.Event() for _ in range(2)]
-            self.free = [torch.cuda.Event() for _ in range(2)]
-            self.free_valid = [False, False]
-
-    def _issue(self, g):
-        torch = self.torch
-        i = g % 2
-        if self.free_valid[i]:
-            self.comm.wait_event(self.free[i])
-        with torch.cuda.stream(self.comm):
-            if self.rank == 0:
-                for j in range(self.group):
-                    src = self.blocks[(g * self.group + j) % len(self.blocks)]
-                    self.recv[i][j * BLOCK_BYTES:(j + 1) * BLOCK_BYTES].copy_(src, non_blocking=True)
-            self.dist.broadcast(self.recv[i], src=0)  # the path's only exchange step
-            self.ready[i].record(self.comm)
-        self.issued = g + 1
-
-    def get(self, k, stream):
-        """Device pointer of block k, valid on `stream`; call consumed(k, stream) after enqueuing its consumer."""
-        if self.world == 1:
-            return self.blocks[k % len(self.blocks)].data_ptr()
-        g, j = divmod(k, self.group)
-        while self.issued <= g + 1:  # keep one broadcast in flight ahead of the consumer
-            self._issue(self.issued)
-        if j == 0:
-            stream.wait_event(self.ready[g % 2])
-        return self.recv[g % 2].data_ptr() + j * BLOCK_BYTES
-
-    def consumed(self, k, stream):
-        if self.world > 1 and k % self.group == self.group - 1:
-            g = k // self.group
-            self.free[g % 2].record(stream)
-            self.free_valid[g % 2] = True
-
-
-def run_workload(xl, torch, dist, args, rank, world, ntaps_rate, steps, warmup, dev_blocks, mode=None, poly=None):
-    """Build this rank's engine with its shard of clients and time `steps` blocks.  Returns dict of measurements.
-    poly: None = the engine's own choice of arithmetic path for the optimized variant; 0 = direct FIR kernels only
-    (the engine reads the XL_EXP_POLY tuning switch when it is created)."""
-    code, taps = xl.create_low_pass_filter(1.0, FS, RATE // 2, RATE // ntaps_rate)
-    assert code == 0
-    total_clients = args.clients_per_gpu * world
-    mine = shard_clients(total_clients, world, rank)
-    saved = os.environ.get("XL_EXP_POLY")
-    if poly is not None:
-        os.environ["XL_EXP_POLY"] = str(poly)
-    eng = xl.BatchEngine(FS, "cu8", BLOCK_BYTES, device=torch.cuda.current_device())
-    if poly is not None:
-        if saved is None:
-            del os.environ["XL_EXP_POLY"]
-        else:
-            os.environ["XL_EXP_POLY"] = saved
-    for c in mine:
-        eng.add_client(D, taps, client_center_freq(c))
-    stream = torch.cuda.current_stream()
-    feeder = BlockFeeder(torch, dist, rank, world, dev_blocks)
-
-    def step(k):
-        ptr = feeder.get(k, stream)
-        eng.process_device(ptr, BLOCK_BYTES, mode or args.mode, stream.cuda_stream)
-        feeder.consumed(k, stream)
-
-    for k in range(warmup):
-        step(k)
-    eng.sync()
-    torch.cuda.synchronize()
-    eng.timing_stride(TIMING_STRIDE)
-    eng.timing(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        step(warmup + k)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    nt, fir_ms, nco_ms = eng.timing_read(reset=True)
-    eng.timing(False)
-    if world > 1:
-        dt = reduce_max_seconds(dist, torch, dt, "cuda")
-    klen = eng.output_len(0)
-    plan = eng.describe()
-    use_mode = mode or args.mode
-    polyphase = use_mode == "optimized" and "polyphase: none" not in plan
-    kernels_ms = None
-    if polyphase:  # separate durations of the three launches: a short extra pass, OUTSIDE the timed region
-        eng.timing_stride(1)
-        eng.timing(2)
-        extra = 40
-        for k in range(extra):
-            step(warmup + steps + k)
-        torch.cuda.synchronize()
-        n3, ms3 = eng.timing_polyphase(reset=True)
-        eng.timing(False)
-        if n3 > 0:
-            kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), "xlp_mix_kernel": round(ms3[1] / n3, 4),
-                          "xlp_inverse_kernel": round(ms3[2] / n3, 4)}
-    eng.close()
-    return {"ntaps": int(taps.size), "seconds": dt, "fir_ms_avg": fir_ms / max(nt, 1), "nco_ms_avg": nco_ms / max(nt, 1),
-            "timed_launches": nt, "clients_this_rank": len(mine), "total_clients": total_clients, "K": int(klen),
-            "plan": plan, "polyphase": polyphase, "kernels_ms": kernels_ms}
-
-
-def polyphase_traffic_model(nclients, K, ntaps, M=128):
-    """HBM bytes one block moves by design on the polyphase path (xl_polyphase.h), per GPU: branch spectra R read
-    once (8 D M bytes per client), mixed spectra Y written and read back (8 M bytes per client and segment), outputs
-    written, NCO phase table (every 16th phase) written and read; the shared spectra X and the raw block are noise."""
+def polyphase_traffic_model(nclients, K_call, ntaps, group, M=128):
+    """HBM bytes one CALL of `group` blocks moves by design on the polyphase path (xl_polyphase.h), per GPU: branch
+    spectra R read once per call (8 D M bytes per client), mixed spectra Y written and read back (8 M bytes per client
+    and segment), outputs written, NCO phase table (every 16th phase) written and read; the shared spectra X and the
+    raw blocks are noise."""
     A = -(-ntaps // D)
     V = M - A + 1
-    nseg = -(-K // V)
+    nseg = -(-(K_call + 2) // V)
     dpad = -(-D // 7) * 7
-    per_client = 8 * dpad * M + 2 * 8 * M * nseg + 8 * K + 2 * 8 * (K // 16)
-    return {"transform_length_M": M, "bytes_per_block": int(nclients * per_client), "bytes_per_client": int(per_client),
-            "R_branch_spectra": 8 * dpad * M, "Y_mixed_spectra_write_plus_read": 2 * 8 * M * nseg,
-            "out": 8 * K, "phase_table_write_plus_read": 2 * 8 * (K // 16)}
+    per_client = 8 * dpad * M + 2 * 8 * M * nseg + 8 * K_call + 2 * 8 * (K_call // 16)
+    return {"transform_length_M": M, "blocks_per_call": group, "bytes_per_call": int(nclients * per_client),
+            "bytes_per_block": int(nclients * per_client / group), "bytes_per_client_per_block": int(per_client / group),
+            "R_branch_spectra_per_call": 8 * dpad * M, "Y_mixed_spectra_write_plus_read_per_call": 2 * 8 * M * nseg,
+            "out_per_call": 8 * K_call, "phase_table_write_plus_read_per_call": 2 * 8 * (K_call // 16)}
 
 
-def summarize(m, steps, world):
-    """value and roofline figures from the timed region of `m` (HIP-event duration of the FIR launches in it)."""
-    units_per_step = m["total_clients"] * S
-    value = units_per_step * steps / m["seconds"] / 1e6
-    per_gpu_units = m["clients_this_rank"] * S
+def summarize(m):
+    """value and roofline figures from the timed region of `m` (HIP-event duration of the calls' launches in it)."""
+    blocks = m["steps"] * BLOCKS_PER_STEP
+    value = m["total_clients"] * S * blocks / m["seconds"] / 1e6
+    units_per_call = m["clients_this_rank"] * S * m["group"]
     bpu = algorithmic_bytes_per_unit(D)
     fpu = flops_per_unit(m["ntaps"], D)
-    fir_s = m["fir_ms_avg"] * 1e-3
-    ach_gbs = per_gpu_units * bpu / fir_s / 1e9 if fir_s > 0 else 0.0
-    ach_tf = per_gpu_units * fpu / fir_s / 1e12 if fir_s > 0 else 0.0
+    call_s = m["call_ms_avg"] * 1e-3
+    ach_gbs = units_per_call * bpu / call_s / 1e9 if call_s > 0 else 0.0
+    ach_tf = units_per_call * fpu / call_s / 1e12 if call_s > 0 else 0.0
     return value, ach_gbs, ach_tf, bpu, fpu
+
+
+def variant_entry(m, note=None):
+    v, g, t, _, f = summarize(m)
+    e = {"value": round(v, 1), "ms_per_step": round(m["seconds"] / m["steps"] * 1e3, 4),
+         "us_per_block": round(m["seconds"] / (m["steps"] * BLOCKS_PER_STEP) * 1e6, 3),
+         "launches_ms_per_call": round(m["call_ms_avg"], 4), "blocks_per_call": m["group"],
+         "path": "polyphase" if m["polyphase"] else "direct FIR kernel",
+         "roofline_hbm_frac": round(g / HBM_PEAK_GBS, 4),
+         "fp32_frac": None if m["polyphase"] else round(t / FP32_PEAK_TFLOPS, 4),
+         "achieved_TFLOPs": None if m["polyphase"] else round(t, 2), "plan": m["plan"]}
+    if note:
+        e["note"] = note
+    return e
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--clients-per-gpu", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clients", type=int, default=1024, help="strong scaling: clients in total; weak: per GPU")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--mode", default="optimized", choices=["native", "optimized"])
     ap.add_argument("--lpf-cutoff-rate", type=int, default=5, help="server config lpf_cutoff_rate: 5 -> 505 taps, 1 -> 101")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spot", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_launch.py only
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch
 
@@ -300,63 +462,65 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
-    if not torch.cuda.is_available():
+        raise SystemExit(f"--gpus {args.gpus} but the torch.distributed environment has WORLD_SIZE={world}")
+    cuda = not args.plumbing_test
+    if cuda and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU path to time)")
-    torch.cuda.set_device(local_rank)
+    if cuda:
+        torch.cuda.set_device(local_rank)
     dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if cuda:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+        rccl_ranks = dist.get_world_size()
 
-    import sdr_server_amd as xl
+    if cuda:
+        import sdr_server_amd as xl
 
-    blocks = make_blocks(8, 0x5DEECE66D)
-    dev_blocks = [torch.from_numpy(b).cuda() for b in blocks] if (rank == 0 or world == 1) else []
+        lpf = xl.create_low_pass_filter
+    else:
+        xl, lpf = None, (lambda gain, fs, cutoff, tw: (0, np.ones(505 if tw < 20000 else 101, np.float32)))
 
-    m = run_workload(xl, torch, dist, args, rank, world, args.lpf_cutoff_rate, args.steps, args.warmup, dev_blocks)
-    value, ach_gbs, ach_tf, bpu, fpu = summarize(m, args.steps, world)
+    dev_groups = []
+    if rank == 0 or world == 1:
+        dev_groups = [torch.from_numpy(make_group(g)) for g in range(NSRC_GROUPS)]
+        if cuda:
+            dev_groups = [t.cuda() for t in dev_groups]
+    ctx = {"xl": xl, "torch": torch, "dist": dist, "rank": rank, "world": world, "cuda": cuda, "lpf": lpf, "dev_groups": dev_groups}
+
+    total_clients = args.clients if args.scaling == "strong" else args.clients * world
+    m = run_workload(ctx, total_clients, args.lpf_cutoff_rate, args.steps, args.warmup, args.mode,
+                     spot=not args.no_spot)
+    value, ach_gbs, ach_tf, bpu, fpu = summarize(m)
 
     variants = {}
-    if not args.no_variants:
-        other_rate = 1 if args.lpf_cutoff_rate != 1 else 5
-        vs = max(20, args.steps // 2)
-        mv = run_workload(xl, torch, dist, args, rank, world, other_rate, vs, min(args.warmup, 5), dev_blocks)
-        v2, g2, t2, _, f2 = summarize(mv, vs, world)
-        variants[f"lpf_cutoff_rate={other_rate} ({mv['ntaps']} taps)"] = {
-            "value": round(v2, 1), "ms_per_step": round(mv["seconds"] / vs * 1e3, 4),
-            "path": "polyphase" if mv["polyphase"] else "direct FIR kernel",
-            "roofline_hbm_frac": round(g2 / HBM_PEAK_GBS, 4), "achieved_GBs": round(g2, 1),
-            "fp32_frac": None if mv["polyphase"] else round(t2 / FP32_PEAK_TFLOPS, 4),
-            "achieved_TFLOPs": None if mv["polyphase"] else round(t2, 2),
-            "kernel_ms": round(mv["fir_ms_avg"], 4),
-            "flop_per_unit": round(f2, 2)}
-        # the other arithmetic variant on the headline workload (native = bit-exact reference arithmetic,
-        # the reference's default cpu_optimization: always the direct FIR kernel)
+    native = None
+    if not args.no_variants and cuda:
+        vs = max(2, args.steps // 4)
         other_mode = "native" if args.mode == "optimized" else "optimized"
-        mn = run_workload(xl, torch, dist, args, rank, world, args.lpf_cutoff_rate, vs, min(args.warmup, 5), dev_blocks,
-                          mode=other_mode)
-        v3, g3, t3, _, _ = summarize(mn, vs, world)
-        variants[f"process_{other_mode}_cu8_cf32 semantics ({mn['ntaps']} taps)"] = {
-            "value": round(v3, 1), "ms_per_step": round(mn["seconds"] / vs * 1e3, 4), "kernel_ms": round(mn["fir_ms_avg"], 4),
-            "path": "polyphase" if mn["polyphase"] else "direct FIR kernel",
-            "roofline_hbm_frac": round(g3 / HBM_PEAK_GBS, 4),
-            "achieved_TFLOPs": None if mn["polyphase"] else round(t3, 2),
-            "fp32_frac": None if mn["polyphase"] else round(t3 / FP32_PEAK_TFLOPS, 4)}
-        if m["polyphase"]:  # the same workload through the direct FIR kernels (tuning switch): the FP32-bound design
-            md = run_workload(xl, torch, dist, args, rank, world, args.lpf_cutoff_rate, vs, min(args.warmup, 5), dev_blocks,
-                              poly=0)
-            v4, g4, t4, _, f4 = summarize(md, vs, world)
-            variants[f"process_{args.mode}_cu8_cf32 through the direct FIR kernel ({md['ntaps']} taps)"] = {
-                "value": round(v4, 1), "ms_per_step": round(md["seconds"] / vs * 1e3, 4), "kernel_ms": round(md["fir_ms_avg"], 4),
-                "path": "direct FIR kernel", "roofline_hbm_frac": round(g4 / HBM_PEAK_GBS, 4),
-                "achieved_TFLOPs": round(t4, 2), "fp32_frac": round(t4 / FP32_PEAK_TFLOPS, 4), "flop_per_unit": round(f4, 2),
-                "note": "FP32-bound: 96 flop per (client, sample) caps the HBM fraction at "
-                        f"{min(1.0, FP32_PEAK_TFLOPS * 1e12 / f4 * bpu / (HBM_PEAK_GBS * 1e9)):.3f}"}
+        mn = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, other_mode, spot=not args.no_spot, poly3=False)
+        native = variant_entry(mn, "the reference's default arithmetic (cpu_optimization NATIVE_CF32, src/config.c:252-264): bit-exact "
+                                   "scalar tap order, 4 packed unfused ops per complex MAC, direct FIR kernel")
+        native["parity_spot"] = mn["parity_spot"]
+        other_rate = 1 if args.lpf_cutoff_rate != 1 else 5
+        mv = run_workload(ctx, total_clients, other_rate, vs, 1, args.mode, poly3=False)
+        variants[f"lpf_cutoff_rate={other_rate} ({mv['ntaps']} taps)"] = variant_entry(mv)
+        m1 = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, group=1, poly3=False)
+        variants["one block per call (the reference's call granularity)"] = variant_entry(m1)
+        ms = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, staggered=True, poly3=False)
+        variants["staggered joins (clients joined over 21 consecutive blocks: 21 output grids, one polyphase class)"] = variant_entry(ms)
+        if m["polyphase"]:  # the same workload through the direct FIR kernels: the FP32-bound design
+            md = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, options={"polyphase": 0}, poly3=False)
+            variants[f"process_{args.mode}_cu8_cf32 through the direct FIR kernel ({md['ntaps']} taps)"] = variant_entry(
+                md, "FP32-bound: 96 flop per (client, sample) caps the HBM fraction at "
+                    f"{min(1.0, FP32_PEAK_TFLOPS * 1e12 / fpu * bpu / (HBM_PEAK_GBS * 1e9)):.3f}")
 
     if rank != 0:
         if world > 1:
@@ -364,51 +528,49 @@ def main():
             dist.destroy_process_group()
         return
 
-    traffic = None
+    traffic, traffic_source = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and world == 1 and args.clients == 1024:
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_block_polyphase" if m["polyphase"] else "hbm_bytes_per_launch")
+            pj = json.load(open(pmc_path))
+            traffic = pj.get("hbm_bytes_per_call_polyphase" if m["polyphase"] else "hbm_bytes_per_call_direct")
+            traffic_source = ("replayed from profiles/pmc_latest.json, NOT measured in this run: " + pj.get("source", "?"))
         except Exception:
             traffic = None
 
-    kernel_s = m["fir_ms_avg"] * 1e-3
+    call_s = m["call_ms_avg"] * 1e-3
     nloc = m["clients_this_rank"]
     roofline = {
         "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "kernel_ms": round(m["fir_ms_avg"], 4),
-        "kernel_ms_note": f"mean HIP-event duration of one block's launches, every {TIMING_STRIDE}th block of the timed region, on the launch stream",
-        "bytes_per_unit": round(bpu, 4), "units_per_launch": nloc * S,
-        "model": "per-client-read (SURVEY 8(d)): 2 B in + 8/D B out per (client, input sample)",
-        "shared_read_model": {"bytes_per_unit": round(2.0 / nloc + 8.0 / D, 5),
-                              "achieved_GBs": round(nloc * S * (2.0 / nloc + 8.0 / D) / kernel_s / 1e9, 1),
-                              "note": "the block is read once per GPU and shared through L2/LDS: 2/N + 8/D B per unit (SURVEY 8(d))"},
+        "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+        "hbm_counter_frac": round(traffic / call_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and call_s > 0 else None,
+        "kernel_ms": round(m["call_ms_avg"], 4),
+        "kernel_ms_note": f"mean HIP-event duration of one call's launches ({m['group']} blocks per call), every {TIMING_STRIDE}th call of the timed region, on the launch stream",
+        "bytes_per_unit": round(bpu, 4), "units_per_launch": nloc * S * m["group"],
+        "model": "per-client-read (SURVEY 8(d)): 2 B in + 8/D B out per (client, input sample); the block is in fact read once per GPU "
+                 "and shared, so this 'frac' is a model number that can exceed what HBM moves -- see hbm_counter_frac",
+        "shared_read_model": {"bytes_per_unit": round(2.0 / max(nloc, 1) + 8.0 / D, 5),
+                              "achieved_GBs": round(nloc * S * m["group"] * (2.0 / max(nloc, 1) + 8.0 / D) / call_s / 1e9, 1) if call_s > 0 else None,
+                              "note": "the blocks are read once per GPU and shared through L2/LDS: 2/N + 8/D B per unit (SURVEY 8(d))"},
     }
     if m["polyphase"]:
         import re
         mm = re.search(r"polyphase: cls0 .*? M(\d+)", m["plan"])
-        tm = polyphase_traffic_model(nloc, m["K"], m["ntaps"], int(mm.group(1)) if mm else 256)
+        tm = polyphase_traffic_model(nloc, m["K_call"], m["ntaps"], m["group"], int(mm.group(1)) if mm else 256)
         roofline["kernel"] = ("xlp_forward_kernel + xlp_mix_kernel (dominant) + xlp_inverse_kernel: the three launches of one "
-                              "block on the polyphase overlap-save path (each also carries a slice of the next block's NCO "
+                              "call on the polyphase overlap-save path (each also carries a slice of the next call's NCO "
                               "phase recurrence; the forward launch rolls the raw history)")
         roofline["kernels_ms"] = m["kernels_ms"]
-        roofline["kernels_ms_note"] = "separate HIP-event durations of the three launches, 40 extra blocks after the timed region"
-        roofline["design_traffic"] = dict(tm, achieved_GBs=round(tm["bytes_per_block"] / kernel_s / 1e9, 1),
-                                          frac_of_peak=round(tm["bytes_per_block"] / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
-                                          note="bytes the path moves through HBM per block by design (xl_polyphase.h); compare with 'traffic'")
+        roofline["kernels_ms_note"] = "separate HIP-event durations of the three launches, 8 extra calls after the timed region"
+        roofline["design_traffic"] = dict(tm, achieved_GBs=round(tm["bytes_per_call"] / call_s / 1e9, 1) if call_s > 0 else None,
+                                          frac_of_peak=round(tm["bytes_per_call"] / call_s / 1e9 / HBM_PEAK_GBS, 4) if call_s > 0 else None,
+                                          note="bytes the path moves through HBM per call by design (xl_polyphase.h); compare with 'traffic'")
         roofline["direct_equivalent_TFLOPs"] = round(ach_tf, 2)
-        roofline["direct_equivalent_note"] = (f"what the reference's direct {m['ntaps']}-tap dot product would need for this rate "
-                                               f"({fpu:.1f} flop per unit; FP32 vector peak {FP32_PEAK_TFLOPS} TFLOP/s) -- the polyphase path "
-                                               "does ~10x fewer flops, which is why it can pass the FP32 ceiling of the direct kernel")
     else:
         roofline["kernel"] = (f"xl_fir_kernel<H,{1 if args.mode == 'optimized' else 0},wide> (H = register-tile height chosen by the "
-                              "engine; one launch per block: history roll + FIR + next block's NCO phase table)")
+                              "engine; one launch per call: history roll + FIR + next call's NCO phase table)")
         roofline["fp32"] = {"achieved": round(ach_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(ach_tf / FP32_PEAK_TFLOPS, 4), "flop_per_unit": round(fpu, 2),
-                            "note": "binding ceiling at this tap count (SURVEY H2): HBM frac cannot exceed "
-                                    f"{min(1.0, FP32_PEAK_TFLOPS * 1e12 / fpu * bpu / (HBM_PEAK_GBS * 1e9)):.3f}"}
-        roofline["nco_table_kernel_ms"] = round(m["nco_ms_avg"], 4) if m["nco_ms_avg"] > 0 else "fused into the FIR launch"
+                            "frac": round(ach_tf / FP32_PEAK_TFLOPS, 4), "flop_per_unit": round(fpu, 2)}
 
     out = {
         "metric": "input IQ Msamples/s processed (all clients), 2.016 Msps->48 kHz xlating FIR",
@@ -419,24 +581,29 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(m["seconds"] / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if cuda else "cpu-plumbing-test",
         "config": {
-            "workload": f"{args.clients_per_gpu} clients/GPU x 48 kHz off one 2.016 Msps cu8 stream, {BLOCK_BYTES}-byte blocks, "
-                        f"D={D}, {m['ntaps']} taps (lpf_cutoff_rate={args.lpf_cutoff_rate}), process_{args.mode}_cu8_cf32 semantics "
-                        f"(BASELINE configs[3] per-GPU share x8 = the 1-GPU >=1000-client target)",
-            "clients_total": m["total_clients"], "block_samples": S, "outputs_per_client_per_block": m["K"],
-            "parallelism": (f"clients sharded c%{world}; one RCCL broadcast per {FEED_GROUP} raw IQ blocks ({FEED_GROUP * BLOCK_BYTES} bytes) "
-                            "on a separate stream (overlaps the previous group's filtering), no other collective") if world > 1 else "single GPU",
+            "workload": f"{total_clients} clients x 48 kHz off one 2.016 Msps cu8 stream ({nloc} on this GPU), {BLOCK_BYTES}-byte blocks, "
+                        f"D={D}, {m['ntaps']} taps (lpf_cutoff_rate={args.lpf_cutoff_rate}), process_{args.mode}_cu8_cf32 semantics, "
+                        f"{GROUP} blocks per engine call (BASELINE configs[3]; N=1: the >=1000-client single-GPU target)",
+            "step": f"{BLOCKS_PER_STEP} consecutive blocks = {BLOCKS_PER_STEP // GROUP} calls = {BLOCKS_PER_STEP * S} stream samples per client",
+            "clients_total": total_clients, "block_samples": S, "blocks_per_call": GROUP,
+            "outputs_per_client_per_call": m["K_call"], "us_per_block": round(m["seconds"] / (args.steps * BLOCKS_PER_STEP) * 1e6, 3),
+            "parallelism": (f"clients sharded c%{world}; one RCCL broadcast per {GROUP} raw IQ blocks ({GROUP * BLOCK_BYTES} bytes) "
+                            "on a separate stream (overlaps the previous call's filtering), no other collective") if world > 1 else "single GPU",
+            "rccl_ranks": rccl_ranks, "rank0_device": (f"cuda:{local_rank}" if cuda else "cpu"),
         },
         "roofline": roofline,
+        "parity_spot": m["parity_spot"],
         "plan": m["plan"],
+        "native": native,
         "variants": variants,
-        "device": xl.device_info(),
+        "device": xl.device_info() if cuda else "none (plumbing test)",
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and cuda:
         out["cpu_baseline"] = cpu_baseline(args.lpf_cutoff_rate, args.cpu_seconds)
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -66,6 +66,8 @@ class Oracle:
             for n in ("orc_xlating_phase", "orc_xlating_phase_incr"):
                 getattr(L, n).argtypes = [C.c_void_p, _c_float_p, _c_float_p]
             L.orc_xlating_phase_q15.argtypes = [C.c_void_p, _c_i16_p, _c_i16_p]
+            L.orc_xlating_skip_calls_cf32.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+            L.orc_xlating_skip_calls_cf32.restype = None
             L.orc_hypotf_via_double.argtypes = [C.c_float, C.c_float]
             L.orc_hypotf_via_double.restype = C.c_float
             for fmt, (_, ct) in cls.IN_FMTS.items():
@@ -130,6 +132,11 @@ class Oracle:
         if n.value == 0:
             return np.zeros((0, 2), np.int16)
         return np.ctypeslib.as_array(p, shape=(n.value, 2)).copy()
+
+    def skip_calls(self, nsamples, ncalls):
+        """Advance the stream state (phase, history counter) over ncalls cf32-family calls of nsamples complex samples
+        without filtering; feed one real block afterwards before comparing outputs."""
+        self.lib().orc_xlating_skip_calls_cf32(self.h, nsamples, ncalls)
 
     @property
     def history(self):

@@ -269,6 +269,31 @@ static void run_cf32(orc_xlating *f, size_t fresh, float **output, size_t *outpu
   *output_len = made;
 }
 
+/* Test-harness helper (bench.py's parity spot check after millions of blocks): what `ncalls` process_*_cf32 calls of
+ * `fresh` samples each do to the stream state (xlating.c:52-83) WITHOUT the filtering: output counts, the float32 phase
+ * recurrence + per-call renormalisation (:70-73), the history counter (:76).  The sample history itself is not
+ * maintained: feed one real block afterwards before comparing outputs. */
+void orc_xlating_skip_calls_cf32(orc_xlating *f, size_t fresh, size_t ncalls) {
+  const size_t T = f->T;
+  for (size_t c = 0; c < ncalls; c++) {
+    const size_t avail = f->hist + fresh;
+    size_t pos = 0;
+    if (avail > T - 1) {
+      const size_t limit = avail - (T - 1);
+      for (; pos < limit; pos += f->D) {
+        float nr = f->ph_re * f->inc_re - f->ph_im * f->inc_im;
+        float ni = f->ph_re * f->inc_im + f->ph_im * f->inc_re;
+        f->ph_re = nr;
+        f->ph_im = ni;
+      }
+      float mag = hypotf(f->ph_re, f->ph_im);
+      f->ph_re = f->ph_re / mag;
+      f->ph_im = f->ph_im / mag;
+    }
+    f->hist = avail - pos;
+  }
+}
+
 /* xlating.c:92-140 (process_native_cs16) */
 static void run_q15(orc_xlating *f, size_t fresh, int16_t **output, size_t *output_len) {
   const size_t T = f->T;

@@ -531,10 +531,10 @@ def test_polyphase_plan_switches_transform_length_mid_stream():
     eng.close()
 
 
-def test_bench_block_feeder_stream_plumbing():
-    """bench.py's multi-GPU feed (broadcast of block k+1 on a side stream while block k is filtered, two receive
-    buffers, event-ordered reuse) with a stand-in for torch.distributed whose broadcast is the identity (this box has
-    one GPU): the engine must see exactly the blocks in order."""
+def test_bench_group_feeder_stream_plumbing():
+    """bench.py's multi-GPU feed (broadcast of super-block k+1 on a side stream while super-block k is filtered, two
+    receive buffers, event-ordered reuse) with a stand-in for torch.distributed whose broadcast is the identity (this
+    box has one GPU): the engine must see exactly the super-blocks in order, 8 blocks per call."""
     import torch
 
     import bench
@@ -543,21 +543,21 @@ def test_bench_block_feeder_stream_plumbing():
         def broadcast(self, t, src=0):
             return None
 
-    blocks = [siggen.xs_u8(8100 + k, bench.BLOCK_BYTES) for k in range(5)]
-    dev = [torch.from_numpy(b).cuda() for b in blocks]
-    feeder = bench.BlockFeeder(torch, FakeDist(), 0, 2, dev)
+    groups = [siggen.xs_u8(8100 + k, bench.GROUP * bench.BLOCK_BYTES) for k in range(3)]
+    dev = [torch.from_numpy(b).cuda() for b in groups]
+    feeder = bench.GroupFeeder(torch, FakeDist(), 0, 2, dev)
     taps = lpf(FS, 24000, 48000)
-    eng = xl.BatchEngine(FS, "cu8", bench.BLOCK_BYTES)
+    eng = xl.BatchEngine(FS, "cu8", bench.BLOCK_BYTES, group_blocks=bench.GROUP)
     oracles = {}
     for c in range(12):
         cid = eng.add_client(42, taps, bench.client_center_freq(c * 37))
         oracles[cid] = Oracle(42, taps, bench.client_center_freq(c * 37), FS, bench.BLOCK_BYTES)
     stream = torch.cuda.current_stream()
-    for k in range(9):
+    for k in range(7):
         ptr = feeder.get(k, stream)
-        eng.process_device(ptr, bench.BLOCK_BYTES, "optimized", stream.cuda_stream)
+        eng.process_device_group(ptr, bench.BLOCK_BYTES, bench.GROUP, "optimized", stream.cuda_stream)
         feeder.consumed(k, stream)
-        want = {cid: o.process("cu8", blocks[k % 5]) for cid, o in oracles.items()}
+        want = {cid: np.concatenate([o.process("cu8", bl) for bl in np.split(groups[k % 3], bench.GROUP)]) for cid, o in oracles.items()}
         if k % 3 == 2:
             eng.fetch()
             for cid in oracles:

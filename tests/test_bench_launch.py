@@ -1,0 +1,48 @@
+"""CPU tests (-m "not gpu") of bench.py's N > 1 launcher: `python bench.py --gpus 2` re-launches itself under
+torch.distributed.run (two ranks, gloo on this GPU-less box through the hidden --plumbing-test switch) and runs the
+same sharding / super-block broadcast / barrier / max-over-ranks timing / JSON code the GPU run uses.  The compute is a
+no-op stand-in here -- it proves the launch plumbing, not two HIP engines (those need GPUs; the engine itself is covered
+by the -m gpu tests, and tools/feed_nccl_selftest.py runs the feed over the real RCCL backend)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing-test", "--steps", "2", "--warmup", "1",
+                        "--no-variants", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks_strong_scaling():
+    j = _run(["--gpus", "2"])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1
+    assert j["scaling"] == "strong" and j["config"]["clients_total"] == 1024  # BASELINE configs[3]: 1024 clients in total
+    assert j["config"]["rccl_ranks"] == 2
+    assert "512 on this GPU" in j["config"]["workload"]
+    assert j["data"] == "cpu-plumbing-test" and j["value"] > 0
+    assert abs(j["ms_per_step"] * j["steps"] / 1e3 - j["config"]["us_per_block"] * 320 * j["steps"] / 1e6) < 1e-3
+
+
+def test_self_launch_weak_scaling_and_single_rank():
+    j = _run(["--gpus", "2", "--scaling", "weak", "--clients", "64"])
+    assert j["scaling"] == "weak" and j["config"]["clients_total"] == 128
+    j1 = _run(["--gpus", "1", "--clients", "64"])
+    assert j1["n_gpus"] == 1 and j1["config"]["clients_total"] == 64 and j1["config"]["parallelism"] == "single GPU"
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing-test", "--gpus", "2"], capture_output=True,
+                       text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

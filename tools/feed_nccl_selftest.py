@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/feed_nccl_selftest.py -- bench.py's multi-GPU block feed over the REAL RCCL backend on a one-GPU box: a
+"""tools/feed_nccl_selftest.py -- bench.py's multi-GPU super-block feed over the REAL RCCL backend on a one-GPU box: a
 world-size-1 process group (the broadcast is then trivial, but every call -- init with device_id, broadcast issued on the
 side stream, event ordering, buffer reuse -- is the one the N > 1 run makes), the feeder driven as rank 0 of 2.
 Checks that every client's output equals the directly-fed run bit for bit.  Run: python tools/feed_nccl_selftest.py"""
@@ -20,23 +20,22 @@ import sdr_server_amd as xl  # noqa: E402
 
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-blocks = bench.make_blocks(8, 0x5DEECE66D)
-dev_blocks = [torch.from_numpy(b).cuda() for b in blocks]
+dev_groups = [torch.from_numpy(bench.make_group(g)).cuda() for g in range(bench.NSRC_GROUPS)]
 taps = xl.create_low_pass_filter(1.0, bench.FS, 24000, 9600)[1]
 
 
 def run(world):
-    eng = xl.BatchEngine(bench.FS, "cu8", bench.BLOCK_BYTES)
+    eng = xl.BatchEngine(bench.FS, "cu8", bench.BLOCK_BYTES, group_blocks=bench.GROUP)
     for c in range(256):
         eng.add_client(bench.D, taps, -984000 + 1920 * c)
-    feeder = bench.BlockFeeder(torch, dist, 0, world, dev_blocks)
+    feeder = bench.GroupFeeder(torch, dist, 0, world, dev_groups)
     stream = torch.cuda.current_stream()
     outs = []
-    for k in range(40):
+    for k in range(12):
         ptr = feeder.get(k, stream)
-        eng.process_device(ptr, bench.BLOCK_BYTES, "optimized", stream.cuda_stream)
+        eng.process_device_group(ptr, bench.BLOCK_BYTES, bench.GROUP, "optimized", stream.cuda_stream)
         feeder.consumed(k, stream)
-        if k % 13 == 5:
+        if k % 5 == 3:
             torch.cuda.synchronize()
             eng.fetch()
             outs.append([eng.output(c).copy() for c in (0, 100, 255)])

@@ -4,7 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-import bench, sdr_server_amd as xl
+import bench, siggen, sdr_server_amd as xl
 
 def run(n, poly, rate=5, steps=100, mode="optimized"):
     os.environ["XL_EXP_POLY"] = poly
@@ -13,7 +13,7 @@ def run(n, poly, rate=5, steps=100, mode="optimized"):
     for c in range(n):
         eng.add_client(bench.D, taps, bench.client_center_freq(c))
     desc = eng.describe()
-    blocks = [torch.from_numpy(b).cuda() for b in bench.make_blocks(4, 123)]
+    blocks = [torch.from_numpy(b).cuda() for b in [siggen.xs_u8(123 + k, bench.BLOCK_BYTES) for k in range(4)]]
     st = torch.cuda.current_stream()
     outs = []
     for k in range(6):

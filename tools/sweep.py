@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+import siggen  # noqa: E402
 import sdr_server_amd as xl  # noqa: E402
 
 
@@ -23,7 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--depths", default="1")
     args = ap.parse_args()
-    blocks = [torch.from_numpy(b).cuda() for b in bench.make_blocks(4, 123)]
+    blocks = [torch.from_numpy(b).cuda() for b in [siggen.xs_u8(123 + k, bench.BLOCK_BYTES) for k in range(4)]]
     stream = torch.cuda.current_stream()
     depths = [int(d) for d in args.depths.split(",")]
     print(f"{'mode':10s} {'dp':>2s} {'taps':>5s} {'clients':>7s} {'step_ms':>9s} {'fir_ms':>9s} {'nco_ms':>9s} {'TFLOP/s':>8s} {'algGB/s':>8s} {'Msps':>10s}")
