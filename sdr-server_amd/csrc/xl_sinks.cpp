@@ -8,6 +8,7 @@
 #include <signal.h>
 #include <stdio.h>
 #include <string.h>
+#include <sys/eventfd.h>
 #include <sys/socket.h>
 #include <sys/types.h>
 #include <unistd.h>
@@ -44,9 +45,15 @@ struct Sink {
   gzFile gz = nullptr;
   std::vector<uint8_t> ring;  // byte queue
   size_t head = 0, used = 0;  // head = read position
-  bool busy = false;          // a writer thread holds bytes popped from the ring
+  bool busy = false;          // the writer thread holds bytes popped from the ring (in flight, or pending below)
   bool failed = false, reported = false;
   std::atomic<bool> cancel{false};  // abandon an in-flight write (the sink failed or is being torn down)
+  // descriptor sinks only, touched by the writer thread alone: bytes popped from the ring that the peer has not taken
+  // yet.  A peer that stops reading parks its bytes here and the thread goes on serving its other sinks -- one stalled
+  // client must never drop another (the reference has a thread per client, dsp_worker.c:41-88).
+  std::vector<uint8_t> pend;
+  size_t pend_off = 0;
+  bool is_sock = true;
 };
 
 struct Worker {
@@ -56,6 +63,7 @@ struct Worker {
   std::thread th;
   bool stop = false;
   int rr = 0;  // round-robin start for fairness
+  int wake_fd = -1;  // eventfd: wakes the thread out of its poll() on the pending descriptors
 };
 
 }  // namespace
@@ -71,38 +79,35 @@ namespace {
 
 const size_t kChunk = 1u << 20;  // most bytes a writer takes out of a queue at a time
 
-// write_to_socket() semantics (dsp_worker.c:28-39): every byte, or failure -- but never stuck on a peer for good: the
-// writes are non-blocking, and while the descriptor is not writable the sink's cancel flag is polled every 50 ms (set
-// when the client's queue overflowed behind this very write, or at teardown).
-bool xl_write_all_fd(int fd, const uint8_t *p, size_t n, const std::atomic<bool> &cancel) {
-  bool is_sock = true;
-  while (n > 0) {
-    ssize_t w = is_sock ? send(fd, p, n, MSG_NOSIGNAL | MSG_DONTWAIT) : write(fd, p, n);
+// write_to_socket() semantics (dsp_worker.c:28-39): every byte, or failure -- but never stuck on a peer: the writes are
+// non-blocking.  Pushes as much of the sink's pending bytes as the descriptor takes now.
+// Returns 1 = all gone, 0 = the descriptor is full (try again when it is writable), -1 = failed.
+int xl_push_pending(Sink *s) {
+  while (s->pend_off < s->pend.size()) {
+    const uint8_t *p = s->pend.data() + s->pend_off;
+    const size_t n = s->pend.size() - s->pend_off;
+    ssize_t w = s->is_sock ? send(s->fd, p, n, MSG_NOSIGNAL | MSG_DONTWAIT) : write(s->fd, p, n);
     if (w < 0) {
-      if (is_sock && errno == ENOTSOCK) {
-        is_sock = false;
-        const int fl = fcntl(fd, F_GETFL);
-        if (fl >= 0 && !(fl & O_NONBLOCK)) (void)fcntl(fd, F_SETFL, fl | O_NONBLOCK);  // pipes / files: same rule
+      if (s->is_sock && errno == ENOTSOCK) {
+        s->is_sock = false;
+        const int fl = fcntl(s->fd, F_GETFL);
+        if (fl >= 0 && !(fl & O_NONBLOCK)) (void)fcntl(s->fd, F_SETFL, fl | O_NONBLOCK);  // pipes / files: same rule
         continue;
       }
       if (errno == EINTR) continue;
-      if (errno == EAGAIN || errno == EWOULDBLOCK) {
-        if (cancel.load()) return false;
-        struct pollfd pfd = {fd, POLLOUT, 0};
-        (void)poll(&pfd, 1, 50);
-        continue;
-      }
-      return false;
+      if (errno == EAGAIN || errno == EWOULDBLOCK) return 0;
+      return -1;
     }
-    p += w;
-    n -= (size_t)w;
+    s->pend_off += (size_t)w;
   }
-  return true;
+  s->pend.clear();
+  s->pend_off = 0;
+  return 1;
 }
 
 bool xl_sink_emit(Sink *s, const uint8_t *p, size_t n) {
   switch (s->kind) {
-    case K_FD: return xl_write_all_fd(s->fd, p, n, s->cancel);
+    case K_FD: return false;  // (descriptor sinks go through xl_push_pending)
     case K_FILE: return fwrite(p, 1, n, s->file) == n;  // short write (disk full) ends the client (dsp_worker.c:20-24)
     case K_GZ: {
       while (n > 0) {
@@ -133,11 +138,42 @@ void xl_worker_main(xlating_sinks *S, Worker *w) {
   sigaddset(&set, SIGPIPE);
   (void)pthread_sigmask(SIG_BLOCK, &set, nullptr);
   std::vector<uint8_t> buf;
+  std::vector<Sink *> parked;  // descriptor sinks with pending bytes (busy == true)
   std::unique_lock<std::mutex> lk(w->m);
+  auto finish = [&](Sink *s, bool ok, size_t n) {  // (lock held)
+    s->busy = false;
+    if (ok) {
+      std::lock_guard<std::mutex> g(S->stats_m);
+      S->bytes_written += n;
+    } else {
+      s->failed = true;
+      s->used = 0;
+      s->pend.clear();
+      s->pend_off = 0;
+    }
+    w->cv_done.notify_all();
+  };
   for (;;) {
+    bool progressed = false;
+    // ---- 1. parked descriptor sinks: push what their peers take now (never waits)
+    for (size_t k = 0; k < parked.size();) {
+      Sink *s = parked[k];
+      const size_t total = s->pend.size();
+      lk.unlock();
+      const int rc = s->cancel.load() ? -1 : xl_push_pending(s);
+      lk.lock();
+      if (rc == 0) {
+        ++k;
+        continue;
+      }
+      finish(s, rc > 0, total);
+      parked[k] = parked.back();
+      parked.pop_back();
+      progressed = true;
+    }
+    // ---- 2. one sink with queued bytes, round-robin
     Sink *pick = nullptr;
     if (!w->sinks.empty()) {
-      // round-robin over the sinks with queued bytes
       auto it = w->sinks.lower_bound(w->rr);
       for (size_t k = 0; k < w->sinks.size(); ++k, ++it) {
         if (it == w->sinks.end()) it = w->sinks.begin();
@@ -149,33 +185,53 @@ void xl_worker_main(xlating_sinks *S, Worker *w) {
         }
       }
     }
-    if (pick == nullptr) {
+    if (pick != nullptr) {
+      const size_t n = std::min(pick->used, kChunk);
+      std::vector<uint8_t> &dst = pick->kind == K_FD ? pick->pend : buf;
+      dst.resize(n);
+      const size_t cap = pick->ring.size();
+      const size_t first = std::min(n, cap - pick->head);
+      memcpy(dst.data(), pick->ring.data() + pick->head, first);
+      memcpy(dst.data() + first, pick->ring.data(), n - first);
+      pick->head = (pick->head + n) % cap;
+      pick->used -= n;
+      pick->busy = true;
+      pick->pend_off = 0;
+      lk.unlock();
+      int rc;
+      if (pick->kind == K_FD) rc = xl_push_pending(pick);
+      else rc = xl_sink_emit(pick, buf.data(), n) ? 1 : -1;
+      lk.lock();
+      if (rc == 0) parked.push_back(pick);  // the peer is not taking bytes right now: come back to it, serve the others
+      else finish(pick, rc > 0, n);
+      continue;
+    }
+    if (progressed) continue;
+    if (parked.empty()) {
       if (w->stop) return;
       w->cv_work.wait(lk);
       continue;
     }
-    const size_t n = std::min(pick->used, kChunk);
-    buf.resize(n);
-    const size_t cap = pick->ring.size();
-    const size_t first = std::min(n, cap - pick->head);
-    memcpy(buf.data(), pick->ring.data() + pick->head, first);
-    memcpy(buf.data() + first, pick->ring.data(), n - first);
-    pick->head = (pick->head + n) % cap;
-    pick->used -= n;
-    pick->busy = true;
+    // ---- 3. only parked sinks are left: sleep until one of their descriptors is writable, new bytes are queued
+    // (wake_fd) or 50 ms pass (cancel flags are polled at that rate)
+    if (w->stop) {
+      bool all_cancelled = true;
+      for (Sink *s : parked) all_cancelled = all_cancelled && s->cancel.load();
+      if (!all_cancelled) {  // teardown: nobody will wait for these peers
+        for (Sink *s : parked) s->cancel.store(true);
+      }
+    }
+    std::vector<struct pollfd> pfds;
+    for (Sink *s : parked) pfds.push_back({s->fd, POLLOUT, 0});
+    if (w->wake_fd >= 0) pfds.push_back({w->wake_fd, POLLIN, 0});
     lk.unlock();
-    const bool ok = xl_sink_emit(pick, buf.data(), n);
-    if (ok) {
-      std::lock_guard<std::mutex> g(S->stats_m);
-      S->bytes_written += n;
+    (void)poll(pfds.data(), (nfds_t)pfds.size(), 50);
+    if (w->wake_fd >= 0) {
+      uint64_t v;
+      while (read(w->wake_fd, &v, sizeof(v)) > 0) {
+      }
     }
     lk.lock();
-    pick->busy = false;
-    if (!ok) {
-      pick->failed = true;
-      pick->used = 0;
-    }
-    w->cv_done.notify_all();
   }
 }
 
@@ -204,7 +260,10 @@ extern "C" int xlating_sinks_create(unsigned writer_threads, size_t queue_bytes,
   if (S == nullptr) return -ENOMEM;
   S->queue_bytes = queue_bytes;
   try {
-    for (unsigned i = 0; i < writer_threads; ++i) S->workers.emplace_back(new Worker());
+    for (unsigned i = 0; i < writer_threads; ++i) {
+      S->workers.emplace_back(new Worker());
+      S->workers.back()->wake_fd = eventfd(0, EFD_NONBLOCK | EFD_CLOEXEC);
+    }
     for (auto &w : S->workers) w->th = std::thread(xl_worker_main, S, w.get());
   } catch (...) {
     xlating_sinks_destroy(S);
@@ -295,6 +354,10 @@ extern "C" int xlating_sinks_write(xlating_sinks *S, int client_id, const float 
   memcpy(s->ring.data(), src + first, n - first);
   s->used += n;
   w->cv_work.notify_one();
+  if (w->wake_fd >= 0) {
+    const uint64_t one = 1;
+    (void)!write(w->wake_fd, &one, sizeof(one));
+  }
   return 0;
 }
 
@@ -360,7 +423,17 @@ extern "C" int xlating_sinks_detach(xlating_sinks *S, int client_id) {
     if (it == w->sinks.end()) return -ENOENT;
     Sink *p = it->second.get();
     if (p->failed) p->cancel.store(true);
-    w->cv_done.wait(lk, [&] { return !p->busy && (p->used == 0 || p->failed); });
+    // a healthy peer gets two seconds to take what is queued; one that has stopped reading is cut off
+    if (!w->cv_done.wait_for(lk, std::chrono::seconds(2), [&] { return !p->busy && (p->used == 0 || p->failed); })) {
+      p->cancel.store(true);
+      p->failed = true;
+      p->used = 0;
+      if (w->wake_fd >= 0) {
+        const uint64_t one = 1;
+        (void)!write(w->wake_fd, &one, sizeof(one));
+      }
+      w->cv_done.wait(lk, [&] { return !p->busy; });
+    }
     s = std::move(it->second);
     w->sinks.erase(it);
   }
@@ -396,7 +469,13 @@ extern "C" void xlating_sinks_destroy(xlating_sinks *S) {
       w->stop = true;
     }
     w->cv_work.notify_all();
+    if (w->wake_fd >= 0) {
+      const uint64_t one = 1;
+      (void)!write(w->wake_fd, &one, sizeof(one));
+    }
     if (w->th.joinable()) w->th.join();
+    if (w->wake_fd >= 0) close(w->wake_fd);
+    w->wake_fd = -1;
     for (auto &kv : w->sinks) xl_sink_close(kv.second.get());
     w->sinks.clear();
   }

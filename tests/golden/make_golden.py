@@ -12,6 +12,13 @@ Outputs (data only -- numbers, never reference source text):
                                        parsed out of the C initialisers as numbers.
   tests/golden/live_<name>.npz         outputs of the unmodified reference (canonical flags) for the
                                        scenarios in scenarios.py.
+  tests/golden/fast_<name>.npz         outputs of the unmodified reference's x86 Release-like build (oracle/_ref/
+                                       libref_fast.so: -O3 -ffast-math -mavx2 -mfma, i.e. the hand-written AVX
+                                       process_optimized_* of xlating.c:271-348, which does NOT renormalise the phase,
+                                       :338-339) for blocks 0-9 of the g9 / g10 / g11 shapes: what an x86 server's
+                                       "optimized" setting computes.  Head and tail of every block + block 9 in full.
+  tests/golden/fast_divergence.json    how far the reference's own two builds drift apart over a long stream
+                                       (canonical native vs AVX optimized; max |d| / max |y| per block).
 """
 import json
 import os
@@ -83,6 +90,52 @@ def main():
         total += sz
         print(f"{sc['name']:28s} T={taps.size:5d} D={sc['D']:4d} calls={len(sc['calls']):4d} -> {sz/1024:.1f} KiB")
     print(f"total {total/1024:.1f} KiB")
+    make_fast()
+
+
+FAST_SHAPES, FAST_BLOCKS, FAST_HEAD, FAST_TAIL = scenarios.FAST_SHAPES, scenarios.FAST_BLOCKS, scenarios.FAST_HEAD, scenarios.FAST_TAIL
+fast_block = scenarios.fast_block
+
+
+def make_fast():
+    if not RefLib.available("fast") or " avx2 " not in (" " + open("/proc/cpuinfo").read().replace("\n", " ") + " "):
+        print("fast fixtures skipped: libref_fast.so / AVX2 not available here")
+        return
+    assert RefLib.simd_status("fast") == "AVX", RefLib.simd_status("fast")
+    for name in FAST_SHAPES:
+        sc = scenarios.BY_NAME[name]
+        taps = scenarios.make_taps(sc, lpf=lambda *a: RefLib.lpf(*a)[1])
+        fast = RefLib(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"], flavour="fast", variant="optimized")
+        arrays = {"taps": taps}
+        for k in range(FAST_BLOCKS):
+            y = fast.process(sc["fmt"], fast_block(sc, k), "cf32")
+            arrays[f"n{k}"] = np.int64(len(y))
+            if k == FAST_BLOCKS - 1:
+                arrays[f"y{k}"] = y
+            else:
+                arrays[f"head{k}"] = y[:FAST_HEAD]
+                arrays[f"tail{k}"] = y[-FAST_TAIL:]
+        fast.close()
+        p = os.path.join(HERE, f"fast_{name}.npz")
+        np.savez_compressed(p, **arrays)
+        print(f"fast_{name:24s} T={taps.size:5d} -> {os.path.getsize(p)/1024:.1f} KiB")
+    # how far the reference's own builds drift apart (g9 shape): canonical native renormalises every call, AVX never does
+    sc = scenarios.BY_NAME["g9_default"]
+    taps = scenarios.make_taps(sc, lpf=lambda *a: RefLib.lpf(*a)[1])
+    canon = RefLib(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"], flavour="canon", variant="native")
+    fast = RefLib(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"], flavour="fast", variant="optimized")
+    div = {}
+    for k in range(400):
+        x = fast_block(sc, k % 16)
+        a, b = canon.process("cu8", x), fast.process("cu8", x)
+        if k in (0, 1, 4, 9, 19, 49, 99, 199, 399):
+            div[str(k)] = float(np.abs(a.astype(np.complex128) - b).max() / np.abs(a).max())
+    canon.close()
+    fast.close()
+    json.dump({"_comment": "max|canonical native - AVX optimized| / max|y| per block of the g9 shape (505 taps, D=42, 262144-byte cu8 "
+                           "blocks); both are the UNMODIFIED reference, oracle/_ref/libref_canon.so vs libref_fast.so",
+               "block": div}, open(os.path.join(HERE, "fast_divergence.json"), "w"), indent=1)
+    print("reference canon-vs-fast divergence:", div)
 
 
 if __name__ == "__main__":

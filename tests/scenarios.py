@@ -79,6 +79,17 @@ SCENARIOS = [
 
 BY_NAME = {s["name"]: s for s in SCENARIOS}
 
+# ---- "fast" fixtures: the reference's x86 Release-like build (AVX process_optimized_*, no phase renormalisation) on
+# blocks 0-9 of three shapes (tests/golden/fast_<name>.npz; generator: make_golden.py make_fast)
+FAST_SHAPES = ("g9_default", "g10_96k", "g11_t101")
+FAST_BLOCKS, FAST_HEAD, FAST_TAIL = 10, 256, 64
+
+
+def fast_block(sc, k):
+    """Input block k of the fast fixtures: the scenario's first call shape with its own seed."""
+    c0 = sc["calls"][0]
+    return make_input(sc, dict(gen="xs", a=SEED + 7000 + 16 * FAST_SHAPES.index(sc["name"]) + k, n=c0["n"]))
+
 
 def make_taps(sc, lpf):
     """lpf(gain, fs, cutoff, tw) -> float32 taps (reference, oracle or HIP-side designer: they must agree)."""

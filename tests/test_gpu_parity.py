@@ -10,7 +10,9 @@ import pytest
 
 import scenarios
 import sdr_server_amd as xl
-from conftest import assert_ref_cf32, bits_equal, load_live
+import os
+
+from conftest import GOLDEN, assert_ref_cf32, bits_equal, load_live
 from pyoracle import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -293,3 +295,32 @@ def test_randomised_dropin_filter_vs_oracle(seed):
     assert worst <= REL_TOL, worst
     f.close()
     o.close()
+
+
+# ---- "optimized" pinned against the reference's x86 AVX build (tests/golden/fast_*.npz, see tests/test_oracle.py):
+# outright on block 0 and on all ten blocks of the g9 shape; on every block up to the drifted phasor's scale.
+@pytest.mark.parametrize("name", scenarios.FAST_SHAPES)
+@pytest.mark.parametrize("path", ["dropin", "batch_direct", "batch_polyphase"])
+def test_optimized_vs_reference_avx_build_fixtures(name, path):
+    from test_oracle import check_fast_fixture
+
+    sc = scenarios.BY_NAME[name]
+    fx = np.load(os.path.join(GOLDEN, f"fast_{name}.npz"))
+    if path == "dropin":
+        f = xl.XlatingFilter(sc["D"], fx["taps"], sc["fc"], sc["fs"], sc["max_input"])
+        check_fast_fixture(name, lambda x: f.process("optimized", sc["fmt"], "cf32", x))
+        f.close()
+        return
+    eng = xl.BatchEngine(sc["fs"], sc["fmt"], sc["max_input"])
+    eng.set_option("polyphase", 1 if path == "batch_polyphase" else 0)
+    cid = [eng.add_client(sc["D"], fx["taps"], sc["fc"]) for _ in range(3)][1]
+
+    def process(x):
+        eng.process_host(x, "optimized")
+        eng.fetch()
+        return eng.output(cid)
+
+    check_fast_fixture(name, process)
+    if path == "batch_polyphase":
+        assert "polyphase: cls0" in eng.describe(), eng.describe()
+    eng.close()

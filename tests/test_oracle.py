@@ -10,7 +10,9 @@ import numpy as np
 import pytest
 
 import scenarios
-from conftest import assert_ref_cf32, bits_equal, load_live, trunc1e4
+import os
+
+from conftest import GOLDEN, assert_ref_cf32, bits_equal, load_live, trunc1e4
 from pyoracle import Oracle, RefLib
 
 
@@ -163,3 +165,62 @@ def test_lpf_bit_exact_vs_live_reference():
         a = Oracle.lpf(1.0, fs, cut, tw)[1]
         b = RefLib.lpf(1.0, fs, cut, tw)[1]
         assert bits_equal(a, b)
+
+
+# ---- what "optimized" means on x86: the reference's AVX build (xlating.c:271-348) never renormalises the phase
+# (:338-339), the canonical / NEON semantics (:73, :255) do every call.  The un-normalised float32 phasor drifts in
+# MAGNITUDE by up to ~3e-8 per output, so the reference's own two builds agree within the 1e-5 bar only early in a
+# stream, and how early depends on the increment's rounding: measured here on the unmodified builds, g9 shape
+# (fc = -12 kHz) 1.2e-6 at block 9, 2.3e-5 at block 49, 1.5e-3 at block 399 (tests/golden/fast_divergence.json);
+# g10 shape (6242 outputs per block) 1.0e-5 already at block 3; g11 shape (fc = -500 kHz) 6.8e-5 at block 1.
+# Nothing can stay within 1e-5 of both builds.  This library follows the renormalising semantics; the fast fixtures
+# pin it to the AVX build (a) outright on block 0, before any renormalisation has happened, and on all ten blocks of the
+# g9 shape, and (b) on every block of every shape up to a complex scale factor per 64 outputs (the drifted phasor).
+def fast_fixture_errors(name, process):
+    """-> per block (raw max|d|/max|y|, the same after removing a least-squares complex scale per 64 outputs, last |scale|)"""
+    sc = scenarios.BY_NAME[name]
+    fx = np.load(os.path.join(GOLDEN, f"fast_{name}.npz"))
+    res = []
+    for k in range(scenarios.FAST_BLOCKS):
+        y = process(scenarios.fast_block(sc, k)).astype(np.complex128)
+        assert len(y) == int(fx[f"n{k}"])
+        if k == scenarios.FAST_BLOCKS - 1:
+            a, b = y, fx[f"y{k}"].astype(np.complex128)
+        else:
+            a = np.concatenate([y[:scenarios.FAST_HEAD], y[-scenarios.FAST_TAIL:]])
+            b = np.concatenate([fx[f"head{k}"], fx[f"tail{k}"]]).astype(np.complex128)
+        scale = np.abs(y).max()
+        resid, r = 0.0, 1.0
+        for c in range(0, len(a), 64):  # the AVX phasor drifts up to ~3e-8 per output: one scale per 64 outputs
+            aa, bb = a[c:c + 64], b[c:c + 64]
+            r = np.vdot(bb, aa) / np.vdot(bb, bb)
+            resid = max(resid, float(np.abs(aa - r * bb).max() / scale))
+        res.append((float(np.abs(a - b).max() / scale), resid, float(abs(r))))
+    return res
+
+
+def check_fast_fixture(name, process, tol=1e-5):
+    res = fast_fixture_errors(name, process)
+    assert res[0][0] <= tol, (name, res[0])                       # block 0: same semantics, outright
+    if name == "g9_default":
+        assert max(r[0] for r in res) <= tol, (name, res)         # fc = -12 kHz: the AVX phasor barely drifts in 10 blocks
+    assert max(r[1] for r in res) <= tol, (name, res)             # every block, up to the drifted phasor's scale
+    return res
+
+
+@pytest.mark.parametrize("name", scenarios.FAST_SHAPES)
+def test_oracle_vs_the_reference_avx_build(name):
+    sc = scenarios.BY_NAME[name]
+    fx = np.load(os.path.join(GOLDEN, f"fast_{name}.npz"))
+    o = Oracle(sc["D"], fx["taps"], sc["fc"], sc["fs"], sc["max_input"])
+    res = check_fast_fixture(name, lambda x: o.process(sc["fmt"], x))
+    o.close()
+    if name == "g11_t101":  # the documented drift: the AVX build leaves its own 1e-5 neighbourhood after one block
+        assert res[1][0] > 1e-5 and abs(res[9][2] - 1.0) > 1e-4, res
+
+
+def test_reference_builds_diverge_beyond_tolerance_later():
+    import json
+
+    d = json.load(open(os.path.join(GOLDEN, "fast_divergence.json")))["block"]
+    assert d["9"] < 1e-5 < d["49"] < d["399"]  # the documented reason why only the first blocks are pinned to the AVX build

@@ -120,3 +120,68 @@ def test_fast_writer_pool_many_clients(tmp_path):
     assert (tmp_path / "513.cf32").read_bytes() == b"".join(b.tobytes() for b in blk)
     print(f"sinks: {total / dt / 1e6:.0f} MB/s into {n_clients} files with 4 writer threads")
     s.close()
+
+
+def test_stalled_peer_does_not_starve_the_other_clients_of_its_writer_thread(tmp_path):
+    """ONE writer thread serves a socket whose peer never reads and three healthy clients (a socket that is read and two
+    files).  The stalled client parks its bytes; the healthy ones keep receiving every block in time -- only the stalled
+    client is ever failed, and only by its own queue overflow (advice r1: a blocking write to the stalled peer used to
+    hold the thread until the healthy clients' queues overflowed too)."""
+    s = xl.Sinks(writer_threads=1, queue_bytes=6 * 25000)
+    stalled_w, stalled_r = socket.socketpair()
+    stalled_w.setsockopt(socket.SOL_SOCKET, socket.SO_SNDBUF, 4096)
+    ok_w, ok_r = socket.socketpair()
+    got = bytearray()
+
+    def reader():
+        while True:
+            d = ok_r.recv(65536)
+            if not d:
+                break
+            got.extend(d)
+
+    th = threading.Thread(target=reader)
+    th.start()
+    assert s.attach_fd(0, stalled_w.fileno()) == 0
+    assert s.attach_fd(1, ok_w.fileno()) == 0
+    assert s.attach_file(2, tmp_path) == 0 and s.attach_file(3, tmp_path, use_gzip=True) == 0
+    want = {cid: blocks_for(cid, 40) for cid in (0, 1, 2, 3)}
+    codes = {cid: [] for cid in want}
+    for k in range(40):
+        for cid in want:
+            codes[cid].append(s.write(cid, want[cid][k]))
+        time.sleep(0.005)  # a block period; the healthy clients' queues (6 blocks) must never fill up
+    assert all(c == 0 for cid in (1, 2, 3) for c in codes[cid]), {cid: codes[cid] for cid in (1, 2, 3)}
+    assert codes[0][0] == 0 and -32 in codes[0]  # the stalled client overflowed its own queue and was dropped
+    assert s.failed() == [0]
+    t0 = time.perf_counter()
+    assert s.detach(0) == 0  # does not wait for the dead peer
+    assert time.perf_counter() - t0 < 1.0
+    s.flush()
+    for cid in (1, 2, 3):
+        assert s.detach(cid) == 0
+    ok_w.close()
+    th.join(10)
+    assert bytes(got) == b"".join(b.tobytes() for b in want[1])
+    assert (tmp_path / "2.cf32").read_bytes() == b"".join(b.tobytes() for b in want[2])
+    assert gzip.open(tmp_path / "3.cf32.gz", "rb").read() == b"".join(b.tobytes() for b in want[3])
+    for sk in (stalled_w, stalled_r, ok_r):
+        sk.close()
+    s.close()
+
+
+def test_detach_cuts_off_a_peer_that_stopped_reading():
+    """detach of a NON-failed sink whose peer has stopped reading returns after a bounded wait (advice r1)."""
+    s = xl.Sinks(writer_threads=1, queue_bytes=64 * 25000)
+    a, b = socket.socketpair()
+    a.setsockopt(socket.SOL_SOCKET, socket.SO_SNDBUF, 4096)
+    assert s.attach_fd(9, a.fileno()) == 0
+    blk = blocks_for(9, 1)[0]
+    for _ in range(8):
+        assert s.write(9, blk) == 0  # fits the queue, but the peer takes only a few KB
+    t0 = time.perf_counter()
+    assert s.detach(9) == 0
+    assert time.perf_counter() - t0 < 4.0
+    a.close()
+    b.close()
+    s.close()
