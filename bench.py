@@ -200,6 +200,114 @@ class GroupFeeder:
             self.free_valid[k % 2] = True
 
 
+class TorchHost:
+    """Feed through torch.distributed (GroupFeeder) + one BatchEngine on torch's current stream.  The fallback of the C
+    host below, the path of `--feed torch`, and (with the no-op engine) of the CPU plumbing test."""
+
+    name = "torch.distributed broadcast (python feeder) + xlating_batch"
+
+    def __init__(self, ctx, group):
+        xl, torch = ctx["xl"], ctx["torch"]
+        self.ctx, self.cuda = ctx, ctx["cuda"]
+        if self.cuda:
+            self.eng = xl.BatchEngine(FS, "cu8", BLOCK_BYTES, device=torch.cuda.current_device(), group_blocks=group)
+            self.stream = torch.cuda.current_stream()
+            self.sptr = self.stream.cuda_stream
+        else:
+            self.eng, self.stream, self.sptr = PlumbingEngine(), None, 0
+        self.feeder = GroupFeeder(torch, ctx["dist"], ctx["rank"], ctx["world"], ctx["dev_groups"], self.cuda)
+        self.k = 0
+
+    def add_client(self, c, taps):
+        return self.eng.add_client(D, taps, client_center_freq(c))
+
+    def call(self, mode, nblocks, first_block=0, count=None, advance=True):
+        """Super-block k of the stream in calls of `nblocks` blocks (count: only that many blocks, from first_block;
+        advance=False: more blocks of the same super-block follow)."""
+        ptr = self.feeder.get(self.k, self.stream)
+        last = GROUP if count is None else first_block + count
+        for j in range(first_block, last, nblocks):
+            self.eng.process_device_group(ptr + j * BLOCK_BYTES, BLOCK_BYTES, nblocks, mode, self.sptr)
+        if advance:
+            self.feeder.consumed(self.k, self.stream)
+            self.k += 1
+
+    def sync(self):
+        if self.cuda:
+            self.ctx["torch"].cuda.synchronize()
+
+    def close(self):
+        self.eng.close()
+
+
+class CHost:
+    """include/xlating_multi.h through ctypes: the engines, the RCCL broadcast of every super-block on a communication
+    stream and the event plumbing all live in the C library (north_star: host code stays in C).  torch.distributed is
+    used by bench.py only to hand rank 0's RCCL id to the other ranks and for the barrier / max-over-ranks of the timing."""
+
+    name = "xlating_multi (C host: ncclBroadcast per super-block on a side stream) + xlating_batch"
+
+    def __init__(self, ctx, group):
+        xl, torch, dist = ctx["xl"], ctx["torch"], ctx["dist"]
+        self.ctx = ctx
+        rank, world = ctx["rank"], ctx["world"]
+        uid = None
+        if world > 1:
+            t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                t.copy_(torch.frombuffer(bytearray(xl.MultiHost.unique_id()), dtype=torch.uint8))
+            dist.broadcast(t, src=0)
+            uid = bytes(t.cpu().numpy().tobytes())
+        self.m = xl.MultiHost(FS, "cu8", BLOCK_BYTES, group_blocks=group, rank=rank, world=world, uid=uid,
+                              device=torch.cuda.current_device())
+        self.eng = self.m.engine(rank)
+        self.k = 0
+
+    def add_client(self, c, taps):
+        return self.m.add_client(c, D, taps, client_center_freq(c))
+
+    def call(self, mode, nblocks, first_block=0, count=None, advance=True):
+        groups = self.ctx["dev_groups"]
+        base = groups[self.k % len(groups)].data_ptr() if groups else 0
+        last = GROUP if count is None else first_block + count
+        for j in range(first_block, last, nblocks):
+            self.m.feed(base + j * BLOCK_BYTES if base else 0, BLOCK_BYTES, nblocks, mode)
+        if advance:
+            self.k += 1
+
+    def sync(self):
+        self.m.sync()
+        self.ctx["torch"].cuda.synchronize()
+
+    def close(self):
+        self.m.close()
+
+
+def make_host(ctx, group):
+    """The C host unless `--feed torch`; if any rank cannot create it (e.g. an RCCL set-up problem) every rank falls back
+    to the torch.distributed feeder -- the JSON line says which one ran ("feed")."""
+    torch, dist, world = ctx["torch"], ctx["dist"], ctx["world"]
+    if not ctx["cuda"] or ctx["feed"] == "torch":
+        return TorchHost(ctx, group)
+    host, err = None, None
+    try:
+        host = CHost(ctx, group)
+    except Exception as e:  # noqa: BLE001 -- reported, then the fallback runs
+        err = e
+    ok = 1 if host is not None else 0
+    if world > 1:
+        t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    if ok:
+        return host
+    sys.stderr.write(f"bench.py: the C multi-GPU host is unavailable on rank {ctx['rank']} ({err}); falling back to the torch feeder\n")
+    if host is not None:
+        host.close()
+    ctx["feed"] = "torch"
+    return TorchHost(ctx, group)
+
+
 def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROUP, options=None, staggered=False,
                  spot=False, poly3=True):
     """Build this rank's engine with its shard of clients and time `steps` steps.  Returns dict of measurements.
@@ -210,66 +318,42 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
     code, taps = ctx["lpf"](1.0, FS, RATE // 2, RATE // ntaps_rate)
     assert code == 0
     mine = shard_clients(total_clients, world, rank)
+    host = make_host(ctx, group)
+    eng = host.eng
     if cuda:
-        eng = xl.BatchEngine(FS, "cu8", BLOCK_BYTES, device=torch.cuda.current_device(), group_blocks=group)
         for k, v in (options or {}).items():
             eng.set_option(k, v)
-        stream = torch.cuda.current_stream()
-        sptr = stream.cuda_stream
-    else:
-        eng, stream, sptr = PlumbingEngine(), None, 0
-    feeder = GroupFeeder(torch, dist, rank, world, ctx["dev_groups"], cuda)
     calls_per_step = BLOCKS_PER_STEP // GROUP
-    state = {"k": 0}
     ids = {}
 
     def call(nblocks=group):
-        # (a call of fewer than GROUP blocks reads the head of the super-block)
-        k = state["k"]
-        ptr = feeder.get(k, stream)
-        for j in range(0, GROUP, nblocks):
-            eng.process_device_group(ptr + j * BLOCK_BYTES, BLOCK_BYTES, nblocks, mode, sptr)
-        feeder.consumed(k, stream)
-        state["k"] = k + 1
+        host.call(mode, nblocks)
 
-    if staggered and cuda:  # one block per call while the clients trickle in (21 joins, then 3 blocks to mature + merge)
-        per = -(-len(mine) // 21)
-        ptr0 = ctx["dev_groups"][0].data_ptr() if world == 1 else None
-        for j in range(24):
-            for c in mine[j * per:(j + 1) * per]:
-                ids[c] = eng.add_client(D, taps, client_center_freq(c))
-            if world > 1:
-                ptr0 = feeder.get(state["k"], stream)
-            eng.process_device_group(ptr0 + (j % GROUP) * BLOCK_BYTES, BLOCK_BYTES, 1, mode, sptr)
-            if world > 1:
-                feeder.consumed(state["k"], stream)
-                state["k"] += 1
+    if staggered and cuda:  # one block per call while the clients trickle in: 21 joins, then 3 blocks to mature + merge
+        per = -(-max(len(mine), 1) // 21)
+        for blk in range(24):
+            for c in mine[blk * per:(blk + 1) * per]:
+                ids[c] = host.add_client(c, taps)
+            host.call(mode, 1, first_block=blk % GROUP, count=1, advance=(blk % GROUP == GROUP - 1))
     else:
         for c in mine:
-            ids[c] = eng.add_client(D, taps, client_center_freq(c))
-    blocks_before = (24 if staggered and cuda else 0)
+            ids[c] = host.add_client(c, taps)
 
     for _ in range(warmup * calls_per_step if warmup else 2):
         call()
-    warm_calls = state["k"] - (blocks_before if world > 1 else 0)
-    if cuda:
-        eng.sync()
-        torch.cuda.synchronize()
+    host.sync()
     eng.timing_stride(TIMING_STRIDE)
     eng.timing(True)
     if world > 1:
         dist.barrier()
-    if cuda:
-        torch.cuda.synchronize()
+    host.sync()
     t0 = time.perf_counter()
     for _ in range(steps * calls_per_step):
         call()
-    if cuda:
-        torch.cuda.synchronize()
+    host.sync()
     if world > 1:
         dist.barrier()
-    if cuda:
-        torch.cuda.synchronize()
+    host.sync()
     dt = time.perf_counter() - t0
     nt, fir_ms, nco_ms = eng.timing_read(reset=True)
     eng.timing(False)
@@ -281,7 +365,7 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
 
     spot_res = None
     if spot and cuda and mine and group == GROUP and not staggered and world == 1:
-        spot_res = parity_spot(ctx, eng, ids, mine, taps, mode, state["k"], call)
+        spot_res = parity_spot(ctx, eng, ids, mine, taps, mode, host.k, call)
 
     kernels_ms = None
     if polyphase and poly3 and cuda:  # separate durations of the three launches: a short extra pass, OUTSIDE the timed region
@@ -289,17 +373,18 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
         eng.timing(2)
         for _ in range(8):
             call()
-        torch.cuda.synchronize()
+        host.sync()
         n3, ms3 = eng.timing_polyphase(reset=True)
         eng.timing(False)
         if n3 > 0:
             kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), "xlp_mix_kernel": round(ms3[1] / n3, 4),
                           "xlp_inverse_kernel": round(ms3[2] / n3, 4)}
-    eng.close()
-    return {"ntaps": int(taps.size), "seconds": dt, "call_ms_avg": fir_ms / max(nt, 1), "nco_ms_avg": nco_ms / max(nt, 1),
+    feed_name = host.name
+    host.close()
+    return {"feed": feed_name, "ntaps": int(taps.size), "seconds": dt, "call_ms_avg": fir_ms / max(nt, 1), "nco_ms_avg": nco_ms / max(nt, 1),
             "timed_calls": nt, "clients_this_rank": len(mine), "total_clients": total_clients, "K_call": int(klen),
             "plan": plan, "polyphase": polyphase, "kernels_ms": kernels_ms, "group": group, "steps": steps,
-            "warm_calls": warm_calls, "parity_spot": spot_res}
+            "parity_spot": spot_res}
 
 
 def parity_spot(ctx, eng, ids, mine, taps, mode, calls_done, call):
@@ -450,6 +535,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spot", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--feed", default="c", choices=["c", "torch"], help="c: include/xlating_multi.h (C host, RCCL); torch: torch.distributed feeder")
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_launch.py only
     args = ap.parse_args()
 
@@ -493,7 +579,8 @@ def main():
         dev_groups = [torch.from_numpy(make_group(g)) for g in range(NSRC_GROUPS)]
         if cuda:
             dev_groups = [t.cuda() for t in dev_groups]
-    ctx = {"xl": xl, "torch": torch, "dist": dist, "rank": rank, "world": world, "cuda": cuda, "lpf": lpf, "dev_groups": dev_groups}
+    ctx = {"xl": xl, "torch": torch, "dist": dist, "rank": rank, "world": world, "cuda": cuda, "lpf": lpf, "dev_groups": dev_groups,
+           "feed": args.feed}
 
     total_clients = args.clients if args.scaling == "strong" else args.clients * world
     m = run_workload(ctx, total_clients, args.lpf_cutoff_rate, args.steps, args.warmup, args.mode,
@@ -594,7 +681,7 @@ def main():
             "outputs_per_client_per_call": m["K_call"], "us_per_block": round(m["seconds"] / (args.steps * BLOCKS_PER_STEP) * 1e6, 3),
             "parallelism": (f"clients sharded c%{world}; one RCCL broadcast per {GROUP} raw IQ blocks ({GROUP * BLOCK_BYTES} bytes) "
                             "on a separate stream (overlaps the previous call's filtering), no other collective") if world > 1 else "single GPU",
-            "rccl_ranks": rccl_ranks, "rank0_device": (f"cuda:{local_rank}" if cuda else "cpu"),
+            "rccl_ranks": rccl_ranks, "rank0_device": (f"cuda:{local_rank}" if cuda else "cpu"), "feed": m["feed"],
         },
         "roofline": roofline,
         "parity_spot": m["parity_spot"],

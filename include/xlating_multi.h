@@ -1,0 +1,79 @@
+/*
+ * include/xlating_multi.h -- C host for the multi-GPU path (BASELINE.json configs[3]).
+ *
+ * The reference fans one IQ block out to its clients inside one process (src/tcp_server.c:257-271 -> src/queue.c:87-119).
+ * Across the GPUs of one node the same fan-out is: client c lives on GPU (c mod G); the raw block is BROADCAST once over
+ * RCCL/xGMI (the path's only exchange step) and every GPU then filters its own clients -- no other collective, outputs
+ * stay per client.  This library is that host in C: it owns the engines (include/xlating_batch.h), the RCCL
+ * communicators, two receive buffers per GPU and the streams/events that overlap the broadcast of super-block k+1 with
+ * the filtering of super-block k.
+ *
+ * Two ways to run it:
+ *   one process per GPU   (the torch.distributed.run launch shape of bench.py): rank 0 obtains an id with
+ *                         xlating_multi_unique_id(), hands the 128 bytes to the other processes by any means, and every
+ *                         rank calls xlating_multi_create_rank();
+ *   one process, G GPUs   (how a C server would embed it): xlating_multi_create_local() opens G devices at once
+ *                         (ncclCommInitAll) and xlating_multi_feed() drives them all.
+ * Plain C ABI; links librccl and libxlating_hip.
+ */
+#ifndef SDR_SERVER_AMD_XLATING_MULTI_H_
+#define SDR_SERVER_AMD_XLATING_MULTI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "xlating_batch.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xlating_multi_t xlating_multi;
+
+#define XLATING_MULTI_ID_BYTES 128
+
+/* rank 0: fill id[128] (ncclGetUniqueId).  0 or -EIO. */
+int xlating_multi_unique_id(void *id);
+
+/* One process per GPU: this process is `rank` of `world` and drives HIP device `device` (-1: the current one).
+ * Engine parameters as xlating_batch_create_grouped().  Collective: returns when every rank has called it.
+ * 0, -EINVAL, -ENODEV, -ENOMEM, -EIO (RCCL/HIP failure). */
+int xlating_multi_create_rank(int rank, int world, const void *id, uint32_t sampling_freq, int input_format,
+                              uint32_t max_input_buffer_length, unsigned max_group_blocks, int device,
+                              xlating_multi **multi);
+
+/* One process, `ngpus` GPUs (`devices` = HIP ordinals, or NULL for 0 .. ngpus-1). */
+int xlating_multi_create_local(int ngpus, const int *devices, uint32_t sampling_freq, int input_format,
+                               uint32_t max_input_buffer_length, unsigned max_group_blocks, xlating_multi **multi);
+
+/* GPUs in the job, and how many of them this process drives (1, or ngpus). */
+int xlating_multi_world(const xlating_multi *multi);
+int xlating_multi_local(const xlating_multi *multi);
+
+/* Client `global_client` (0, 1, 2, ...) lives on GPU (global_client mod world).  Every process makes the same calls;
+ * the call adds the client where this process drives its GPU and is a no-op elsewhere.
+ * Returns the client id inside its engine (>= 0) if the GPU is local, -ENOENT if another process owns it, or the
+ * error of xlating_batch_add_client(). */
+int xlating_multi_add_client(xlating_multi *multi, int global_client, uint32_t decimation, const float *taps,
+                             size_t taps_len, int32_t center_freq);
+/* The engine of GPU `gpu` (0 .. world-1) if this process drives it, else NULL: fetch outputs, describe, timing. */
+xlating_batch *xlating_multi_engine(xlating_multi *multi, int gpu);
+
+/* Feed one super-block: `nblocks` blocks of `input_len` scalar elements each, back to back.
+ *   d_src  device memory on GPU 0 holding the blocks (the process that drives GPU 0 passes it; the others pass NULL).
+ * The blocks are broadcast from GPU 0 into the next receive buffer of every GPU on the communication stream, and every
+ * local engine then processes them there (xlating_batch_process_device_group) on its compute stream.  Asynchronous:
+ * returns once the work is enqueued; d_src may be reused after xlating_multi_feed_done(multi) of the NEXT call or a sync.
+ * With world == 1 nothing is broadcast (the engine reads d_src in place).
+ * 0, -EINVAL, -EIO. */
+int xlating_multi_feed(xlating_multi *multi, const void *d_src, size_t input_len, unsigned nblocks, int mode);
+
+/* Wait until everything fed so far has been filtered on the local GPUs. */
+int xlating_multi_sync(xlating_multi *multi);
+
+void xlating_multi_destroy(xlating_multi *multi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDR_SERVER_AMD_XLATING_MULTI_H_ */

@@ -56,7 +56,52 @@ EXPORTED_SYMBOLS = (
        "xlating_wire_build_header", "xlating_wire_parse_response", "xlating_wire_admit", "xlating_wire_add_client"]
 )
 
+MULTI_SYMBOLS = ["xlating_multi_unique_id", "xlating_multi_create_rank", "xlating_multi_create_local", "xlating_multi_world",
+                 "xlating_multi_local", "xlating_multi_add_client", "xlating_multi_engine", "xlating_multi_feed",
+                 "xlating_multi_sync", "xlating_multi_destroy"]
+
 _lib = None
+_mlib = None
+
+
+def multi_library_path():
+    return os.path.join(os.path.dirname(library_path()), "libxlating_multi.so")
+
+
+def multi_lib():
+    """include/xlating_multi.h: the C host of the multi-GPU path (engines + RCCL broadcast).  Loads librccl."""
+    global _mlib
+    if _mlib is not None:
+        return _mlib
+    lib()
+    path = multi_library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    M = C.CDLL(path)
+    M.xlating_multi_unique_id.argtypes = [C.c_void_p]
+    M.xlating_multi_unique_id.restype = C.c_int
+    M.xlating_multi_create_rank.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint, C.c_int,
+                                            C.POINTER(C.c_void_p)]
+    M.xlating_multi_create_rank.restype = C.c_int
+    M.xlating_multi_create_local.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_uint32, C.c_int, C.c_uint32, C.c_uint,
+                                             C.POINTER(C.c_void_p)]
+    M.xlating_multi_create_local.restype = C.c_int
+    M.xlating_multi_world.argtypes = [C.c_void_p]
+    M.xlating_multi_world.restype = C.c_int
+    M.xlating_multi_local.argtypes = [C.c_void_p]
+    M.xlating_multi_local.restype = C.c_int
+    M.xlating_multi_add_client.argtypes = [C.c_void_p, C.c_int, C.c_uint32, _c_float_p, C.c_size_t, C.c_int32]
+    M.xlating_multi_add_client.restype = C.c_int
+    M.xlating_multi_engine.argtypes = [C.c_void_p, C.c_int]
+    M.xlating_multi_engine.restype = C.c_void_p
+    M.xlating_multi_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_int]
+    M.xlating_multi_feed.restype = C.c_int
+    M.xlating_multi_sync.argtypes = [C.c_void_p]
+    M.xlating_multi_sync.restype = C.c_int
+    M.xlating_multi_destroy.argtypes = [C.c_void_p]
+    M.xlating_multi_destroy.restype = None
+    _mlib = M
+    return M
 
 
 def lib():
@@ -390,6 +435,79 @@ class BatchEngine:
     def close(self):
         if getattr(self, "h", None):
             lib().xlating_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiHost:
+    """`xlating_multi *` (include/xlating_multi.h): the C host of the multi-GPU path.  One process per GPU
+    (rank / world / 128-byte id from `MultiHost.unique_id()` on rank 0) or one process driving `ngpus` GPUs."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        code = multi_lib().xlating_multi_unique_id(buf)
+        if code != 0:
+            raise XlatingError("xlating_multi_unique_id", code)
+        return buf.raw
+
+    def __init__(self, sampling_freq, in_fmt, max_input_buffer_length, group_blocks=1, rank=0, world=1, uid=None, device=-1,
+                 ngpus=None):
+        h = C.c_void_p()
+        M = multi_lib()
+        if ngpus is not None:
+            code = M.xlating_multi_create_local(ngpus, None, sampling_freq, FMT[in_fmt], max_input_buffer_length, group_blocks,
+                                                C.byref(h))
+        else:
+            idbuf = C.create_string_buffer(uid, 128) if uid is not None else None
+            code = M.xlating_multi_create_rank(rank, world, idbuf, sampling_freq, FMT[in_fmt], max_input_buffer_length,
+                                               group_blocks, device, C.byref(h))
+        if code != 0:
+            raise XlatingError("xlating_multi_create", code)
+        self.h = h
+        self.in_fmt = in_fmt
+        self.world = M.xlating_multi_world(h)
+
+    def engine(self, gpu):
+        """The BatchEngine of job GPU `gpu` if this process drives it (owned by the host: do not close it)."""
+        p = multi_lib().xlating_multi_engine(self.h, gpu)
+        if not p:
+            return None
+        e = BatchEngine.__new__(BatchEngine)
+        e.h = C.c_void_p(p)
+        e.in_fmt = self.in_fmt
+        e.close = lambda: None
+        return e
+
+    def add_client(self, global_client, decimation, taps, center_freq):
+        """-> engine-local client id, or None when another process drives the client's GPU (global_client mod world)."""
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        cid = multi_lib().xlating_multi_add_client(self.h, global_client, decimation, taps.ctypes.data_as(_c_float_p), taps.size,
+                                                   center_freq)
+        if cid == -2:
+            return None
+        if cid < 0:
+            raise XlatingError("xlating_multi_add_client", cid)
+        return cid
+
+    def feed(self, d_src, input_len, nblocks, variant="optimized"):
+        code = multi_lib().xlating_multi_feed(self.h, C.c_void_p(d_src) if d_src else None, input_len, nblocks, MODE[variant])
+        if code != 0:
+            raise XlatingError("xlating_multi_feed", code)
+
+    def sync(self):
+        code = multi_lib().xlating_multi_sync(self.h)
+        if code != 0:
+            raise XlatingError("xlating_multi_sync", code)
+
+    def close(self):
+        if getattr(self, "h", None):
+            multi_lib().xlating_multi_destroy(self.h)
             self.h = None
 
     def __del__(self):

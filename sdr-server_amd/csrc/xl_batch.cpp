@@ -110,6 +110,15 @@ struct xlating_batch_t {
   hipStream_t own_stream = nullptr;   // used when the caller passes no stream / host path
   hipStream_t last_stream = nullptr;  // caller stream of the latest call
   hipEvent_t dep_ev = nullptr;        // orders a call on a new stream behind the previous call's stream
+  // Side-stream NCO chain (calls of several blocks): the next call's phase table is tabulated by xl_nco_chain_kernel on
+  // nco_stream while this call's launches run on the caller's stream.  ev_chain[t]: the tabulation of table t is complete (the
+  // caller's stream waits for it before the first launch that reads the table); ev_done[t]: the launches that read
+  // table t have been passed by the caller's stream (nco_stream waits for it before overwriting that table).
+  hipStream_t nco_stream = nullptr;
+  hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};  // per phase table
+  bool ev_done_valid[2] = {false, false};
+  bool spec_on_side = false;  // the look-ahead table was produced on nco_stream (ev_chain must be waited for)
+  int nco_side = -1;          // option "nco_side_stream": 1 always, 0 never (NCO role inside the launches), -1: calls of >= 2 blocks
   bool poisoned = false;              // a launch failed mid-call: device state is undefined, every later call fails
 
   std::vector<Client> clients;
@@ -199,6 +208,7 @@ static hipError_t xl_batch_timing_event(xlating_batch *b, hipEvent_t *out) {
 static void xl_batch_sync_all(xlating_batch *b) {
   (void)hipStreamSynchronize(b->last_stream);  // may be the NULL (legacy default) stream: still a real stream
   if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
+  if (b->nco_stream) (void)hipStreamSynchronize(b->nco_stream);
 }
 
 static void xl_batch_free_plan(xlating_batch *b) {
@@ -241,6 +251,11 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   for (hipEvent_t e : b->ev_poly) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
   if (b->dep_ev) (void)hipEventDestroy(b->dep_ev);
+  for (hipEvent_t e : b->ev_chain)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : b->ev_done)
+    if (e) (void)hipEventDestroy(e);
+  if (b->nco_stream) (void)hipStreamDestroy(b->nco_stream);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
 }
@@ -264,6 +279,9 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
   } else if (n == "tile_height") {
     if (value != 0 && value != 8 && value != 9 && value != 10 && value != 12) return -EINVAL;
     b->exp_h = (int)value;
+  } else if (n == "nco_side_stream") {
+    if (value < -1 || value > 1) return -EINVAL;
+    b->nco_side = (int)value;
   } else if (n == "nco_slices") {  // value = slice1 * 65536 + slice2, both in 1/65536 of a call
     b->poly_slice1 = (uint32_t)((value >> 16) & 0xFFFF);
     b->poly_slice2 = (uint32_t)(value & 0xFFFF);
@@ -300,6 +318,11 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
     XL_TRY(hipSetDevice(dev));
     XL_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     XL_TRY(hipEventCreateWithFlags(&b->dep_ev, hipEventDisableTiming));
+    XL_TRY(hipStreamCreateWithFlags(&b->nco_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      XL_TRY(hipEventCreateWithFlags(&b->ev_chain[i], hipEventDisableTiming));
+      XL_TRY(hipEventCreateWithFlags(&b->ev_done[i], hipEventDisableTiming));
+    }
     for (int i = 0; i < 2; ++i) {
       XL_TRY(hipMalloc(&b->d_hist[i], hbytes));
       XL_TRY(hipMemsetAsync(b->d_hist[i], 0, hbytes, b->own_stream));
@@ -316,6 +339,7 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
   if (getenv("XL_EXP_POLY")) (void)xlating_batch_set_option(b, "polyphase", atol(getenv("XL_EXP_POLY")));
   if (getenv("XL_EXP_POLY_M")) (void)xlating_batch_set_option(b, "polyphase_m", atol(getenv("XL_EXP_POLY_M")));
   if (getenv("XL_EXP_POLY_MIN")) (void)xlating_batch_set_option(b, "polyphase_min_clients", atol(getenv("XL_EXP_POLY_MIN")));
+  if (getenv("XL_EXP_NCO_SIDE")) (void)xlating_batch_set_option(b, "nco_side_stream", atol(getenv("XL_EXP_NCO_SIDE")));
   if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
   if (getenv("XL_EXP_MIXSKIP")) b->mix_skip_at = (uint32_t)atoi(getenv("XL_EXP_MIXSKIP"));
   if (getenv("XL_EXP_INVSKIP")) b->inv_skip_at = (uint32_t)atoi(getenv("XL_EXP_INVSKIP"));
@@ -893,12 +917,16 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     pos.S = (uint32_t)S;
     pos.G = G;
     pos.pad = 0;
+    // Who tabulates the NEXT call's phases: the NCO role inside this call's launches (fuse), or -- calls of several
+    // blocks -- xl_nco_chain_kernel on the side stream, concurrently with them (side).
+    const bool side = b->nco_side > 0 || (b->nco_side < 0 && G >= 2);
 #ifdef XL_TUNING
-    const bool fuse = !b->exp_nofuse;  // tuning: tabulate by a launch of its own before every call
+    const bool fuse = !side && !b->exp_nofuse;  // tuning: tabulate by a launch of its own before every call
 #else
-    const bool fuse = true;
+    const bool fuse = !side;
 #endif
     bool nco_fused = false;
+    bool chain_wait = false;  // this call's table comes from the side stream: wait for it before the first reader
     // the most outputs any client produces in this call
     uint32_t maxK = 0;
     for (const DirectClass &cs : b->classes) maxK = std::max(maxK, xl_grid_dyn(cs.D, cs.T, cs.rem0, cs.hv0, pos).K);
@@ -908,13 +936,31 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     int pcur = b->pcur;
     if (b->spec_valid && b->spec_S == S && b->spec_G == G) {
       tab = b->spec_tab;
+      chain_wait = b->spec_on_side;
     } else {
       tab = b->spec_valid ? b->spec_tab : (b->tab ^ 1);
+      // (a look-ahead of the wrong shape may still be running on the side stream, on these very buffers)
+      if (b->spec_valid && b->spec_on_side) XL_TRY(hipStreamWaitEvent(s, b->ev_chain[b->spec_tab], 0));
+      if (b->ev_done_valid[tab]) XL_TRY(hipStreamWaitEvent(s, b->ev_done[tab], 0));  // (same stream normally: a no-op)
       XL_TRY(xl_batch_nco(b, pos, tab, s));
     }
     pcur ^= 1;  // the phases written by that tabulation are now the committed ones
     b->spec_valid = false;  // (from here on a failure poisons the engine)
     b->poisoned = true;
+
+    // ---- side stream: the NEXT call's table (same shape assumed) into table[tab ^ 1], concurrently with the launches
+    // below.  That table was last read by the previous call's launches (ev_done), the committed phases d_phase[pcur]
+    // were written by the tabulation of THIS call's table (earlier on the same side stream, or on `s`: ordered below).
+    if (side) {
+      if (!chain_wait) {  // this call's table was tabulated on `s` just now: order the side stream behind it
+        XL_TRY(hipEventRecord(b->dep_ev, s));
+        XL_TRY(hipStreamWaitEvent(b->nco_stream, b->dep_ev, 0));
+      }
+      if (b->ev_done_valid[tab ^ 1]) XL_TRY(hipStreamWaitEvent(b->nco_stream, b->ev_done[tab ^ 1], 0));
+      XL_TRY(xl_launch_nco_chain(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[pcur], b->d_phase[pcur ^ 1],
+                                 b->d_phtab[tab ^ 1], xl_grid_next(pos), b->nco_stream));
+      XL_TRY(hipEventRecord(b->ev_chain[tab ^ 1], b->nco_stream));
+    }
 
     // ---- the launches on the caller's stream: window images from [d_hist[hb] | blocks], phases from table[tab] ->
     // d_out[p]; the first launch also rolls the raw history into d_hist[hn], and the launches tabulate table[tab ^ 1]
@@ -999,6 +1045,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           a.trace = b->d_trace;
         }
 #endif
+        if (chain_wait) {
+          XL_TRY(hipStreamWaitEvent(s, b->ev_chain[tab], 0));
+          chain_wait = false;
+        }
         XL_TRY(xl_launch_fir(L.ct, mode, L.nw, a, L.lds, s));
 #ifdef XL_TUNING
         if (b->exp_trace) XL_TRY(xl_dump_trace(b->exp_trace, b->d_trace, trace_n, s));
@@ -1122,6 +1172,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
             pa.trace = b->d_ptrace;
           }
 #endif
+          if (chain_wait) {  // (the forward and mix launches do not read the table)
+            XL_TRY(hipStreamWaitEvent(s, b->ev_chain[tab], 0));
+            chain_wait = false;
+          }
           XL_TRY(xlp_launch_inverse(pa, s));
 #ifdef XL_TUNING
           if (trace_inv) {
@@ -1136,6 +1190,9 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     }
     if (!rolled)  // no client produced output in this call (tiny block): roll the history on its own
       XL_TRY(xl_launch_update_history(b->d_hist[hb], d_blocks, XL_HCAP, N, b->bps, b->d_hist[hn], s));
+    // table[tab] has been read by everything enqueued so far
+    XL_TRY(hipEventRecord(b->ev_done[tab], s));
+    b->ev_done_valid[tab] = true;
 
     // ---- everything is enqueued: commit the host-side state of the call
     b->poisoned = false;
@@ -1160,11 +1217,12 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     b->ncalls++;
     // ---- the NEXT call's phases, guessing it has the same shape, were tabulated inside the launches above;
     // without them (tiny call, or the tuning switch) the next call tabulates for itself
-    if (nco_fused) {
+    if (nco_fused || side) {
       b->spec_valid = true;
       b->spec_S = (uint32_t)S;
       b->spec_G = G;
       b->spec_tab = tab ^ 1;
+      b->spec_on_side = side;
     }
   }
   return 0;

@@ -53,6 +53,25 @@ __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__r
   xl_nco_client_chain(k, bnd, 0u, bnd.K, state_in, state_out, tab);
 }
 
+// The same tabulation for a call of many blocks, run on the engine's side stream WHILE the previous call's launches run
+// on the main stream (xl_batch.cpp).  The recurrence is a dependent chain of ~17.5 cycles per step that any neighbour
+// on its SIMD slows by 35-60 % (the neighbour's packed FMAs occupy the VALU for 4 cycles each: measured 7.3 ns per step
+// alone, 9.8-13.5 ns next to the mix kernel's waves), and it is what bounds a call once the filtering itself takes less
+// than ~23 us per block.  So this kernel claims every VGPR of its SIMDs (v255 / a255 are declared clobbered: the kernel
+// descriptor then asks for 512 registers per lane and the hardware places ONE wave per SIMD): four waves = one CU per
+// 256 clients, nothing else resident there, the chain runs at its lone-wave speed.
+__global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
+                                                           const float2 *state_in, float2 *state_out,
+                                                           float2 *__restrict__ tab, const XlPos pos) {
+  asm volatile("" ::: "v255", "a255");
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= n) return;
+  const XlNcoClient k = cl[c];
+  const XlBnd bnd = xl_nco_bnd(k, pos, 0xFFFFFFFFu);
+  xl_nco_client_chain(k, bnd, 0u, bnd.K, state_in, state_out, tab);
+}
+
 // Window staging: raw samples -> cf32 image in LDS.  Four independent loads per thread are issued before any is
 // consumed (every workgroup of a launch stages at the same time and all its waves wait at the barrier, so this
 // phase is pure latency: 12 dependent load->convert->write rounds measured 6 us of a 130 us launch).
@@ -380,6 +399,14 @@ hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, co
   const uint32_t lanes = XL_NCO_LANES;
   hipLaunchKernelGGL(xl_nco_table_kernel, dim3((nclients + lanes - 1) / lanes), dim3(64), 0, s, clients, nclients,
                      state_in, state_out, phtab, pos, explicit_K, prio, lanes);
+  return hipGetLastError();
+}
+
+hipError_t xl_launch_nco_chain(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in, float2 *state_out,
+                               float2 *phtab, XlPos pos, hipStream_t s) {
+  if (nclients == 0) return hipSuccess;
+  hipLaunchKernelGGL(xl_nco_chain_kernel, dim3((nclients + 255u) / 256u), dim3(256), 0, s, clients, nclients, state_in,
+                     state_out, phtab, pos);
   return hipGetLastError();
 }
 

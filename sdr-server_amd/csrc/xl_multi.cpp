@@ -1,0 +1,246 @@
+// xl_multi.cpp -- C host of the multi-GPU path (include/xlating_multi.h): G engines, one RCCL broadcast of the raw
+// super-block per feed on a communication stream, c mod G sharding.  Reference fan-out replaced:
+// src/tcp_server.c:257-271, src/queue.c:87-119.
+//
+// Per GPU: an engine, a communicator, a communication stream, a compute stream, two receive buffers and per buffer an
+// event pair: `ready` (recorded on the communication stream behind the broadcast; the compute stream waits for it before
+// the engine's launches) and `free` (recorded on the compute stream behind the launches that read the buffer; the
+// communication stream waits for it before the broadcast two feeds later overwrites the buffer).  Consecutive feeds
+// alternate the buffers, so the broadcast of super-block k+1 runs while super-block k is filtered.
+#include <errno.h>
+#include <rccl/rccl.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/xlating_multi.h"
+#include "xl_common.h"
+
+namespace {
+struct Gpu {
+  int index = 0;   // position in the job (0 .. world-1)
+  int device = 0;  // HIP ordinal
+  xlating_batch *engine = nullptr;
+  ncclComm_t comm = nullptr;
+  hipStream_t comm_stream = nullptr, compute = nullptr;
+  void *recv[2] = {nullptr, nullptr};
+  hipEvent_t ready[2] = {nullptr, nullptr}, free_[2] = {nullptr, nullptr};
+  bool free_valid[2] = {false, false};
+};
+}  // namespace
+
+struct xlating_multi_t {
+  int world = 1;
+  std::vector<Gpu> gpus;  // the GPUs this process drives
+  size_t recv_bytes = 0;
+  uint32_t bps = 2;
+  uint64_t feeds = 0;
+};
+
+#define XL_NCCL(expr)                                                                          \
+  do {                                                                                         \
+    ncclResult_t xl_r_ = (expr);                                                               \
+    if (xl_r_ != ncclSuccess) {                                                                \
+      XL_LOG_ERR("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(xl_r_), __FILE__, __LINE__); \
+      goto fail;                                                                               \
+    }                                                                                          \
+  } while (0)
+
+extern "C" int xlating_multi_unique_id(void *id) {
+  if (id == nullptr) return -EINVAL;
+  static_assert(sizeof(ncclUniqueId) == XLATING_MULTI_ID_BYTES, "id size");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return -EIO;
+  memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+static int xl_multi_open_gpu(xlating_multi *m, Gpu &g, uint32_t fs, int fmt, uint32_t max_len, unsigned gcap) {
+  int rc = xlating_batch_create_grouped(fs, fmt, max_len, gcap, g.device, &g.engine);
+  if (rc != 0) return rc;
+  XL_TRY(hipSetDevice(g.device));
+  XL_TRY(hipStreamCreateWithFlags(&g.comm_stream, hipStreamNonBlocking));
+  XL_TRY(hipStreamCreateWithFlags(&g.compute, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    if (m->world > 1) XL_TRY(hipMalloc(&g.recv[i], m->recv_bytes));
+    XL_TRY(hipEventCreateWithFlags(&g.ready[i], hipEventDisableTiming));
+    XL_TRY(hipEventCreateWithFlags(&g.free_[i], hipEventDisableTiming));
+  }
+  return 0;
+fail:
+  return xl_errno_of_last_hip_error();
+}
+
+static int xl_multi_check(uint32_t fs, int fmt, uint32_t max_len, unsigned gcap) {
+  if (fs == 0 || fmt < XL_FMT_CU8 || fmt > XL_FMT_CF32 || max_len < 2 || gcap < 1 || gcap > 64) return -EINVAL;
+  return 0;
+}
+
+extern "C" int xlating_multi_create_rank(int rank, int world, const void *id, uint32_t fs, int fmt, uint32_t max_len,
+                                         unsigned gcap, int device, xlating_multi **out) {
+  if (out == nullptr || world < 1 || rank < 0 || rank >= world || (world > 1 && id == nullptr) ||
+      xl_multi_check(fs, fmt, max_len, gcap) != 0)
+    return -EINVAL;
+  const int dev = xl_hip_select_device(device);
+  if (dev < 0) {
+    XL_LOG_ERR("no usable HIP device (%s); this build has no CPU arithmetic path", xlating_hip_device_info());
+    return -ENODEV;
+  }
+  xlating_multi *m = new (std::nothrow) xlating_multi_t();
+  if (m == nullptr) return -ENOMEM;
+  m->world = world;
+  m->bps = fmt <= XL_FMT_CS8 ? 2u : (fmt == XL_FMT_CS16 ? 4u : 8u);
+  m->recv_bytes = (size_t)(max_len / 2) * gcap * m->bps + 16;
+  m->gpus.resize(1);
+  m->gpus[0].index = rank;
+  m->gpus[0].device = dev;
+  int rc = xl_multi_open_gpu(m, m->gpus[0], fs, fmt, max_len, gcap);
+  if (rc != 0) {
+    xlating_multi_destroy(m);
+    return rc;
+  }
+  if (world > 1) {
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    XL_NCCL(ncclCommInitRank(&m->gpus[0].comm, world, u, rank));
+  }
+  *out = m;
+  return 0;
+fail:
+  xlating_multi_destroy(m);
+  return -EIO;
+}
+
+extern "C" int xlating_multi_create_local(int ngpus, const int *devices, uint32_t fs, int fmt, uint32_t max_len,
+                                          unsigned gcap, xlating_multi **out) {
+  if (out == nullptr || ngpus < 1 || ngpus > 64 || xl_multi_check(fs, fmt, max_len, gcap) != 0) return -EINVAL;
+  if (xl_hip_select_device(devices ? devices[0] : 0) < 0) {
+    XL_LOG_ERR("no usable HIP device (%s); this build has no CPU arithmetic path", xlating_hip_device_info());
+    return -ENODEV;
+  }
+  xlating_multi *m = new (std::nothrow) xlating_multi_t();
+  if (m == nullptr) return -ENOMEM;
+  m->world = ngpus;
+  m->bps = fmt <= XL_FMT_CS8 ? 2u : (fmt == XL_FMT_CS16 ? 4u : 8u);
+  m->recv_bytes = (size_t)(max_len / 2) * gcap * m->bps + 16;
+  m->gpus.resize((size_t)ngpus);
+  std::vector<int> devs((size_t)ngpus);
+  std::vector<ncclComm_t> comms((size_t)ngpus, nullptr);
+  for (int i = 0; i < ngpus; ++i) {
+    devs[i] = devices ? devices[i] : i;
+    if (xl_hip_select_device(devs[i]) < 0) {
+      xlating_multi_destroy(m);
+      return -ENODEV;
+    }
+    m->gpus[i].index = i;
+    m->gpus[i].device = devs[i];
+    int rc = xl_multi_open_gpu(m, m->gpus[i], fs, fmt, max_len, gcap);
+    if (rc != 0) {
+      xlating_multi_destroy(m);
+      return rc;
+    }
+  }
+  if (ngpus > 1) {
+    XL_NCCL(ncclCommInitAll(comms.data(), ngpus, devs.data()));
+    for (int i = 0; i < ngpus; ++i) m->gpus[i].comm = comms[i];
+  }
+  *out = m;
+  return 0;
+fail:
+  xlating_multi_destroy(m);
+  return -EIO;
+}
+
+extern "C" int xlating_multi_world(const xlating_multi *m) { return m ? m->world : 0; }
+extern "C" int xlating_multi_local(const xlating_multi *m) { return m ? (int)m->gpus.size() : 0; }
+
+static Gpu *xl_multi_find(xlating_multi *m, int gpu) {
+  for (Gpu &g : m->gpus)
+    if (g.index == gpu) return &g;
+  return nullptr;
+}
+
+extern "C" xlating_batch *xlating_multi_engine(xlating_multi *m, int gpu) {
+  if (m == nullptr) return nullptr;
+  Gpu *g = xl_multi_find(m, gpu);
+  return g ? g->engine : nullptr;
+}
+
+extern "C" int xlating_multi_add_client(xlating_multi *m, int global_client, uint32_t decimation, const float *taps,
+                                        size_t taps_len, int32_t center_freq) {
+  if (m == nullptr || global_client < 0) return -EINVAL;
+  Gpu *g = xl_multi_find(m, global_client % m->world);  // client c -> GPU (c mod G)
+  if (g == nullptr) return -ENOENT;
+  return xlating_batch_add_client(g->engine, decimation, taps, taps_len, center_freq);
+}
+
+extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t input_len, unsigned nblocks, int mode) {
+  if (m == nullptr || nblocks < 1) return -EINVAL;
+  const size_t bytes = (input_len / 2) * nblocks * m->bps;
+  if (m->world > 1 && bytes > m->recv_bytes) return -EINVAL;
+  Gpu *root = xl_multi_find(m, 0);
+  if (root != nullptr && d_src == nullptr && bytes > 0) return -EINVAL;  // the driver of GPU 0 holds the source
+  const int i = (int)(m->feeds & 1);
+  if (m->world == 1) {
+    Gpu &g = m->gpus[0];
+    int rc = xlating_batch_process_device_group(g.engine, d_src, input_len, nblocks, mode, g.compute);
+    if (rc != 0) return rc;
+    m->feeds++;
+    return 0;
+  }
+  // ---- the path's only exchange step: GPU 0's raw blocks -> every GPU, on the communication streams
+  for (Gpu &g : m->gpus) {
+    XL_TRY(hipSetDevice(g.device));
+    if (g.free_valid[i]) XL_TRY(hipStreamWaitEvent(g.comm_stream, g.free_[i], 0));
+  }
+  if (m->gpus.size() > 1) XL_NCCL(ncclGroupStart());
+  for (Gpu &g : m->gpus) {
+    XL_TRY(hipSetDevice(g.device));
+    XL_NCCL(ncclBroadcast(g.index == 0 ? d_src : g.recv[i], g.recv[i], bytes, ncclUint8, 0, g.comm, g.comm_stream));
+  }
+  if (m->gpus.size() > 1) XL_NCCL(ncclGroupEnd());
+  // ---- independent per-GPU work: every local engine filters its own clients from its receive buffer
+  for (Gpu &g : m->gpus) {
+    XL_TRY(hipSetDevice(g.device));
+    XL_TRY(hipEventRecord(g.ready[i], g.comm_stream));
+    XL_TRY(hipStreamWaitEvent(g.compute, g.ready[i], 0));
+    int rc = xlating_batch_process_device_group(g.engine, g.recv[i], input_len, nblocks, mode, g.compute);
+    if (rc != 0) return rc;
+    XL_TRY(hipEventRecord(g.free_[i], g.compute));
+    g.free_valid[i] = true;
+  }
+  m->feeds++;
+  return 0;
+fail:
+  return -EIO;
+}
+
+extern "C" int xlating_multi_sync(xlating_multi *m) {
+  if (m == nullptr) return -EINVAL;
+  for (Gpu &g : m->gpus) {
+    if (hipSetDevice(g.device) != hipSuccess) return -EIO;
+    if (g.comm_stream && hipStreamSynchronize(g.comm_stream) != hipSuccess) return -EIO;
+    if (g.compute && hipStreamSynchronize(g.compute) != hipSuccess) return -EIO;
+  }
+  return 0;
+}
+
+extern "C" void xlating_multi_destroy(xlating_multi *m) {
+  if (m == nullptr) return;
+  (void)xlating_multi_sync(m);
+  for (Gpu &g : m->gpus) {
+    (void)hipSetDevice(g.device);
+    if (g.engine) xlating_batch_destroy(g.engine);
+    if (g.comm) (void)ncclCommDestroy(g.comm);
+    for (int i = 0; i < 2; ++i) {
+      if (g.recv[i]) (void)hipFree(g.recv[i]);
+      if (g.ready[i]) (void)hipEventDestroy(g.ready[i]);
+      if (g.free_[i]) (void)hipEventDestroy(g.free_[i]);
+    }
+    if (g.comm_stream) (void)hipStreamDestroy(g.comm_stream);
+    if (g.compute) (void)hipStreamDestroy(g.compute);
+  }
+  delete m;
+}

@@ -872,3 +872,56 @@ def test_set_option_and_unknown_option():
         eng.add_client(42, t48, 1000 * c)
     assert "polyphase: cls0 D42 T505 cols5 V244 M256" in eng.describe()
     eng.close()
+
+
+@pytest.mark.parametrize("side,G", [(1, 1), (0, 4), (1, 3)])
+@pytest.mark.parametrize("poly", [0, 1])
+def test_nco_tabulation_side_stream_or_inside_the_launches(side, G, poly):
+    """The next call's phase table comes either from the NCO role inside the launches or from xl_nco_chain_kernel on
+    the side stream (default for calls of >= 2 blocks): both forced here for both call shapes, native bit-exact incl.
+    the committed phases, a shape change in between (the look-ahead table is dropped and redone)."""
+    t48 = lpf(FS, 24000, 9600)
+    clients = [(42, t48, -700000 + 47000 * c) for c in range(70)]
+    eng, oracles = _group_engine("cu8", 100002, 4, clients, poly=poly)
+    eng.set_option("nco_side_stream", side)
+    for k, (g, n, variant) in enumerate(((G, 100002, "native"), (G, 100002, "optimized"), (G, 100002, "native"),
+                                        (1 if G > 1 else 2, 65536, "native"), (G, 100002, "optimized"), (G, 100002, "native"))):
+        x = siggen.xs_u8(5100 + k, g * n)
+        _check_group(eng, oracles, "cu8", x, g, variant)
+    for cid, o in oracles.items():
+        assert tuple(np.float32(v).tobytes() for v in eng.phase(cid)) == tuple(np.float32(v).tobytes() for v in o.phase)
+    eng.close()
+
+
+@pytest.mark.parametrize("how", ["rank", "local"])
+def test_c_multi_host_single_gpu(how):
+    """include/xlating_multi.h on the one GPU of this box (world 1 as a rank, and the one-process form with ngpus = 1):
+    sharding call, feed of 4-block super-blocks from device memory, engine access, sync -- every client vs the oracle."""
+    import torch
+
+    t48 = lpf(FS, 24000, 9600)
+    if how == "rank":
+        m = xl.MultiHost(FS, "cu8", 100002, group_blocks=4, rank=0, world=1)
+    else:
+        m = xl.MultiHost(FS, "cu8", 100002, group_blocks=4, ngpus=1)
+    assert m.world == 1
+    eng = m.engine(0)
+    assert eng is not None and m.engine(1) is None
+    oracles = {}
+    for c in range(20):
+        cid = m.add_client(c, 42, t48, -500000 + 50000 * c)
+        oracles[cid] = Oracle(42, t48, -500000 + 50000 * c, FS, 100002)
+    for k in range(3):
+        x = siggen.xs_u8(5300 + k, 4 * 100002)
+        d = torch.from_numpy(x).cuda()
+        m.feed(d.data_ptr(), 100002, 4, "optimized" if k == 1 else "native")
+        m.sync()
+        eng.fetch()
+        for cid, o in oracles.items():
+            want = np.concatenate([o.process("cu8", bl) for bl in np.split(x, 4)])
+            got = eng.output(cid)
+            if k == 1:
+                assert rel_err(got, want) <= REL_TOL
+            else:
+                assert bits_equal(got, want), (k, cid)
+    m.close()

@@ -60,3 +60,100 @@ def test_c_caller_output_matches_oracle(variant):
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), call
         else:
             assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), call
+
+
+# ---- the reference's OWN callers (test/perf_xlating.c, test/test_xlating.c), compiled where they lie against the
+# reference's own headers and linked to libxlating_hip.so by tests/c/Makefile -> tests/c/_refbin/ (shipped to the GPU box)
+REFBIN = os.path.join(ROOT, "tests", "c", "_refbin")
+API = ["create_low_pass_filter", "create_frequency_xlating_filter", "process_native_cu8_cf32",
+       "process_optimized_cu8_cf32", "process_native_cu8_cs16", "process_optimized_cu8_cs16"]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/test/perf_xlating.c"), reason="build container only (needs /root/reference)")
+def test_reference_callers_link_against_the_library():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    perf, unit = os.path.join(REFBIN, "perf_xlating_hip"), os.path.join(REFBIN, "test_xlating_hip")
+    und = subprocess.run(["nm", "-u", perf], capture_output=True, text=True).stdout
+    for sym in API:
+        assert sym in und, sym  # unresolved in the reference's object, resolved by libxlating_hip.so at load time
+    assert "SIMD_STATUS" in subprocess.run(["nm", perf], capture_output=True, text=True).stdout
+    und = subprocess.run(["nm", "-u", unit], capture_output=True, text=True).stdout
+    for sym in ("create_frequency_xlating_filter", "process_native_cu8_cf32", "process_native_cu8_cs16", "destroy_xlating"):
+        assert sym in und, sym
+    for exe in (perf, unit):
+        assert "libxlating_hip.so" in subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    defined = subprocess.run(["nm", "-D", "--defined-only", xl.library_path()], capture_output=True, text=True).stdout
+    for sym in API + ["SIMD_STATUS", "destroy_xlating"]:
+        assert f" {sym}" in defined, sym
+
+
+@pytest.mark.gpu
+def test_reference_unit_test_passes_against_the_library():
+    """test/test_xlating.c (Unity): its three tests with the reference's expected arrays, run unmodified on the GPU."""
+    exe = os.path.join(REFBIN, "test_xlating_hip")
+    if not os.path.exists(exe):
+        pytest.skip("tests/c/_refbin not built (needs the build container)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "3 Tests 0 Failures 0 Ignored" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_reference_perf_program_runs_against_the_library():
+    """test/perf_xlating.c: 4 x 1000 calls of 200000 bytes through the drop-in API; prints SIMD_STATUS and four timings."""
+    exe = os.path.join(REFBIN, "perf_xlating_hip")
+    if not os.path.exists(exe):
+        pytest.skip("tests/c/_refbin not built (needs the build container)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert "SIMD optimization: HIP gfx950" in r.stdout
+    times = [float(l.split(":")[1].split()[0]) for l in r.stdout.splitlines() if "seconds" in l]
+    assert len(times) == 4 and all(0.0 < t < 0.01 for t in times), r.stdout
+    print(r.stdout)
+
+
+@pytest.mark.gpu
+def test_create_process_destroy_cycle_is_leak_clean():
+    """The reference runs every test under valgrind (test/resources/run_tests.sh:8).  Stand-in here: 1000 cycles of
+    create / process (both families) / destroy of the drop-in filter and 200 of the batch engine (plan, polyphase images,
+    group call, fetch) leave the device's free memory and the process's resident set flat."""
+    import psutil
+    import torch
+
+    proc = psutil.Process()
+    code, taps = xl.create_low_pass_filter(1.0, 2016000, 24000, 9600)
+    x = ((np.arange(20000) * 7) & 0xFF).astype(np.uint8)
+
+    def cycle_filter():
+        f = xl.XlatingFilter(42, taps, -12000, 2016000, 20000)
+        f.process("native", "cu8", "cf32", x)
+        f.process("optimized", "cu8", "cs16", x)
+        f.close()
+
+    def cycle_engine():
+        e = xl.BatchEngine(2016000, "cu8", 20000, group_blocks=2)
+        e.set_option("polyphase", 1)
+        for c in range(9):
+            e.add_client(42, taps, 1000 * c)
+        e.process_host(x, "optimized")
+        e.process_host_group(np.concatenate([x, x]), 2, "optimized")
+        e.fetch()
+        e.remove_client(3)
+        e.process_host(x, "native")
+        e.close()
+
+    for _ in range(30):  # warm up allocator pools, code objects, the HIP runtime's own caches
+        cycle_filter()
+    for _ in range(10):
+        cycle_engine()
+    torch.cuda.synchronize()
+    free0, rss0 = torch.cuda.mem_get_info()[0], proc.memory_info().rss
+    for _ in range(1000):
+        cycle_filter()
+    for _ in range(200):
+        cycle_engine()
+    torch.cuda.synchronize()
+    free1, rss1 = torch.cuda.mem_get_info()[0], proc.memory_info().rss
+    assert free0 - free1 <= 8 << 20, f"device memory leaked: {free0 - free1} bytes"
+    assert rss1 - rss0 <= 48 << 20, f"host memory leaked: {rss1 - rss0} bytes"
