@@ -116,7 +116,8 @@ hipError_t xl_launch_fir(int ct, int mode, int nw, const XlFirArgs &a, size_t ld
 hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
                                float2 *state_out, float2 *phtab, XlPos pos, uint32_t explicit_K, uint32_t prio,
                                hipStream_t s);
-// the same for a whole call on a side stream: one wave per SIMD (all of its VGPRs), 256 clients per workgroup
+// the same for a whole call on a side stream: one wave per SIMD (all of its VGPRs), 64 clients per workgroup (one
+// chain wave writing into an LDS ring + three waves draining it into the table)
 hipError_t xl_launch_nco_chain(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in, float2 *state_out,
                                float2 *phtab, XlPos pos, hipStream_t s);
 // raw -> converted sample images of the single-filter path (xlating.c:352-433)

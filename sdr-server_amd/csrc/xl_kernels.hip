@@ -54,22 +54,185 @@ __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__r
 }
 
 // The same tabulation for a call of many blocks, run on the engine's side stream WHILE the previous call's launches run
-// on the main stream (xl_batch.cpp).  The recurrence is a dependent chain of ~17.5 cycles per step that any neighbour
-// on its SIMD slows by 35-60 % (the neighbour's packed FMAs occupy the VALU for 4 cycles each: measured 7.3 ns per step
-// alone, 9.8-13.5 ns next to the mix kernel's waves), and it is what bounds a call once the filtering itself takes less
-// than ~23 us per block.  So this kernel claims every VGPR of its SIMDs (v255 / a255 are declared clobbered: the kernel
-// descriptor then asks for 512 registers per lane and the hardware places ONE wave per SIMD): four waves = one CU per
-// 256 clients, nothing else resident there, the chain runs at its lone-wave speed.
+// on the main stream (xl_batch.cpp).  The recurrence is a dependent chain of ~17.5 cycles per step and it is what bounds
+// a call once the filtering itself takes less than ~25 us per block, so everything that could slow the chain wave is
+// kept away from it:
+//  * neighbours on its SIMD cost it 35-60 % (their packed FMAs occupy the VALU 4 cycles at a time: 7.3 ns per step
+//    alone, 9.8-13.5 ns next to the mix kernel's waves) -> the kernel claims every VGPR of its SIMDs (v255 / a255 are
+//    declared clobbered: the kernel descriptor then asks for 512 registers per lane and the hardware places ONE wave per
+//    SIMD); a workgroup of four waves is alone on its CU;
+//  * its own table stores cost it most: on a chip whose memory system is saturated by the mix / inverse launches every
+//    global store blocked the wave's instruction issue ~265 ns (measured: 15.6 ns per step with one 16-byte store per 32
+//    steps, whatever the layout) -> the chain wave (wave 0) only writes the phases into an LDS ring; the other three
+//    waves of the workgroup drain the ring into the table, and it is they who wait for the memory system.
+// One workgroup = 64 clients: wave 0 lane l carries client blockIdx * 64 + l through all its steps in lockstep with
+// the other lanes; drainer j (waves 1-3) stores the entry pairs q = j, j + 3, ... (16 bytes per client).
+#define XLC_RING 64u  // ring entries (x 64 lanes x 8 bytes = 32 KB)
+// LDS mailbox operations of the chain kernel, hand-placed: `volatile` accesses would make the compiler wait for ALL
+// outstanding memory operations (vmcnt(0) + lgkmcnt(0)) around each of them -- an LDS round trip per table entry on the
+// chain wave, a completed global store per poll on the drainers.  LDS operations of one wave execute in order.
+XL_DEV uint32_t xl_lds_off(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p; }
+XL_DEV void xl_lds_post(const uint32_t addr, const uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+XL_DEV void xl_lds_post64(const uint32_t addr, const v2f v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+XL_DEV uint32_t xl_lds_poll(const uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+// One table entry of the chain wave = 16 recurrence steps, hand-scheduled.  A lone wave issues in order, and each step
+// is mul, mul, (wait ~6 cycles), add, (wait ~6 cycles): an independent instruction placed in a wait costs nothing,
+// anywhere else it costs its 4-5 issue cycles (the compiler's version of the entry bookkeeping took the step from 17.5
+// to 25.7 cycles).  So the bookkeeping rides in the shadow of the first steps' multiplies:
+//   step 0: the entry (phase of output 16 e, still in p) into the ring    step 1-2: entry count + 1, posted
+//   step 3-5: ring address of the next entry ((offset + 512) mod 32 KB + base)
+#define XLC_MUL "v_pk_mul_f32 %[t1], %[p], %[inc] op_sel_hi:[1,0]\n\tv_pk_mul_f32 %[t2], %[p], %[inc] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+#define XLC_ADD "v_pk_add_f32 %[p], %[t1], %[t2] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+#define XLC_STEP XLC_MUL XLC_ADD
+#define XLC_ENTRY                                                       \
+  XLC_MUL "ds_write_b64 %[addr], %[p]\n\t" XLC_ADD                      \
+  XLC_MUL "v_add_u32 %[cnt], 1, %[cnt]\n\t" XLC_ADD                     \
+  XLC_MUL "ds_write_b32 %[paddr], %[cnt]\n\t" XLC_ADD                   \
+  XLC_MUL "v_add_u32 %[off], 0x200, %[off]\n\t" XLC_ADD                 \
+  XLC_MUL "v_and_b32 %[off], 0x7fff, %[off]\n\t" XLC_ADD                \
+  XLC_MUL "v_add_u32 %[addr], %[off], %[base]\n\t" XLC_ADD              \
+  XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP
+static_assert(XL_PH_STRIDE == 16u && XLC_RING * 64u * 8u == 0x8000u, "XLC_ENTRY is written for 16 steps per entry and a 32 KB ring");
+
 __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
                                                            const float2 *state_in, float2 *state_out,
                                                            float2 *__restrict__ tab, const XlPos pos) {
   asm volatile("" ::: "v255", "a255");
-  __builtin_amdgcn_s_setprio(3);
-  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
-  if (c >= n) return;
-  const XlNcoClient k = cl[c];
-  const XlBnd bnd = xl_nco_bnd(k, pos, 0xFFFFFFFFu);
-  xl_nco_client_chain(k, bnd, 0u, bnd.K, state_in, state_out, tab);
+  __shared__ v2f ring[XLC_RING][64];
+  __shared__ uint32_t s_emax;
+  __shared__ uint32_t s_prod;     // entries written by the chain wave
+  __shared__ uint32_t s_next[3];  // per drainer: the next entry pair it will store
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t c = blockIdx.x * 64u + lane;
+  const bool have = c < n;
+  XlNcoClient k;
+  k.incr = make_float2(1.0f, 0.0f);
+  k.out_off = 0u, k.slot = 0u, k.D = 1u, k.rem0 = 0u;
+  if (have) k = cl[c];
+  XlBnd bnd = xl_nco_bnd(k, pos, 0xFFFFFFFFu);
+  if (!have) bnd.K = 0u;
+  const uint32_t K = bnd.K, E = (K + XL_PH_STRIDE - 1u) >> XL_PH_SHIFT;  // this client's table entries
+  if (threadIdx.x == 0) {
+    s_emax = 0u;
+    s_prod = 0u;
+    s_next[0] = 0u, s_next[1] = 1u, s_next[2] = 2u;
+  }
+  __syncthreads();
+  if (w == 0 && E > 0u) atomicMax(&s_emax, E);
+  __syncthreads();
+  const uint32_t Emax = s_emax;
+  const uint32_t a_prod = xl_lds_off(&s_prod), a_ring0 = xl_lds_off(&ring[0][0]), a_ring = xl_lds_off(&ring[0][lane]);
+  v2f *__restrict__ o = reinterpret_cast<v2f *>(tab) + (k.out_off >> XL_PH_SHIFT);  // out_off = 0 mod 2 * XL_PH_STRIDE: 16-byte pairs
+  if (w == 0) {
+    __builtin_amdgcn_s_setprio(3);
+    v2f p = {1.0f, 0.0f};
+    if (have) p = (v2f){state_in[k.slot].x, state_in[k.slot].y};
+    const v2f inc = {k.incr.x, k.incr.y};
+    uint32_t nb = xl_bnd_next(bnd, 0u);  // the phase is renormalised after output nb - 1 (xlating.c:73)
+    const uint32_t a_n0 = xl_lds_off(&s_next[0]), a_n1 = xl_lds_off(&s_next[1]), a_n2 = xl_lds_off(&s_next[2]);
+    uint32_t e = 0;  // (wave-uniform: the lanes step in lockstep)
+    while (e < Emax) {
+      // the next output index at which ANY lane has something other than a plain step to do: its block ends (renormalise)
+      // or its call ends.  Up to there the loop below is branch-free per lane: an entry into the ring, 16 steps.
+      uint32_t ev = (e << XL_PH_SHIFT) < K ? (nb < K ? nb : K) : 0xFFFFFFFFu;
+#pragma unroll
+      for (int sh = 1; sh < 64; sh <<= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)ev, sh);
+        ev = other < ev ? other : ev;
+      }
+      const uint32_t evs = __builtin_amdgcn_readfirstlane(ev);
+      // entries e .. e_stop - 1: their steps hold no block end for anybody ((e + 1) * 16 < evs)
+      uint32_t e_stop = evs == 0u ? 0u : (evs - 1u) >> XL_PH_SHIFT;
+      e_stop = e_stop < Emax ? e_stop : Emax;
+      if ((e << XL_PH_SHIFT) < K) {  // (a lane whose call has ended sits the region out; the others' mask is constant in it)
+        uint32_t ee = e;
+        while (ee < e_stop) {
+          if ((ee & (XLC_RING / 2u - 1u)) == 0u && ee >= XLC_RING) {
+            // the next XLC_RING / 2 entries go to the slots of entries e - RING .. e - RING / 2 - 1: all pairs below
+            // (e - RING / 2) / 2 must have left the ring (checked once per half ring: an LDS round trip is ~50 ns).
+            // Bounded: a drainer that never shows up must not hang the device (cannot happen while the four waves of
+            // the workgroup are resident, which a launch guarantees) -- ~0.1 s, then the table is wrong, the launch ends.
+            const uint32_t q = (ee - XLC_RING / 2u) >> 1;
+            for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+              if (xl_lds_poll(a_n0) >= q && xl_lds_poll(a_n1) >= q && xl_lds_poll(a_n2) >= q) break;
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          // entries ee .. chunk_end - 1 (up to the next drain check), two per trip
+          const uint32_t next_check = (ee | (XLC_RING / 2u - 1u)) + 1u;
+          const uint32_t chunk_end = e_stop < next_check ? e_stop : next_check;
+          uint32_t off = ((ee & (XLC_RING - 1u)) << 9) + lane * (uint32_t)sizeof(v2f);  // ring offset of entry ee, this lane
+          uint32_t addr = a_ring0 + off, cnt = ee;
+          v2f t1, t2;
+          for (; ee + 2u <= chunk_end; ee += 2u)
+            asm volatile(XLC_ENTRY XLC_ENTRY
+                         : [p] "+v"(p), [off] "+v"(off), [addr] "+v"(addr), [cnt] "+v"(cnt), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                         : [inc] "v"(inc), [base] "v"(a_ring0), [paddr] "v"(a_prod)
+                         : "memory");
+          if (ee < chunk_end) {
+            asm volatile(XLC_ENTRY
+                         : [p] "+v"(p), [off] "+v"(off), [addr] "+v"(addr), [cnt] "+v"(cnt), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                         : [inc] "v"(inc), [base] "v"(a_ring0), [paddr] "v"(a_prod)
+                         : "memory");
+            ++ee;
+          }
+        }
+      }
+      if (e_stop > e) e = e_stop;
+      // ---- the entry that holds the event (or the tail of the call): per-step checks, every lane for itself
+      if (e < Emax) {
+        if ((e & (XLC_RING / 2u - 1u)) == 0u && e >= XLC_RING) {
+          const uint32_t q = (e - XLC_RING / 2u) >> 1;
+          for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+            if (xl_lds_poll(a_n0) >= q && xl_lds_poll(a_n1) >= q && xl_lds_poll(a_n2) >= q) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        const uint32_t m0 = e << XL_PH_SHIFT;
+        if (m0 < K) xl_lds_post64(a_ring + (e & (XLC_RING - 1u)) * 64u * (uint32_t)sizeof(v2f), p);
+        xl_lds_post(a_prod, e + 1u);
+        for (uint32_t m = m0; m < m0 + XL_PH_STRIDE && m < K; ++m) {
+          p = xl_nco_next(p, inc);
+          if (m + 1u == nb) {
+            p = xl_nco_renorm(p);
+            nb = xl_bnd_next(bnd, m + 1u);
+          }
+        }
+        ++e;
+      }
+    }
+    if (have) state_out[k.slot] = make_float2(p.x, p.y);  // (K == 0: untouched, xlating.c:58)
+    return;
+  }
+  // ---- drainers: ring -> table, two entries (16 bytes) per client and store
+  const uint32_t j = w - 1u;
+  const uint32_t a_next = xl_lds_off(&s_next[j]);
+  v4f *__restrict__ o4 = reinterpret_cast<v4f *>(o);
+  for (uint32_t q = j; 2u * q < Emax; q += 3u) {
+    const uint32_t need = 2u * q + 2u < Emax ? 2u * q + 2u : Emax;
+    for (uint32_t spin = 0; spin < (1u << 24); ++spin) {
+      if (xl_lds_poll(a_prod) >= need) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (2u * q < E) {
+      v2f a, b2 = {0.0f, 0.0f};
+      const uint32_t ra = a_ring + ((2u * q) & (XLC_RING - 1u)) * 64u * (uint32_t)sizeof(v2f);
+      const uint32_t rb = a_ring + ((2u * q + 1u) & (XLC_RING - 1u)) * 64u * (uint32_t)sizeof(v2f);
+      const bool two = 2u * q + 1u < E;
+      asm volatile("ds_read_b64 %0, %1" : "=v"(a) : "v"(ra) : "memory");
+      if (two) asm volatile("ds_read_b64 %0, %1" : "=v"(b2) : "v"(rb) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring slots have been read: they may be overwritten
+      if (two) o4[q] = (v4f){a.x, a.y, b2.x, b2.y};
+      else o[2u * q] = a;
+    }
+    xl_lds_post(a_next, q + 3u);
+  }
+  xl_lds_post(a_next, 0xFFFFFFFFu);
 }
 
 // Window staging: raw samples -> cf32 image in LDS.  Four independent loads per thread are issued before any is
@@ -405,7 +568,7 @@ hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, co
 hipError_t xl_launch_nco_chain(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in, float2 *state_out,
                                float2 *phtab, XlPos pos, hipStream_t s) {
   if (nclients == 0) return hipSuccess;
-  hipLaunchKernelGGL(xl_nco_chain_kernel, dim3((nclients + 255u) / 256u), dim3(256), 0, s, clients, nclients, state_in,
+  hipLaunchKernelGGL(xl_nco_chain_kernel, dim3((nclients + 63u) / 64u), dim3(256), 0, s, clients, nclients, state_in,
                      state_out, phtab, pos);
   return hipGetLastError();
 }
