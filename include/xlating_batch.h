@@ -88,6 +88,15 @@ int xlating_batch_process_host_group(xlating_batch *batch, const void *input, si
                                      int mode);
 int xlating_batch_process_device_group(xlating_batch *batch, const void *d_input, size_t input_len, unsigned nblocks,
                                        int mode, void *hip_stream);
+/* hip_stream may be XL_STREAM_ENGINE: the work then runs on a compute stream the engine owns (xlating_batch_sync waits for
+ * it).  For calls of several blocks on the polyphase path that stream is CU-masked: it leaves a few CUs (one per 64
+ * clients) to the kernel that tabulates the next call's NCO phases on the engine's side stream, which needs whole CUs
+ * and otherwise has to wait for a kernel boundary of the caller's stream to find them.
+ * _ev: `wait_event` (a hipEvent_t or NULL) is waited for on that stream before the call's work, `record_event` is recorded
+ * behind it -- how a host orders its own streams (e.g. an RCCL broadcast into d_input) against the engine's. */
+#define XL_STREAM_ENGINE ((void *)(intptr_t)-1)
+int xlating_batch_process_device_group_ev(xlating_batch *batch, const void *d_input, size_t input_len, unsigned nblocks,
+                                          int mode, void *hip_stream, void *wait_event, void *record_event);
 
 /* Number of complex output samples client produced in the last processed call (host-side integer state), and in
  * block `block` of that call (the client's output row holds the blocks' outputs back to back). */

@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = (
     + [f"process_{v}_{i}_{o}" for v in ("native", "optimized") for i in ("cu8", "cs8", "cs16") for o in ("cf32", "cs16")]
     + ["process_native_cf32_cf32", "process_optimized_cf32_cf32"]
     + ["xlating_batch_create", "xlating_batch_create_grouped", "xlating_batch_set_option", "xlating_batch_process_host_group",
-       "xlating_batch_process_device_group", "xlating_batch_output_len_block", "xlating_batch_add_client", "xlating_batch_remove_client", "xlating_batch_num_clients",
+       "xlating_batch_process_device_group", "xlating_batch_process_device_group_ev", "xlating_batch_output_len_block", "xlating_batch_add_client", "xlating_batch_remove_client", "xlating_batch_num_clients",
        "xlating_batch_process_host", "xlating_batch_process_device", "xlating_batch_output_len", "xlating_batch_fetch",
        "xlating_batch_output_host", "xlating_batch_output_device", "xlating_batch_client_phase", "xlating_batch_sync",
        "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_timing_polyphase", "xlating_batch_timing_stride", "xlating_batch_describe", "xlating_batch_destroy",
@@ -326,8 +326,10 @@ class BatchEngine:
             raise XlatingError("xlating_batch_process_host_group", code)
 
     def process_device_group(self, d_ptr, input_len, nblocks, variant="native", stream=0):
-        code = lib().xlating_batch_process_device_group(self.h, C.c_void_p(d_ptr), input_len, nblocks, MODE[variant],
-                                                        C.c_void_p(stream) if stream else None)
+        """stream: a hipStream_t value, 0 (HIP's default stream) or "engine" (XL_STREAM_ENGINE: the engine's own compute
+        stream, CU-masked for calls whose NCO chain runs on the side stream; wait with sync())."""
+        sp = C.c_void_p(-1) if stream == "engine" else (C.c_void_p(stream) if stream else None)
+        code = lib().xlating_batch_process_device_group(self.h, C.c_void_p(d_ptr), input_len, nblocks, MODE[variant], sp)
         if code != 0:
             raise XlatingError("xlating_batch_process_device_group", code)
 

@@ -115,6 +115,15 @@ struct xlating_batch_t {
   // caller's stream waits for it before the first launch that reads the table); ev_done[t]: the launches that read
   // table t have been passed by the caller's stream (nco_stream waits for it before overwriting that table).
   hipStream_t nco_stream = nullptr;
+  // CU reservation: the chain kernel needs whole CUs (one wave per SIMD) and finds them only if nothing else is resident
+  // there -- behind a launch that fills the chip its workgroups waited for the next kernel boundary (measured: chain
+  // kernel 215 us alone, 262-293 us launched next to the forward / mix launches).  So nco_stream is created with a CU
+  // mask of `reserve_r` CUs per XCD (mask bit b = XCD b % 8, CU b / 8 of it; tools/ubench_cumask.hip) and the engine's
+  // own compute stream for side-stream calls, cs_masked, with the complement.  Callers that pass XL_STREAM_ENGINE get it.
+  hipStream_t cs_masked = nullptr;
+  hipStream_t last_nco = nullptr;    // the side stream of the latest chain launch
+  hipStream_t nco_masked = nullptr;  // the side stream that goes with cs_masked; nco_stream (unmasked) serves callers' own streams
+  uint32_t reserve_r = 0;
   hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};  // per phase table
   bool ev_done_valid[2] = {false, false};
   bool spec_on_side = false;  // the look-ahead table was produced on nco_stream (ev_chain must be waited for)
@@ -209,6 +218,8 @@ static void xl_batch_sync_all(xlating_batch *b) {
   (void)hipStreamSynchronize(b->last_stream);  // may be the NULL (legacy default) stream: still a real stream
   if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
   if (b->nco_stream) (void)hipStreamSynchronize(b->nco_stream);
+  if (b->cs_masked) (void)hipStreamSynchronize(b->cs_masked);
+  if (b->nco_masked) (void)hipStreamSynchronize(b->nco_masked);
 }
 
 static void xl_batch_free_plan(xlating_batch *b) {
@@ -256,6 +267,8 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   for (hipEvent_t e : b->ev_done)
     if (e) (void)hipEventDestroy(e);
   if (b->nco_stream) (void)hipStreamDestroy(b->nco_stream);
+  if (b->cs_masked) (void)hipStreamDestroy(b->cs_masked);
+  if (b->nco_masked) (void)hipStreamDestroy(b->nco_masked);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
 }
@@ -730,6 +743,42 @@ static int xl_batch_plan(xlating_batch *b) {
     if (rc != 0) return rc;
   }
 
+  // ---- CU reservation for the side-stream chain kernel (64 clients per workgroup = per CU, dealt round-robin to the
+  // 8 XCDs): recreate the two masked streams when the number of reserved CUs changes
+  {
+    const uint32_t nwg = ((uint32_t)b->nco.size() + 63u) / 64u;
+    uint32_t want = (b->gcap >= 2 && !b->poly.empty() && b->nco_side != 0) ? (nwg + 7u) / 8u : 0u;
+    if (want > 16u) want = 0u;  // (more than half the chip for the chain: such engines are bound by the filtering anyway)
+    if (getenv("XL_EXP_NOMASK")) want = 0u;
+    if (want != b->reserve_r) {
+      if (b->cs_masked) (void)hipStreamDestroy(b->cs_masked);
+      if (b->nco_masked) (void)hipStreamDestroy(b->nco_masked);
+      b->cs_masked = b->nco_masked = nullptr;
+      b->last_nco = nullptr;
+      b->reserve_r = 0;
+      b->last_stream = b->own_stream;  // (everything was synchronised at the top of the plan)
+      for (int i = 0; i < 2; ++i) b->ev_done_valid[i] = false;
+      if (want > 0u) {
+        uint32_t chain_mask[8], main_mask[8];
+        for (uint32_t wd = 0; wd < 8; ++wd) {
+          chain_mask[wd] = 0u;
+          for (uint32_t bit = 0; bit < 32; ++bit)
+            if (wd * 32u + bit < 8u * want) chain_mask[wd] |= 1u << bit;
+          main_mask[wd] = ~chain_mask[wd];
+        }
+        if (hipExtStreamCreateWithCUMask(&b->nco_masked, 8, chain_mask) == hipSuccess &&
+            hipExtStreamCreateWithCUMask(&b->cs_masked, 8, main_mask) == hipSuccess) {
+          b->reserve_r = want;
+        } else {
+          XL_LOG_ERR("CU-masked streams are not available (%s): the NCO chain kernel shares the chip", hipGetErrorString(hipGetLastError()));
+          if (b->cs_masked) (void)hipStreamDestroy(b->cs_masked);
+          if (b->nco_masked) (void)hipStreamDestroy(b->nco_masked);
+          b->cs_masked = b->nco_masked = nullptr;
+        }
+      }
+    }
+  }
+
   // upload
   if (b->nco.empty()) {
     b->dirty = false;
@@ -877,8 +926,15 @@ static hipError_t xl_dump_trace(const char *path, const unsigned long long *d, s
 #endif
 
 // One call: G blocks of S samples each, contiguous at d_blocks.
-static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len, unsigned G, int mode, hipStream_t s) {
+#define XL_STREAM_ENGINE_P (reinterpret_cast<hipStream_t>((intptr_t)-1))
+
+// One call: G blocks of S samples each, contiguous at d_blocks.  s_in: the caller's stream, or XL_STREAM_ENGINE_P = the
+// engine's own compute stream (the CU-masked one for calls whose NCO chain runs on the side stream).  wait_ev / record_ev:
+// optional events of the caller, waited for before / recorded after the call's work on that stream.
+static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len, unsigned G, int mode, hipStream_t s_in,
+                        hipEvent_t wait_ev = nullptr, hipEvent_t record_ev = nullptr) {
   const size_t S = input_len / 2;
+  hipStream_t s = s_in;
   if (S > b->max_samples || G < 1 || G > b->gcap || (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED)) return -EINVAL;
   if (b->poisoned) return -EIO;
   // a client that was still inside its zero-history when the plan was built may be mature by now: it then joins
@@ -898,6 +954,18 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     XL_LOG_ERR("a call of %u blocks needs blocks of at least the largest decimation (%u samples); got %zu", G, b->plan_maxD, S);
     return -EINVAL;
   }
+  XlPos pos;
+  pos.trel = b->trel;
+  pos.S = (uint32_t)S;
+  pos.G = G;
+  pos.pad = 0;
+  // optimized mode: the polyphase classes leave the direct launches (tiny calls stay direct: a segment is 128 or 256
+  // branch samples whatever the call holds)
+  uint32_t maxK = 0;  // the most outputs any client produces in this call
+  for (const DirectClass &cs : b->classes) maxK = std::max(maxK, xl_grid_dyn(cs.D, cs.T, cs.rem0, cs.hv0, pos).K);
+  const bool use_poly = mode == XL_MODE_OPTIMIZED && !b->poly.empty() && maxK >= 2 * XLP_M_MAX;
+  const bool side_call = b->nco_side > 0 || (b->nco_side < 0 && G >= 2 && use_poly);
+  if (s == XL_STREAM_ENGINE_P) s = (side_call && b->cs_masked) ? b->cs_masked : b->own_stream;
   // Calls depend on each other through the engine's device state (history, phases, tables): a call on another
   // stream than the previous one is ordered behind it.
   if (s != b->last_stream) {
@@ -906,20 +974,23 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
   }
   b->last_stream = s;
   b->fetched = false;
-  if (b->nco.empty()) return 0;
+  if (wait_ev) XL_TRY(hipStreamWaitEvent(s, wait_ev, 0));
+  if (b->nco.empty()) {
+    if (record_ev) XL_TRY(hipEventRecord(record_ev, s));
+    return 0;
+  }
 
   {
     const int p = (int)(b->ncalls & 1);  // parity of this call: output buffer
     const int hb = b->hcur, hn = b->hcur ^ 1;
     const uint32_t N = (uint32_t)(S * G);
-    XlPos pos;
-    pos.trel = b->trel;
-    pos.S = (uint32_t)S;
-    pos.G = G;
-    pos.pad = 0;
-    // Who tabulates the NEXT call's phases: the NCO role inside this call's launches (fuse), or -- calls of several
-    // blocks -- xl_nco_chain_kernel on the side stream, concurrently with them (side).
-    const bool side = b->nco_side > 0 || (b->nco_side < 0 && G >= 2);
+    // Who tabulates the NEXT call's phases: the NCO role inside this call's launches (fuse), or xl_nco_chain_kernel on
+    // the side stream, concurrently with them (side).  The side stream pays for calls of several blocks on the
+    // polyphase path, whose three launches are short against the chain (measured, 8 blocks per call: 42.7 -> 36.8 us per
+    // block at 1024 clients, 30.7 -> 28.8 at 128); a direct FIR launch hides the chain in its spare waves for free and
+    // would only lose the chain kernel's CUs (1024 clients, native: 203 -> 212 us per block), and with one block per
+    // call the cross-stream events cost more than the overlap gains (51.3 -> 58.6).
+    const bool side = side_call;
 #ifdef XL_TUNING
     const bool fuse = !side && !b->exp_nofuse;  // tuning: tabulate by a launch of its own before every call
 #else
@@ -927,9 +998,6 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
 #endif
     bool nco_fused = false;
     bool chain_wait = false;  // this call's table comes from the side stream: wait for it before the first reader
-    // the most outputs any client produces in this call
-    uint32_t maxK = 0;
-    for (const DirectClass &cs : b->classes) maxK = std::max(maxK, xl_grid_dyn(cs.D, cs.T, cs.rem0, cs.hv0, pos).K);
 
     // ---- this call's phase table: tabulated ahead by the previous call's launches if the shape guess was right
     int tab;
@@ -952,14 +1020,24 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     // below.  That table was last read by the previous call's launches (ev_done), the committed phases d_phase[pcur]
     // were written by the tabulation of THIS call's table (earlier on the same side stream, or on `s`: ordered below).
     if (side) {
+      // (the CU-masked pair of streams goes together: a chain kernel confined to CUs that the caller's own, unmasked
+      // stream keeps filling would wait for kernel boundaries)
+      hipStream_t ns = (s == b->cs_masked && b->nco_masked) ? b->nco_masked : b->nco_stream;
+      if (ns != b->last_nco) {  // consecutive chains depend on each other through the phase buffers
+        if (b->last_nco) {
+          XL_TRY(hipEventRecord(b->dep_ev, b->last_nco));
+          XL_TRY(hipStreamWaitEvent(ns, b->dep_ev, 0));
+        }
+        b->last_nco = ns;
+      }
       if (!chain_wait) {  // this call's table was tabulated on `s` just now: order the side stream behind it
         XL_TRY(hipEventRecord(b->dep_ev, s));
-        XL_TRY(hipStreamWaitEvent(b->nco_stream, b->dep_ev, 0));
+        XL_TRY(hipStreamWaitEvent(ns, b->dep_ev, 0));
       }
-      if (b->ev_done_valid[tab ^ 1]) XL_TRY(hipStreamWaitEvent(b->nco_stream, b->ev_done[tab ^ 1], 0));
+      if (b->ev_done_valid[tab ^ 1]) XL_TRY(hipStreamWaitEvent(ns, b->ev_done[tab ^ 1], 0));
       XL_TRY(xl_launch_nco_chain(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[pcur], b->d_phase[pcur ^ 1],
-                                 b->d_phtab[tab ^ 1], xl_grid_next(pos), b->nco_stream));
-      XL_TRY(hipEventRecord(b->ev_chain[tab ^ 1], b->nco_stream));
+                                 b->d_phtab[tab ^ 1], xl_grid_next(pos), ns));
+      XL_TRY(hipEventRecord(b->ev_chain[tab ^ 1], ns));
     }
 
     // ---- the launches on the caller's stream: window images from [d_hist[hb] | blocks], phases from table[tab] ->
@@ -976,9 +1054,6 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
       f1 = b->ev[b->ev.size() - 1];
     }
     bool rolled = false;
-    // optimized mode: the polyphase classes leave the direct launches (tiny calls stay direct: a segment is 128 or 256
-    // branch samples whatever the call holds)
-    const bool use_poly = mode == XL_MODE_OPTIMIZED && !b->poly.empty() && maxK >= 2 * XLP_M_MAX;
     Launch *const Ls = use_poly ? b->launches_rest : b->launches;
     if (maxK > 0) {
       if (f0) XL_TRY(hipEventRecord(f0, s));
@@ -1198,6 +1273,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
       b->ev_done_valid[tab] = false;
     }
 
+    if (record_ev) XL_TRY(hipEventRecord(record_ev, s));
     // ---- everything is enqueued: commit the host-side state of the call
     b->poisoned = false;
     for (Client &c : b->clients) {
@@ -1268,13 +1344,20 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
   return (int)len;
 }
 
-extern "C" int xlating_batch_process_device_group(xlating_batch *b, const void *d_input, size_t input_len,
-                                                  unsigned nblocks, int mode, void *hip_stream) {
+extern "C" int xlating_batch_process_device_group_ev(xlating_batch *b, const void *d_input, size_t input_len,
+                                                     unsigned nblocks, int mode, void *hip_stream, void *wait_event,
+                                                     void *record_event) {
   if (b == nullptr || (d_input == nullptr && input_len > 0)) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
   // NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is by default): pass it through
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-  return xl_batch_run(b, d_input, input_len, nblocks, mode, s);
+  return xl_batch_run(b, d_input, input_len, nblocks, mode, s, reinterpret_cast<hipEvent_t>(wait_event),
+                      reinterpret_cast<hipEvent_t>(record_event));
+}
+
+extern "C" int xlating_batch_process_device_group(xlating_batch *b, const void *d_input, size_t input_len,
+                                                  unsigned nblocks, int mode, void *hip_stream) {
+  return xlating_batch_process_device_group_ev(b, d_input, input_len, nblocks, mode, hip_stream, nullptr, nullptr);
 }
 
 extern "C" int xlating_batch_process_device(xlating_batch *b, const void *d_input, size_t input_len, int mode,

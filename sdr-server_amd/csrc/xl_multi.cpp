@@ -2,9 +2,9 @@
 // super-block per feed on a communication stream, c mod G sharding.  Reference fan-out replaced:
 // src/tcp_server.c:257-271, src/queue.c:87-119.
 //
-// Per GPU: an engine, a communicator, a communication stream, a compute stream, two receive buffers and per buffer an
-// event pair: `ready` (recorded on the communication stream behind the broadcast; the compute stream waits for it before
-// the engine's launches) and `free` (recorded on the compute stream behind the launches that read the buffer; the
+// Per GPU: an engine (which owns the compute stream: XL_STREAM_ENGINE), a communicator, a communication stream, two
+// receive buffers and per buffer an event pair: `ready` (recorded on the communication stream behind the broadcast; the
+// compute stream waits for it before the engine's launches) and `free` (recorded behind the launches that read the buffer; the
 // communication stream waits for it before the broadcast two feeds later overwrites the buffer).  Consecutive feeds
 // alternate the buffers, so the broadcast of super-block k+1 runs while super-block k is filtered.
 #include <errno.h>
@@ -24,7 +24,7 @@ struct Gpu {
   int device = 0;  // HIP ordinal
   xlating_batch *engine = nullptr;
   ncclComm_t comm = nullptr;
-  hipStream_t comm_stream = nullptr, compute = nullptr;
+  hipStream_t comm_stream = nullptr;
   void *recv[2] = {nullptr, nullptr};
   hipEvent_t ready[2] = {nullptr, nullptr}, free_[2] = {nullptr, nullptr};
   bool free_valid[2] = {false, false};
@@ -62,7 +62,6 @@ static int xl_multi_open_gpu(xlating_multi *m, Gpu &g, uint32_t fs, int fmt, uin
   if (rc != 0) return rc;
   XL_TRY(hipSetDevice(g.device));
   XL_TRY(hipStreamCreateWithFlags(&g.comm_stream, hipStreamNonBlocking));
-  XL_TRY(hipStreamCreateWithFlags(&g.compute, hipStreamNonBlocking));
   for (int i = 0; i < 2; ++i) {
     if (m->world > 1) XL_TRY(hipMalloc(&g.recv[i], m->recv_bytes));
     XL_TRY(hipEventCreateWithFlags(&g.ready[i], hipEventDisableTiming));
@@ -185,7 +184,7 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
   const int i = (int)(m->feeds & 1);
   if (m->world == 1) {
     Gpu &g = m->gpus[0];
-    int rc = xlating_batch_process_device_group(g.engine, d_src, input_len, nblocks, mode, g.compute);
+    int rc = xlating_batch_process_device_group(g.engine, d_src, input_len, nblocks, mode, XL_STREAM_ENGINE);
     if (rc != 0) return rc;
     m->feeds++;
     return 0;
@@ -205,10 +204,10 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
   for (Gpu &g : m->gpus) {
     XL_TRY(hipSetDevice(g.device));
     XL_TRY(hipEventRecord(g.ready[i], g.comm_stream));
-    XL_TRY(hipStreamWaitEvent(g.compute, g.ready[i], 0));
-    int rc = xlating_batch_process_device_group(g.engine, g.recv[i], input_len, nblocks, mode, g.compute);
+    // on the engine's own compute stream (CU-masked for these calls): wait for the broadcast, filter, mark the buffer free
+    int rc = xlating_batch_process_device_group_ev(g.engine, g.recv[i], input_len, nblocks, mode, XL_STREAM_ENGINE, g.ready[i],
+                                                   g.free_[i]);
     if (rc != 0) return rc;
-    XL_TRY(hipEventRecord(g.free_[i], g.compute));
     g.free_valid[i] = true;
   }
   m->feeds++;
@@ -222,7 +221,7 @@ extern "C" int xlating_multi_sync(xlating_multi *m) {
   for (Gpu &g : m->gpus) {
     if (hipSetDevice(g.device) != hipSuccess) return -EIO;
     if (g.comm_stream && hipStreamSynchronize(g.comm_stream) != hipSuccess) return -EIO;
-    if (g.compute && hipStreamSynchronize(g.compute) != hipSuccess) return -EIO;
+    if (g.engine && xlating_batch_sync(g.engine) != 0) return -EIO;
   }
   return 0;
 }
@@ -240,7 +239,6 @@ extern "C" void xlating_multi_destroy(xlating_multi *m) {
       if (g.free_[i]) (void)hipEventDestroy(g.free_[i]);
     }
     if (g.comm_stream) (void)hipStreamDestroy(g.comm_stream);
-    if (g.compute) (void)hipStreamDestroy(g.compute);
   }
   delete m;
 }

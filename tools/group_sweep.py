@@ -28,11 +28,13 @@ def main():
     ap.add_argument("--blocks", type=int, default=320, help="blocks in the timed region")
     ap.add_argument("--poly3", action="store_true", help="also time the three polyphase launches separately")
     ap.add_argument("--slices", default="")
+    ap.add_argument("--engine-stream", type=int, default=1, help="1: XL_STREAM_ENGINE (the engine's own, CU-masked compute stream); 0: torch's stream")
     args = ap.parse_args()
     code, taps = xl.create_low_pass_filter(1.0, FS, 24000, 48000 // args.rate)
     gmax = max(int(g) for g in args.groups.split(","))
     data = torch.from_numpy(siggen.xs_u8(99, gmax * BLOCK)).cuda()
     st = torch.cuda.current_stream()
+    sarg = "engine" if args.engine_stream else st.cuda_stream
     print(f"{'mode':10s} {'M':>4s} {'clients':>7s} {'G':>2s} {'us/block':>9s} {'kern us/blk':>11s} {'Msps':>10s}   plan / launches us per block")
     for mode in args.modes.split(","):
         for m in [int(v) for v in args.m.split(",")]:
@@ -48,13 +50,13 @@ def main():
                         eng.add_client(D, taps, -984000 + 1920 * (c % 1024) + 240 * (c // 1024))
                     calls = max(4, args.blocks // G)
                     for k in range(4):
-                        eng.process_device_group(data.data_ptr(), BLOCK, G, mode, st.cuda_stream)
+                        eng.process_device_group(data.data_ptr(), BLOCK, G, mode, sarg)
                     torch.cuda.synchronize()
                     eng.timing_stride(2)
                     eng.timing(1)
                     t0 = time.perf_counter()
                     for k in range(calls):
-                        eng.process_device_group(data.data_ptr(), BLOCK, G, mode, st.cuda_stream)
+                        eng.process_device_group(data.data_ptr(), BLOCK, G, mode, sarg)
                     torch.cuda.synchronize()
                     dt = (time.perf_counter() - t0) / (calls * G)
                     nt, fir, nco = eng.timing_read()
@@ -64,7 +66,7 @@ def main():
                         eng.timing_stride(1)
                         eng.timing(2)
                         for k in range(8):
-                            eng.process_device_group(data.data_ptr(), BLOCK, G, mode, st.cuda_stream)
+                            eng.process_device_group(data.data_ptr(), BLOCK, G, mode, sarg)
                         torch.cuda.synchronize()
                         n3, ms3 = eng.timing_polyphase()
                         eng.timing(0)
