@@ -122,6 +122,7 @@ struct xlating_batch_t {
   // own compute stream for side-stream calls, cs_masked, with the complement.  Callers that pass XL_STREAM_ENGINE get it.
   hipStream_t cs_masked = nullptr;
   hipStream_t last_nco = nullptr;    // the side stream of the latest chain launch
+  unsigned long long *d_chain_stats = nullptr;  // tuning (XL_EXP_CHAIN_STATS): per chain workgroup cycles / ticks of the latest launch
   hipStream_t nco_masked = nullptr;  // the side stream that goes with cs_masked; nco_stream (unmasked) serves callers' own streams
   uint32_t reserve_r = 0;
   hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};  // per phase table
@@ -251,6 +252,7 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
                  b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_W,        b->d_phase_run};
   for (void *p : dev)
     if (p) (void)hipFree(p);
+  if (b->d_chain_stats) (void)hipFree(b->d_chain_stats);
 #ifdef XL_TUNING
   if (b->d_trace) (void)hipFree(b->d_trace);
   if (b->d_ptrace) (void)hipFree(b->d_ptrace);
@@ -352,6 +354,7 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
   if (getenv("XL_EXP_POLY")) (void)xlating_batch_set_option(b, "polyphase", atol(getenv("XL_EXP_POLY")));
   if (getenv("XL_EXP_POLY_M")) (void)xlating_batch_set_option(b, "polyphase_m", atol(getenv("XL_EXP_POLY_M")));
   if (getenv("XL_EXP_POLY_MIN")) (void)xlating_batch_set_option(b, "polyphase_min_clients", atol(getenv("XL_EXP_POLY_MIN")));
+  if (getenv("XL_EXP_CHAIN_STATS")) (void)hipMalloc((void **)&b->d_chain_stats, 4096 * 4 * sizeof(unsigned long long));
   if (getenv("XL_EXP_NCO_SIDE")) (void)xlating_batch_set_option(b, "nco_side_stream", atol(getenv("XL_EXP_NCO_SIDE")));
   if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
   if (getenv("XL_EXP_MIXSKIP")) b->mix_skip_at = (uint32_t)atoi(getenv("XL_EXP_MIXSKIP"));
@@ -1036,7 +1039,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
       }
       if (b->ev_done_valid[tab ^ 1]) XL_TRY(hipStreamWaitEvent(ns, b->ev_done[tab ^ 1], 0));
       XL_TRY(xl_launch_nco_chain(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[pcur], b->d_phase[pcur ^ 1],
-                                 b->d_phtab[tab ^ 1], xl_grid_next(pos), ns));
+                                 b->d_phtab[tab ^ 1], xl_grid_next(pos), b->d_chain_stats, ns));
       XL_TRY(hipEventRecord(b->ev_chain[tab ^ 1], ns));
     }
 
@@ -1490,6 +1493,13 @@ static int xl_batch_drain_events(xlating_batch *b) {
   b->ev.clear();
   b->ev_ncot.clear();
   return 0;
+}
+
+// tuning: cycles / wall ticks of the chain wave of the first `n` chain workgroups of the latest side-stream launch
+extern "C" int xlating_batch_debug_chain_stats(xlating_batch *b, unsigned long long *out, int n) {
+  if (b == nullptr || out == nullptr || b->d_chain_stats == nullptr || n < 1 || n > 4096) return -EINVAL;
+  xl_batch_sync_all(b);
+  return hipMemcpy(out, b->d_chain_stats, (size_t)n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -EIO;
 }
 
 extern "C" int xlating_batch_timing(xlating_batch *b, int enable) {

@@ -101,7 +101,8 @@ static_assert(XL_PH_STRIDE == 16u && XLC_RING * 64u * 8u == 0x8000u, "XLC_ENTRY 
 
 __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
                                                            const float2 *state_in, float2 *state_out,
-                                                           float2 *__restrict__ tab, const XlPos pos) {
+                                                           float2 *__restrict__ tab, const XlPos pos,
+                                                           unsigned long long *stats) {
   asm volatile("" ::: "v255", "a255");
   __shared__ v2f ring[XLC_RING][64];
   __shared__ uint32_t s_emax;
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
     const v2f inc = {k.incr.x, k.incr.y};
     uint32_t nb = xl_bnd_next(bnd, 0u);  // the phase is renormalised after output nb - 1 (xlating.c:73)
     const uint32_t a_n0 = xl_lds_off(&s_next[0]), a_n1 = xl_lds_off(&s_next[1]), a_n2 = xl_lds_off(&s_next[2]);
+    const unsigned long long c0 = stats ? clock64() : 0ull, w0 = stats ? wall_clock64() : 0ull;  // (tuning: shader cycles / 100 MHz ticks)
     uint32_t e = 0;  // (wave-uniform: the lanes step in lockstep)
     while (e < Emax) {
       // the next output index at which ANY lane has something other than a plain step to do: its block ends (renormalise)
@@ -207,6 +209,12 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
       }
     }
     if (have) state_out[k.slot] = make_float2(p.x, p.y);  // (K == 0: untouched, xlating.c:58)
+    if (stats && lane == 0u) {
+      stats[4u * blockIdx.x] = clock64() - c0;
+      stats[4u * blockIdx.x + 1u] = wall_clock64() - w0;
+      stats[4u * blockIdx.x + 2u] = Emax;
+      stats[4u * blockIdx.x + 3u] = w0;
+    }
     return;
   }
   // ---- drainers: ring -> table, two entries (16 bytes) per client and store
@@ -566,10 +574,10 @@ hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, co
 }
 
 hipError_t xl_launch_nco_chain(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in, float2 *state_out,
-                               float2 *phtab, XlPos pos, hipStream_t s) {
+                               float2 *phtab, XlPos pos, unsigned long long *stats, hipStream_t s) {
   if (nclients == 0) return hipSuccess;
   hipLaunchKernelGGL(xl_nco_chain_kernel, dim3((nclients + 63u) / 64u), dim3(256), 0, s, clients, nclients, state_in,
-                     state_out, phtab, pos);
+                     state_out, phtab, pos, stats);
   return hipGetLastError();
 }
 

@@ -73,6 +73,17 @@ def main():
                         if n3:
                             extra = "fwd %.1f mix %.1f inv %.1f" % tuple(v / n3 / G * 1e3 for v in ms3)
                     plan = eng.describe()
+                    if os.environ.get("XL_EXP_CHAIN_STATS"):
+                        import ctypes as C
+                        nwg = (n + 63) // 64
+                        buf = (C.c_ulonglong * (4 * nwg))()
+                        xl.lib().xlating_batch_debug_chain_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+                        if xl.lib().xlating_batch_debug_chain_stats(eng.h, buf, nwg) == 0:
+                            cyc = [buf[4 * i] for i in range(nwg)]; tick = [buf[4 * i + 1] for i in range(nwg)]; ent = buf[2]
+                            st = [buf[4 * i + 3] for i in range(nwg)]
+                            ent = max(ent, 1)
+                            extra += "  chain: %.1f cycles/step, %.2f ns/step, clock %.2f GHz, start spread %.1f us" % (
+                                sum(cyc) / nwg / (ent * 16), sum(tick) / nwg * 10.0 / (ent * 16), sum(cyc) / max(sum(tick), 1) / 10.0, (max(st) - min(st)) / 100.0)
                     eng.close()
                     kern = fir / max(nt, 1) / G * 1e3
                     print(f"{mode:10s} {m:4d} {n:7d} {G:2d} {dt*1e6:9.2f} {kern:11.2f} {n*131072/dt/1e6:10.0f}   {plan.split('|')[2].strip()[:60]} {extra}", flush=True)
