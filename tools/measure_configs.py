@@ -35,33 +35,41 @@ _r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "measure_dropin
 out["config1_single_client_dropin_process_cu8_cf32"] = json.loads(_r.stdout.strip().splitlines()[-1]) if _r.returncode == 0 else {"error": _r.stderr[-300:]}
 
 
-def run_batch(fs, fmt, nbytes_per_block, clients, blocks, steps=60, variant="optimized", host=False):
-    eng = xl.BatchEngine(fs, fmt, nbytes_per_block if fmt in ("cu8", "cs8") else nbytes_per_block)
+GROUP = 8  # blocks per engine call on the device-resident path (bench.py's super-block)
+
+
+def run_batch(fs, fmt, nbytes_per_block, clients, blocks, steps=60, variant="optimized", host=False, group=GROUP):
+    """-> (seconds per BLOCK, launch milliseconds per BLOCK)"""
+    g = 1 if host else group
+    eng = xl.BatchEngine(fs, fmt, nbytes_per_block, group_blocks=g)
     for D, taps, fc in clients:
         eng.add_client(D, taps, fc)
-    stream = torch.cuda.current_stream()
-    dev = [torch.from_numpy(b).cuda() for b in blocks]
     nelem = blocks[0].size
+    dev = None if host else torch.from_numpy(np.concatenate([blocks[k % len(blocks)] for k in range(g)])).cuda()
 
     def step(k):
         if host:
             eng.process_host(blocks[k % len(blocks)], variant)
             eng.fetch()
         else:
-            eng.process_device(dev[k % len(dev)].data_ptr(), nelem, variant, stream.cuda_stream)
+            eng.process_device_group(dev.data_ptr(), nelem, g, variant, "engine")
 
     for k in range(8):
         step(k)
+    eng.sync()
     torch.cuda.synchronize()
+    eng.timing_stride(2)
     eng.timing(True)
+    calls = max(8, steps // g)
     t0 = time.perf_counter()
-    for k in range(steps):
+    for k in range(calls):
         step(k)
+    eng.sync()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = (time.perf_counter() - t0) / (calls * g)
     nt, fir, _ = eng.timing_read()
     eng.close()
-    return dt, fir / max(nt, 1)
+    return dt, fir / max(nt, 1) / g
 
 
 t48, t96 = lpf(FS, 24000, 9600), lpf(FS, 48000, 19200)
@@ -70,14 +78,22 @@ S = 131072
 # ---- [2] 64 mixed clients
 cl = [((42, t48) if c % 2 == 0 else (21, t96)) + (-900000 + c * 28000,) for c in range(64)]
 dt, fir = run_batch(FS, "cu8", 262144, cl, blocks)
-out["config2_64_clients_mixed_48k_96k"] = {"ms_per_block": round(dt * 1e3, 4), "fir_launch_ms": round(fir, 4),
+out["config2_64_clients_mixed_48k_96k"] = {"us_per_block": round(dt * 1e6, 2), "launches_us_per_block": round(fir * 1e3, 2),
                                            "Msps_all_clients": round(64 * S / dt / 1e6, 0)}
-# ---- [3] 128 and 1024 clients, 505 taps
+dt1, fir1 = run_batch(FS, "cu8", 262144, cl, blocks, group=1)
+out["config2_64_clients_mixed_48k_96k_one_block_per_call"] = {"us_per_block": round(dt1 * 1e6, 2), "Msps_all_clients": round(64 * S / dt1 / 1e6, 0)}
+out["blocks_per_call_device_paths"] = GROUP
+# ---- [3] per-GPU shares of the 1024-client config (8 / 4 / 2 GPUs: 128 / 256 / 512 clients) and the 1-GPU target
+for n in (128, 256, 512, 1024, 2048, 4096):
+    cl = [(42, t48, -984000 + 1920 * (c % 1024) + 240 * (c // 1024)) for c in range(n)]
+    dt, fir = run_batch(FS, "cu8", 262144, cl, blocks, steps=320)
+    out[f"config3_{n}_clients_48k_505taps"] = {"us_per_block": round(dt * 1e6, 2), "launches_us_per_block": round(fir * 1e3, 2),
+                                               "Msps_all_clients": round(n * S / dt / 1e6, 0)}
 for n in (128, 1024):
     cl = [(42, t48, -984000 + 1920 * c) for c in range(n)]
-    dt, fir = run_batch(FS, "cu8", 262144, cl, blocks)
-    out[f"config3_{n}_clients_48k_505taps"] = {"ms_per_block": round(dt * 1e3, 4), "fir_launch_ms": round(fir, 4),
-                                               "Msps_all_clients": round(n * S / dt / 1e6, 0)}
+    dt, fir = run_batch(FS, "cu8", 262144, cl, blocks, steps=160, variant="native")
+    out[f"config3_{n}_clients_48k_505taps_native"] = {"us_per_block": round(dt * 1e6, 2), "launches_us_per_block": round(fir * 1e3, 2),
+                                                      "Msps_all_clients": round(n * S / dt / 1e6, 0)}
 # ---- PCIe-inclusive host path
 for n in (64, 1024):
     cl = [(42, t48, -984000 + 1920 * c) for c in range(n)]
@@ -92,6 +108,7 @@ for n in (64, 256, 1024):
     dt, fir = run_batch(10000000, "cf32", 2 * S, cl, fblocks)
     bpu = 8 + 8 / 100
     out[f"config4_cf32_10Msps_D100_257taps_{n}_clients"] = {
-        "ms_per_block": round(dt * 1e3, 4), "fir_launch_ms": round(fir, 4), "Msps_all_clients": round(n * S / dt / 1e6, 0),
-        "algorithmic_GBs_launch": round(n * S * bpu / (fir * 1e-3) / 1e9, 0), "hbm_frac_launch": round(n * S * bpu / (fir * 1e-3) / 8e12, 3)}
+        "us_per_block": round(dt * 1e6, 2), "launches_us_per_block": round(fir * 1e3, 2), "Msps_all_clients": round(n * S / dt / 1e6, 0),
+        "algorithmic_GBs_launch": round(n * S * bpu / (fir * 1e-3) / 1e9, 0), "hbm_model_frac_launch": round(n * S * bpu / (fir * 1e-3) / 8e12, 3),
+        "note": "per-client-read model (8 B in + 8/D B out per client and sample); the block is read once and shared, so the model number passes 1"}
 print(json.dumps(out, indent=1))

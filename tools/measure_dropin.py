@@ -33,4 +33,18 @@ for rate, name in ((5, "505 taps"), (1, "101 taps")):
         mean = sum(ts) / len(ts)
         res[f"{name} {variant}"] = {"us_per_block": round(mean * 1e6, 1), "median_us": round(ts[len(ts) // 2] * 1e6, 1),
                                     "Msps": round(131072 / mean / 1e6, 1)}
+# the Q15 family (process_*_cu8_cs16; the server itself never calls it: dsp_worker.c:110-124 picks the cf32 family)
+taps = xl.create_low_pass_filter(1.0, FS, 24000, 9600)[1]
+f = xl.XlatingFilter(42, taps, -12000, FS, 262144)
+for _ in range(10):
+    f.process("native", "cu8", "cs16", x)
+ts = []
+for _ in range(100):
+    t0 = time.perf_counter()
+    f.process("native", "cu8", "cs16", x)
+    ts.append(time.perf_counter() - t0)
+f.close()
+ts.sort()
+res["505 taps cs16 (Q15) output"] = {"us_per_block": round(sum(ts) / len(ts) * 1e6, 1), "median_us": round(ts[len(ts) // 2] * 1e6, 1),
+                                      "Msps": round(131072 / (sum(ts) / len(ts)) / 1e6, 1)}
 print(json.dumps(res))
