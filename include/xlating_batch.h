@@ -28,7 +28,14 @@ typedef struct xlating_batch_t xlating_batch;
 /* input sample formats == the reference's three device formats (dsp_worker.c:55-67) + the cf32 extension */
 enum { XL_FMT_CU8 = 0, XL_FMT_CS8 = 1, XL_FMT_CS16 = 2, XL_FMT_CF32 = 3 };
 /* arithmetic variants == the reference's cpu_optimization setting (config.h:20-23, dsp_worker.c:110-124) */
-enum { XL_MODE_NATIVE = 0, XL_MODE_OPTIMIZED = 1 };
+enum { XL_MODE_NATIVE = 0, XL_MODE_OPTIMIZED = 1,
+       /* the reference's cs16 output family (process_*_cs16, xlating.c:92-140, 416-447: exact Q15 integer arithmetic, its
+        * own never-renormalised int16 phase; optimized == native there).  Outputs are int16 (re, im) pairs:
+        * xlating_batch_output_host_cs16().  cu8 / cs8 / cs16 engines only.  The reference server itself only ever calls the
+        * cf32 family (dsp_worker.c:110-124); a client stream should stay in one family (the reference keeps separate sample
+        * buffers per family behind one history counter, a quirk the single-filter API reproduces and this engine -- one raw
+        * history -- does not). */
+       XL_MODE_Q15 = 2 };
 
 /* Create an engine for one input stream on one GPU.
  *   sampling_freq             band sampling rate (server_config->band_sampling_rate)
@@ -105,8 +112,10 @@ size_t xlating_batch_output_len_block(const xlating_batch *batch, int client_id,
 
 /* Copy every client's last-block output D2H into engine-owned pinned memory (one copy) and wait for it. */
 int xlating_batch_fetch(xlating_batch *batch);
-/* After xlating_batch_fetch(): pointer to client's samples as interleaved (re,im) float pairs. */
+/* After xlating_batch_fetch(): pointer to client's samples as interleaved (re,im) float pairs (-EINVAL after an
+ * XL_MODE_Q15 call: use the _cs16 accessor, interleaved (re,im) int16 pairs, and vice versa). */
 int xlating_batch_output_host(xlating_batch *batch, int client_id, const float **output, size_t *output_len);
+int xlating_batch_output_host_cs16(xlating_batch *batch, int client_id, const int16_t **output, size_t *output_len);
 /* Device pointer to the client's last-block output (valid until the next process call). */
 int xlating_batch_output_device(xlating_batch *batch, int client_id, const void **d_output, size_t *output_len);
 

@@ -34,7 +34,7 @@ _c_float_p = C.POINTER(C.c_float)
 _c_i16_p = C.POINTER(C.c_int16)
 
 FMT = {"cu8": 0, "cs8": 1, "cs16": 2, "cf32": 3}
-MODE = {"native": 0, "optimized": 1}
+MODE = {"native": 0, "optimized": 1, "q15": 2}
 _NP = {"cu8": np.uint8, "cs8": np.int8, "cs16": np.int16, "cf32": np.float32}
 _CT = {"cu8": C.c_uint8, "cs8": C.c_int8, "cs16": C.c_int16, "cf32": C.c_float}
 
@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = (
     + ["xlating_batch_create", "xlating_batch_create_grouped", "xlating_batch_set_option", "xlating_batch_process_host_group",
        "xlating_batch_process_device_group", "xlating_batch_process_device_group_ev", "xlating_batch_output_len_block", "xlating_batch_add_client", "xlating_batch_remove_client", "xlating_batch_num_clients",
        "xlating_batch_process_host", "xlating_batch_process_device", "xlating_batch_output_len", "xlating_batch_fetch",
-       "xlating_batch_output_host", "xlating_batch_output_device", "xlating_batch_client_phase", "xlating_batch_sync",
+       "xlating_batch_output_host", "xlating_batch_output_host_cs16", "xlating_batch_output_device", "xlating_batch_client_phase", "xlating_batch_sync",
        "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_timing_polyphase", "xlating_batch_timing_stride", "xlating_batch_describe", "xlating_batch_destroy",
        "xlating_hip_device_info"]
     + ["xlating_sinks_create", "xlating_sinks_attach_fd", "xlating_sinks_attach_file", "xlating_sinks_write",
@@ -157,6 +157,8 @@ def lib():
     L.xlating_batch_fetch.restype = C.c_int
     L.xlating_batch_output_host.argtypes = [C.c_void_p, C.c_int, C.POINTER(_c_float_p), C.POINTER(C.c_size_t)]
     L.xlating_batch_output_host.restype = C.c_int
+    L.xlating_batch_output_host_cs16.argtypes = [C.c_void_p, C.c_int, C.POINTER(_c_i16_p), C.POINTER(C.c_size_t)]
+    L.xlating_batch_output_host_cs16.restype = C.c_int
     L.xlating_batch_output_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.xlating_batch_output_device.restype = C.c_int
     L.xlating_batch_client_phase.argtypes = [C.c_void_p, C.c_int, _c_float_p, _c_float_p]
@@ -378,6 +380,17 @@ class BatchEngine:
         if n.value == 0:
             return np.zeros(0, np.complex64)
         return np.ctypeslib.as_array(p, shape=(2 * n.value,)).copy().view(np.complex64)
+
+    def output_cs16(self, cid):
+        """After a "q15" call + fetch(): int16[K, 2]."""
+        p = _c_i16_p()
+        n = C.c_size_t(0)
+        code = lib().xlating_batch_output_host_cs16(self.h, cid, C.byref(p), C.byref(n))
+        if code != 0:
+            raise XlatingError("xlating_batch_output_host_cs16", code)
+        if n.value == 0:
+            return np.zeros((0, 2), np.int16)
+        return np.ctypeslib.as_array(p, shape=(n.value, 2)).copy()
 
     def output_len(self, cid):
         return lib().xlating_batch_output_len(self.h, cid)

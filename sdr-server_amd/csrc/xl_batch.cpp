@@ -53,7 +53,9 @@ struct Client {
   bool alive = false;
   uint32_t D = 0, T = 0, Tpad = 0;
   std::vector<float> rt;  // [Tpad] interleaved re,im, zero padded
+  std::vector<int16_t> rtq;  // [T] the same taps in Q15 (xlating.c:486-487), interleaved re,im
   float incr[2] = {1.0f, 0.0f};
+  int16_t qincr[2] = {0, 0};  // Q15 phase increment (xlating.c:548-549)
   uint64_t consumed = 0;
   uint32_t out_off = 0, out_cap = 0;
   uint32_t last_K = 0;
@@ -161,6 +163,11 @@ struct xlating_batch_t {
   void *d_block = nullptr;
   void *h_block = nullptr;  // pinned staging
   float2 *d_taps = nullptr;
+  double *d_qtaps = nullptr;   // Q15 taps as doubles, same indexing as d_taps (XL_MODE_Q15)
+  uint32_t *d_qinc = nullptr;  // per nco entry: packed Q15 phase increment
+  short2 *d_qphase = nullptr;  // per slot: running Q15 phase (xlating.c:546-547: starts at 32767 + 0j)
+  short2 *d_qphtab = nullptr;  // Q15 phase table (every XL_PH_STRIDE-th phase)
+  bool last_q15 = false;       // the latest call produced cs16 outputs
   XlNcoClient *d_nco = nullptr;
   float2 *d_phase[2] = {nullptr, nullptr};  // [pcur] = committed running phases, [pcur^1] = next
   int pcur = 0;
@@ -238,8 +245,12 @@ static void xl_batch_free_plan(xlating_batch *b) {
   }
   b->poly.clear();
   if (b->d_taps) (void)hipFree(b->d_taps);
+  if (b->d_qtaps) (void)hipFree(b->d_qtaps);
+  if (b->d_qinc) (void)hipFree(b->d_qinc);
   if (b->d_nco) (void)hipFree(b->d_nco);
   b->d_taps = nullptr;
+  b->d_qtaps = nullptr;
+  b->d_qinc = nullptr;
   b->d_nco = nullptr;
 }
 
@@ -249,7 +260,8 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   xl_batch_sync_all(b);
   xl_batch_free_plan(b);
   void *dev[] = {b->d_hist[0],  b->d_hist[1],  b->d_block,  b->d_phase[0], b->d_phase[1],
-                 b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_W,        b->d_phase_run};
+                 b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_W,        b->d_phase_run,
+                 b->d_qphase,   b->d_qphtab};
   for (void *p : dev)
     if (p) (void)hipFree(p);
   if (b->d_chain_stats) (void)hipFree(b->d_chain_stats);
@@ -414,9 +426,8 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
   c.T = (uint32_t)taps_len;
   c.Tpad = Tpad;
   c.rt.assign(2 * (size_t)Tpad, 0.0f);
-  std::vector<int16_t> q15(2 * taps_len);
-  int16_t qinc[2];
-  xl_prepare_taps(taps, taps_len, center_freq, b->fs, decimation, c.rt.data(), q15.data(), c.incr, qinc);
+  c.rtq.assign(2 * taps_len, 0);
+  xl_prepare_taps(taps, taps_len, center_freq, b->fs, decimation, c.rt.data(), c.rtq.data(), c.incr, c.qincr);
   c.out_cap = b->gcap * (b->max_samples / decimation + 1);  // xlating.c:568 per block
   b->nalive++;
   b->dirty = true;
@@ -440,11 +451,26 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
       }
       b->d_phase[i] = np;
     }
+    {
+      short2 *nq = nullptr;
+      if (hipMalloc((void **)&nq, ncap * sizeof(short2)) != hipSuccess) {
+        c.alive = false;
+        b->nalive--;
+        return -ENOMEM;
+      }
+      if (b->d_qphase) {
+        (void)hipMemcpy(nq, b->d_qphase, b->phase_cap * sizeof(short2), hipMemcpyDeviceToDevice);
+        (void)hipFree(b->d_qphase);
+      }
+      b->d_qphase = nq;
+    }
     b->phase_cap = ncap;
   }
   {
     const float2 one = make_float2(1.0f, 0.0f);
+    const short2 qone = make_short2(INT16_MAX, 0);  // xlating.c:546-547
     if (hipMemcpy(b->d_phase[b->pcur] + id, &one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess) return -EIO;
+    if (hipMemcpy(b->d_qphase + id, &qone, sizeof(qone), hipMemcpyHostToDevice) != hipSuccess) return -EIO;
   }
   return id;
 }
@@ -496,7 +522,7 @@ static void xl_direct_classes(const xlating_batch *b, const std::vector<bool> &u
 
 // Builds one set of direct-FIR launches over `classes`: tiles, groups, tap image rows (appended to `image`).
 static int xl_build_launches(xlating_batch *b, Launch *Ls, const std::vector<DirectClass> &classes, int big_h,
-                             std::vector<float> *image) {
+                             std::vector<float> *image, std::vector<double> *imageq) {
   struct TileDesc {
     size_t cls;
     std::vector<int> ids;
@@ -555,14 +581,20 @@ static int xl_build_launches(xlating_batch *b, Launch *Ls, const std::vector<Dir
       t.tap_off = real_off;
       t.nclients = (uint32_t)td.ids.size();  // a partial last tile keeps zero taps for the missing clients
       image->resize(image->size() + (size_t)2 * Tpad * ct, 0.0f);
+      if (imageq) imageq->resize(image->size(), 0.0);
       float *dst = image->data() + (size_t)2 * real_off;
       for (size_t j = 0; j < td.ids.size(); ++j) {
         const Client &c = b->clients[td.ids[j]];
         t.out_off[j] = c.out_off;
         t.incr[j] = make_float2(c.incr[0], c.incr[1]);
+        t.qincr[j] = (uint32_t)(uint16_t)c.qincr[0] | ((uint32_t)(uint16_t)c.qincr[1] << 16);
         for (uint32_t i = 0; i < cs.T; ++i) {
           dst[((size_t)i * ct + j) * 2] = c.rt[2 * i];
           dst[((size_t)i * ct + j) * 2 + 1] = c.rt[2 * i + 1];
+          if (imageq) {
+            (*imageq)[(size_t)2 * real_off + ((size_t)i * ct + j) * 2] = (double)c.rtq[2 * i];
+            (*imageq)[(size_t)2 * real_off + ((size_t)i * ct + j) * 2 + 1] = (double)c.rtq[2 * i + 1];
+          }
         }
       }
     }
@@ -740,9 +772,11 @@ static int xl_batch_plan(xlating_batch *b) {
     if (b->exp_h == 8 || b->exp_h == 9 || b->exp_h == 10 || b->exp_h == 12) big_h = b->exp_h;
   }
   std::vector<float> image;  // tap image, floats (shared by both launch sets)
+  std::vector<double> imageq;  // Q15 taps of the all-clients launch set (input formats that have a Q15 family)
+  const bool has_q15 = b->fmt != XL_FMT_CF32;
   {
-    int rc = xl_build_launches(b, b->launches, b->classes, big_h, &image);
-    if (rc == 0 && !b->poly.empty()) rc = xl_build_launches(b, b->launches_rest, b->classes_rest, big_h, &image);
+    int rc = xl_build_launches(b, b->launches, b->classes, big_h, &image, has_q15 ? &imageq : nullptr);
+    if (rc == 0 && !b->poly.empty()) rc = xl_build_launches(b, b->launches_rest, b->classes_rest, big_h, &image, nullptr);
     if (rc != 0) return rc;
   }
 
@@ -791,6 +825,17 @@ static int xl_batch_plan(xlating_batch *b) {
   XL_TRY(hipMemcpy(b->d_taps, image.data(), image.size() * sizeof(float), hipMemcpyHostToDevice));
   XL_TRY(hipMalloc((void **)&b->d_nco, b->nco.size() * sizeof(XlNcoClient)));
   XL_TRY(hipMemcpy(b->d_nco, b->nco.data(), b->nco.size() * sizeof(XlNcoClient), hipMemcpyHostToDevice));
+  if (has_q15) {
+    std::vector<uint32_t> qinc;
+    for (const XlNcoClient &nc : b->nco) {
+      const Client &c = b->clients[nc.slot];
+      qinc.push_back((uint32_t)(uint16_t)c.qincr[0] | ((uint32_t)(uint16_t)c.qincr[1] << 16));
+    }
+    XL_TRY(hipMalloc((void **)&b->d_qinc, qinc.size() * sizeof(uint32_t)));
+    XL_TRY(hipMemcpy(b->d_qinc, qinc.data(), qinc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    XL_TRY(hipMalloc((void **)&b->d_qtaps, imageq.size() * sizeof(double) + 256));
+    XL_TRY(hipMemcpy(b->d_qtaps, imageq.data(), imageq.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   for (Launch *set : {b->launches, b->launches_rest})
     for (int i = 0; i < XL_NLAUNCH; ++i) {
       Launch &L = set[i];
@@ -875,6 +920,9 @@ static int xl_batch_plan(xlating_batch *b) {
       b->d_out[i] = b->d_phtab[i] = nullptr;
     }
     b->out_alloc = 0;
+    if (b->d_qphtab) (void)hipFree(b->d_qphtab);
+    b->d_qphtab = nullptr;
+    XL_TRY(hipMalloc((void **)&b->d_qphtab, (b->out_total / XL_PH_STRIDE + 8) * sizeof(short2)));
     for (int i = 0; i < 2; ++i) {
       XL_TRY(hipMalloc((void **)&b->d_out[i], b->out_total * sizeof(float2)));
       XL_TRY(hipMalloc((void **)&b->d_phtab[i], (b->out_total / XL_PH_STRIDE + 8) * sizeof(float2)));  // every XL_PH_STRIDE-th phase
@@ -938,7 +986,9 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
                         hipEvent_t wait_ev = nullptr, hipEvent_t record_ev = nullptr) {
   const size_t S = input_len / 2;
   hipStream_t s = s_in;
-  if (S > b->max_samples || G < 1 || G > b->gcap || (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED)) return -EINVAL;
+  if (S > b->max_samples || G < 1 || G > b->gcap || (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED && mode != XL_MODE_Q15) ||
+      (mode == XL_MODE_Q15 && b->fmt == XL_FMT_CF32))
+    return -EINVAL;
   if (b->poisoned) return -EIO;
   // a client that was still inside its zero-history when the plan was built may be mature by now: it then joins
   // the class of its grid (direct kernel) / its (D, T) class (polyphase) -- re-plan
@@ -967,7 +1017,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
   uint32_t maxK = 0;  // the most outputs any client produces in this call
   for (const DirectClass &cs : b->classes) maxK = std::max(maxK, xl_grid_dyn(cs.D, cs.T, cs.rem0, cs.hv0, pos).K);
   const bool use_poly = mode == XL_MODE_OPTIMIZED && !b->poly.empty() && maxK >= 2 * XLP_M_MAX;
-  const bool side_call = b->nco_side > 0 || (b->nco_side < 0 && G >= 2 && use_poly);
+  const bool side_call = mode != XL_MODE_Q15 && (b->nco_side > 0 || (b->nco_side < 0 && G >= 2 && use_poly));
   if (s == XL_STREAM_ENGINE_P) s = (side_call && b->cs_masked) ? b->cs_masked : b->own_stream;
   // Calls depend on each other through the engine's device state (history, phases, tables): a call on another
   // stream than the previous one is ordered behind it.
@@ -982,6 +1032,67 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     if (record_ev) XL_TRY(hipEventRecord(record_ev, s));
     return 0;
   }
+
+  if (mode == XL_MODE_Q15) {
+    // ---- the Q15 family (xlating.c:92-140, 416-447): its own phase (never renormalised), the same raw history.  The
+    // float phases stay where they are; a float phase table tabulated ahead was for a call at this stream position and
+    // is dropped.
+    const int p = (int)(b->ncalls & 1);
+    const int hb = b->hcur, hn = b->hcur ^ 1;
+    const uint32_t N = (uint32_t)(S * G);
+    if (b->spec_valid && b->spec_on_side) XL_TRY(hipStreamWaitEvent(s, b->ev_chain[b->spec_tab], 0));
+    b->spec_valid = false;
+    b->poisoned = true;
+    XL_TRY(xl_launch_nco_q15_batch(b->d_nco, b->d_qinc, (uint32_t)b->nco.size(), b->d_qphase, b->d_qphtab, pos, s));
+    bool rolled = false;
+    for (int lq = 0; lq < XL_NLAUNCH && maxK > 0; ++lq) {
+      Launch &L = b->launches[lq];
+      if (L.groups.empty()) continue;
+      XlFirArgs a;
+      memset(&a, 0, sizeof(a));
+      a.in0 = b->d_hist[hb];
+      a.n0 = XL_HCAP;
+      a.in1 = d_blocks;
+      a.n1 = N;
+      a.fmt = b->fmt;
+      a.pos = pos;
+      a.groups = L.d_groups;
+      a.ngroups = (uint32_t)L.groups.size();
+      a.ota = L.ota;
+      a.xtiles = (std::min((N + L.minD - 1) / L.minD, maxK) + L.ota - 1) / L.ota;
+      a.out = b->d_out[p];
+      if (!rolled) {
+        a.hist_out = b->d_hist[hn];
+        a.hist_units = XL_HCAP * (b->bps / 2);
+        a.block_units = N * (b->bps / 2);
+        rolled = true;
+      }
+      XL_TRY(xl_launch_fir_q15_batch(L.ct, L.nw, a, b->d_qtaps, b->d_qphtab, L.lds, s));
+    }
+    if (!rolled) XL_TRY(xl_launch_update_history(b->d_hist[hb], d_blocks, XL_HCAP, N, b->bps, b->d_hist[hn], s));
+    if (record_ev) XL_TRY(hipEventRecord(record_ev, s));
+    b->poisoned = false;
+    for (Client &c : b->clients) {
+      if (!c.alive) continue;
+      const uint32_t j0 = (uint32_t)((c.D - c.consumed % c.D) % c.D);
+      c.last_Kg.resize(G);
+      uint32_t prev = 0;
+      for (uint32_t g = 1; g <= G; ++g) {
+        const uint32_t ms = xl_grid_mstart(j0, c.D, (uint32_t)S, g);
+        c.last_Kg[g - 1] = ms - prev;
+        prev = ms;
+      }
+      c.last_K = prev;
+      c.consumed += N;
+    }
+    b->trel += N;
+    b->ocur = p;
+    b->hcur = hn;
+    b->ncalls++;
+    b->last_q15 = true;
+    return 0;
+  }
+  b->last_q15 = false;
 
   {
     const int p = (int)(b->ncalls & 1);  // parity of this call: output buffer
@@ -1431,9 +1542,19 @@ extern "C" int xlating_batch_fetch(xlating_batch *b) {
   return 0;
 }
 
+extern "C" int xlating_batch_output_host_cs16(xlating_batch *b, int id, const int16_t **output, size_t *output_len) {
+  if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive || !b->fetched ||
+      output == nullptr || output_len == nullptr || !b->last_q15)
+    return -EINVAL;
+  const Client &c = b->clients[id];
+  *output = b->h_out ? reinterpret_cast<const int16_t *>(b->h_out + c.out_off) : nullptr;
+  *output_len = c.last_K;
+  return 0;
+}
+
 extern "C" int xlating_batch_output_host(xlating_batch *b, int id, const float **output, size_t *output_len) {
   if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive || !b->fetched ||
-      output == nullptr || output_len == nullptr)
+      output == nullptr || output_len == nullptr || b->last_q15)
     return -EINVAL;
   const Client &c = b->clients[id];
   *output = b->h_out ? reinterpret_cast<const float *>(b->h_out + c.out_off) : nullptr;

@@ -43,8 +43,9 @@ struct XlTile {
   uint32_t nclients;             // 1..ct real clients (the rest of the tile has zero taps)
   uint32_t out_off[XL_CT_MAX];   // per client: float2 index into the output image (a multiple of 2 * XL_PH_STRIDE); / XL_PH_STRIDE into the phase table
   float2 incr[XL_CT_MAX];        // per client: NCO phase increment (xlating.c:544)
+  uint32_t qincr[XL_CT_MAX];     // per client: Q15 phase increment, (uint16) re | (uint16) im << 16 (xlating.c:548-549)
 };
-#define XL_TILE_DWORDS (2u + 3u * XL_CT_MAX)
+#define XL_TILE_DWORDS (2u + 4u * XL_CT_MAX)
 
 struct XlGroup {
   uint32_t D, T, Tpad;
@@ -134,6 +135,16 @@ hipError_t xl_launch_nco_table_q15(int16_t incr_re, int16_t incr_im, short2 *pha
                                    hipStream_t s);
 hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T, uint32_t D, uint32_t K,
                              const short2 *phtab, short2 *out, hipStream_t s);
+
+// Q15 family on the batched boundary (xlating.c:92-140 per client): phase table (every XL_PH_STRIDE-th phase of the
+// truncating int16 recurrence, never renormalised) and the FIR launch -- exact integer arithmetic carried in float64 FMAs.
+//   qinc[i]: increment of clients[i] packed like XlTile::qincr; qstate[slot]: running Q15 phase (updated in place)
+hipError_t xl_launch_nco_q15_batch(const XlNcoClient *clients, const uint32_t *qinc, uint32_t nclients, short2 *qstate,
+                                   short2 *qphtab, XlPos pos, hipStream_t s);
+//   a: as for xl_launch_fir (no NCO role); qtaps: [tile][Tpad][ct] (re, im) doubles, same indexing as a.taps;
+//   outputs: short2 rows at the addresses of the float2 rows (a.out + out_off)
+hipError_t xl_launch_fir_q15_batch(int ct, int nw, const XlFirArgs &a, const double *qtaps, const short2 *qphtab,
+                                   size_t lds_bytes, hipStream_t s);
 
 // window image bytes for `ota` outputs per tile
 size_t xl_fir_lds_bytes_ota(uint32_t D, uint32_t Tpad, uint32_t ota);

@@ -718,3 +718,166 @@ hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T,
                      reinterpret_cast<const int32_t *>(taps), T, D, K, phtab, out);
   return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------- Q15 family, batched
+// xlating.c:92-140 for every client of the engine.  The reference accumulates int16 x int16 products in int64; here
+// the same integers are carried in float64 FMAs (a product is < 2^30, a sum of 2 T of them < 2^53: every operation is
+// exact, so the result IS the integer sum) -- v_fma_f64 runs at half the FP32 rate, an int64 multiply-add at a quarter
+// or less.  Window image: the block's samples as Q15 integers held in float32 (exact), shared by the 4 tiles of a group;
+// taps: wave-uniform doubles through scalar loads, SGPR operands of the FMAs, like the float kernel.
+XL_DEV v2f xl_sample_q15(const void *__restrict__ p, int fmt, uint32_t i) {
+  v2f r;
+  if (fmt == XLF_CU8) {  // xlating.c:418: ((int16_t) u8 - 128) << 8
+    const uint32_t v = reinterpret_cast<const uint16_t *>(p)[i];
+    r.x = (float)(((int32_t)(v & 0xFFu) - 128) * 256);
+    r.y = (float)(((int32_t)(v >> 8) - 128) * 256);
+  } else if (fmt == XLF_CS8) {  // :425: s8 << 8
+    const int32_t v = reinterpret_cast<const int16_t *>(p)[i];
+    r.x = (float)((int32_t)(int8_t)(v & 0xFF) * 256);
+    r.y = (float)((v >> 8) * 256);
+  } else {  // :432: the int16 samples as they are
+    const int32_t v = reinterpret_cast<const int32_t *>(p)[i];
+    r.x = (float)(int32_t)(int16_t)(v & 0xFFFF);
+    r.y = (float)(v >> 16);
+  }
+  return r;
+}
+
+// one lane per client: the truncating Q15 phase recurrence (xlating.c:126-129), every XL_PH_STRIDE-th phase tabulated
+__global__ __launch_bounds__(64) void xl_nco_q15_batch_kernel(const XlNcoClient *__restrict__ cl, const uint32_t *__restrict__ qinc,
+                                                              uint32_t n, short2 *qstate, short2 *__restrict__ tab, const XlPos pos) {
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (c >= n) return;
+  const XlNcoClient k = cl[c];
+  const uint32_t K = xl_nco_bnd(k, pos, 0xFFFFFFFFu).K;
+  const int32_t ir = (int16_t)(qinc[c] & 0xFFFFu), ii = (int16_t)(qinc[c] >> 16);
+  int32_t pr = qstate[k.slot].x, pi = qstate[k.slot].y;
+  short2 *__restrict__ o = tab + (k.out_off >> XL_PH_SHIFT);
+  for (uint32_t m = 0; m < K; ++m) {
+    if ((m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = make_short2((short)pr, (short)pi);
+    const int32_t tr = pr * ir - pi * ii, ti = pr * ii + pi * ir;
+    pr = xl_sat16(tr >> 15);
+    pi = xl_sat16(ti >> 15);
+  }
+  qstate[k.slot] = make_short2((short)pr, (short)pi);
+}
+
+hipError_t xl_launch_nco_q15_batch(const XlNcoClient *clients, const uint32_t *qinc, uint32_t nclients, short2 *qstate,
+                                   short2 *qphtab, XlPos pos, hipStream_t s) {
+  if (nclients == 0) return hipSuccess;
+  hipLaunchKernelGGL(xl_nco_q15_batch_kernel, dim3((nclients + 63u) / 64u), dim3(64), 0, s, clients, qinc, nclients, qstate,
+                     qphtab, pos);
+  return hipGetLastError();
+}
+
+typedef const double __attribute__((address_space(4))) *cdouble_p;
+
+template <int CT>
+__global__ __launch_bounds__(64 * XL_NW_MAX) void xl_fir_q15_batch_kernel(const XlFirArgs a, const double *__restrict__ qtaps,
+                                                                          const short2 *__restrict__ qphtab) {
+  extern __shared__ __attribute__((aligned(16))) v2f xl_qwin[];
+  const uint32_t OT = a.ota;
+  const uint32_t b = blockIdx.x;
+  // raw-history roll, as in xl_fir_kernel
+  const uint32_t roll_blocks = gridDim.x < XL_ROLL_BLOCKS ? gridDim.x : XL_ROLL_BLOCKS;
+  if (a.hist_out != nullptr && b < roll_blocks) {
+    const uint16_t *__restrict__ h0 = reinterpret_cast<const uint16_t *>(a.in0);
+    const uint16_t *__restrict__ h1 = reinterpret_cast<const uint16_t *>(a.in1);
+    uint16_t *__restrict__ ho = reinterpret_cast<uint16_t *>(a.hist_out);
+    for (uint32_t j = b * blockDim.x + threadIdx.x; j < a.hist_units; j += roll_blocks * blockDim.x) {
+      const uint32_t sidx = a.block_units + j;
+      ho[j] = (sidx < a.hist_units) ? h0[sidx] : h1[sidx - a.hist_units];
+    }
+  }
+  const uint32_t y = b / a.xtiles, x = b - y * a.xtiles;
+  if (y >= a.ngroups) return;
+  const cu32_p g = (cu32_p)(uintptr_t)(a.groups + y);
+  const uint32_t D = g[0], T = g[1], Tpad = g[2], ntiles = g[4];
+  const XlDyn d = xl_grid_dyn(D, T, g[3], g[7], a.pos);
+  const uint32_t K = d.K;
+  if (x * OT >= K) return;
+  {
+    const uint32_t win0 = d.base + x * OT * D, wlen = (OT - 1u) * D + Tpad;
+    for (uint32_t j = threadIdx.x; j < wlen; j += blockDim.x) {
+      const uint32_t sidx = win0 + j;
+      const bool first = sidx < a.n0;
+      const bool ok = sidx >= d.zero_below && (first || sidx - a.n0 < a.n1);
+      const v2f v = xl_sample_q15((first || !ok) ? a.in0 : a.in1, a.fmt, ok ? (first ? sidx : sidx - a.n0) : 0u);
+      xl_qwin[j] = ok ? v : (v2f){0.0f, 0.0f};
+    }
+  }
+  __syncthreads();
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (w >= ntiles) return;
+  const cu32_p t = g + 8 + w * XL_TILE_DWORDS;
+  const uint32_t ncl = t[1];
+  const cdouble_p tq = (cdouble_p)(uintptr_t)(qtaps + (size_t)t[0] * 2u);
+  double accr[CT], acci[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) accr[c] = acci[c] = 0.0;
+  const v2f *lp = xl_qwin + (lane >= OT ? 0u : lane) * D;
+  for (uint32_t i = 0; i < T; ++i) {
+    const v2f xs = lp[i];
+    const double xr = (double)xs.x, xi = (double)xs.y;
+    const cdouble_p h = tq + (size_t)i * (2 * CT);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const double hr = h[2 * c], hi = h[2 * c + 1];
+      accr[c] = __builtin_fma(xr, hr, accr[c]);  // temp_real += ar * br - ai * bi   (xlating.c:114)
+      accr[c] = __builtin_fma(-xi, hi, accr[c]);
+      acci[c] = __builtin_fma(xr, hi, acci[c]);  // temp_imag += ar * bi + ai * br   (:115)
+      acci[c] = __builtin_fma(xi, hr, acci[c]);
+    }
+  }
+  const uint32_t m = x * OT + lane;
+  if (m >= K || lane >= OT) return;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    if ((uint32_t)c >= ncl) continue;
+    const uint32_t off = t[2 + c], qi = t[2 + 3 * XL_CT_MAX + c];
+    // >> 15 of the int64 sums (arithmetic shift = floor), saturated (xlating.c:118-119)
+    const int32_t ar = xl_sat16((int32_t)__builtin_floor(accr[c] * (1.0 / 32768.0)));
+    const int32_t ai = xl_sat16((int32_t)__builtin_floor(acci[c] * (1.0 / 32768.0)));
+    // this output's phase: the tabulated one below it, stepped m % XL_PH_STRIDE times (:126-129)
+    const short2 p0 = qphtab[(off >> XL_PH_SHIFT) + (m >> XL_PH_SHIFT)];
+    const int32_t ir = (int16_t)(qi & 0xFFFFu), ii = (int16_t)(qi >> 16);
+    int32_t pr = p0.x, pi = p0.y;
+    for (uint32_t j = m & (XL_PH_STRIDE - 1u); j > 0u; --j) {
+      const int32_t tr = pr * ir - pi * ii, ti = pr * ii + pi * ir;
+      pr = xl_sat16(tr >> 15);
+      pi = xl_sat16(ti >> 15);
+    }
+    const int32_t orr = ar * pr - ai * pi, oi = ar * pi + ai * pr;  // xlating.c:121-124
+    reinterpret_cast<short2 *>(a.out + off)[m] = make_short2((short)xl_sat16(orr >> 15), (short)xl_sat16(oi >> 15));
+  }
+}
+
+template <int CT>
+static hipError_t xl_fir_q15_go(int nw, const XlFirArgs &a, const double *qtaps, const short2 *qphtab, size_t lds, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&xl_fir_q15_batch_kernel<CT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const uint32_t nblocks = a.ngroups * a.xtiles;
+  if (nblocks == 0) return hipSuccess;
+  hipLaunchKernelGGL((xl_fir_q15_batch_kernel<CT>), dim3(nblocks), dim3(64 * nw), lds, s, a, qtaps, qphtab);
+  return hipGetLastError();
+}
+
+hipError_t xl_launch_fir_q15_batch(int ct, int nw, const XlFirArgs &a, const double *qtaps, const short2 *qphtab,
+                                   size_t lds, hipStream_t s) {
+  if (lds > 160 * 1024 || nw < 1 || nw > XL_NW_MAX) return hipErrorInvalidValue;
+  switch (ct) {
+    case 1: return xl_fir_q15_go<1>(nw, a, qtaps, qphtab, lds, s);
+    case 2: return xl_fir_q15_go<2>(nw, a, qtaps, qphtab, lds, s);
+    case 4: return xl_fir_q15_go<4>(nw, a, qtaps, qphtab, lds, s);
+    case 8: return xl_fir_q15_go<8>(nw, a, qtaps, qphtab, lds, s);
+    case 9: return xl_fir_q15_go<9>(nw, a, qtaps, qphtab, lds, s);
+    case 10: return xl_fir_q15_go<10>(nw, a, qtaps, qphtab, lds, s);
+    case 12: return xl_fir_q15_go<12>(nw, a, qtaps, qphtab, lds, s);
+    default: return hipErrorInvalidValue;
+  }
+}

@@ -925,3 +925,41 @@ def test_c_multi_host_single_gpu(how):
             else:
                 assert bits_equal(got, want), (k, cid)
     m.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The Q15 (cs16 output) family on the batched boundary (XL_MODE_Q15): exact integers.
+@pytest.mark.parametrize("fmt", ["cu8", "cs8", "cs16"])
+def test_q15_mode_bit_exact(fmt):
+    """Every client's cs16 stream == the oracle's process_<fmt>_cs16 (xlating.c:92-140, 416-447) bit for bit: mixed
+    rates, ragged blocks, a late joiner, a call of 3 blocks, many blocks so that the truncating phase recurrence drifts."""
+    t48, t96, t101 = lpf(FS, 24000, 9600), lpf(FS, 48000, 19200), lpf(FS, 24000, 48000)
+    maxin = 65536
+    eng = xl.BatchEngine(FS, fmt, maxin, group_blocks=3)
+    oracles = {}
+    clients = [(42, t48, -700000 + 101000 * c) for c in range(13)] + [(21, t96, 9000 * c) for c in range(3)] + [(42, t101, 123456)]
+    for D, taps, fc in clients:
+        oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, FS, maxin)
+    gen = {"cu8": siggen.xs_u8, "cs8": siggen.xs_s8, "cs16": siggen.xs_s16}[fmt]
+    for k, (G, n) in enumerate(((1, 65536), (1, 20002), (3, 30000), (1, 65536), (1, 2), (2, 65536), (1, 40000))):
+        if k == 3:
+            oracles[eng.add_client(42, t48, 31337)] = Oracle(42, t48, 31337, FS, maxin)
+        x = gen(6000 + k, G * n)
+        eng.process_host_group(x, G, "q15")
+        eng.fetch()
+        for cid, o in oracles.items():
+            want = np.concatenate([o.process(fmt, bl, "cs16") for bl in np.split(x, G)])
+            got = eng.output_cs16(cid)
+            assert got.shape == want.shape and np.array_equal(got, want), (k, cid)
+        with pytest.raises(xl.XlatingError):
+            eng.output(next(iter(oracles)))  # float accessor after a Q15 call
+    eng.close()
+
+
+def test_q15_mode_rejected_for_cf32_engines():
+    eng = xl.BatchEngine(FS, "cf32", 4096)
+    eng.add_client(42, lpf(FS, 24000, 48000), 1000)
+    with pytest.raises(xl.XlatingError) as e:
+        eng.process_host(np.zeros(4096, np.float32), "q15")
+    assert e.value.code == -22
+    eng.close()
