@@ -541,6 +541,8 @@ def main():
 
     if "RANK" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args, sys.argv[1:]))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (before the HIP runtime comes up: RCCL's IPC needs dmabuf here)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
     import torch
 

@@ -113,6 +113,13 @@ def lib():
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+    # PyTorch bundles its own copy of the HIP runtime.  If this library (linked against /opt/rocm's) initialises HIP first
+    # and torch is imported later in the same process, torch ends up on a second runtime that sees no GPU ("No HIP GPUs are
+    # available"); with torch's copy loaded first both share it.  Tests and bench.py use torch for device buffers, so:
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for this host; a pure C deployment never has this problem
+        pass
     L = C.CDLL(path)
     L.create_low_pass_filter.argtypes = [C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_c_float_p), C.POINTER(C.c_size_t)]
     L.create_low_pass_filter.restype = C.c_int

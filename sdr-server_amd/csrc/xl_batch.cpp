@@ -32,6 +32,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <new>
 #include <string>
@@ -136,6 +137,12 @@ struct xlating_batch_t {
   std::vector<Client> clients;
   int nalive = 0;
   bool dirty = true;
+  // Plan buffers are recycled across re-plans (a client joining or leaving rebuilds the plan; hipMalloc / hipFree of a few
+  // hundred MB took 30-90 ms per re-plan at 1024-4096 clients): live allocations with their capacities, and the ones the
+  // previous plan released, waiting to be taken again.
+  std::map<void *, size_t> plan_caps;
+  std::vector<void *> plan_spare;
+  bool want_q15 = false;  // the Q15 tap image is built from the first XL_MODE_Q15 call on
   int planned_immature = 0;  // clients that were not mature when the plan was built (they merge once they are)
   uint32_t trel = 0;         // samples consumed since the plan was built (XlPos::trel)
   uint32_t plan_maxD = 1;
@@ -230,24 +237,58 @@ static void xl_batch_sync_all(xlating_batch *b) {
   if (b->nco_masked) (void)hipStreamSynchronize(b->nco_masked);
 }
 
+// A plan buffer of at least `bytes`: the smallest spare one that fits (and is not more than twice too big), else a fresh
+// allocation with 1/8 of headroom, so that the next few joins find room in place.
+static hipError_t xl_plan_alloc(xlating_batch *b, void **out, size_t bytes) {
+  int best = -1;
+  for (size_t i = 0; i < b->plan_spare.size(); ++i) {
+    const size_t cap = b->plan_caps[b->plan_spare[i]];
+    if (cap >= bytes && cap <= 2 * bytes + 4096 && (best < 0 || cap < b->plan_caps[b->plan_spare[best]])) best = (int)i;
+  }
+  if (best >= 0) {
+    *out = b->plan_spare[best];
+    b->plan_spare.erase(b->plan_spare.begin() + best);
+    return hipSuccess;
+  }
+  const size_t cap = bytes + bytes / 8 + 256;
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, cap);
+  if (e != hipSuccess) return e;
+  b->plan_caps[p] = cap;
+  *out = p;
+  return hipSuccess;
+}
+
+static void xl_plan_release(xlating_batch *b, void *p) {
+  if (p) b->plan_spare.push_back(p);
+}
+
+// what the finished plan did not take again goes back to the device
+static void xl_plan_trim(xlating_batch *b) {
+  for (void *p : b->plan_spare) {
+    (void)hipFree(p);
+    b->plan_caps.erase(p);
+  }
+  b->plan_spare.clear();
+}
+
 static void xl_batch_free_plan(xlating_batch *b) {
   for (Launch *set : {b->launches, b->launches_rest})
     for (int i = 0; i < XL_NLAUNCH; ++i) {
       Launch &l = set[i];
-      if (l.d_groups) (void)hipFree(l.d_groups);
+      xl_plan_release(b, l.d_groups);
       l.d_groups = nullptr;
       l.groups.clear();
     }
   for (PolyClass &pc : b->poly) {
     void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_cols};
-    for (void *q : dev)
-      if (q) (void)hipFree(q);
+    for (void *q : dev) xl_plan_release(b, q);
   }
   b->poly.clear();
-  if (b->d_taps) (void)hipFree(b->d_taps);
-  if (b->d_qtaps) (void)hipFree(b->d_qtaps);
-  if (b->d_qinc) (void)hipFree(b->d_qinc);
-  if (b->d_nco) (void)hipFree(b->d_nco);
+  xl_plan_release(b, b->d_taps);
+  xl_plan_release(b, b->d_qtaps);
+  xl_plan_release(b, b->d_qinc);
+  xl_plan_release(b, b->d_nco);
   b->d_taps = nullptr;
   b->d_qtaps = nullptr;
   b->d_qinc = nullptr;
@@ -259,6 +300,7 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   if (b->device >= 0) (void)hipSetDevice(b->device);
   xl_batch_sync_all(b);
   xl_batch_free_plan(b);
+  xl_plan_trim(b);
   void *dev[] = {b->d_hist[0],  b->d_hist[1],  b->d_block,  b->d_phase[0], b->d_phase[1],
                  b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_W,        b->d_phase_run,
                  b->d_qphase,   b->d_qphtab};
@@ -650,7 +692,17 @@ static int xl_build_launches(xlating_batch *b, Launch *Ls, const std::vector<Dir
 }
 
 static int xl_batch_plan(xlating_batch *b) {
+  // tuning: XL_EXP_PLAN_TIMING=1 prints where a re-plan spends its time
+  static const bool plan_timing = getenv("XL_EXP_PLAN_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!plan_timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "plan: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
   xl_batch_sync_all(b);
+  lap("sync");
   b->spec_valid = false;
   xl_batch_free_plan(b);
   b->classes.clear();
@@ -734,6 +786,7 @@ static int xl_batch_plan(xlating_batch *b) {
   }
   xl_direct_classes(b, all_use, &b->classes);
   if (!b->poly.empty()) xl_direct_classes(b, rest_use, &b->classes_rest);
+  lap("classes");
 
   // ---- register-tile height.  Every wave does the same work (64 outputs x H clients x T taps) and a CU holds
   // floor(160 KiB / window image) workgroups of 4 waves (6 at the server-default shape).  A launch whose workgroups
@@ -773,12 +826,13 @@ static int xl_batch_plan(xlating_batch *b) {
   }
   std::vector<float> image;  // tap image, floats (shared by both launch sets)
   std::vector<double> imageq;  // Q15 taps of the all-clients launch set (input formats that have a Q15 family)
-  const bool has_q15 = b->fmt != XL_FMT_CF32;
+  const bool has_q15 = b->fmt != XL_FMT_CF32 && b->want_q15;
   {
     int rc = xl_build_launches(b, b->launches, b->classes, big_h, &image, has_q15 ? &imageq : nullptr);
     if (rc == 0 && !b->poly.empty()) rc = xl_build_launches(b, b->launches_rest, b->classes_rest, big_h, &image, nullptr);
     if (rc != 0) return rc;
   }
+  lap("tiles + tap images (host)");
 
   // ---- CU reservation for the side-stream chain kernel (64 clients per workgroup = per CU, dealt round-robin to the
   // 8 XCDs): recreate the two masked streams when the number of reserved CUs changes
@@ -787,7 +841,9 @@ static int xl_batch_plan(xlating_batch *b) {
     uint32_t want = (b->gcap >= 2 && !b->poly.empty() && b->nco_side != 0) ? (nwg + 7u) / 8u : 0u;
     if (want > 16u) want = 0u;  // (more than half the chip for the chain: such engines are bound by the filtering anyway)
     if (getenv("XL_EXP_NOMASK")) want = 0u;
-    if (want != b->reserve_r) {
+    // (creating a masked stream pair takes ~25 ms: grow at once, shrink only when two CUs per XCD too many are held, so that
+    // a client count hovering around a multiple of 512 does not recreate the streams at every join and leave)
+    if (want > b->reserve_r || want + 2u <= b->reserve_r || (want == 0u && b->reserve_r != 0u)) {
       if (b->cs_masked) (void)hipStreamDestroy(b->cs_masked);
       if (b->nco_masked) (void)hipStreamDestroy(b->nco_masked);
       b->cs_masked = b->nco_masked = nullptr;
@@ -816,14 +872,16 @@ static int xl_batch_plan(xlating_batch *b) {
     }
   }
 
+  lap("masked streams");
   // upload
   if (b->nco.empty()) {
+    xl_plan_trim(b);
     b->dirty = false;
     return 0;
   }
-  XL_TRY(hipMalloc((void **)&b->d_taps, image.size() * sizeof(float) + 256));
+  XL_TRY(xl_plan_alloc(b, (void **)&b->d_taps, image.size() * sizeof(float) + 256));
   XL_TRY(hipMemcpy(b->d_taps, image.data(), image.size() * sizeof(float), hipMemcpyHostToDevice));
-  XL_TRY(hipMalloc((void **)&b->d_nco, b->nco.size() * sizeof(XlNcoClient)));
+  XL_TRY(xl_plan_alloc(b, (void **)&b->d_nco, b->nco.size() * sizeof(XlNcoClient)));
   XL_TRY(hipMemcpy(b->d_nco, b->nco.data(), b->nco.size() * sizeof(XlNcoClient), hipMemcpyHostToDevice));
   if (has_q15) {
     std::vector<uint32_t> qinc;
@@ -831,18 +889,19 @@ static int xl_batch_plan(xlating_batch *b) {
       const Client &c = b->clients[nc.slot];
       qinc.push_back((uint32_t)(uint16_t)c.qincr[0] | ((uint32_t)(uint16_t)c.qincr[1] << 16));
     }
-    XL_TRY(hipMalloc((void **)&b->d_qinc, qinc.size() * sizeof(uint32_t)));
+    XL_TRY(xl_plan_alloc(b, (void **)&b->d_qinc, qinc.size() * sizeof(uint32_t)));
     XL_TRY(hipMemcpy(b->d_qinc, qinc.data(), qinc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    XL_TRY(hipMalloc((void **)&b->d_qtaps, imageq.size() * sizeof(double) + 256));
+    XL_TRY(xl_plan_alloc(b, (void **)&b->d_qtaps, imageq.size() * sizeof(double) + 256));
     XL_TRY(hipMemcpy(b->d_qtaps, imageq.data(), imageq.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   for (Launch *set : {b->launches, b->launches_rest})
     for (int i = 0; i < XL_NLAUNCH; ++i) {
       Launch &L = set[i];
       if (L.groups.empty()) continue;
-      XL_TRY(hipMalloc((void **)&L.d_groups, L.groups.size() * sizeof(XlGroup)));
+      XL_TRY(xl_plan_alloc(b, (void **)&L.d_groups, L.groups.size() * sizeof(XlGroup)));
       XL_TRY(hipMemcpy(L.d_groups, L.groups.data(), L.groups.size() * sizeof(XlGroup), hipMemcpyHostToDevice));
     }
+  lap("uploads (taps, groups, nco)");
   // ---- polyphase classes: images and the per-client branch spectra (device kernel, double arithmetic)
   if (!b->poly.empty()) {
     if (b->d_W == nullptr) {
@@ -870,11 +929,14 @@ static int xl_batch_plan(xlating_batch *b) {
       const std::vector<int> &m = pc.members;
       const size_t rows = (size_t)pc.ncg * pc.Dpad + 1;  // (+1 x M rows: covers the XLP_BSTEP rows of tail padding)
       const uint32_t passes = (pc.nseg_cap + XLP_SEG - 1) / XLP_SEG;
-      XL_TRY(hipMalloc((void **)&pc.d_R, rows * pc.M * XLP_COLS * sizeof(float2)));
-      XL_TRY(hipMemset(pc.d_R, 0, rows * pc.M * XLP_COLS * sizeof(float2)));
-      XL_TRY(hipMalloc((void **)&pc.d_X, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2)));
-      XL_TRY(hipMemset(pc.d_X, 0, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2)));
-      XL_TRY(hipMalloc((void **)&pc.d_Y, (size_t)pc.ncg * pc.nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
+      // (R: the tables kernel writes every entry of the image proper, zeros included; its tail padding rows are only ever
+      // loaded, never used.  X: the padding branches and the unused segment slots of the last pass are multiplied by zeros
+      // / accumulated into segments that are never stored, but must be finite: cleared here, on the engine's stream.)
+      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_R, rows * pc.M * XLP_COLS * sizeof(float2)));
+      XL_TRY(hipMemsetAsync(pc.d_R + ((size_t)pc.ncg * pc.Dpad) * pc.M * XLP_COLS, 0, (size_t)pc.M * XLP_COLS * sizeof(float2), b->own_stream));
+      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_X, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2)));
+      XL_TRY(hipMemsetAsync(pc.d_X, 0, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2), b->own_stream));
+      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_Y, (size_t)pc.ncg * pc.nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
       std::vector<XlpCol> cols((size_t)pc.ncg * XLP_COLS);
       for (XlpCol &cc : cols) {
         cc.out_off = 0xFFFFFFFFu;
@@ -894,26 +956,28 @@ static int xl_batch_plan(xlating_batch *b) {
           rt[((size_t)i * pc.ncols + j) * 2 + 1] = c.rt[2 * i + 1];
         }
       }
-      XL_TRY(hipMalloc((void **)&pc.d_cols, cols.size() * sizeof(XlpCol)));
+      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_cols, cols.size() * sizeof(XlpCol)));
       XL_TRY(hipMemcpy(pc.d_cols, cols.data(), cols.size() * sizeof(XlpCol), hipMemcpyHostToDevice));
       float2 *d_rt = nullptr;
       uint32_t *d_delta = nullptr;
-      XL_TRY(hipMalloc((void **)&d_rt, rt.size() * sizeof(float)));
-      hipError_t e = hipMalloc((void **)&d_delta, delta.size() * sizeof(uint32_t));
+      XL_TRY(xl_plan_alloc(b, (void **)&d_rt, rt.size() * sizeof(float)));
+      hipError_t e = xl_plan_alloc(b, (void **)&d_delta, delta.size() * sizeof(uint32_t));
       if (e == hipSuccess) e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
       if (e == hipSuccess) e = hipMemcpy(d_delta, delta.data(), delta.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
       if (e == hipSuccess)
         e = xlp_launch_tables(d_rt, d_delta, pc.ncols, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.ncg, pc.d_R, b->own_stream);
       if (e == hipSuccess) e = hipStreamSynchronize(b->own_stream);
-      (void)hipFree(d_rt);
-      if (d_delta) (void)hipFree(d_delta);
+      xl_plan_release(b, d_rt);  // (scratch: spare again at once)
+      xl_plan_release(b, d_delta);
       if (e != hipSuccess) {
         xl_last_hip_error = e;
         goto fail;
       }
     }
   }
+  lap("polyphase images + R kernel");
   if (b->out_total > b->out_alloc) {
+    const size_t want = b->out_total + b->out_total / 8 + 64;  // (headroom: the next joins do not reallocate the outputs)
     for (int i = 0; i < 2; ++i) {
       if (b->d_out[i]) (void)hipFree(b->d_out[i]);
       if (b->d_phtab[i]) (void)hipFree(b->d_phtab[i]);
@@ -922,13 +986,16 @@ static int xl_batch_plan(xlating_batch *b) {
     b->out_alloc = 0;
     if (b->d_qphtab) (void)hipFree(b->d_qphtab);
     b->d_qphtab = nullptr;
-    XL_TRY(hipMalloc((void **)&b->d_qphtab, (b->out_total / XL_PH_STRIDE + 8) * sizeof(short2)));
+    XL_TRY(hipMalloc((void **)&b->d_qphtab, (want / XL_PH_STRIDE + 8) * sizeof(short2)));
     for (int i = 0; i < 2; ++i) {
-      XL_TRY(hipMalloc((void **)&b->d_out[i], b->out_total * sizeof(float2)));
-      XL_TRY(hipMalloc((void **)&b->d_phtab[i], (b->out_total / XL_PH_STRIDE + 8) * sizeof(float2)));  // every XL_PH_STRIDE-th phase
+      XL_TRY(hipMalloc((void **)&b->d_out[i], want * sizeof(float2)));
+      XL_TRY(hipMalloc((void **)&b->d_phtab[i], (want / XL_PH_STRIDE + 8) * sizeof(float2)));  // every XL_PH_STRIDE-th phase
     }
-    b->out_alloc = b->out_total;
+    b->out_alloc = want;
   }
+  lap("output buffers");
+  xl_plan_trim(b);
+  lap("trim");
   b->dirty = false;
   return 0;
 fail:
@@ -989,6 +1056,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
   if (S > b->max_samples || G < 1 || G > b->gcap || (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED && mode != XL_MODE_Q15) ||
       (mode == XL_MODE_Q15 && b->fmt == XL_FMT_CF32))
     return -EINVAL;
+  if (mode == XL_MODE_Q15 && !b->want_q15) {  // (the Q15 tap image is built from the first Q15 call on)
+    b->want_q15 = true;
+    b->dirty = true;
+  }
   if (b->poisoned) return -EIO;
   // a client that was still inside its zero-history when the plan was built may be mature by now: it then joins
   // the class of its grid (direct kernel) / its (D, T) class (polyphase) -- re-plan
