@@ -97,6 +97,21 @@ XL_DEV uint32_t xl_lds_poll(const uint32_t addr) {
   XLC_MUL "v_and_b32 %[off], 0x7fff, %[off]\n\t" XLC_ADD                \
   XLC_MUL "v_add_u32 %[addr], %[off], %[base]\n\t" XLC_ADD              \
   XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP
+// Four consecutive entries whose ring slots do not wrap (entry index = 0 mod 4): the slots are addressed with immediate
+// offsets, the ring address is advanced once per four entries, and the loop around it closes once per 64 steps.
+#define XLC_STEPS10 XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP XLC_STEP
+#define XLC_QENTRY(OFFS)                                                \
+  XLC_MUL "ds_write_b64 %[addr], %[p] offset:" OFFS "\n\t" XLC_ADD      \
+  XLC_MUL "v_add_u32 %[cnt], 1, %[cnt]\n\t" XLC_ADD                     \
+  XLC_MUL "ds_write_b32 %[paddr], %[cnt]\n\t" XLC_ADD
+#define XLC_QUAD                                                        \
+  XLC_QENTRY("0") XLC_STEP XLC_STEP XLC_STEP XLC_STEPS10                \
+  XLC_QENTRY("512") XLC_STEP XLC_STEP XLC_STEP XLC_STEPS10              \
+  XLC_QENTRY("1024") XLC_STEP XLC_STEP XLC_STEP XLC_STEPS10             \
+  XLC_QENTRY("1536")                                                    \
+  XLC_MUL "v_add_u32 %[off], 0x800, %[off]\n\t" XLC_ADD                 \
+  XLC_MUL "v_and_b32 %[off], 0x7fff, %[off]\n\t" XLC_ADD                \
+  XLC_MUL "v_add_u32 %[addr], %[off], %[base]\n\t" XLC_ADD XLC_STEPS10
 static_assert(XL_PH_STRIDE == 16u && XLC_RING * 64u * 8u == 0x8000u, "XLC_ENTRY is written for 16 steps per entry and a 32 KB ring");
 
 __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
@@ -171,18 +186,21 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
           uint32_t off = ((ee & (XLC_RING - 1u)) << 9) + lane * (uint32_t)sizeof(v2f);  // ring offset of entry ee, this lane
           uint32_t addr = a_ring0 + off, cnt = ee;
           v2f t1, t2;
-          for (; ee + 2u <= chunk_end; ee += 2u)
-            asm volatile(XLC_ENTRY XLC_ENTRY
-                         : [p] "+v"(p), [off] "+v"(off), [addr] "+v"(addr), [cnt] "+v"(cnt), [t1] "=&v"(t1), [t2] "=&v"(t2)
-                         : [inc] "v"(inc), [base] "v"(a_ring0), [paddr] "v"(a_prod)
-                         : "memory");
-          if (ee < chunk_end) {
+          for (; ee < chunk_end && (ee & 3u) != 0u; ++ee)  // up to a multiple of four
             asm volatile(XLC_ENTRY
                          : [p] "+v"(p), [off] "+v"(off), [addr] "+v"(addr), [cnt] "+v"(cnt), [t1] "=&v"(t1), [t2] "=&v"(t2)
                          : [inc] "v"(inc), [base] "v"(a_ring0), [paddr] "v"(a_prod)
                          : "memory");
-            ++ee;
-          }
+          for (; ee + 4u <= chunk_end; ee += 4u)
+            asm volatile(XLC_QUAD
+                         : [p] "+v"(p), [off] "+v"(off), [addr] "+v"(addr), [cnt] "+v"(cnt), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                         : [inc] "v"(inc), [base] "v"(a_ring0), [paddr] "v"(a_prod)
+                         : "memory");
+          for (; ee < chunk_end; ++ee)
+            asm volatile(XLC_ENTRY
+                         : [p] "+v"(p), [off] "+v"(off), [addr] "+v"(addr), [cnt] "+v"(cnt), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                         : [inc] "v"(inc), [base] "v"(a_ring0), [paddr] "v"(a_prod)
+                         : "memory");
         }
       }
       if (e_stop > e) e = e_stop;
