@@ -62,7 +62,7 @@ struct XlpArgs {
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
   const float2 *R;     // branch spectra   [cg][M][Dpad][XLP_COLS] (+ XLP_BSTEP rows of tail padding)
-  float2 *Y;           // mixed spectra    [cg][nseg_cap][M][XLP_COLS]
+  float2 *Y;           // mixed spectra    [cg][nseg_cap][sub][M][CW], CW = 32 (M = 128) / 16 (M = 256) columns: one inverse tile contiguous
   const XlpCol *cols;  // per column
   const float2 *phtab;
   float2 *out;

@@ -313,12 +313,16 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
       }
     }
   }
+  // Y image [cg][segment][sub][bin][CW columns]: the tile one inverse workgroup reads -- (segment, CW columns), all bins --
+  // is one contiguous 32 KB run; this wave's 128 columns of one bin land as 128 / CW pieces of CW * 8 bytes.
   const uint32_t s0 = pass * XLP_SEG;
-  v4f *__restrict__ Yp =
-      reinterpret_cast<v4f *>(a.Y) + (((size_t)cg * a.nseg_cap + s0) * M + m) * (XLP_COLS / 2) + lane;
+  const uint32_t CW = M == 256u ? 16u : 32u, NSUB = XLP_COLS / CW;
+  const uint32_t sub = (2u * lane) / CW, cw = (2u * lane) % CW;
+  v4f *__restrict__ Yp = reinterpret_cast<v4f *>(a.Y) +
+                         ((((size_t)cg * a.nseg_cap + s0) * NSUB + sub) * M + m) * (CW / 2) + cw / 2;
 #pragma unroll
   for (int i = 0; i < (int)XLP_SEG; ++i)
-    if (s0 + i < a.nseg) Yp[(size_t)i * M * (XLP_COLS / 2)] = (v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y};
+    if (s0 + i < a.nseg) Yp[(size_t)i * NSUB * M * (CW / 2)] = (v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y};
   xlp_trace_work(a, t_begin);
 }
 
@@ -350,15 +354,15 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
   const uint32_t h = j / L, l = j % L;  // (h = 0 for M = 256)
   const XlpTw tw = xlp_twiddles<+1, M>(reinterpret_cast<const v2f *>(a.W), l);
   {
-    // Y tile: M bins x CW columns = M chunks of CW * 8 contiguous bytes, 1 KB apart.  CW / 2 lanes share a chunk
-    // (16 bytes = 2 columns each), so a load instruction touches full lines instead of 64 partial ones.
+    // Y tile: M bins x CW columns, one contiguous 32 KB run (the mix kernel lays it out so): thread (mrow, part) takes
+    // 16 bytes = 2 columns of bin mrow + MR i -- every load instruction of the workgroup covers 4 KB back to back.
     constexpr uint32_t PARTS = CW / 2, MR = 256 / PARTS;
     const uint32_t part = threadIdx.x % PARTS, mrow = threadIdx.x / PARTS;
     const v4f *__restrict__ src = reinterpret_cast<const v4f *>(
-        a.Y + (((size_t)cg * a.nseg_cap + s) * M) * XLP_COLS + sub * CW) + part;
+        a.Y + ((((size_t)cg * a.nseg_cap + s) * NSUB + sub) * M) * CW) + part;
     v4f v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(mrow + MR * i) * (XLP_COLS / 2)];
+    for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(mrow + MR * i) * PARTS];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t m = mrow + MR * i;
