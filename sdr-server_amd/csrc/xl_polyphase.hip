@@ -151,6 +151,7 @@ XL_DEV void xlp_nco_role(const XlpArgs &a) {
 
 // tuning: time span of the work (non-NCO) waves of a launch
 XL_DEV void xlp_trace_work(const XlpArgs &a, const unsigned long long t0) {
+#ifdef XL_TUNING  // (the engine only ever sets a.trace in a tuning build; outside one the bookkeeping is not carried along)
   if (a.trace && (threadIdx.x & 63u) == 0u) {  // per work wave: start, end, placement (own slot: no atomics)
     const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
     const uint32_t slot = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -162,6 +163,10 @@ XL_DEV void xlp_trace_work(const XlpArgs &a, const unsigned long long t0) {
              __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
     }
   }
+#else
+  (void)a;
+  (void)t0;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------- forward transforms
@@ -233,6 +238,40 @@ XL_DEV void xlp_cmac(v2f &acc, const v2f r, const v2f x) {
       : "v"(r), "v"(x));
 }
 
+// the same product with the X operand in SGPRs (wave-uniform)
+XL_DEV void xlp_cmac_s(v2f &acc, const v2f r, const v2f x) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "+v"(acc)
+      : "v"(r), "s"(x));
+}
+// one row of the shared-spectrum image: XLP_SEG = 14 complex values = 28 dwords, fetched by scalar loads
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+struct XlpXRow {
+  v16f a;  // segments 0..7
+  v8f b;   // segments 8..11
+  v4f c;   // segments 12, 13
+};
+static_assert(XLP_SEG == 14u && XLP_XS == 16u, "XlpXRow is written for rows of 14 segments in 128 bytes");
+// Scalar loads return out of order and the compiler sinks them to their first use (one exposed latency per row), so the
+// request and the wait are placed by hand: xlp_xrow_request() only ISSUES the three loads -- the row is not valid until
+// xlp_xrow_wait(), which every later use depends on through its tied operands.  Between the two the row must not be
+// touched (the compiler has no reason to: nothing else reads it).
+// `pin` (a VGPR value the following multiplies read / the preceding ones wrote) keeps the compiler from moving them across.
+XL_DEV void xlp_xrow_request(XlpXRow &x, const uint64_t row, v4f &pin) {
+  asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x40\n\ts_load_dwordx4 %2, %4, 0x60"
+               : "=&s"(x.a), "=&s"(x.b), "=&s"(x.c), "+v"(pin)
+               : "s"(row));
+}
+XL_DEV void xlp_xrow_wait(XlpXRow &x, v2f &pin0, v2f &pin1) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x.a), "+s"(x.b), "+s"(x.c), "+v"(pin0), "+v"(pin1));
+}
+#define XLP_X2(ROW, I)                                                   \
+  ((I) < 8    ? (v2f){(ROW).a[2 * ((I) & 7)], (ROW).a[2 * ((I) & 7) + 1]} \
+   : (I) < 12 ? (v2f){(ROW).b[2 * ((I) & 3)], (ROW).b[2 * ((I) & 3) + 1]} \
+              : (v2f){(ROW).c[2 * ((I) & 1)], (ROW).c[2 * ((I) & 1) + 1]})
+
 // grid = nco_blocks + M * ncg * passes workgroups of ONE wave = (bin m, column group, pass = 14 segments); lane l =
 // client columns cg*128 + 2l, 2l+1; the spectrum bin m is workgroup-uniform.  The bin's column of the shared spectra
 // (Dpad rows of 14 segments, 128 bytes each) is staged in LDS once and read back row by row as broadcast reads (every
@@ -244,8 +283,12 @@ XL_DEV void xlp_cmac(v2f &acc, const v2f r, const v2f x) {
 // the grid -- same XCD (workgroups are dealt to the XCDs round-robin), dispatched together -- so that R comes from HBM
 // once and the other passes hit that XCD's L2.  (The passes as waves of one workgroup gave the same traffic but an
 // uneven deal: two-wave workgroups left SIMDs with 1 to 3 waves, and the launch ends with the fullest.)
+// TRIPS > 0: the branch count is TRIPS * XLP_BSTEP and the row loop is unrolled completely; 0: any count, a loop.  (A row
+// waiting in SGPRs across the loop's back edge is something the compiler will not do: it parks the row in VGPRs, and the
+// first row of every trip multiplies from there -- 28 more VGPRs, 14 copies per trip.  The server default, D = 42, gets
+// the straight-line variant.)
+template <int TRIPS>
 __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
-  extern __shared__ __attribute__((aligned(16))) v4f xlp_xcol[];  // [Dpad][8]
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a);
     return;
@@ -267,62 +310,76 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
   const v4f *__restrict__ Rp =
       reinterpret_cast<const v4f *>(a.R) + ((size_t)cg * M + m) * a.Dpad * (XLP_COLS / 2) + lane;
   const size_t rstride = XLP_COLS / 2;
-  v4f r[XLP_BSTEP];
+  // (ring slots: the straight-line variant knows every row's slot at compile time and gets by with 4 -- 8 VGPRs fewer,
+  // which is what takes it from 4 to 5 waves per SIMD; the loop needs a slot count that divides its trip length)
+  constexpr int RING = TRIPS > 0 ? 4 : (int)XLP_BSTEP;
+  v4f r[RING];
 #pragma unroll
-  for (int u = 0; u < (int)XLP_BSTEP - 1; ++u) r[u] = Rp[(size_t)u * rstride];
-  {
-    const v4f *__restrict__ Xc =
-        reinterpret_cast<const v4f *>(a.X + ((size_t)pass * a.Dpad * M + m) * XLP_XS);  // row stride M * 8 v4f
-    const uint32_t n8 = a.Dpad * 8u;
-    for (uint32_t base = 0; base < n8; base += 512u) {  // one trip for D <= 64; all loads of a trip in flight together
-      v4f t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t i = base + lane + 64u * u;
-        const uint32_t ic = i < n8 ? i : 0u;
-        t[u] = Xc[(size_t)(ic >> 3) * (M * 8u) + (ic & 7u)];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t i = base + lane + 64u * u;
-        if (i < n8) xlp_xcol[i] = t[u];
-      }
-    }
-  }
-  __syncthreads();
-  v2f acc0[XLP_SEG], acc1[XLP_SEG];
-#pragma unroll
-  for (int i = 0; i < (int)XLP_SEG; ++i) acc0[i] = acc1[i] = (v2f){0.0f, 0.0f};
-  for (uint32_t b0 = 0; b0 < a.Dpad; b0 += XLP_BSTEP) {
-#pragma unroll
-    for (int u = 0; u < (int)XLP_BSTEP; ++u) {
-      // (the last trips request rows past this workgroup's: the next one's, or the tail padding the engine
-      // allocates -- loaded, never used)
-      constexpr int PF = (int)XLP_BSTEP - 1;
-      r[(u + PF) % (int)XLP_BSTEP] = Rp[(size_t)(b0 + u + PF) * rstride];
-      const v4f *__restrict__ xr = xlp_xcol + (b0 + u) * 8u;
-      const v2f ra = {r[u].x, r[u].y}, rb = {r[u].z, r[u].w};
-#pragma unroll
-      for (int i = 0; i < (int)XLP_SEG / 2; ++i) {
-        const v4f x2 = xr[i];
-        const v2f xa = {x2.x, x2.y}, xb = {x2.z, x2.w};
-        xlp_cmac(acc0[2 * i], ra, xa);
-        xlp_cmac(acc1[2 * i], rb, xa);
-        xlp_cmac(acc0[2 * i + 1], ra, xb);
-        xlp_cmac(acc1[2 * i + 1], rb, xb);
-      }
-    }
-  }
+  for (int u = 0; u < RING - 1; ++u) r[u] = Rp[(size_t)u * rstride];
+  // X rows of this (pass, bin): 128 bytes each (14 segments + pad), M * 128 bytes apart -- wave-uniform, so they travel
+  // through the scalar cache into SGPRs (one row = s_load_dwordx16 + x8 + x4) and enter the packed FMAs as the scalar
+  // operand: no LDS traffic, and an FMA reads two 64-bit VGPR operands instead of three.
   // Y image [cg][segment][sub][bin][CW columns]: the tile one inverse workgroup reads -- (segment, CW columns), all bins --
-  // is one contiguous 32 KB run; this wave's 128 columns of one bin land as 128 / CW pieces of CW * 8 bytes.
+  // is one contiguous 32 KB run; this wave's 128 columns of one bin land as 128 / CW pieces of CW * 8 bytes.  (Address and
+  // bounds are worked out here, before the row loop: what it keeps alive across it is then two VGPRs and two SGPRs --
+  // the loop itself needs all the SGPRs it can get.)
   const uint32_t s0 = pass * XLP_SEG;
   const uint32_t CW = M == 256u ? 16u : 32u, NSUB = XLP_COLS / CW;
   const uint32_t sub = (2u * lane) / CW, cw = (2u * lane) % CW;
   v4f *__restrict__ Yp = reinterpret_cast<v4f *>(a.Y) +
                          ((((size_t)cg * a.nseg_cap + s0) * NSUB + sub) * M + m) * (CW / 2) + cw / 2;
+  const uint32_t ystride = NSUB * M * (CW / 2);  // v4f per segment
+  const uint32_t nvalid = a.nseg > s0 ? a.nseg - s0 : 0u;
+  // (wave-uniform by construction; the readfirstlanes make it so for the register allocator as well -- a uniform value
+  // it chose to compute on the VALU would otherwise reach the s_loads in VGPRs)
+  const uint64_t xbase_v = (uint64_t)(uintptr_t)(a.X + ((size_t)pass * a.Dpad * M + m) * XLP_XS);
+  const uint64_t xbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(xbase_v >> 32)) << 32) |
+                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)xbase_v);  // (the builtin returns int)
+  const uint32_t xstride = M * XLP_XS * (uint32_t)sizeof(float2);
+  XlpXRow xa, xb;
+  xlp_xrow_request(xa, xbase, r[0]);  // (u below: the row's position in the ring's cycle)
+  v2f acc0[XLP_SEG], acc1[XLP_SEG];
+#pragma unroll
+  for (int i = 0; i < (int)XLP_SEG; ++i) acc0[i] = acc1[i] = (v2f){0.0f, 0.0f};
+  xlp_xrow_wait(xa, acc0[0], acc1[0]);
+  // one row: request the next (clamped to the last: loaded, never used), multiply this one, wait for the next
+  auto row = [&](const XlpXRow &cur, XlpXRow &nxt, const uint32_t b, const int u) __attribute__((always_inline)) {
+    // (the last trips request R rows past this workgroup's: the next one's, or the tail padding the engine allocates)
+    constexpr int PF = RING - 1;
+    r[(u + PF) % RING] = Rp[(size_t)(b + PF) * rstride];
+    const uint32_t nrows = TRIPS > 0 ? (uint32_t)TRIPS * XLP_BSTEP : a.Dpad;
+    const uint32_t bn = b + 1u < nrows ? b + 1u : b;
+    xlp_xrow_request(nxt, xbase + (uint32_t)__builtin_amdgcn_readfirstlane(bn * xstride), r[u % RING]);
+    const v2f ra = {r[u % RING].x, r[u % RING].y}, rb = {r[u % RING].z, r[u % RING].w};
+#pragma unroll
+    for (int i = 0; i < (int)XLP_SEG; ++i) {
+      xlp_cmac_s(acc0[i], ra, XLP_X2(cur, i));
+      xlp_cmac_s(acc1[i], rb, XLP_X2(cur, i));
+    }
+    xlp_xrow_wait(nxt, acc0[XLP_SEG - 1], acc1[XLP_SEG - 1]);
+  };
+  static_assert(XLP_BSTEP % 2u == 0u, "the two row buffers alternate: an even number of rows per trip");
+  if (TRIPS > 0) {
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+#pragma unroll
+      for (int u = 0; u < (int)XLP_BSTEP; u += 2) {
+        row(xa, xb, (uint32_t)(t * (int)XLP_BSTEP + u), t * (int)XLP_BSTEP + u);
+        row(xb, xa, (uint32_t)(t * (int)XLP_BSTEP + u + 1), t * (int)XLP_BSTEP + u + 1);
+      }
+    }
+  } else {
+    for (uint32_t b0 = 0; b0 < a.Dpad; b0 += XLP_BSTEP) {
+#pragma unroll
+      for (int u = 0; u < (int)XLP_BSTEP; u += 2) {
+        row(xa, xb, b0 + (uint32_t)u, u);
+        row(xb, xa, b0 + (uint32_t)u + 1u, u + 1);
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < (int)XLP_SEG; ++i)
-    if (s0 + i < a.nseg) Yp[(size_t)i * NSUB * M * (CW / 2)] = (v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y};
+    if ((uint32_t)i < nvalid) Yp[(size_t)i * ystride] = (v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y};
   xlp_trace_work(a, t_begin);
 }
 
@@ -509,12 +566,12 @@ static XlpArgs xlp_checked_skip(const XlpArgs &a, uint32_t work_blocks) {
 hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
   const uint32_t passes = (a0.nseg + XLP_SEG - 1) / XLP_SEG;
-  const size_t lds = (size_t)a0.Dpad * 8u * sizeof(v4f);
-  if (lds > 64 * 1024) return hipErrorInvalidValue;
   const uint32_t work = a0.M * a0.ncg * passes;
   XlpArgs a = xlp_checked_skip(a0, work);
   a.mix_passes = passes;
-  hipLaunchKernelGGL(xlp_mix_kernel, dim3(a.nco_blocks + a.nco_skip + work), dim3(64), lds, s, a);
+  const dim3 grid(a.nco_blocks + a.nco_skip + work);
+  if (a.Dpad == 7u * XLP_BSTEP) hipLaunchKernelGGL(xlp_mix_kernel<7>, grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(xlp_mix_kernel<0>, grid, dim3(64), 0, s, a);
   return hipGetLastError();
 }
 
