@@ -1221,8 +1221,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
       }
       if (b->ev_done_valid[tab ^ 1]) XL_TRY(hipStreamWaitEvent(ns, b->ev_done[tab ^ 1], 0));
       XL_TRY(xl_launch_nco_chain(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[pcur], b->d_phase[pcur ^ 1],
-                                 b->d_phtab[tab ^ 1], xl_grid_next(pos), b->d_chain_stats, ns));
-      XL_TRY(hipEventRecord(b->ev_chain[tab ^ 1], ns));
+                                 b->d_phtab[tab ^ 1], xl_grid_next(pos), b->d_chain_stats, ns, b->ev_chain[tab ^ 1]));
     }
 
     // ---- the launches on the caller's stream: window images from [d_hist[hb] | blocks], phases from table[tab] ->

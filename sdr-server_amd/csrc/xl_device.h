@@ -121,7 +121,7 @@ hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, co
 // chain wave writing into an LDS ring + three waves draining it into the table)
 // stats (tuning, may be null): per workgroup {shader cycles, 100 MHz ticks, entries, start tick} of the chain wave
 hipError_t xl_launch_nco_chain(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in, float2 *state_out,
-                               float2 *phtab, XlPos pos, unsigned long long *stats, hipStream_t s);
+                               float2 *phtab, XlPos pos, unsigned long long *stats, hipStream_t s, hipEvent_t done);
 // raw -> converted sample images of the single-filter path (xlating.c:352-433)
 hipError_t xl_launch_convert_cf32(const void *raw, int fmt, uint32_t nsamples, float2 *dst, hipStream_t s);
 hipError_t xl_launch_convert_q15(const void *raw, int fmt, uint32_t nelems, int16_t *dst, hipStream_t s);

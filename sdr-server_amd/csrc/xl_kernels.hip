@@ -26,6 +26,8 @@
 //               output tiles of a group re-read the same taps, which then stay in that XCD's L2.
 #include "xl_dev_inline.h"
 
+#include <hip/hip_ext.h>
+
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------- NCO phase table
@@ -591,11 +593,17 @@ hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, co
   return hipGetLastError();
 }
 
+// `done` (optional): recorded with the kernel's own completion signal (hipExtLaunchKernelGGL's stop event) -- one packet
+// on the queue instead of the kernel plus a separate event record.
 hipError_t xl_launch_nco_chain(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in, float2 *state_out,
-                               float2 *phtab, XlPos pos, unsigned long long *stats, hipStream_t s) {
-  if (nclients == 0) return hipSuccess;
-  hipLaunchKernelGGL(xl_nco_chain_kernel, dim3((nclients + 63u) / 64u), dim3(256), 0, s, clients, nclients, state_in,
-                     state_out, phtab, pos, stats);
+                               float2 *phtab, XlPos pos, unsigned long long *stats, hipStream_t s, hipEvent_t done) {
+  if (nclients == 0) return done ? hipEventRecord(done, s) : hipSuccess;
+  if (done)
+    hipExtLaunchKernelGGL(xl_nco_chain_kernel, dim3((nclients + 63u) / 64u), dim3(256), 0, s, nullptr, done, 0, clients,
+                          nclients, state_in, state_out, phtab, pos, stats);
+  else
+    hipLaunchKernelGGL(xl_nco_chain_kernel, dim3((nclients + 63u) / 64u), dim3(256), 0, s, clients, nclients, state_in,
+                       state_out, phtab, pos, stats);
   return hipGetLastError();
 }
 
