@@ -131,6 +131,7 @@ struct xlating_batch_t {
   hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};  // per phase table
   bool ev_done_valid[2] = {false, false};
   bool spec_on_side = false;  // the look-ahead table was produced on nco_stream (ev_chain must be waited for)
+  double macs_all = 0.0, macs_rest = 0.0;  // complex MACs per sample of a block: all clients' direct launches / those outside `poly`
   int nco_side = -1;          // option "nco_side_stream": 1 always, 0 never (NCO role inside the launches), -1: calls of >= 2 blocks
   bool poisoned = false;              // a launch failed mid-call: device state is undefined, every later call fails
 
@@ -691,6 +692,13 @@ static int xl_build_launches(xlating_batch *b, Launch *Ls, const std::vector<Dir
   return 0;
 }
 
+// Direct FIR launches whose own work is short against the NCO chain (~25-32 us per block) gain from the side-stream chain
+// kernel on reserved CUs like the polyphase launches do; heavier ones hide the chain in their spare waves for free and
+// would only lose the reserved CUs.  Measured, 8 blocks per call, us per block fused -> side: 128 clients x 101 taps
+// (40 M complex MACs per block) 29.9 -> 27.1; 128 x 505 native (202 M) 40.5 -> 35.5; 1024 x 101 (323 M) 37.9 -> 40.4;
+// 1024 x 505 native (1615 M) 203 -> 227.
+static bool xl_direct_is_light(double macs_per_block) { return macs_per_block < 250e6; }
+
 static int xl_batch_plan(xlating_batch *b) {
   // tuning: XL_EXP_PLAN_TIMING=1 prints where a re-plan spends its time
   static const bool plan_timing = getenv("XL_EXP_PLAN_TIMING") != nullptr;
@@ -838,7 +846,11 @@ static int xl_batch_plan(xlating_batch *b) {
   // 8 XCDs): recreate the two masked streams when the number of reserved CUs changes
   {
     const uint32_t nwg = ((uint32_t)b->nco.size() + 63u) / 64u;
-    uint32_t want = (b->gcap >= 2 && !b->poly.empty() && b->nco_side != 0) ? (nwg + 7u) / 8u : 0u;
+    b->macs_all = b->macs_rest = 0.0;
+    for (const DirectClass &cs : b->classes) b->macs_all += (double)cs.members.size() * cs.T / cs.D;
+    for (const DirectClass &cs : b->classes_rest) b->macs_rest += (double)cs.members.size() * cs.T / cs.D;
+    const bool light = xl_direct_is_light(b->macs_all * b->max_samples) || (!b->poly.empty() && xl_direct_is_light(b->macs_rest * b->max_samples));
+    uint32_t want = (b->gcap >= 2 && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? (nwg + 7u) / 8u : 0u;
     if (want > 16u) want = 0u;  // (more than half the chip for the chain: such engines are bound by the filtering anyway)
     if (getenv("XL_EXP_NOMASK")) want = 0u;
     // (creating a masked stream pair takes ~25 ms: grow at once, shrink only when two CUs per XCD too many are held, so that
@@ -1088,7 +1100,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
   uint32_t maxK = 0;  // the most outputs any client produces in this call
   for (const DirectClass &cs : b->classes) maxK = std::max(maxK, xl_grid_dyn(cs.D, cs.T, cs.rem0, cs.hv0, pos).K);
   const bool use_poly = mode == XL_MODE_OPTIMIZED && !b->poly.empty() && maxK >= 2 * XLP_M_MAX;
-  const bool side_call = mode != XL_MODE_Q15 && (b->nco_side > 0 || (b->nco_side < 0 && G >= 2 && use_poly));
+  const bool light = xl_direct_is_light((use_poly ? b->macs_rest : b->macs_all) * (double)S);
+  const bool side_call = mode != XL_MODE_Q15 && (b->nco_side > 0 || (b->nco_side < 0 && G >= 2 && (use_poly || (light && b->cs_masked && s == XL_STREAM_ENGINE_P))));  // (a caller's own, unmasked stream would keep filling the chain's CUs)
   if (s == XL_STREAM_ENGINE_P) s = (side_call && b->cs_masked) ? b->cs_masked : b->own_stream;
   // Calls depend on each other through the engine's device state (history, phases, tables): a call on another
   // stream than the previous one is ordered behind it.
