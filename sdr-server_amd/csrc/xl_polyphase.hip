@@ -170,20 +170,24 @@ XL_DEV void xlp_trace_work(const XlpArgs &a, const unsigned long long t0) {
 }
 
 // ------------------------------------------------------------------------------------------- forward transforms
-// grid = nco_blocks + ceil(nseg * D / TPW) transform workgroups (one wave each: TPW = 256 / M transforms) +
-// a.roll_blocks history-roll workgroups.
+// grid = nco_blocks + passes * D transform workgroups + a.roll_blocks history-roll workgroups.  A transform workgroup =
+// (pass, branch b): the XLP_SEG = 14 segments of the pass, one transform each on M / 4 lanes (14 * M / 4 threads: 448 or
+// 896).  The spectra go through LDS once more so that the image rows X[pass][b][m][0..15] -- what the mix kernel fetches
+// as one 128-byte scalar row -- leave as whole lines: 8 lanes x 16 bytes per row, the workgroup's 16 KB (M = 128) back to
+// back.  (One wave per transform storing its 8-byte values 128 bytes apart wrote 40 MB for an 11 MB image and took 25 us
+// per call of 8 blocks at 1024 clients.)
 template <int M>
-__global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a) {
-  constexpr uint32_t TPW = 256 / M, L = M / 4;
-  __shared__ v2f lds[TPW][XLP_ROW(M)];
+__global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpArgs a) {
+  constexpr uint32_t L = M / 4, NT = XLP_SEG * L;
+  __shared__ v2f lds[XLP_SEG][XLP_ROW(M)];
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a);
     return;
   }
   const uint32_t bid = blockIdx.x - a.nco_blocks;
   const uint32_t j = threadIdx.x;
-  const uint32_t ntr = a.nseg * a.D;
-  const uint32_t nwg = (ntr + TPW - 1u) / TPW;
+  const uint32_t passes = (a.nseg + XLP_SEG - 1u) / XLP_SEG;
+  const uint32_t nwg = passes * a.D;
   if (bid >= nwg) {
     // raw-history roll (as in xl_fir_kernel): hist_out = the last hist_units 2-byte units of [in0 | in1]; nothing in
     // this block's launches reads hist_out
@@ -191,17 +195,17 @@ __global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a) {
     const uint16_t *__restrict__ h0 = reinterpret_cast<const uint16_t *>(a.in0);
     const uint16_t *__restrict__ h1 = reinterpret_cast<const uint16_t *>(a.in1);
     uint16_t *__restrict__ ho = reinterpret_cast<uint16_t *>(a.hist_out);
-    for (uint32_t i = rb * 64u + j; i < a.hist_units; i += a.roll_blocks * 64u) {
+    for (uint32_t i = rb * NT + j; i < a.hist_units; i += a.roll_blocks * NT) {
       const uint32_t sidx = a.block_units + i;
       ho[i] = (sidx < a.hist_units) ? h0[sidx] : h1[sidx - a.hist_units];
     }
     return;
   }
-  const uint32_t h = j / L, l = j % L;  // transform of this wave, lane within it
+  const uint32_t h = j / L, l = j % L;  // transform (= segment of the pass) of this lane, lane within it
   const XlpTw tw = xlp_twiddles<-1, M>(reinterpret_cast<const v2f *>(a.W), l);
-  const uint32_t tr = bid * TPW + h;
-  const bool live = tr < ntr;
-  const uint32_t s = (live ? tr : 0u) / a.D, b = (live ? tr : 0u) - s * a.D;
+  const uint32_t pass = bid / a.D, b = bid - pass * a.D;
+  const uint32_t s = pass * XLP_SEG + h;
+  const bool live = s < a.nseg;  // (the last pass may hold fewer segments: zeros, never read by the mix kernel)
   // branch sample n of segment s = stream sample base + (s V + n) D + b   (base: first tap of shared point 0)
   const uint32_t first = a.base + s * a.V * a.D + b;
   const uint32_t end = a.n0 + a.n1;
@@ -218,11 +222,17 @@ __global__ __launch_bounds__(64) void xlp_forward_kernel(const XlpArgs a) {
   }
   v2f *const bufs[1] = {lds[h]};
   xlp_dft<-1, 1, M>(u, bufs, tw, l);
-  const uint32_t pass = s / XLP_SEG, si = s - pass * XLP_SEG;
-  v2f *__restrict__ X = reinterpret_cast<v2f *>(a.X);
-  if (live) {
+  // the transform's row, natural order (its own scratch: the LDS operations of a wave execute in order)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X[(((size_t)pass * a.Dpad + b) * M + (l + L * r)) * XLP_XS + si] = u[0][r];
+  for (int r = 0; r < 4; ++r) lds[h][l + L * r] = u[0][r];
+  __syncthreads();
+  static_assert(XLP_XS == 16u && XLP_SEG <= XLP_XS, "image rows of 16 complex = 8 x 16 bytes");
+  v4f *__restrict__ X = reinterpret_cast<v4f *>(a.X) + ((size_t)pass * a.Dpad + b) * M * (XLP_XS / 2u);
+  for (uint32_t i = j; i < (uint32_t)M * (XLP_XS / 2u); i += NT) {
+    const uint32_t m = i >> 3, part = i & 7u;  // row m, segments 2 part and 2 part + 1
+    const v2f x0 = 2u * part < XLP_SEG ? lds[2u * part][m] : (v2f){0.0f, 0.0f};
+    const v2f x1 = 2u * part + 1u < XLP_SEG ? lds[2u * part + 1u][m] : (v2f){0.0f, 0.0f};
+    X[i] = (v4f){x0.x, x0.y, x1.x, x1.y};
   }
 }
 
@@ -546,10 +556,10 @@ hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, uint32_t n
 
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s) {
   if (!xlp_valid_m(a.M)) return hipErrorInvalidValue;
-  const uint32_t tpw = 256u / a.M;
-  const dim3 grid(a.nco_blocks + (a.nseg * a.D + tpw - 1u) / tpw + a.roll_blocks);
-  if (a.M == 256u) hipLaunchKernelGGL(xlp_forward_kernel<256>, grid, dim3(64), 0, s, a);
-  else hipLaunchKernelGGL(xlp_forward_kernel<128>, grid, dim3(64), 0, s, a);
+  const uint32_t passes = (a.nseg + XLP_SEG - 1u) / XLP_SEG;
+  const dim3 grid(a.nco_blocks + passes * a.D + a.roll_blocks);
+  if (a.M == 256u) hipLaunchKernelGGL(xlp_forward_kernel<256>, grid, dim3(XLP_SEG * 64u), 0, s, a);
+  else hipLaunchKernelGGL(xlp_forward_kernel<128>, grid, dim3(XLP_SEG * 32u), 0, s, a);
   return hipGetLastError();
 }
 
