@@ -605,6 +605,9 @@ def main():
         variants["one block per call (the reference's call granularity)"] = variant_entry(m1)
         ms = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, staggered=True, poly3=False)
         variants["staggered joins (clients joined over 21 consecutive blocks: 21 output grids, one polyphase class)"] = variant_entry(ms)
+        if world == 1 and total_clients >= 8 * 64:  # what each GPU of an 8-GPU strong-scaling run holds (c mod 8)
+            m8 = run_workload(ctx, total_clients // 8, args.lpf_cutoff_rate, vs, 1, args.mode, poly3=False)
+            variants[f"one GPU's share at 8 GPUs ({total_clients // 8} clients): aggregate = 8 x this value minus the feed"] = variant_entry(m8)
         if m["polyphase"]:  # the same workload through the direct FIR kernels: the FP32-bound design
             md = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, options={"polyphase": 0}, poly3=False)
             variants[f"process_{args.mode}_cu8_cf32 through the direct FIR kernel ({md['ntaps']} taps)"] = variant_entry(
