@@ -290,10 +290,31 @@ def make_host(ctx, group):
     if not ctx["cuda"] or ctx["feed"] == "torch":
         return TorchHost(ctx, group)
     host, err = None, None
-    try:
-        host = CHost(ctx, group)
-    except Exception as e:  # noqa: BLE001 -- reported, then the fallback runs
-        err = e
+    if world > 1 or os.environ.get("XL_BENCH_CHOST_THREAD"):
+        # (RCCL set-up is the one step of this path no single-GPU box can exercise: give it a deadline instead of trusting it)
+        import threading
+
+        box = {}
+
+        cur = torch.cuda.current_device()
+
+        def create():
+            try:
+                torch.cuda.set_device(cur)  # (the current device is per thread)
+                box["host"] = CHost(ctx, group)
+            except Exception as e:  # noqa: BLE001
+                box["err"] = e
+
+        th = threading.Thread(target=create, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("XL_BENCH_CHOST_TIMEOUT", "120")))
+        torch.cuda.set_device(cur)
+        host, err = box.get("host"), box.get("err", "timed out" if th.is_alive() else None)
+    else:
+        try:
+            host = CHost(ctx, group)
+        except Exception as e:  # noqa: BLE001 -- reported, then the fallback runs
+            err = e
     ok = 1 if host is not None else 0
     if world > 1:
         t = torch.tensor([ok], dtype=torch.int32, device="cuda")
