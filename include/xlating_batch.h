@@ -57,6 +57,10 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *   "polyphase_m"           0 by the size rule, 128, 256: its transform length
  *   "polyphase_min_clients" smallest class that takes it under the size rule (default 128)
  *   "riders" 0/1, "riders_min_workgroups" n, "tile_height" 0/8/9/10/12, "nco_slices" (a << 16 | b): launch shaping
+ *   "nco_side_stream"       -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light), 0 never, 1
+ *                           always: the NCO phase recurrence of the following calls runs as a kernel of its own on a side
+ *                           stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE)
+ *   "nco_calls_per_launch"  1..4 (default 2): calls of the same shape one such kernel tabulates ahead
  * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call. */
 int xlating_batch_set_option(xlating_batch *batch, const char *name, long value);
 

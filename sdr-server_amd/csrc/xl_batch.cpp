@@ -50,6 +50,12 @@
 
 namespace {
 
+// Phase tables / phase buffers in the engine's rings.  A chain launch made at call c for calls c+1 .. c+n overwrites the
+// tables of calls c+n-XL_NTAB+1 ..; with XL_NTAB = 2 n the latest of them belongs to the launch before the previous one, whose
+// readers ran while the previous launch was stepping -- the new launch never has to wait for them on a chain-bound engine.
+#define XL_NTAB (2 * XL_CHAIN_MAXCALLS)
+static inline int xl_nx(int i) { return (i + 1) % XL_NTAB; }
+
 struct Client {
   bool alive = false;
   uint32_t D = 0, T = 0, Tpad = 0;
@@ -128,8 +134,9 @@ struct xlating_batch_t {
   unsigned long long *d_chain_stats = nullptr;  // tuning (XL_EXP_CHAIN_STATS): per chain workgroup cycles / ticks of the latest launch
   hipStream_t nco_masked = nullptr;  // the side stream that goes with cs_masked; nco_stream (unmasked) serves callers' own streams
   uint32_t reserve_r = 0;
-  hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};  // per phase table
-  bool ev_done_valid[2] = {false, false};
+  hipEvent_t ev_chain[XL_NTAB] = {}, ev_done[XL_NTAB] = {};  // per phase table
+  bool ev_done_valid[XL_NTAB] = {};
+  hipStream_t ev_done_stream[XL_NTAB] = {};  // where ev_done[t] was recorded
   bool spec_on_side = false;  // the look-ahead table was produced on nco_stream (ev_chain must be waited for)
   double macs_all = 0.0, macs_rest = 0.0;  // complex MACs per sample of a block: all clients' direct launches / those outside `poly`
   int nco_side = -1;          // option "nco_side_stream": 1 always, 0 never (NCO role inside the launches), -1: calls of >= 2 blocks
@@ -177,10 +184,12 @@ struct xlating_batch_t {
   short2 *d_qphtab = nullptr;  // Q15 phase table (every XL_PH_STRIDE-th phase)
   bool last_q15 = false;       // the latest call produced cs16 outputs
   XlNcoClient *d_nco = nullptr;
-  float2 *d_phase[2] = {nullptr, nullptr};  // [pcur] = committed running phases, [pcur^1] = next
+  // Rings of XL_NTAB phase buffers and phase tables: [pcur] = committed running phases, [pcur + 1] = after the next call,
+  // [pcur + 2] = after the one behind it (a chain launch may tabulate two calls ahead); table [tab] = the latest call's.
+  float2 *d_phase[XL_NTAB] = {};
   int pcur = 0;
   size_t phase_cap = 0;
-  float2 *d_phtab[2] = {nullptr, nullptr};
+  float2 *d_phtab[XL_NTAB] = {};
   float2 *d_out[2] = {nullptr, nullptr};
   int ocur = 0;  // d_out[ocur] holds the latest call's outputs
   size_t out_alloc = 0;
@@ -189,9 +198,13 @@ struct xlating_batch_t {
   bool fetched = false;
 
   int tab = 0;              // table used by the latest call
-  bool spec_valid = false;  // table[spec_tab] holds the phases of the NEXT call assuming spec_S samples x spec_G blocks
+  // Look-ahead: tables [tab + 1] .. [tab + spec_n] hold the phases of the next spec_n calls assuming spec_S samples x
+  // spec_G blocks each (the phases after them: d_phase[pcur + 1 ..]); produced by the latest call's launches (spec_n = 1)
+  // or by one chain launch on the side stream (spec_n <= 2), whose completion is ev_chain[spec_ev].
+  int spec_n = 0;
   uint32_t spec_S = 0, spec_G = 0;
-  int spec_tab = 0;
+  int spec_ev = 0;
+  int chain_calls = 2;  // option "nco_calls_per_launch": calls one side-stream chain launch tabulates (1 .. XL_CHAIN_MAXCALLS)
   bool exp_nofuse = false;  // XL_TUNING: keep the NCO tabulation a launch of its own
 
   uint32_t exp_flags = 0;  // tuning knobs
@@ -302,11 +315,13 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   xl_batch_sync_all(b);
   xl_batch_free_plan(b);
   xl_plan_trim(b);
-  void *dev[] = {b->d_hist[0],  b->d_hist[1],  b->d_block,  b->d_phase[0], b->d_phase[1],
-                 b->d_phtab[0], b->d_phtab[1], b->d_out[0], b->d_out[1],   b->d_W,        b->d_phase_run,
-                 b->d_qphase,   b->d_qphtab};
+  void *dev[] = {b->d_hist[0], b->d_hist[1], b->d_block, b->d_out[0], b->d_out[1], b->d_W, b->d_phase_run, b->d_qphase, b->d_qphtab};
   for (void *p : dev)
     if (p) (void)hipFree(p);
+  for (int i = 0; i < XL_NTAB; ++i) {
+    if (b->d_phase[i]) (void)hipFree(b->d_phase[i]);
+    if (b->d_phtab[i]) (void)hipFree(b->d_phtab[i]);
+  }
   if (b->d_chain_stats) (void)hipFree(b->d_chain_stats);
 #ifdef XL_TUNING
   if (b->d_trace) (void)hipFree(b->d_trace);
@@ -349,6 +364,9 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
   } else if (n == "tile_height") {
     if (value != 0 && value != 8 && value != 9 && value != 10 && value != 12) return -EINVAL;
     b->exp_h = (int)value;
+  } else if (n == "nco_calls_per_launch") {
+    if (value < 1 || value > (long)XL_CHAIN_MAXCALLS) return -EINVAL;
+    b->chain_calls = (int)value;
   } else if (n == "nco_side_stream") {
     if (value < -1 || value > 1) return -EINVAL;
     b->nco_side = (int)value;
@@ -389,7 +407,7 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
     XL_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     XL_TRY(hipEventCreateWithFlags(&b->dep_ev, hipEventDisableTiming));
     XL_TRY(hipStreamCreateWithFlags(&b->nco_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < XL_NTAB; ++i) {
       XL_TRY(hipEventCreateWithFlags(&b->ev_chain[i], hipEventDisableTiming));
       XL_TRY(hipEventCreateWithFlags(&b->ev_done[i], hipEventDisableTiming));
     }
@@ -411,6 +429,7 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
   if (getenv("XL_EXP_POLY_MIN")) (void)xlating_batch_set_option(b, "polyphase_min_clients", atol(getenv("XL_EXP_POLY_MIN")));
   if (getenv("XL_EXP_CHAIN_STATS")) (void)hipMalloc((void **)&b->d_chain_stats, 4096 * 4 * sizeof(unsigned long long));
   if (getenv("XL_EXP_NCO_SIDE")) (void)xlating_batch_set_option(b, "nco_side_stream", atol(getenv("XL_EXP_NCO_SIDE")));
+  if (getenv("XL_EXP_CHAIN_CALLS")) (void)xlating_batch_set_option(b, "nco_calls_per_launch", atol(getenv("XL_EXP_CHAIN_CALLS")));
   if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
   if (getenv("XL_EXP_MIXSKIP")) b->mix_skip_at = (uint32_t)atoi(getenv("XL_EXP_MIXSKIP"));
   if (getenv("XL_EXP_INVSKIP")) b->inv_skip_at = (uint32_t)atoi(getenv("XL_EXP_INVSKIP"));
@@ -478,10 +497,10 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
   // tabulated ahead is for the old client set: drop it (the committed phases are untouched by it).
   (void)hipSetDevice(b->device);
   xl_batch_sync_all(b);
-  b->spec_valid = false;
+  b->spec_n = 0;
   if ((size_t)id >= b->phase_cap) {
     const size_t ncap = std::max<size_t>(1024, 2 * b->clients.size());
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < XL_NTAB; ++i) {
       float2 *np = nullptr;
       if (hipMalloc((void **)&np, ncap * sizeof(float2)) != hipSuccess) {
         c.alive = false;
@@ -711,7 +730,7 @@ static int xl_batch_plan(xlating_batch *b) {
   };
   xl_batch_sync_all(b);
   lap("sync");
-  b->spec_valid = false;
+  b->spec_n = 0;
   xl_batch_free_plan(b);
   b->classes.clear();
   b->classes_rest.clear();
@@ -862,7 +881,7 @@ static int xl_batch_plan(xlating_batch *b) {
       b->last_nco = nullptr;
       b->reserve_r = 0;
       b->last_stream = b->own_stream;  // (everything was synchronised at the top of the plan)
-      for (int i = 0; i < 2; ++i) b->ev_done_valid[i] = false;
+      for (int i = 0; i < XL_NTAB; ++i) b->ev_done_valid[i] = false;
       if (want > 0u) {
         uint32_t chain_mask[8], main_mask[8];
         for (uint32_t wd = 0; wd < 8; ++wd) {
@@ -992,17 +1011,19 @@ static int xl_batch_plan(xlating_batch *b) {
     const size_t want = b->out_total + b->out_total / 8 + 64;  // (headroom: the next joins do not reallocate the outputs)
     for (int i = 0; i < 2; ++i) {
       if (b->d_out[i]) (void)hipFree(b->d_out[i]);
+      b->d_out[i] = nullptr;
+    }
+    for (int i = 0; i < XL_NTAB; ++i) {
       if (b->d_phtab[i]) (void)hipFree(b->d_phtab[i]);
-      b->d_out[i] = b->d_phtab[i] = nullptr;
+      b->d_phtab[i] = nullptr;
     }
     b->out_alloc = 0;
     if (b->d_qphtab) (void)hipFree(b->d_qphtab);
     b->d_qphtab = nullptr;
     XL_TRY(hipMalloc((void **)&b->d_qphtab, (want / XL_PH_STRIDE + 8) * sizeof(short2)));
-    for (int i = 0; i < 2; ++i) {
-      XL_TRY(hipMalloc((void **)&b->d_out[i], want * sizeof(float2)));
+    for (int i = 0; i < 2; ++i) XL_TRY(hipMalloc((void **)&b->d_out[i], want * sizeof(float2)));
+    for (int i = 0; i < XL_NTAB; ++i)
       XL_TRY(hipMalloc((void **)&b->d_phtab[i], (want / XL_PH_STRIDE + 8) * sizeof(float2)));  // every XL_PH_STRIDE-th phase
-    }
     b->out_alloc = want;
   }
   lap("output buffers");
@@ -1034,7 +1055,7 @@ static hipError_t xl_batch_nco(xlating_batch *b, const XlPos pos, int tab, hipSt
     e = hipEventRecord(n0, st);
     if (e != hipSuccess) return e;
   }
-  e = xl_launch_nco_table(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[b->pcur], b->d_phase[b->pcur ^ 1],
+  e = xl_launch_nco_table(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[b->pcur], b->d_phase[xl_nx(b->pcur)],
                           b->d_phtab[tab], pos, 0xFFFFFFFFu, b->nco_prio, st);
   if (e != hipSuccess) return e;
   return n1 ? hipEventRecord(n1, st) : hipSuccess;
@@ -1124,8 +1145,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     const int p = (int)(b->ncalls & 1);
     const int hb = b->hcur, hn = b->hcur ^ 1;
     const uint32_t N = (uint32_t)(S * G);
-    if (b->spec_valid && b->spec_on_side) XL_TRY(hipStreamWaitEvent(s, b->ev_chain[b->spec_tab], 0));
-    b->spec_valid = false;
+    if (b->spec_n > 0 && b->spec_on_side) XL_TRY(hipStreamWaitEvent(s, b->ev_chain[b->spec_ev], 0));
+    b->spec_n = 0;
     b->poisoned = true;
     XL_TRY(xl_launch_nco_q15_batch(b->d_nco, b->d_qinc, (uint32_t)b->nco.size(), b->d_qphase, b->d_qphtab, pos, s));
     bool rolled = false;
@@ -1189,35 +1210,38 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     // would only lose the chain kernel's CUs (1024 clients, native: 203 -> 212 us per block), and with one block per
     // call the cross-stream events cost more than the overlap gains (51.3 -> 58.6).
     const bool side = side_call;
-#ifdef XL_TUNING
-    const bool fuse = !side && !b->exp_nofuse;  // tuning: tabulate by a launch of its own before every call
-#else
-    const bool fuse = !side;
-#endif
     bool nco_fused = false;
     bool chain_wait = false;  // this call's table comes from the side stream: wait for it before the first reader
 
     // ---- this call's phase table: tabulated ahead by the previous call's launches if the shape guess was right
-    int tab;
+    const int tab = xl_nx(b->tab);
     int pcur = b->pcur;
-    if (b->spec_valid && b->spec_S == S && b->spec_G == G) {
-      tab = b->spec_tab;
+    int spec_left = 0;  // look-ahead calls that stay valid behind this one (a chain launch covers up to two)
+    const int chain_ev = b->spec_ev;
+    if (b->spec_n > 0 && b->spec_S == S && b->spec_G == G) {
       chain_wait = b->spec_on_side;
+      spec_left = b->spec_n - 1;
     } else {
-      tab = b->spec_valid ? b->spec_tab : (b->tab ^ 1);
       // (a look-ahead of the wrong shape may still be running on the side stream, on these very buffers)
-      if (b->spec_valid && b->spec_on_side) XL_TRY(hipStreamWaitEvent(s, b->ev_chain[b->spec_tab], 0));
+      if (b->spec_n > 0 && b->spec_on_side) XL_TRY(hipStreamWaitEvent(s, b->ev_chain[chain_ev], 0));
       if (b->ev_done_valid[tab]) XL_TRY(hipStreamWaitEvent(s, b->ev_done[tab], 0));  // (same stream normally: a no-op)
       XL_TRY(xl_batch_nco(b, pos, tab, s));
     }
-    pcur ^= 1;  // the phases written by that tabulation are now the committed ones
-    b->spec_valid = false;  // (from here on a failure poisons the engine)
+    pcur = xl_nx(pcur);  // the phases written by that tabulation are now the committed ones
+    b->spec_n = 0;       // (from here on a failure poisons the engine)
     b->poisoned = true;
+    // (with a look-ahead table still in hand the launches carry no NCO role: the call after this one has its table)
+#ifdef XL_TUNING
+    const bool fuse = !side && spec_left == 0 && !b->exp_nofuse;  // tuning: tabulate by a launch of its own before every call
+#else
+    const bool fuse = !side && spec_left == 0;
+#endif
+    int launched_n = 0;
 
     // ---- side stream: the NEXT call's table (same shape assumed) into table[tab ^ 1], concurrently with the launches
     // below.  That table was last read by the previous call's launches (ev_done), the committed phases d_phase[pcur]
     // were written by the tabulation of THIS call's table (earlier on the same side stream, or on `s`: ordered below).
-    if (side) {
+    if (side && spec_left == 0) {
       // (the CU-masked pair of streams goes together: a chain kernel confined to CUs that the caller's own, unmasked
       // stream keeps filling would wait for kernel boundaries)
       hipStream_t ns = (s == b->cs_masked && b->nco_masked) ? b->nco_masked : b->nco_stream;
@@ -1232,9 +1256,30 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
         XL_TRY(hipEventRecord(b->dep_ev, s));
         XL_TRY(hipStreamWaitEvent(ns, b->dep_ev, 0));
       }
-      if (b->ev_done_valid[tab ^ 1]) XL_TRY(hipStreamWaitEvent(ns, b->ev_done[tab ^ 1], 0));
-      XL_TRY(xl_launch_nco_chain(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[pcur], b->d_phase[pcur ^ 1],
-                                 b->d_phtab[tab ^ 1], xl_grid_next(pos), b->d_chain_stats, ns, b->ev_chain[tab ^ 1]));
+      XlChainCalls cc;
+      memset(&cc, 0, sizeof(cc));
+      cc.n = (uint32_t)std::min<int>(std::max(b->chain_calls, 1), (int)XL_CHAIN_MAXCALLS);
+      int tt[XL_CHAIN_MAXCALLS];
+      for (int i = 0, t = tab, pp = pcur; i < (int)cc.n; ++i) {
+        t = xl_nx(t), pp = xl_nx(pp);
+        cc.tab[i] = b->d_phtab[t];
+        cc.state_out[i] = b->d_phase[pp];
+        tt[i] = t;
+      }
+      // the tables' last readers (XL_NTAB - 1 - i calls back): one wait for the latest of them covers the earlier ones that
+      // were recorded on the same stream (every wait is a queue packet of its own, ~4 us in front of the chain launch)
+      hipStream_t covered = nullptr;
+      bool any = false;
+      for (int i = (int)cc.n - 1; i >= 0; --i) {
+        const int t = tt[i];
+        if (!b->ev_done_valid[t] || (any && b->ev_done_stream[t] == covered)) continue;
+        XL_TRY(hipStreamWaitEvent(ns, b->ev_done[t], 0));
+        if (!any) covered = b->ev_done_stream[t];
+        any = true;
+      }
+      XL_TRY(xl_launch_nco_chain(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[pcur], cc, xl_grid_next(pos),
+                                 b->d_chain_stats, ns, b->ev_chain[xl_nx(tab)]));
+      launched_n = (int)cc.n;
     }
 
     // ---- the launches on the caller's stream: window images from [d_hist[hb] | blocks], phases from table[tab] ->
@@ -1298,8 +1343,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
               a.nco_blocks = (a.nco_nclients + XL_NCO_LANES * a.nco_wpw - 1) / (XL_NCO_LANES * a.nco_wpw);
             }
             a.nco_state_in = b->d_phase[pcur];
-            a.nco_state_out = b->d_phase[pcur ^ 1];
-            a.nco_tab = b->d_phtab[tab ^ 1];
+            a.nco_state_out = b->d_phase[xl_nx(pcur)];
+            a.nco_tab = b->d_phtab[xl_nx(tab)];
             nco_fused = true;
           }
         }
@@ -1318,7 +1363,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
         }
 #endif
         if (chain_wait) {
-          XL_TRY(hipStreamWaitEvent(s, b->ev_chain[tab], 0));
+          XL_TRY(hipStreamWaitEvent(s, b->ev_chain[chain_ev], 0));
           chain_wait = false;
         }
         XL_TRY(xl_launch_fir(L.ct, mode, L.nw, a, L.lds, s));
@@ -1377,7 +1422,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
             pa.nco_clients = b->d_nco;
             pa.nco_nclients = (uint32_t)b->nco.size();
             pa.nco_blocks = (pa.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
-            pa.nco_tab = b->d_phtab[tab ^ 1];
+            pa.nco_tab = b->d_phtab[xl_nx(tab)];
             pa.nco_prio = b->nco_prio;
             pa.nco_k0 = 0;
             pa.nco_k1 = b->poly_slice1;
@@ -1426,7 +1471,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
 #endif
           if (pe[2]) XL_TRY(hipEventRecord(pe[2], s));
           if (carry) {
-            pa.nco_tab = b->d_phtab[tab ^ 1];
+            pa.nco_tab = b->d_phtab[xl_nx(tab)];
             pa.nco_blocks = (pa.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
             pa.nco_k0 = b->poly_slice2;
             pa.nco_k1 = 65536;
@@ -1434,7 +1479,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
               pa.nco_skip_at = b->inv_skip_at;
               pa.nco_skip = pa.nco_blocks;
             }
-            pa.nco_state_dst = b->d_phase[pcur ^ 1];
+            pa.nco_state_dst = b->d_phase[xl_nx(pcur)];
             nco_fused = true;
           }
 #ifdef XL_TUNING
@@ -1445,7 +1490,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           }
 #endif
           if (chain_wait) {  // (the forward and mix launches do not read the table)
-            XL_TRY(hipStreamWaitEvent(s, b->ev_chain[tab], 0));
+            XL_TRY(hipStreamWaitEvent(s, b->ev_chain[chain_ev], 0));
             chain_wait = false;
           }
           XL_TRY(xlp_launch_inverse(pa, s));
@@ -1466,6 +1511,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     if (side || getenv("XL_EXP_EVDONE")) {
       XL_TRY(hipEventRecord(b->ev_done[tab], s));
       b->ev_done_valid[tab] = true;
+      b->ev_done_stream[tab] = s;
     } else {
       b->ev_done_valid[tab] = false;
     }
@@ -1494,13 +1540,18 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     b->ncalls++;
     // ---- the NEXT call's phases, guessing it has the same shape, were tabulated inside the launches above;
     // without them (tiny call, or the tuning switch) the next call tabulates for itself
-    if (nco_fused || side) {
-      b->spec_valid = true;
-      b->spec_S = (uint32_t)S;
-      b->spec_G = G;
-      b->spec_tab = tab ^ 1;
-      b->spec_on_side = side;
+    if (launched_n > 0) {
+      b->spec_n = launched_n;
+      b->spec_on_side = true;
+      b->spec_ev = xl_nx(tab);
+    } else if (spec_left > 0) {
+      b->spec_n = spec_left;  // (same launch, same event)
+    } else if (nco_fused) {
+      b->spec_n = 1;
+      b->spec_on_side = false;
     }
+    b->spec_S = (uint32_t)S;
+    b->spec_G = G;
   }
   return 0;
 fail:

@@ -120,8 +120,15 @@ hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, co
 // the same for a whole call on a side stream: one wave per SIMD (all of its VGPRs), 64 clients per workgroup (one
 // chain wave writing into an LDS ring + three waves draining it into the table)
 // stats (tuning, may be null): per workgroup {shader cycles, 100 MHz ticks, entries, start tick} of the chain wave
-hipError_t xl_launch_nco_chain(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in, float2 *state_out,
-                               float2 *phtab, XlPos pos, unsigned long long *stats, hipStream_t s, hipEvent_t done);
+#define XL_CHAIN_MAXCALLS 4u
+struct XlChainCalls {  // what one chain launch produces: per call the phase table and the phases after the call
+  float2 *tab[XL_CHAIN_MAXCALLS];
+  float2 *state_out[XL_CHAIN_MAXCALLS];
+  uint32_t n;
+};
+hipError_t xl_launch_nco_chain(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
+                               const XlChainCalls &calls, XlPos pos, unsigned long long *stats, hipStream_t s,
+                               hipEvent_t done);
 // raw -> converted sample images of the single-filter path (xlating.c:352-433)
 hipError_t xl_launch_convert_cf32(const void *raw, int fmt, uint32_t nsamples, float2 *dst, hipStream_t s);
 hipError_t xl_launch_convert_q15(const void *raw, int fmt, uint32_t nelems, int16_t *dst, hipStream_t s);

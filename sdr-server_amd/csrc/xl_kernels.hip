@@ -88,6 +88,9 @@ XL_DEV uint32_t xl_lds_poll(const uint32_t addr) {
 // to 25.7 cycles).  So the bookkeeping rides in the shadow of the first steps' multiplies:
 //   step 0: the entry (phase of output 16 e, still in p) into the ring    step 1-2: entry count + 1, posted
 //   step 3-5: ring address of the next entry ((offset + 512) mod 32 KB + base)
+#ifndef XLC_ALIGN
+#define XLC_ALIGN ".p2align 6\n\t"
+#endif
 #define XLC_MUL "v_pk_mul_f32 %[t1], %[p], %[inc] op_sel_hi:[1,0]\n\tv_pk_mul_f32 %[t2], %[p], %[inc] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
 #define XLC_ADD "v_pk_add_f32 %[p], %[t1], %[t2] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
 #define XLC_STEP XLC_MUL XLC_ADD
@@ -141,11 +144,14 @@ XL_DEV uint32_t xl_lds_poll(const uint32_t addr) {
   XLC_MUL "ds_write_b64 %[addr], %[p] offset:15872\n\t" XLC_ADD XLC_BLOCK_END("32", "0x4000")
 static_assert(XL_PH_STRIDE == 16u && XLC_RING * 64u * 8u == 0x8000u, "XLC_ENTRY is written for 16 steps per entry and a 32 KB ring");
 
+// One launch tabulates `calls.n` consecutive calls of the same shape (pos, then xl_grid_next of it, ...): table and final
+// phases per call -- the launch's fixed costs (~11 us of prologue / epilogue, ~6 us between two dependent launches) are paid
+// once per calls.n calls.  The phases stay in the chain wave's registers from one call to the next.
 __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__restrict__ cl, uint32_t n,
-                                                           const float2 *state_in, float2 *state_out,
-                                                           float2 *__restrict__ tab, const XlPos pos,
-                                                           unsigned long long *stats) {
+                                                           const float2 *state_in, const XlChainCalls calls,
+                                                           XlPos pos, unsigned long long *stats) {
   asm volatile("" ::: "v255", "a255");
+  const unsigned long long t_entry = stats ? wall_clock64() : 0ull;  // (tuning: 100 MHz ticks)
   __shared__ v2f ring[XLC_RING][64];
   __shared__ uint32_t s_emax;
   __shared__ uint32_t s_prod;     // entries written by the chain wave
@@ -157,6 +163,14 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
   k.incr = make_float2(1.0f, 0.0f);
   k.out_off = 0u, k.slot = 0u, k.D = 1u, k.rem0 = 0u;
   if (have) k = cl[c];
+  v2f p = {1.0f, 0.0f};  // (the chain wave's running phases)
+  if (w == 0 && have) p = (v2f){state_in[k.slot].x, state_in[k.slot].y};
+  unsigned long long cyc = 0ull, ticks = 0ull, wfirst = 0ull;
+  uint32_t entries = 0u;
+  for (uint32_t call = 0; call < calls.n; ++call, pos = xl_grid_next(pos)) {
+  float2 *const tab = calls.tab[call];
+  float2 *const state_out = calls.state_out[call];
+  if (call) __syncthreads();  // (the ring and its counters start over)
   XlBnd bnd = xl_nco_bnd(k, pos, 0xFFFFFFFFu);
   if (!have) bnd.K = 0u;
   const uint32_t K = bnd.K, E = (K + XL_PH_STRIDE - 1u) >> XL_PH_SHIFT;  // this client's table entries
@@ -173,8 +187,6 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
   v2f *__restrict__ o = reinterpret_cast<v2f *>(tab) + (k.out_off >> XL_PH_SHIFT);  // out_off = 0 mod 2 * XL_PH_STRIDE: 16-byte pairs
   if (w == 0) {
     __builtin_amdgcn_s_setprio(3);
-    v2f p = {1.0f, 0.0f};
-    if (have) p = (v2f){state_in[k.slot].x, state_in[k.slot].y};
     const v2f inc = {k.incr.x, k.incr.y};
     uint32_t nb = xl_bnd_next(bnd, 0u);  // the phase is renormalised after output nb - 1 (xlating.c:73)
     const uint32_t a_n0 = xl_lds_off(&s_next[0]), a_n1 = xl_lds_off(&s_next[1]), a_n2 = xl_lds_off(&s_next[2]);
@@ -212,11 +224,16 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
           const uint32_t chunk_end = e_stop < next_check ? e_stop : next_check;
           uint32_t off = ((ee & (XLC_RING - 1u)) << 9) + lane * (uint32_t)sizeof(v2f);  // ring offset of entry ee, this lane
           uint32_t addr = a_ring0 + off, cnt = ee;
+          // The four registers of the step are pinned: a VGPR's bank is its number mod 4, and a packed multiply whose two
+          // 64-bit sources sit in the same bank pair takes an extra cycle -- with the allocator's free choice the step
+          // measured 16.5 or 18.8 cycles depending on unrelated code around it.  p and t1 in banks {0, 1}, the increment
+          // and t2 in {2, 3}: every multiply and the add read one operand from each pair.
           v2f t1, t2;
 #define XLC_RUN(BLOCK)                                                                                                  \
-  asm volatile(BLOCK                                                                                                   \
-               : [p] "+v"(p), [off] "+v"(off), [addr] "+v"(addr), [cnt] "+v"(cnt), [t1] "=&v"(t1), [t2] "=&v"(t2)       \
-               : [inc] "v"(inc), [base] "v"(a_ring0), [paddr] "v"(a_prod)                                              \
+  asm volatile(XLC_ALIGN BLOCK                                                                                                   \
+               : [p] "+{v[40:41]}"(p), [off] "+v"(off), [addr] "+v"(addr), [cnt] "+v"(cnt), [t1] "=&{v[44:45]}"(t1),    \
+                 [t2] "=&{v[46:47]}"(t2)                                                                               \
+               : [inc] "{v[42:43]}"(inc), [base] "v"(a_ring0), [paddr] "v"(a_prod)                                     \
                : "memory")
           for (; ee < chunk_end && (ee & 3u) != 0u; ++ee) XLC_RUN(XLC_ENTRY);  // up to a multiple of four
           if ((ee & 7u) == 4u && ee + 4u <= chunk_end) {                       // up to a multiple of eight
@@ -260,13 +277,18 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
       }
     }
     if (have) state_out[k.slot] = make_float2(p.x, p.y);  // (K == 0: untouched, xlating.c:58)
-    if (stats && lane == 0u) {
-      stats[4u * blockIdx.x] = clock64() - c0;
-      stats[4u * blockIdx.x + 1u] = wall_clock64() - w0;
-      stats[4u * blockIdx.x + 2u] = Emax;
-      stats[4u * blockIdx.x + 3u] = w0;
+    if (stats) {
+      cyc += clock64() - c0;
+      const unsigned long long w1 = wall_clock64();
+      ticks += w1 - w0;
+      entries += Emax;
+      if (call == 0u) wfirst = w0;
+      if (lane == 0u && blockIdx.x < 1024u) {  // timeline of the launch: entry, per call start / end of the stepping, exit
+        stats[8192u + 8u * blockIdx.x + 1u + 2u * call] = w0 - t_entry;
+        stats[8192u + 8u * blockIdx.x + 2u + 2u * call] = w1 - t_entry;
+      }
     }
-    return;
+    continue;
   }
   // ---- drainers: ring -> table, two entries (16 bytes) per client and store
   const uint32_t j = w - 1u;
@@ -292,6 +314,18 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
     xl_lds_post(a_next, q + 3u);
   }
   xl_lds_post(a_next, 0xFFFFFFFFu);
+  }  // calls
+  if (stats) __syncthreads();  // (tuning: the exit stamp is taken when every wave is through)
+  if (stats && threadIdx.x == 0u) {
+    if (blockIdx.x < 1024u) {
+      stats[8192u + 8u * blockIdx.x] = t_entry;
+      stats[8192u + 8u * blockIdx.x + 7u] = wall_clock64() - t_entry;
+    }
+    stats[4u * blockIdx.x] = cyc;
+    stats[4u * blockIdx.x + 1u] = ticks;
+    stats[4u * blockIdx.x + 2u] = entries;
+    stats[4u * blockIdx.x + 3u] = wfirst;
+  }
 }
 
 // Window staging: raw samples -> cf32 image in LDS.  Four independent loads per thread are issued before any is
@@ -626,15 +660,17 @@ hipError_t xl_launch_nco_table(const XlNcoClient *clients, uint32_t nclients, co
 
 // `done` (optional): recorded with the kernel's own completion signal (hipExtLaunchKernelGGL's stop event) -- one packet
 // on the queue instead of the kernel plus a separate event record.
-hipError_t xl_launch_nco_chain(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in, float2 *state_out,
-                               float2 *phtab, XlPos pos, unsigned long long *stats, hipStream_t s, hipEvent_t done) {
+hipError_t xl_launch_nco_chain(const XlNcoClient *clients, uint32_t nclients, const float2 *state_in,
+                               const XlChainCalls &calls, XlPos pos, unsigned long long *stats, hipStream_t s,
+                               hipEvent_t done) {
+  if (calls.n < 1u || calls.n > XL_CHAIN_MAXCALLS) return hipErrorInvalidValue;
   if (nclients == 0) return done ? hipEventRecord(done, s) : hipSuccess;
   if (done)
     hipExtLaunchKernelGGL(xl_nco_chain_kernel, dim3((nclients + 63u) / 64u), dim3(256), 0, s, nullptr, done, 0, clients,
-                          nclients, state_in, state_out, phtab, pos, stats);
+                          nclients, state_in, calls, pos, stats);
   else
     hipLaunchKernelGGL(xl_nco_chain_kernel, dim3((nclients + 63u) / 64u), dim3(256), 0, s, clients, nclients, state_in,
-                       state_out, phtab, pos, stats);
+                       calls, pos, stats);
   return hipGetLastError();
 }
 

@@ -82,6 +82,10 @@ def main():
                             cyc = [buf[4 * i] for i in range(nwg)]; tick = [buf[4 * i + 1] for i in range(nwg)]; ent = buf[2]
                             st = [buf[4 * i + 3] for i in range(nwg)]
                             ent = max(ent, 1)
+                            big = (C.c_ulonglong * (4 * 4096))()
+                            if os.environ.get("XL_EXP_CHAIN_TIMELINE") and xl.lib().xlating_batch_debug_chain_stats(eng.h, big, 4096) == 0:
+                                tl = [big[8192 + i] for i in range(8)]
+                                extra += "  launch timeline wg0 (us from entry): " + " ".join("%.1f" % (v / 100.0) for v in tl[1:])
                             extra += "  chain: %.1f cycles/step, %.2f ns/step, clock %.2f GHz, start spread %.1f us" % (
                                 sum(cyc) / nwg / (ent * 16), sum(tick) / nwg * 10.0 / (ent * 16), sum(cyc) / max(sum(tick), 1) / 10.0, (max(st) - min(st)) / 100.0)
                     eng.close()

@@ -68,7 +68,8 @@ int main() {
       for (int rep = 0; rep < 4; ++rep) {
         // the chain first (it needs whole CUs: behind a launch that fills the chip it would wait for that launch to end)
         (void)hipEventRecord(e0, s1);
-        (void)xl_launch_nco_chain(dcl, n, st0, st1, tab, pos, nullptr, s1, nullptr);
+        XlChainCalls cc = {{tab}, {st1}, 1u};
+        (void)xl_launch_nco_chain(dcl, n, st0, cc, pos, nullptr, s1, nullptr);
         (void)hipEventRecord(e1, s1);
         if (mode == 1) hipLaunchKernelGGL(hog_valu, dim3(256 * 16), dim3(256), 0, s2, hout, 3000);
         if (mode == 2) hipLaunchKernelGGL(hog_mem, dim3(256 * 8), dim3(256), 0, s2, msrc, mdst, nvec, 2);
