@@ -204,6 +204,9 @@ struct xlating_batch_t {
   int spec_n = 0;
   uint32_t spec_S = 0, spec_G = 0;
   int spec_ev = 0;
+  bool waited_valid = false;  // stream waited_stream has waited for ev_chain[waited_ev] since that event was last recorded
+  int waited_ev = 0;
+  hipStream_t waited_stream = nullptr;
   int chain_calls = 2;  // option "nco_calls_per_launch": calls one side-stream chain launch tabulates (1 .. XL_CHAIN_MAXCALLS)
   bool exp_nofuse = false;  // XL_TUNING: keep the NCO tabulation a launch of its own
 
@@ -1218,8 +1221,11 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     int pcur = b->pcur;
     int spec_left = 0;  // look-ahead calls that stay valid behind this one (a chain launch covers up to two)
     const int chain_ev = b->spec_ev;
+    bool tab_from_s = true;
     if (b->spec_n > 0 && b->spec_S == S && b->spec_G == G) {
-      chain_wait = b->spec_on_side;
+      tab_from_s = !b->spec_on_side;
+      // (the second call of a chain launch's pair: this stream has already waited for that launch)
+      chain_wait = b->spec_on_side && !(b->waited_valid && b->waited_ev == chain_ev && b->waited_stream == s);
       spec_left = b->spec_n - 1;
     } else {
       // (a look-ahead of the wrong shape may still be running on the side stream, on these very buffers)
@@ -1252,7 +1258,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
         }
         b->last_nco = ns;
       }
-      if (!chain_wait) {  // this call's table was tabulated on `s` just now: order the side stream behind it
+      if (tab_from_s) {  // this call's table was tabulated on `s` (just now, or by the previous call's launches): order the side stream behind it
         XL_TRY(hipEventRecord(b->dep_ev, s));
         XL_TRY(hipStreamWaitEvent(ns, b->dep_ev, 0));
       }
@@ -1280,6 +1286,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
       XL_TRY(xl_launch_nco_chain(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[pcur], cc, xl_grid_next(pos),
                                  b->d_chain_stats, ns, b->ev_chain[xl_nx(tab)]));
       launched_n = (int)cc.n;
+      b->waited_valid = false;  // (ev_chain[xl_nx(tab)] now stands for this launch)
     }
 
     // ---- the launches on the caller's stream: window images from [d_hist[hb] | blocks], phases from table[tab] ->
@@ -1296,6 +1303,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
       f1 = b->ev[b->ev.size() - 1];
     }
     bool rolled = false;
+    bool done_attached = false;  // ev_done[tab] rides on the call's last launch
     Launch *const Ls = use_poly ? b->launches_rest : b->launches;
     if (maxK > 0) {
       if (f0) XL_TRY(hipEventRecord(f0, s));
@@ -1365,6 +1373,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
         if (chain_wait) {
           XL_TRY(hipStreamWaitEvent(s, b->ev_chain[chain_ev], 0));
           chain_wait = false;
+          b->waited_valid = true, b->waited_ev = chain_ev, b->waited_stream = s;
         }
         XL_TRY(xl_launch_fir(L.ct, mode, L.nw, a, L.lds, s));
 #ifdef XL_TUNING
@@ -1492,8 +1501,16 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           if (chain_wait) {  // (the forward and mix launches do not read the table)
             XL_TRY(hipStreamWaitEvent(s, b->ev_chain[chain_ev], 0));
             chain_wait = false;
+            b->waited_valid = true, b->waited_ev = chain_ev, b->waited_stream = s;
           }
-          XL_TRY(xlp_launch_inverse(pa, s));
+          // the call's last launch carries the "table has been read" event the side stream waits for
+          const bool last_launch = side && rolled && &pc == &b->poly.back()
+#ifdef XL_TUNING
+                                   && !trace_inv
+#endif
+              ;
+          XL_TRY(xlp_launch_inverse(pa, s, last_launch ? b->ev_done[tab] : nullptr));
+          done_attached = last_launch;
 #ifdef XL_TUNING
           if (trace_inv) {
             pa.trace = nullptr;
@@ -1509,7 +1526,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
       XL_TRY(xl_launch_update_history(b->d_hist[hb], d_blocks, XL_HCAP, N, b->bps, b->d_hist[hn], s));
     // table[tab] has been read by everything enqueued so far (only the side stream ever waits for this)
     if (side || getenv("XL_EXP_EVDONE")) {
-      XL_TRY(hipEventRecord(b->ev_done[tab], s));
+      if (!done_attached) XL_TRY(hipEventRecord(b->ev_done[tab], s));
       b->ev_done_valid[tab] = true;
       b->ev_done_stream[tab] = s;
     } else {

@@ -90,6 +90,6 @@ hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, uint32_t n
                              uint32_t Dpad, uint32_t A, uint32_t M, uint32_t ncg, float2 *R, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
-hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s);
+hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);
 
 #endif  // XL_POLYPHASE_H_

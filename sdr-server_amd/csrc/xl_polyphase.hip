@@ -17,6 +17,8 @@
 
 #include "xl_dev_inline.h"
 
+#include <hip/hip_ext.h>
+
 XL_DEV v2f xlp_cmul(const v2f a, const v2f b) {
   return (v2f){__builtin_fmaf(-a.y, b.y, a.x * b.x), __builtin_fmaf(a.y, b.x, a.x * b.y)};
 }
@@ -585,12 +587,18 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s) {
+// `done` (optional): recorded with the launch's own completion signal -- one queue packet instead of launch + event record
+hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done) {
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
   const uint32_t work = a0.nseg * a0.ncg * (a0.M == 256u ? 8u : 4u);
   const XlpArgs a = xlp_checked_skip(a0, work);
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
-  if (a.M == 256u) hipLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(xlp_inverse_kernel<128>, grid, dim3(256), 0, s, a);
+  if (done) {
+    if (a.M == 256u) hipExtLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, nullptr, done, 0, a);
+    else hipExtLaunchKernelGGL(xlp_inverse_kernel<128>, grid, dim3(256), 0, s, nullptr, done, 0, a);
+  } else {
+    if (a.M == 256u) hipLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(xlp_inverse_kernel<128>, grid, dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
