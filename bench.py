@@ -55,7 +55,7 @@ GROUP = 8                       # blocks per engine call and per RCCL broadcast 
 BLOCKS_PER_STEP = 320           # blocks per bench step (40 calls): 20 steps ~ 0.2 s of GPU time at 1024 clients
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
-TIMING_STRIDE = 4               # HIP events bracket every 4th call of the timed region (an event pair costs ~6 us of stream time)
+TIMING_STRIDE = 5               # HIP events bracket every 5th call of the timed region (an event pair costs ~6 us of stream time; odd, so that both calls of a chain launch's pair are sampled)
 SPOT_CLIENTS = 16
 
 
