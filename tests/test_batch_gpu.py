@@ -963,3 +963,28 @@ def test_q15_mode_rejected_for_cf32_engines():
         eng.process_host(np.zeros(4096, np.float32), "q15")
     assert e.value.code == -22
     eng.close()
+
+
+@pytest.mark.parametrize("ncalls", [1, 2, 3, 4])
+@pytest.mark.parametrize("poly", [0, 1])
+def test_chain_launch_covers_several_calls(ncalls, poly):
+    """One side-stream chain launch tabulates `nco_calls_per_launch` calls ahead (rings of phase tables and phase buffers
+    in the engine).  Runs of equal calls long enough to consume whole launches, a shape change and a client joining while
+    look-ahead tables are pending (both drop them), a native call in between (fused launches when the direct FIR is
+    heavy): native outputs and the committed phases bit-exact, optimized within tolerance."""
+    t48 = lpf(FS, 24000, 9600)
+    clients = [(42, t48, -700000 + 47000 * c) for c in range(70)]
+    eng, oracles = _group_engine("cu8", 100002, 4, clients, poly=poly)
+    eng.set_option("nco_side_stream", 1)
+    eng.set_option("nco_calls_per_launch", ncalls)
+    seq = [(4, 100002, "native")] * 5 + [(2, 65536, "native")] + [(4, 100002, "optimized")] * 3 + [(4, 100002, "native")] * 2
+    for k, (g, n, variant) in enumerate(seq):
+        if k == 8:  # a join while look-ahead tables are pending
+            oracles[eng.add_client(42, t48, 333333)] = Oracle(42, t48, 333333, FS, 100002)
+        x = siggen.xs_u8(5300 + k, g * n)
+        _check_group(eng, oracles, "cu8", x, g, variant)
+    for cid, o in oracles.items():
+        assert tuple(np.float32(v).tobytes() for v in eng.phase(cid)) == tuple(np.float32(v).tobytes() for v in o.phase)
+    with pytest.raises(xl.XlatingError):
+        eng.set_option("nco_calls_per_launch", 5)
+    eng.close()
