@@ -1525,7 +1525,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     if (!rolled)  // no client produced output in this call (tiny block): roll the history on its own
       XL_TRY(xl_launch_update_history(b->d_hist[hb], d_blocks, XL_HCAP, N, b->bps, b->d_hist[hn], s));
     // table[tab] has been read by everything enqueued so far (only the side stream ever waits for this)
-    if (side || getenv("XL_EXP_EVDONE")) {
+    if (side) {
       if (!done_attached) XL_TRY(hipEventRecord(b->ev_done[tab], s));
       b->ev_done_valid[tab] = true;
       b->ev_done_stream[tab] = s;
