@@ -56,8 +56,8 @@ __global__ __launch_bounds__(64) void xl_nco_table_kernel(const XlNcoClient *__r
 }
 
 // The same tabulation for a call of many blocks, run on the engine's side stream WHILE the previous call's launches run
-// on the main stream (xl_batch.cpp).  The recurrence is a dependent chain of ~17.5 cycles per step and it is what bounds
-// a call once the filtering itself takes less than ~25 us per block, so everything that could slow the chain wave is
+// on the main stream (xl_batch.cpp).  The recurrence is a dependent chain of ~16.5 cycles per step and it is what bounds
+// a call once the filtering itself takes less than ~22 us per block, so everything that could slow the chain wave is
 // kept away from it:
 //  * neighbours on its SIMD cost it 35-60 % (their packed FMAs occupy the VALU 4 cycles at a time: 7.3 ns per step
 //    alone, 9.8-13.5 ns next to the mix kernel's waves) -> the kernel claims every VGPR of its SIMDs (v255 / a255 are
@@ -88,9 +88,9 @@ XL_DEV uint32_t xl_lds_poll(const uint32_t addr) {
 // to 25.7 cycles).  So the bookkeeping rides in the shadow of the first steps' multiplies:
 //   step 0: the entry (phase of output 16 e, still in p) into the ring    step 1-2: entry count + 1, posted
 //   step 3-5: ring address of the next entry ((offset + 512) mod 32 KB + base)
-#ifndef XLC_ALIGN
+// Every block below starts on a 64-byte boundary: a lone wave pays for an 8-byte instruction that straddles a fetch
+// line (~6 cycles) -- the same blocks ran at 16.5 or at 18.8 cycles per step depending on where the compiler put them.
 #define XLC_ALIGN ".p2align 6\n\t"
-#endif
 #define XLC_MUL "v_pk_mul_f32 %[t1], %[p], %[inc] op_sel_hi:[1,0]\n\tv_pk_mul_f32 %[t2], %[p], %[inc] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
 #define XLC_ADD "v_pk_add_f32 %[p], %[t1], %[t2] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
 #define XLC_STEP XLC_MUL XLC_ADD
@@ -119,9 +119,6 @@ XL_DEV uint32_t xl_lds_poll(const uint32_t addr) {
   XLC_QENTRY("512") XLC_STEP XLC_STEP XLC_STEP XLC_STEPS10              \
   XLC_QENTRY("1024") XLC_STEP XLC_STEP XLC_STEP XLC_STEPS10             \
   XLC_MUL "ds_write_b64 %[addr], %[p] offset:1536\n\t" XLC_ADD XLC_BLOCK_END("4", "0x800")
-#ifndef XLC_USE_HEX
-#define XLC_USE_HEX 1
-#endif
 // a whole entry without bookkeeping: 16 steps, the ring slot at an immediate offset
 #define XLC_E(OFFS) XLC_QENTRY(OFFS) XLC_STEP XLC_STEP XLC_STEP XLC_STEPS10
 // eight / sixteen / thirty-two entries (entry index = 0 mod 8 / 16 / 32): straight-line code, 13 instructions of
@@ -168,152 +165,145 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
   unsigned long long cyc = 0ull, ticks = 0ull, wfirst = 0ull;
   uint32_t entries = 0u;
   for (uint32_t call = 0; call < calls.n; ++call, pos = xl_grid_next(pos)) {
-  float2 *const tab = calls.tab[call];
-  float2 *const state_out = calls.state_out[call];
-  if (call) __syncthreads();  // (the ring and its counters start over)
-  XlBnd bnd = xl_nco_bnd(k, pos, 0xFFFFFFFFu);
-  if (!have) bnd.K = 0u;
-  const uint32_t K = bnd.K, E = (K + XL_PH_STRIDE - 1u) >> XL_PH_SHIFT;  // this client's table entries
-  if (threadIdx.x == 0) {
-    s_emax = 0u;
-    s_prod = 0u;
-    s_next[0] = 0u, s_next[1] = 1u, s_next[2] = 2u;
-  }
-  __syncthreads();
-  if (w == 0 && E > 0u) atomicMax(&s_emax, E);
-  __syncthreads();
-  const uint32_t Emax = s_emax;
-  const uint32_t a_prod = xl_lds_off(&s_prod), a_ring0 = xl_lds_off(&ring[0][0]), a_ring = xl_lds_off(&ring[0][lane]);
-  v2f *__restrict__ o = reinterpret_cast<v2f *>(tab) + (k.out_off >> XL_PH_SHIFT);  // out_off = 0 mod 2 * XL_PH_STRIDE: 16-byte pairs
-  if (w == 0) {
-    __builtin_amdgcn_s_setprio(3);
-    const v2f inc = {k.incr.x, k.incr.y};
-    uint32_t nb = xl_bnd_next(bnd, 0u);  // the phase is renormalised after output nb - 1 (xlating.c:73)
-    const uint32_t a_n0 = xl_lds_off(&s_next[0]), a_n1 = xl_lds_off(&s_next[1]), a_n2 = xl_lds_off(&s_next[2]);
-    const unsigned long long c0 = stats ? clock64() : 0ull, w0 = stats ? wall_clock64() : 0ull;  // (tuning: shader cycles / 100 MHz ticks)
-    uint32_t e = 0;  // (wave-uniform: the lanes step in lockstep)
-    while (e < Emax) {
-      // the next output index at which ANY lane has something other than a plain step to do: its block ends (renormalise)
-      // or its call ends.  Up to there the loop below is branch-free per lane: an entry into the ring, 16 steps.
-      uint32_t ev = (e << XL_PH_SHIFT) < K ? (nb < K ? nb : K) : 0xFFFFFFFFu;
+    float2 *const tab = calls.tab[call];
+    float2 *const state_out = calls.state_out[call];
+    if (call) __syncthreads();  // (the ring and its counters start over)
+    XlBnd bnd = xl_nco_bnd(k, pos, 0xFFFFFFFFu);
+    if (!have) bnd.K = 0u;
+    const uint32_t K = bnd.K, E = (K + XL_PH_STRIDE - 1u) >> XL_PH_SHIFT;  // this client's table entries
+    if (threadIdx.x == 0) {
+      s_emax = 0u;
+      s_prod = 0u;
+      s_next[0] = 0u, s_next[1] = 1u, s_next[2] = 2u;
+    }
+    __syncthreads();
+    if (w == 0 && E > 0u) atomicMax(&s_emax, E);
+    __syncthreads();
+    const uint32_t Emax = s_emax;
+    const uint32_t a_prod = xl_lds_off(&s_prod), a_ring0 = xl_lds_off(&ring[0][0]), a_ring = xl_lds_off(&ring[0][lane]);
+    v2f *__restrict__ o = reinterpret_cast<v2f *>(tab) + (k.out_off >> XL_PH_SHIFT);  // out_off = 0 mod 2 * XL_PH_STRIDE: 16-byte pairs
+    if (w == 0) {
+      __builtin_amdgcn_s_setprio(3);
+      const v2f inc = {k.incr.x, k.incr.y};
+      uint32_t nb = xl_bnd_next(bnd, 0u);  // the phase is renormalised after output nb - 1 (xlating.c:73)
+      const uint32_t a_n0 = xl_lds_off(&s_next[0]), a_n1 = xl_lds_off(&s_next[1]), a_n2 = xl_lds_off(&s_next[2]);
+      const unsigned long long c0 = stats ? clock64() : 0ull, w0 = stats ? wall_clock64() : 0ull;  // (tuning: shader cycles / 100 MHz ticks)
+      uint32_t e = 0;  // (wave-uniform: the lanes step in lockstep)
+      while (e < Emax) {
+        // the next output index at which ANY lane has something other than a plain step to do: its block ends (renormalise)
+        // or its call ends.  Up to there the loop below is branch-free per lane: an entry into the ring, 16 steps.
+        uint32_t ev = (e << XL_PH_SHIFT) < K ? (nb < K ? nb : K) : 0xFFFFFFFFu;
 #pragma unroll
-      for (int sh = 1; sh < 64; sh <<= 1) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)ev, sh);
-        ev = other < ev ? other : ev;
-      }
-      const uint32_t evs = __builtin_amdgcn_readfirstlane(ev);
-      // entries e .. e_stop - 1: their steps hold no block end for anybody ((e + 1) * 16 < evs)
-      uint32_t e_stop = evs == 0u ? 0u : (evs - 1u) >> XL_PH_SHIFT;
-      e_stop = e_stop < Emax ? e_stop : Emax;
-      if ((e << XL_PH_SHIFT) < K) {  // (a lane whose call has ended sits the region out; the others' mask is constant in it)
-        uint32_t ee = e;
-        while (ee < e_stop) {
-          if ((ee & (XLC_RING / 2u - 1u)) == 0u && ee >= XLC_RING) {
-            // the next XLC_RING / 2 entries go to the slots of entries e - RING .. e - RING / 2 - 1: all pairs below
-            // (e - RING / 2) / 2 must have left the ring (checked once per half ring: an LDS round trip is ~50 ns).
-            // Bounded: a drainer that never shows up must not hang the device (cannot happen while the four waves of
-            // the workgroup are resident, which a launch guarantees) -- ~0.1 s, then the table is wrong, the launch ends.
-            const uint32_t q = (ee - XLC_RING / 2u) >> 1;
+        for (int sh = 1; sh < 64; sh <<= 1) {
+          const uint32_t other = (uint32_t)__shfl_xor((int)ev, sh);
+          ev = other < ev ? other : ev;
+        }
+        const uint32_t evs = __builtin_amdgcn_readfirstlane(ev);
+        // entries e .. e_stop - 1: their steps hold no block end for anybody ((e + 1) * 16 < evs)
+        uint32_t e_stop = evs == 0u ? 0u : (evs - 1u) >> XL_PH_SHIFT;
+        e_stop = e_stop < Emax ? e_stop : Emax;
+        if ((e << XL_PH_SHIFT) < K) {  // (a lane whose call has ended sits the region out; the others' mask is constant in it)
+          uint32_t ee = e;
+          while (ee < e_stop) {
+            if ((ee & (XLC_RING / 2u - 1u)) == 0u && ee >= XLC_RING) {
+              // the next XLC_RING / 2 entries go to the slots of entries e - RING .. e - RING / 2 - 1: all pairs below
+              // (e - RING / 2) / 2 must have left the ring (checked once per half ring: an LDS round trip is ~50 ns).
+              // Bounded: a drainer that never shows up must not hang the device (cannot happen while the four waves of
+              // the workgroup are resident, which a launch guarantees) -- ~0.1 s, then the table is wrong, the launch ends.
+              const uint32_t q = (ee - XLC_RING / 2u) >> 1;
+              for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+                if (xl_lds_poll(a_n0) >= q && xl_lds_poll(a_n1) >= q && xl_lds_poll(a_n2) >= q) break;
+                __builtin_amdgcn_s_sleep(1);
+              }
+            }
+            // entries ee .. chunk_end - 1 (up to the next drain check), two per trip
+            const uint32_t next_check = (ee | (XLC_RING / 2u - 1u)) + 1u;
+            const uint32_t chunk_end = e_stop < next_check ? e_stop : next_check;
+            uint32_t off = ((ee & (XLC_RING - 1u)) << 9) + lane * (uint32_t)sizeof(v2f);  // ring offset of entry ee, this lane
+            uint32_t addr = a_ring0 + off, cnt = ee;
+            v2f t1, t2;
+#define XLC_RUN(BLOCK)                                                                                            \
+  asm volatile(XLC_ALIGN BLOCK                                                                                   \
+               : [p] "+v"(p), [off] "+v"(off), [addr] "+v"(addr), [cnt] "+v"(cnt), [t1] "=&v"(t1), [t2] "=&v"(t2) \
+               : [inc] "v"(inc), [base] "v"(a_ring0), [paddr] "v"(a_prod)                                        \
+               : "memory")
+            for (; ee < chunk_end && (ee & 3u) != 0u; ++ee) XLC_RUN(XLC_ENTRY);  // up to a multiple of four
+            if ((ee & 7u) == 4u && ee + 4u <= chunk_end) {                       // up to a multiple of eight
+              XLC_RUN(XLC_QUAD);
+              ee += 4u;
+            }
+            if ((ee & 15u) == 8u && ee + 8u <= chunk_end) {  // up to a multiple of sixteen
+              XLC_RUN(XLC_OCT);
+              ee += 8u;
+            }
+            for (; ee + 16u <= chunk_end; ee += 16u) XLC_RUN(XLC_HEX);
+            for (; ee + 8u <= chunk_end; ee += 8u) XLC_RUN(XLC_OCT);
+            for (; ee + 4u <= chunk_end; ee += 4u) XLC_RUN(XLC_QUAD);
+            for (; ee < chunk_end; ++ee) XLC_RUN(XLC_ENTRY);
+#undef XLC_RUN
+          }
+        }
+        if (e_stop > e) e = e_stop;
+        // ---- the entry that holds the event (or the tail of the call): per-step checks, every lane for itself
+        if (e < Emax) {
+          if ((e & (XLC_RING / 2u - 1u)) == 0u && e >= XLC_RING) {
+            const uint32_t q = (e - XLC_RING / 2u) >> 1;
             for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
               if (xl_lds_poll(a_n0) >= q && xl_lds_poll(a_n1) >= q && xl_lds_poll(a_n2) >= q) break;
               __builtin_amdgcn_s_sleep(1);
             }
           }
-          // entries ee .. chunk_end - 1 (up to the next drain check), two per trip
-          const uint32_t next_check = (ee | (XLC_RING / 2u - 1u)) + 1u;
-          const uint32_t chunk_end = e_stop < next_check ? e_stop : next_check;
-          uint32_t off = ((ee & (XLC_RING - 1u)) << 9) + lane * (uint32_t)sizeof(v2f);  // ring offset of entry ee, this lane
-          uint32_t addr = a_ring0 + off, cnt = ee;
-          // The four registers of the step are pinned: a VGPR's bank is its number mod 4, and a packed multiply whose two
-          // 64-bit sources sit in the same bank pair takes an extra cycle -- with the allocator's free choice the step
-          // measured 16.5 or 18.8 cycles depending on unrelated code around it.  p and t1 in banks {0, 1}, the increment
-          // and t2 in {2, 3}: every multiply and the add read one operand from each pair.
-          v2f t1, t2;
-#define XLC_RUN(BLOCK)                                                                                                  \
-  asm volatile(XLC_ALIGN BLOCK                                                                                                   \
-               : [p] "+{v[40:41]}"(p), [off] "+v"(off), [addr] "+v"(addr), [cnt] "+v"(cnt), [t1] "=&{v[44:45]}"(t1),    \
-                 [t2] "=&{v[46:47]}"(t2)                                                                               \
-               : [inc] "{v[42:43]}"(inc), [base] "v"(a_ring0), [paddr] "v"(a_prod)                                     \
-               : "memory")
-          for (; ee < chunk_end && (ee & 3u) != 0u; ++ee) XLC_RUN(XLC_ENTRY);  // up to a multiple of four
-          if ((ee & 7u) == 4u && ee + 4u <= chunk_end) {                       // up to a multiple of eight
-            XLC_RUN(XLC_QUAD);
-            ee += 4u;
+          const uint32_t m0 = e << XL_PH_SHIFT;
+          if (m0 < K) xl_lds_post64(a_ring + (e & (XLC_RING - 1u)) * 64u * (uint32_t)sizeof(v2f), p);
+          xl_lds_post(a_prod, e + 1u);
+          for (uint32_t m = m0; m < m0 + XL_PH_STRIDE && m < K; ++m) {
+            p = xl_nco_next(p, inc);
+            if (m + 1u == nb) {
+              p = xl_nco_renorm(p);
+              nb = xl_bnd_next(bnd, m + 1u);
+            }
           }
-#if XLC_USE_HEX
-          if ((ee & 15u) == 8u && ee + 8u <= chunk_end) {  // up to a multiple of sixteen
-            XLC_RUN(XLC_OCT);
-            ee += 8u;
-          }
-          for (; ee + 16u <= chunk_end; ee += 16u) XLC_RUN(XLC_HEX);
-#endif
-          for (; ee + 8u <= chunk_end; ee += 8u) XLC_RUN(XLC_OCT);
-          for (; ee + 4u <= chunk_end; ee += 4u) XLC_RUN(XLC_QUAD);
-          for (; ee < chunk_end; ++ee) XLC_RUN(XLC_ENTRY);
-#undef XLC_RUN
+          ++e;
         }
       }
-      if (e_stop > e) e = e_stop;
-      // ---- the entry that holds the event (or the tail of the call): per-step checks, every lane for itself
-      if (e < Emax) {
-        if ((e & (XLC_RING / 2u - 1u)) == 0u && e >= XLC_RING) {
-          const uint32_t q = (e - XLC_RING / 2u) >> 1;
-          for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
-            if (xl_lds_poll(a_n0) >= q && xl_lds_poll(a_n1) >= q && xl_lds_poll(a_n2) >= q) break;
-            __builtin_amdgcn_s_sleep(1);
-          }
+      if (have) state_out[k.slot] = make_float2(p.x, p.y);  // (K == 0: untouched, xlating.c:58)
+      if (stats) {
+        cyc += clock64() - c0;
+        const unsigned long long w1 = wall_clock64();
+        ticks += w1 - w0;
+        entries += Emax;
+        if (call == 0u) wfirst = w0;
+        if (lane == 0u && blockIdx.x < 1024u) {  // timeline of the launch: entry, per call start / end of the stepping, exit
+          stats[8192u + 8u * blockIdx.x + 1u + 2u * call] = w0 - t_entry;
+          stats[8192u + 8u * blockIdx.x + 2u + 2u * call] = w1 - t_entry;
         }
-        const uint32_t m0 = e << XL_PH_SHIFT;
-        if (m0 < K) xl_lds_post64(a_ring + (e & (XLC_RING - 1u)) * 64u * (uint32_t)sizeof(v2f), p);
-        xl_lds_post(a_prod, e + 1u);
-        for (uint32_t m = m0; m < m0 + XL_PH_STRIDE && m < K; ++m) {
-          p = xl_nco_next(p, inc);
-          if (m + 1u == nb) {
-            p = xl_nco_renorm(p);
-            nb = xl_bnd_next(bnd, m + 1u);
-          }
-        }
-        ++e;
       }
+      continue;
     }
-    if (have) state_out[k.slot] = make_float2(p.x, p.y);  // (K == 0: untouched, xlating.c:58)
-    if (stats) {
-      cyc += clock64() - c0;
-      const unsigned long long w1 = wall_clock64();
-      ticks += w1 - w0;
-      entries += Emax;
-      if (call == 0u) wfirst = w0;
-      if (lane == 0u && blockIdx.x < 1024u) {  // timeline of the launch: entry, per call start / end of the stepping, exit
-        stats[8192u + 8u * blockIdx.x + 1u + 2u * call] = w0 - t_entry;
-        stats[8192u + 8u * blockIdx.x + 2u + 2u * call] = w1 - t_entry;
+    // ---- drainers: ring -> table, two entries (16 bytes) per client and store
+    const uint32_t j = w - 1u;
+    const uint32_t a_next = xl_lds_off(&s_next[j]);
+    v4f *__restrict__ o4 = reinterpret_cast<v4f *>(o);
+    for (uint32_t q = j; 2u * q < Emax; q += 3u) {
+      const uint32_t need = 2u * q + 2u < Emax ? 2u * q + 2u : Emax;
+      for (uint32_t spin = 0; spin < (1u << 24); ++spin) {
+        if (xl_lds_poll(a_prod) >= need) break;
+        __builtin_amdgcn_s_sleep(1);
       }
+      if (2u * q < E) {
+        v2f a, b2 = {0.0f, 0.0f};
+        const uint32_t ra = a_ring + ((2u * q) & (XLC_RING - 1u)) * 64u * (uint32_t)sizeof(v2f);
+        const uint32_t rb = a_ring + ((2u * q + 1u) & (XLC_RING - 1u)) * 64u * (uint32_t)sizeof(v2f);
+        const bool two = 2u * q + 1u < E;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(a) : "v"(ra) : "memory");
+        if (two) asm volatile("ds_read_b64 %0, %1" : "=v"(b2) : "v"(rb) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring slots have been read: they may be overwritten
+        if (two) o4[q] = (v4f){a.x, a.y, b2.x, b2.y};
+        else o[2u * q] = a;
+      }
+      xl_lds_post(a_next, q + 3u);
     }
-    continue;
-  }
-  // ---- drainers: ring -> table, two entries (16 bytes) per client and store
-  const uint32_t j = w - 1u;
-  const uint32_t a_next = xl_lds_off(&s_next[j]);
-  v4f *__restrict__ o4 = reinterpret_cast<v4f *>(o);
-  for (uint32_t q = j; 2u * q < Emax; q += 3u) {
-    const uint32_t need = 2u * q + 2u < Emax ? 2u * q + 2u : Emax;
-    for (uint32_t spin = 0; spin < (1u << 24); ++spin) {
-      if (xl_lds_poll(a_prod) >= need) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (2u * q < E) {
-      v2f a, b2 = {0.0f, 0.0f};
-      const uint32_t ra = a_ring + ((2u * q) & (XLC_RING - 1u)) * 64u * (uint32_t)sizeof(v2f);
-      const uint32_t rb = a_ring + ((2u * q + 1u) & (XLC_RING - 1u)) * 64u * (uint32_t)sizeof(v2f);
-      const bool two = 2u * q + 1u < E;
-      asm volatile("ds_read_b64 %0, %1" : "=v"(a) : "v"(ra) : "memory");
-      if (two) asm volatile("ds_read_b64 %0, %1" : "=v"(b2) : "v"(rb) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring slots have been read: they may be overwritten
-      if (two) o4[q] = (v4f){a.x, a.y, b2.x, b2.y};
-      else o[2u * q] = a;
-    }
-    xl_lds_post(a_next, q + 3u);
-  }
-  xl_lds_post(a_next, 0xFFFFFFFFu);
+    xl_lds_post(a_next, 0xFFFFFFFFu);
   }  // calls
   if (stats) __syncthreads();  // (tuning: the exit stamp is taken when every wave is through)
   if (stats && threadIdx.x == 0u) {
