@@ -60,7 +60,7 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *   "nco_side_stream"       -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light), 0 never, 1
  *                           always: the NCO phase recurrence of the following calls runs as a kernel of its own on a side
  *                           stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE)
- *   "nco_calls_per_launch"  1..4 (default 2): calls of the same shape one such kernel tabulates ahead
+ *   "nco_calls_per_launch"  1..4 (default 4): calls of the same shape one such kernel tabulates ahead
  * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call. */
 int xlating_batch_set_option(xlating_batch *batch, const char *name, long value);
 

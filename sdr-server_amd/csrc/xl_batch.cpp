@@ -207,7 +207,7 @@ struct xlating_batch_t {
   bool waited_valid = false;  // stream waited_stream has waited for ev_chain[waited_ev] since that event was last recorded
   int waited_ev = 0;
   hipStream_t waited_stream = nullptr;
-  int chain_calls = 2;  // option "nco_calls_per_launch": calls one side-stream chain launch tabulates (1 .. XL_CHAIN_MAXCALLS)
+  int chain_calls = 4;  // option "nco_calls_per_launch": calls one side-stream chain launch tabulates (1 .. XL_CHAIN_MAXCALLS)
   bool exp_nofuse = false;  // XL_TUNING: keep the NCO tabulation a launch of its own
 
   uint32_t exp_flags = 0;  // tuning knobs
