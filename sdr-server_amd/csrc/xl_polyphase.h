@@ -29,7 +29,7 @@
 #define XLP_SEG 14u    // segments accumulated per lane in one pass of the mix kernel
 #define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: XLP_SEG padded to 128 bytes
 #define XLP_COLS 128u  // client columns per column group (= one mix workgroup: a wave with two columns per lane)
-#define XLP_BSTEP 6u   // slots of the mix kernel's R-row register ring (branch count is padded to a multiple in the images)
+#define XLP_BSTEP 6u   // rows per trip of the mix kernel's row loop (even; the branch count is padded to a multiple in the images)
 
 // One client column of a class: 16 bytes, one load.
 struct XlpCol {

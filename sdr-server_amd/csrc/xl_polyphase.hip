@@ -1,18 +1,16 @@
 // xl_polyphase.hip -- polyphase overlap-save evaluation of the frequency-xlating FIR (see xl_polyphase.h for the
 // algebra and why it is the same operator as /root/reference/src/xlating.c:52-72).  Hand-written for gfx950.
 //
-// Three launches per block and class (stream order is the only synchronisation):
-//   xlp_forward_kernel  one wave per (segment, branch) -- two per wave at M = 128: raw samples -> cf32
-//                       (xlating.c:357-378, exact) -> M-point DFT of the branch -> shared spectra X[pass][b][m][s].
-//                       D * nseg small transforms: ~1 MB.
+// Three launches per call and class (stream order is the only synchronisation):
+//   xlp_forward_kernel  one workgroup per (pass of 14 segments, branch): raw samples -> cf32 (xlating.c:357-378, exact)
+//                       -> M-point DFT of the branch per segment -> shared spectra X[pass][b][m][s], stored as whole rows.
 //   xlp_mix_kernel      Y[c][s][m] = sum_b X[s][b][m] * R[c][b][m].  lane = two client columns, the bin m is
-//                       workgroup-uniform: its column of X is staged in LDS once and broadcast-read row by row, R is
-//                       streamed from HBM once, coalesced (16 bytes per lane and branch): 8 * D * M bytes per client
-//                       and block, which bounds the launch with many clients.
+//                       workgroup-uniform: its rows of X arrive through the scalar cache as SGPR operands of the FMAs,
+//                       R is streamed coalesced (16 bytes per lane and branch): 8 * D * M bytes per client and call.
 //   xlp_inverse_kernel  per (segment, 16 or 32 columns): Y tile -> LDS (transposed) -> M-point inverse DFT per column
 //                       -> scale, NCO rotate (xlating.c:70) with the tabulated float32 phase -> out[k], k < K.
-// M = 256 or 128 per class (xl_polyphase.h).  Each launch also carries a slice of the NEXT block's NCO phase recurrence
-// (a ~23 us dependent chain per block that would otherwise serialise with these short kernels).
+// M = 256 or 128 per class (xl_polyphase.h).  When the NCO phases of the next call are not tabulated by the side-stream
+// chain kernel (xl_kernels.hip), each launch also carries a slice of that recurrence ("NCO role").
 #include "xl_polyphase.h"
 
 #include "xl_dev_inline.h"
@@ -286,11 +284,11 @@ XL_DEV void xlp_xrow_wait(XlpXRow &x, v2f &pin0, v2f &pin1) {
 
 // grid = nco_blocks + M * ncg * passes workgroups of ONE wave = (bin m, column group, pass = 14 segments); lane l =
 // client columns cg*128 + 2l, 2l+1; the spectrum bin m is workgroup-uniform.  The bin's column of the shared spectra
-// (Dpad rows of 14 segments, 128 bytes each) is staged in LDS once and read back row by row as broadcast reads (every
-// lane the same address): a uniform operand with short, in-order latency (scalar loads of the rows were
-// latency-bound).  R is streamed through a ring of XLP_BSTEP register slots, 16 bytes per lane and branch,
-// XLP_BSTEP - 1 rows ahead of the multiply (a stage-wise double buffer ran one short stage ahead and every stage
-// waited out a memory latency; a ring of 14 changed nothing).  A block with more than 14 segments (M = 128 at the
+// (Dpad rows of 14 segments, 128 bytes each) is wave-uniform: it is fetched by scalar loads, one row ahead, and multiplies
+// as an SGPR operand (staged in LDS and read back as broadcast ds_read_b128 -- round 1 -- every FMA read three 64-bit VGPR
+// operands: 135 instead of 119 us per call).  R is streamed through a ring of register slots, 16 bytes per lane and
+// branch, ring - 1 rows ahead of the multiply (a stage-wise double buffer ran one short stage ahead and every stage
+// waited out a memory latency; a ring of 14 changed nothing, a ring of 2-3 for more waves per SIMD was slower).  A block with more than 14 segments (M = 128 at the
 // server default: 27) takes several passes over the same R rows: the passes of one (m, cg) sit 8 positions apart in
 // the grid -- same XCD (workgroups are dealt to the XCDs round-robin), dispatched together -- so that R comes from HBM
 // once and the other passes hit that XCD's L2.  (The passes as waves of one workgroup gave the same traffic but an
