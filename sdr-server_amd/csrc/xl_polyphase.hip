@@ -389,7 +389,9 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
   }
 #pragma unroll
   for (int i = 0; i < (int)XLP_SEG; ++i)
-    if ((uint32_t)i < nvalid) Yp[(size_t)i * ystride] = (v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y};
+    if ((uint32_t)i < nvalid)  // (written once, read once by the next launch: streamed past the L2 lines that hold R and X;
+                               // A/B on one box: 34.2 -> 33.3 us per block at 1024 clients, 122.3 -> 120.6 at 4096)
+      __builtin_nontemporal_store((v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y}, &Yp[(size_t)i * ystride]);
   xlp_trace_work(a, t_begin);
 }
 
