@@ -236,6 +236,11 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
               XLC_RUN(XLC_OCT);
               ee += 8u;
             }
+            if ((ee & 31u) == 16u && ee + 16u <= chunk_end) {
+              XLC_RUN(XLC_HEX);
+              ee += 16u;
+            }
+            for (; ee + 32u <= chunk_end; ee += 32u) XLC_RUN(XLC_B32);
             for (; ee + 16u <= chunk_end; ee += 16u) XLC_RUN(XLC_HEX);
             for (; ee + 8u <= chunk_end; ee += 8u) XLC_RUN(XLC_OCT);
             for (; ee + 4u <= chunk_end; ee += 4u) XLC_RUN(XLC_QUAD);
