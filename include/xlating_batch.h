@@ -143,9 +143,12 @@ int xlating_batch_timing_stride(xlating_batch *batch, unsigned every_n);
  * reset; returns the number of timed blocks. */
 int xlating_batch_timing_polyphase(xlating_batch *batch, double ms_total[3], int reset);
 
-/* One-line description of the resident plan (builds it if clients changed), e.g.
+/* One-line description of the resident plan, e.g.
  * "clients 1024 classes 1 | direct: h10 x 104 groups | polyphase: cls0 D42 T505 cols1024 V244".  For logs and tests:
- * which arithmetic path the optimized mode takes for which class.  Returns the length written (excluding NUL). */
+ * which arithmetic path the optimized mode takes for which class.  If the client set or an option changed and no call
+ * has run since the last plan, the plan is built first; if calls HAVE run, their outputs must stay where they are until
+ * the next process call, so the plan they ran with is described, followed by "| re-plan pending ...".
+ * Returns the length written (excluding NUL). */
 int xlating_batch_describe(xlating_batch *batch, char *buf, size_t buf_len);
 
 void xlating_batch_destroy(xlating_batch *batch);

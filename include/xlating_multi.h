@@ -37,6 +37,8 @@ int xlating_multi_unique_id(void *id);
 
 /* One process per GPU: this process is `rank` of `world` and drives HIP device `device` (-1: the current one).
  * Engine parameters as xlating_batch_create_grouped().  Collective: returns when every rank has called it.
+ * world == 1: `id` NULL -> no communicator, feeds are filtered in place from d_src; `id` given -> a one-rank "loop-back"
+ * communicator, feeds take the broadcast path of world > 1 line for line (what the one-GPU tests run).
  * 0, -EINVAL, -ENODEV, -ENOMEM, -EIO (RCCL/HIP failure). */
 int xlating_multi_create_rank(int rank, int world, const void *id, uint32_t sampling_freq, int input_format,
                               uint32_t max_input_buffer_length, unsigned max_group_blocks, int device,
@@ -63,10 +65,22 @@ xlating_batch *xlating_multi_engine(xlating_multi *multi, int gpu);
  *   d_src  device memory on GPU 0 holding the blocks (the process that drives GPU 0 passes it; the others pass NULL).
  * The blocks are broadcast from GPU 0 into the next receive buffer of every GPU on the communication stream, and every
  * local engine then processes them there (xlating_batch_process_device_group) on its compute stream.  Asynchronous:
- * returns once the work is enqueued; d_src may be reused after xlating_multi_feed_done(multi) of the NEXT call or a sync.
- * With world == 1 nothing is broadcast (the engine reads d_src in place).
+ * returns once the work is enqueued; d_src is still being read then -- by the root's broadcast on the communication
+ * stream, or (world == 1 without a communicator: nothing is broadcast) by the engine's launches, in place -- and may be
+ * overwritten once xlating_multi_feed_done() returns (or _feed_query() says 1, or on a stream that has passed
+ * _feed_wait_on_stream(), or after xlating_multi_sync()).
  * 0, -EINVAL, -EIO. */
 int xlating_multi_feed(xlating_multi *multi, const void *d_src, size_t input_len, unsigned nblocks, int mode);
+
+/* The source buffer of the LATEST feed: block the calling thread until it is no longer read / poll (1 free, 0 still read)
+ * / make `hip_stream` (a hipStream_t of GPU 0's device; NULL = the default stream) wait for that moment, so that an
+ * asynchronous refill of d_src enqueued there afterwards is safe.  With a communicator the event sits behind the root's
+ * broadcast only -- the filtering of the receive buffers goes on -- so a streaming host refills ONE buffer per feed and
+ * the broadcast of super-block k+1 still overlaps the filtering of k.  Processes that do not drive GPU 0 hold no source:
+ * 0 / 1 / 0 at once.  0 (query: 0 or 1), -EINVAL, -EIO. */
+int xlating_multi_feed_done(xlating_multi *multi);
+int xlating_multi_feed_query(xlating_multi *multi);
+int xlating_multi_feed_wait_on_stream(xlating_multi *multi, void *hip_stream);
 
 /* Wait until everything fed so far has been filtered on the local GPUs. */
 int xlating_multi_sync(xlating_multi *multi);

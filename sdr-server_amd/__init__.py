@@ -58,6 +58,7 @@ EXPORTED_SYMBOLS = (
 
 MULTI_SYMBOLS = ["xlating_multi_unique_id", "xlating_multi_create_rank", "xlating_multi_create_local", "xlating_multi_world",
                  "xlating_multi_local", "xlating_multi_add_client", "xlating_multi_engine", "xlating_multi_feed",
+                 "xlating_multi_feed_done", "xlating_multi_feed_query", "xlating_multi_feed_wait_on_stream",
                  "xlating_multi_sync", "xlating_multi_destroy"]
 
 _lib = None
@@ -98,6 +99,11 @@ def multi_lib():
     M.xlating_multi_feed.restype = C.c_int
     M.xlating_multi_sync.argtypes = [C.c_void_p]
     M.xlating_multi_sync.restype = C.c_int
+    for name in ("xlating_multi_feed_done", "xlating_multi_feed_query"):
+        getattr(M, name).argtypes = [C.c_void_p]
+        getattr(M, name).restype = C.c_int
+    M.xlating_multi_feed_wait_on_stream.argtypes = [C.c_void_p, C.c_void_p]
+    M.xlating_multi_feed_wait_on_stream.restype = C.c_int
     M.xlating_multi_destroy.argtypes = [C.c_void_p]
     M.xlating_multi_destroy.restype = None
     _mlib = M
@@ -521,6 +527,23 @@ class MultiHost:
         code = multi_lib().xlating_multi_feed(self.h, C.c_void_p(d_src) if d_src else None, input_len, nblocks, MODE[variant])
         if code != 0:
             raise XlatingError("xlating_multi_feed", code)
+
+    def feed_done(self):
+        """Block until the source buffer of the latest feed may be overwritten (xlating_multi_feed_done)."""
+        code = multi_lib().xlating_multi_feed_done(self.h)
+        if code != 0:
+            raise XlatingError("xlating_multi_feed_done", code)
+
+    def feed_query(self):
+        code = multi_lib().xlating_multi_feed_query(self.h)
+        if code < 0:
+            raise XlatingError("xlating_multi_feed_query", code)
+        return bool(code)
+
+    def feed_wait_on_stream(self, stream=0):
+        code = multi_lib().xlating_multi_feed_wait_on_stream(self.h, C.c_void_p(stream) if stream else None)
+        if code != 0:
+            raise XlatingError("xlating_multi_feed_wait_on_stream", code)
 
     def sync(self):
         code = multi_lib().xlating_multi_sync(self.h)

@@ -153,6 +153,7 @@ struct xlating_batch_t {
   bool want_q15 = false;  // the Q15 tap image is built from the first XL_MODE_Q15 call on
   int planned_immature = 0;  // clients that were not mature when the plan was built (they merge once they are)
   uint32_t trel = 0;         // samples consumed since the plan was built (XlPos::trel)
+  uint64_t calls_since_plan = 0;  // calls run with the current plan (their outputs live in its rows)
   uint32_t plan_maxD = 1;
   std::vector<DirectClass> classes;       // direct classes over ALL clients (native mode)
   std::vector<DirectClass> classes_rest;  // direct classes over the clients outside `poly` (optimized mode)
@@ -501,41 +502,44 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
   (void)hipSetDevice(b->device);
   xl_batch_sync_all(b);
   b->spec_n = 0;
+  // Every failure from here on rolls the client back (a phantom client with an undefined phase would otherwise be
+  // planned and filtered on every later call, with no id in the caller's hands to remove it).
+  auto rollback = [&](int code) {
+    c.alive = false;
+    c.rt.clear();
+    b->nalive--;
+    return code;
+  };
   if ((size_t)id >= b->phase_cap) {
+    // grow all running-phase buffers or none: allocate the whole new set first, swap it in only when complete
     const size_t ncap = std::max<size_t>(1024, 2 * b->clients.size());
+    float2 *np[XL_NTAB] = {};
+    short2 *nq = nullptr;
+    bool ok = hipMalloc((void **)&nq, ncap * sizeof(short2)) == hipSuccess;
+    for (int i = 0; ok && i < XL_NTAB; ++i) ok = hipMalloc((void **)&np[i], ncap * sizeof(float2)) == hipSuccess;
+    for (int i = 0; ok && i < XL_NTAB; ++i)
+      if (b->d_phase[i]) ok = hipMemcpy(np[i], b->d_phase[i], b->phase_cap * sizeof(float2), hipMemcpyDeviceToDevice) == hipSuccess;
+    if (ok && b->d_qphase) ok = hipMemcpy(nq, b->d_qphase, b->phase_cap * sizeof(short2), hipMemcpyDeviceToDevice) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      for (int i = 0; i < XL_NTAB; ++i)
+        if (np[i]) (void)hipFree(np[i]);
+      if (nq) (void)hipFree(nq);
+      return rollback(-ENOMEM);
+    }
     for (int i = 0; i < XL_NTAB; ++i) {
-      float2 *np = nullptr;
-      if (hipMalloc((void **)&np, ncap * sizeof(float2)) != hipSuccess) {
-        c.alive = false;
-        b->nalive--;
-        return -ENOMEM;
-      }
-      if (b->d_phase[i]) {
-        (void)hipMemcpy(np, b->d_phase[i], b->phase_cap * sizeof(float2), hipMemcpyDeviceToDevice);
-        (void)hipFree(b->d_phase[i]);
-      }
-      b->d_phase[i] = np;
+      if (b->d_phase[i]) (void)hipFree(b->d_phase[i]);
+      b->d_phase[i] = np[i];
     }
-    {
-      short2 *nq = nullptr;
-      if (hipMalloc((void **)&nq, ncap * sizeof(short2)) != hipSuccess) {
-        c.alive = false;
-        b->nalive--;
-        return -ENOMEM;
-      }
-      if (b->d_qphase) {
-        (void)hipMemcpy(nq, b->d_qphase, b->phase_cap * sizeof(short2), hipMemcpyDeviceToDevice);
-        (void)hipFree(b->d_qphase);
-      }
-      b->d_qphase = nq;
-    }
+    if (b->d_qphase) (void)hipFree(b->d_qphase);
+    b->d_qphase = nq;
     b->phase_cap = ncap;
   }
   {
     const float2 one = make_float2(1.0f, 0.0f);
     const short2 qone = make_short2(INT16_MAX, 0);  // xlating.c:546-547
-    if (hipMemcpy(b->d_phase[b->pcur] + id, &one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess) return -EIO;
-    if (hipMemcpy(b->d_qphase + id, &qone, sizeof(qone), hipMemcpyHostToDevice) != hipSuccess) return -EIO;
+    if (hipMemcpy(b->d_phase[b->pcur] + id, &one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess) return rollback(-EIO);
+    if (hipMemcpy(b->d_qphase + id, &qone, sizeof(qone), hipMemcpyHostToDevice) != hipSuccess) return rollback(-EIO);
   }
   return id;
 }
@@ -739,6 +743,7 @@ static int xl_batch_plan(xlating_batch *b) {
   b->classes_rest.clear();
   b->nco.clear();
   b->trel = 0;
+  b->calls_since_plan = 0;
   b->planned_immature = 0;
   b->plan_maxD = 1;
   const uint32_t cap_samples = b->max_samples * b->gcap;
@@ -1197,6 +1202,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     b->ocur = p;
     b->hcur = hn;
     b->ncalls++;
+    b->calls_since_plan++;
     b->last_q15 = true;
     return 0;
   }
@@ -1525,7 +1531,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     if (!rolled)  // no client produced output in this call (tiny block): roll the history on its own
       XL_TRY(xl_launch_update_history(b->d_hist[hb], d_blocks, XL_HCAP, N, b->bps, b->d_hist[hn], s));
     // table[tab] has been read by everything enqueued so far (only the side stream ever waits for this)
-    if (side) {
+    // -- and a LATER side-stream chain launch may find this slot in its ring even when this call ran no side stream
+    // (alternating modes, alternating caller streams, nco_calls_per_launch < 4): once a side stream has been used the
+    // event is recorded for every call.  Engines that never use the side stream never pay for it.
+    if (side || b->last_nco != nullptr) {
       if (!done_attached) XL_TRY(hipEventRecord(b->ev_done[tab], s));
       b->ev_done_valid[tab] = true;
       b->ev_done_stream[tab] = s;
@@ -1555,6 +1564,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     b->ocur = p;
     b->hcur = hn;
     b->ncalls++;
+    b->calls_since_plan++;
     // ---- the NEXT call's phases, guessing it has the same shape, were tabulated inside the launches above;
     // without them (tiny call, or the tuning switch) the next call tabulates for itself
     if (launched_n > 0) {
@@ -1578,7 +1588,11 @@ fail:
 extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
   if (b == nullptr || buf == nullptr || n == 0) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
-  if (b->dirty) {
+  // A re-plan reassigns every client's output row and may reallocate the output buffers, while the latest call's outputs
+  // stay valid "until the next process call" (xlating_batch.h): with calls behind it a dirty engine reports the plan
+  // those calls ran with and says that a new one is pending; before the first call after a plan nothing can be lost.
+  const bool pending = b->dirty && b->calls_since_plan > 0;
+  if (b->dirty && !pending) {
     int rc = xl_batch_plan(b);
     if (rc != 0) return rc;
   }
@@ -1603,6 +1617,7 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
       }
     if (!any) d += " none";
   }
+  if (pending) d += " | re-plan pending (client set or options changed: the next process call plans again)";
   const size_t len = std::min(d.size(), n - 1);
   memcpy(buf, d.data(), len);
   buf[len] = 0;
@@ -1715,7 +1730,8 @@ extern "C" int xlating_batch_output_host(xlating_batch *b, int id, const float *
 
 extern "C" int xlating_batch_output_device(xlating_batch *b, int id, const void **d_output, size_t *output_len) {
   if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive || d_output == nullptr ||
-      output_len == nullptr || b->dirty || b->d_out[b->ocur] == nullptr)
+      output_len == nullptr || b->d_out[b->ocur] == nullptr)  // (a dirty engine still holds the latest call's rows: the plan
+                                                               // is only rebuilt by the next process call)
     return -EINVAL;
   const Client &c = b->clients[id];
   *d_output = b->d_out[b->ocur] + c.out_off;

@@ -10,6 +10,7 @@
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <new>
 #include <utility>
@@ -212,8 +213,24 @@ static bool xl_check_len(xlating *f, size_t nsamples) {
   return false;
 }
 
+// Latency trace of the drop-in call (XL_DROPIN_TRACE_US=<threshold>): a call that takes longer than the threshold prints
+// where its time went -- copy into the pinned block | enqueue of the launches | wait for the stream | the look-ahead
+// request -- as one "<6>" line.  Off by default; the stamps cost ~20 ns each.
+static long xl_trace_threshold_us() {
+  static const long v = getenv("XL_DROPIN_TRACE_US") ? atol(getenv("XL_DROPIN_TRACE_US")) : -1;
+  return v;
+}
+static inline double xl_now_us() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+
 static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt, int mode, XL_CF32 **output,
                         size_t *output_len) {
+  const long trace_us = xl_trace_threshold_us();
+  double ts0 = 0.0, ts1 = 0.0, ts2 = 0.0, ts3 = 0.0;
+  if (trace_us >= 0) ts0 = xl_now_us();
   *output = reinterpret_cast<XL_CF32 *>(f->h_out_f);
   *output_len = 0;
   const size_t n = input_len / 2;
@@ -225,6 +242,7 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
   XL_TRY(hipSetDevice(f->device));
   if (n > 0) {
     memcpy(f->h_in, input, bytes);
+    if (trace_us >= 0) ts1 = xl_now_us();
     // the convert kernel reads the pinned block over PCIe itself: one stream operation less than copy + convert
     if (!f->zero_copy) XL_TRY(hipMemcpyAsync(f->d_raw, f->h_in, bytes, hipMemcpyHostToDevice, f->stream));
     XL_TRY(xl_launch_convert_cf32(f->zero_copy ? f->h_in : f->d_raw, fmt, (uint32_t)n, f->d_work_f + f->hist, f->stream));
@@ -297,7 +315,9 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
       f->spec_K = Kn;
     }
   }
+  if (trace_us >= 0) ts2 = xl_now_us();
   XL_TRY(hipStreamSynchronize(f->stream));
+  if (trace_us >= 0) ts3 = xl_now_us();
   if (K > 0 && f->lookahead && !f->spec_valid) {
     // look-ahead: if the next call brings the same number of samples (and no cs16-family call moves the shared
     // history in between) it produces Knext outputs; tabulate them now, off the caller's critical path.
@@ -314,6 +334,12 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
       f->spec_valid = true;
       f->spec_K = Kn;
     }
+  }
+  if (trace_us >= 0) {
+    const double ts4 = xl_now_us();
+    if (ts4 - ts0 > (double)trace_us)
+      fprintf(stderr, "<6>xlating-hip: slow call %.1f us = copy-in %.1f + enqueue %.1f + stream wait %.1f + look-ahead %.1f (K %zu, ahead %d)\n",
+              ts4 - ts0, ts1 - ts0, ts2 - ts1, ts3 - ts2, ts4 - ts3, K, (int)ahead);
   }
   *output_len = K;
   return;

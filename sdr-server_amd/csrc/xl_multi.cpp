@@ -7,6 +7,12 @@
 // compute stream waits for it before the engine's launches) and `free` (recorded behind the launches that read the buffer; the
 // communication stream waits for it before the broadcast two feeds later overwrites the buffer).  Consecutive feeds
 // alternate the buffers, so the broadcast of super-block k+1 runs while super-block k is filtered.
+// The driver of GPU 0 also owns `src_done`: recorded behind the root's broadcast (or, without a communicator, behind the
+// launches that read d_src in place) -- what xlating_multi_feed_done / _feed_query / _feed_wait_on_stream observe.
+//
+// Loop-back communicator: world == 1 WITH an id creates a one-rank RCCL communicator and takes the broadcast path of
+// world > 1 line for line (receive buffers, ready / free events, source event).  It exists so that a one-GPU box can
+// execute that path (tests/test_batch_gpu.py); a deployment with one GPU passes no id and filters d_src in place.
 #include <errno.h>
 #include <rccl/rccl.h>
 #include <stdlib.h>
@@ -28,11 +34,14 @@ struct Gpu {
   void *recv[2] = {nullptr, nullptr};
   hipEvent_t ready[2] = {nullptr, nullptr}, free_[2] = {nullptr, nullptr};
   bool free_valid[2] = {false, false};
+  hipEvent_t src_done = nullptr;  // GPU 0's driver only: the latest feed no longer reads d_src
+  bool src_valid = false;
 };
 }  // namespace
 
 struct xlating_multi_t {
   int world = 1;
+  bool bcast = false;     // the feed goes through the communicators (world > 1, or the one-rank loop-back)
   std::vector<Gpu> gpus;  // the GPUs this process drives
   size_t recv_bytes = 0;
   uint32_t bps = 2;
@@ -62,8 +71,9 @@ static int xl_multi_open_gpu(xlating_multi *m, Gpu &g, uint32_t fs, int fmt, uin
   if (rc != 0) return rc;
   XL_TRY(hipSetDevice(g.device));
   XL_TRY(hipStreamCreateWithFlags(&g.comm_stream, hipStreamNonBlocking));
+  if (g.index == 0) XL_TRY(hipEventCreateWithFlags(&g.src_done, hipEventDisableTiming));
   for (int i = 0; i < 2; ++i) {
-    if (m->world > 1) XL_TRY(hipMalloc(&g.recv[i], m->recv_bytes));
+    if (m->bcast) XL_TRY(hipMalloc(&g.recv[i], m->recv_bytes));
     XL_TRY(hipEventCreateWithFlags(&g.ready[i], hipEventDisableTiming));
     XL_TRY(hipEventCreateWithFlags(&g.free_[i], hipEventDisableTiming));
   }
@@ -90,6 +100,7 @@ extern "C" int xlating_multi_create_rank(int rank, int world, const void *id, ui
   xlating_multi *m = new (std::nothrow) xlating_multi_t();
   if (m == nullptr) return -ENOMEM;
   m->world = world;
+  m->bcast = world > 1 || id != nullptr;
   m->bps = fmt <= XL_FMT_CS8 ? 2u : (fmt == XL_FMT_CS16 ? 4u : 8u);
   m->recv_bytes = (size_t)(max_len / 2) * gcap * m->bps + 16;
   m->gpus.resize(1);
@@ -100,7 +111,7 @@ extern "C" int xlating_multi_create_rank(int rank, int world, const void *id, ui
     xlating_multi_destroy(m);
     return rc;
   }
-  if (world > 1) {
+  if (m->bcast) {
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
     XL_NCCL(ncclCommInitRank(&m->gpus[0].comm, world, u, rank));
@@ -122,6 +133,7 @@ extern "C" int xlating_multi_create_local(int ngpus, const int *devices, uint32_
   xlating_multi *m = new (std::nothrow) xlating_multi_t();
   if (m == nullptr) return -ENOMEM;
   m->world = ngpus;
+  m->bcast = ngpus > 1;
   m->bps = fmt <= XL_FMT_CS8 ? 2u : (fmt == XL_FMT_CS16 ? 4u : 8u);
   m->recv_bytes = (size_t)(max_len / 2) * gcap * m->bps + 16;
   m->gpus.resize((size_t)ngpus);
@@ -178,14 +190,16 @@ extern "C" int xlating_multi_add_client(xlating_multi *m, int global_client, uin
 extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t input_len, unsigned nblocks, int mode) {
   if (m == nullptr || nblocks < 1) return -EINVAL;
   const size_t bytes = (input_len / 2) * nblocks * m->bps;
-  if (m->world > 1 && bytes > m->recv_bytes) return -EINVAL;
+  if (m->bcast && bytes > m->recv_bytes) return -EINVAL;
   Gpu *root = xl_multi_find(m, 0);
   if (root != nullptr && d_src == nullptr && bytes > 0) return -EINVAL;  // the driver of GPU 0 holds the source
   const int i = (int)(m->feeds & 1);
-  if (m->world == 1) {
+  if (!m->bcast) {  // one GPU, no communicator: the engine reads d_src in place; the source is free behind its launches
     Gpu &g = m->gpus[0];
-    int rc = xlating_batch_process_device_group(g.engine, d_src, input_len, nblocks, mode, XL_STREAM_ENGINE);
+    int rc = xlating_batch_process_device_group_ev(g.engine, d_src, input_len, nblocks, mode, XL_STREAM_ENGINE, nullptr,
+                                                   g.src_done);
     if (rc != 0) return rc;
+    g.src_valid = true;
     m->feeds++;
     return 0;
   }
@@ -200,6 +214,11 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
     XL_NCCL(ncclBroadcast(g.index == 0 ? d_src : g.recv[i], g.recv[i], bytes, ncclUint8, 0, g.comm, g.comm_stream));
   }
   if (m->gpus.size() > 1) XL_NCCL(ncclGroupEnd());
+  if (root != nullptr) {  // the broadcast is the only reader of d_src
+    XL_TRY(hipSetDevice(root->device));
+    XL_TRY(hipEventRecord(root->src_done, root->comm_stream));
+    root->src_valid = true;
+  }
   // ---- independent per-GPU work: every local engine filters its own clients from its receive buffer
   for (Gpu &g : m->gpus) {
     XL_TRY(hipSetDevice(g.device));
@@ -214,6 +233,37 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
   return 0;
 fail:
   return -EIO;
+}
+
+// ---- "may d_src of the latest feed be overwritten?"  Only the driver of GPU 0 holds a source; elsewhere: yes, at once.
+extern "C" int xlating_multi_feed_done(xlating_multi *m) {
+  if (m == nullptr) return -EINVAL;
+  Gpu *root = xl_multi_find(m, 0);
+  if (root == nullptr || !root->src_valid) return 0;
+  if (hipSetDevice(root->device) != hipSuccess) return -EIO;
+  return hipEventSynchronize(root->src_done) == hipSuccess ? 0 : -EIO;
+}
+
+extern "C" int xlating_multi_feed_query(xlating_multi *m) {
+  if (m == nullptr) return -EINVAL;
+  Gpu *root = xl_multi_find(m, 0);
+  if (root == nullptr || !root->src_valid) return 1;
+  if (hipSetDevice(root->device) != hipSuccess) return -EIO;
+  const hipError_t e = hipEventQuery(root->src_done);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();  // (not an error: clear the sticky code)
+    return 0;
+  }
+  return -EIO;
+}
+
+extern "C" int xlating_multi_feed_wait_on_stream(xlating_multi *m, void *hip_stream) {
+  if (m == nullptr) return -EINVAL;
+  Gpu *root = xl_multi_find(m, 0);
+  if (root == nullptr || !root->src_valid) return 0;
+  if (hipSetDevice(root->device) != hipSuccess) return -EIO;
+  return hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), root->src_done, 0) == hipSuccess ? 0 : -EIO;
 }
 
 extern "C" int xlating_multi_sync(xlating_multi *m) {
@@ -238,6 +288,7 @@ extern "C" void xlating_multi_destroy(xlating_multi *m) {
       if (g.ready[i]) (void)hipEventDestroy(g.ready[i]);
       if (g.free_[i]) (void)hipEventDestroy(g.free_[i]);
     }
+    if (g.src_done) (void)hipEventDestroy(g.src_done);
     if (g.comm_stream) (void)hipStreamDestroy(g.comm_stream);
   }
   delete m;

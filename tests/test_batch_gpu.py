@@ -893,7 +893,7 @@ def test_nco_tabulation_side_stream_or_inside_the_launches(side, G, poly):
     eng.close()
 
 
-@pytest.mark.parametrize("how", ["rank", "local"])
+@pytest.mark.parametrize("how", ["rank", "local", "loopback"])
 def test_c_multi_host_single_gpu(how):
     """include/xlating_multi.h on the one GPU of this box (world 1 as a rank, and the one-process form with ngpus = 1):
     sharding call, feed of 4-block super-blocks from device memory, engine access, sync -- every client vs the oracle."""
@@ -902,6 +902,8 @@ def test_c_multi_host_single_gpu(how):
     t48 = lpf(FS, 24000, 9600)
     if how == "rank":
         m = xl.MultiHost(FS, "cu8", 100002, group_blocks=4, rank=0, world=1)
+    elif how == "loopback":  # a one-rank RCCL communicator: the feed takes the broadcast path of world > 1
+        m = xl.MultiHost(FS, "cu8", 100002, group_blocks=4, rank=0, world=1, uid=xl.MultiHost.unique_id())
     else:
         m = xl.MultiHost(FS, "cu8", 100002, group_blocks=4, ngpus=1)
     assert m.world == 1
@@ -924,6 +926,58 @@ def test_c_multi_host_single_gpu(how):
                 assert rel_err(got, want) <= REL_TOL
             else:
                 assert bits_equal(got, want), (k, cid)
+    m.close()
+
+
+@pytest.mark.parametrize("loopback", [False, True], ids=["in-place", "loop-back communicator"])
+def test_multi_feed_done_one_source_buffer_refilled_every_feed(loopback):
+    """xlating_multi_feed_done / _feed_query / _feed_wait_on_stream (include/xlating_multi.h): a streaming host that owns
+    ONE resident source buffer and refills it for every feed.  `loopback`: world 1 with an RCCL id -- a one-rank
+    communicator, i.e. the broadcast path of world > 1 line for line (receive buffers, ready / free events, the source
+    event behind the broadcast); otherwise the engine filters the source in place and the event sits behind its launches.
+    Every client of every feed vs the oracle; a refill that came too early would corrupt a feed."""
+    import torch
+
+    t48 = lpf(FS, 24000, 9600)
+    n, G = 100002, 4
+    uid = xl.MultiHost.unique_id() if loopback else None
+    m = xl.MultiHost(FS, "cu8", n, group_blocks=G, rank=0, world=1, uid=uid)
+    eng = m.engine(0)
+    oracles = {}
+    for c in range(160):  # (>= 128 mature clients: optimized calls take the polyphase launches + side-stream chain)
+        cid = m.add_client(c, 42, t48, -900000 + 11000 * c)
+        if c % 9 == 0:
+            oracles[cid] = Oracle(42, t48, -900000 + 11000 * c, FS, n)
+    assert m.feed_query() is True  # nothing fed yet
+    src = torch.empty(G * n, dtype=torch.uint8, device="cuda")
+    pinned = torch.empty(G * n, dtype=torch.uint8).pin_memory()
+    copy_stream = torch.cuda.Stream()
+    feeds = []
+    for k in range(6):
+        x = siggen.xs_u8(5400 + k, G * n)
+        feeds.append(x)
+        if k % 2 == 0:   # host-side wait, then a blocking refill
+            m.feed_done()
+            assert m.feed_query() is True
+            src.copy_(torch.from_numpy(x))
+            torch.cuda.synchronize()
+        else:            # stream-side wait: an asynchronous refill ordered behind the source event
+            m.feed_wait_on_stream(copy_stream.cuda_stream)
+            pinned.copy_(torch.from_numpy(x))
+            with torch.cuda.stream(copy_stream):
+                src.copy_(pinned, non_blocking=True)
+            copy_stream.synchronize()
+        m.feed(src.data_ptr(), n, G, "optimized" if k >= 2 else "native")
+        if k in (2, 5):  # compare some feeds right away, let the others run back to back
+            m.sync()
+            eng.fetch()
+            for cid, o in oracles.items():
+                for xb in feeds:
+                    want = np.concatenate([o.process("cu8", bl) for bl in np.split(xb, G)])
+                got = eng.output(cid)
+                assert rel_err(got, want) <= REL_TOL, (k, cid)
+            feeds = []
+    m.feed_done()
     m.close()
 
 
@@ -987,4 +1041,65 @@ def test_chain_launch_covers_several_calls(ncalls, poly):
         assert tuple(np.float32(v).tobytes() for v in eng.phase(cid)) == tuple(np.float32(v).tobytes() for v in o.phase)
     with pytest.raises(xl.XlatingError):
         eng.set_option("nco_calls_per_launch", 5)
+    eng.close()
+
+
+def test_describe_after_a_change_keeps_the_latest_outputs():
+    """Outputs stay valid until the next process call (xlating_batch.h) -- also across add_client / remove_client /
+    set_option followed by describe(): with calls behind it a dirty engine describes the plan those calls ran with and
+    says a re-plan is pending, instead of re-planning (which reassigns every client's output row)."""
+    t48 = lpf(FS, 24000, 9600)
+    clients = [(42, t48, -700000 + 47000 * c) for c in range(20)]
+    eng, oracles = _group_engine("cu8", 100002, 1, clients, poly=0)
+    first = eng.describe()  # no call yet: plans
+    assert "clients 20" in first and "pending" not in first
+    x = siggen.xs_u8(7100, 100002)
+    eng.process_host(x, "native")
+    want = {cid: o.process("cu8", x) for cid, o in oracles.items()}
+    eng.remove_client(3)
+    late = eng.add_client(42, t48, 31337)  # reuses row / id 3 in a naive re-plan
+    d = eng.describe()
+    assert "re-plan pending" in d, d
+    eng.fetch()
+    for cid in oracles:
+        if cid != 3:
+            assert bits_equal(eng.output(cid), want[cid]), cid
+    ptr, n = eng.output_device(5)
+    assert n == len(want[5]) and ptr
+    oracles.pop(3)
+    oracles[late] = Oracle(42, t48, 31337, FS, 100002)
+    check_clients(eng, oracles, "cu8", siggen.xs_u8(7101, 100002), "native")
+    assert "pending" not in eng.describe() and "clients 20" in eng.describe()
+    eng.close()
+
+
+@pytest.mark.parametrize("ncalls", [1, 2, 4])
+def test_side_and_fused_calls_mixed_while_the_host_runs_ahead(ncalls):
+    """Calls whose NCO chain runs on the side stream (optimized, polyphase) alternate with calls that carry it inside their
+    launches (native, heavy direct launches), enqueued back to back WITHOUT host synchronisation, with chain launches
+    shorter than the table ring (nco_calls_per_launch < 4): a chain launch must wait for the readers of every table slot
+    it overwrites, whichever kind of call read it last.  Outputs of the final calls and the committed phases vs the oracle."""
+    import torch
+
+    t48 = lpf(FS, 24000, 9600)
+    n, G = 100002, 4
+    clients = [(42, t48, -900000 + 12000 * c) for c in range(150)]
+    eng, oracles = _group_engine("cu8", n, G, clients)
+    eng.set_option("nco_calls_per_launch", ncalls)
+    keep = sorted(oracles)[::15]
+    seq = ["optimized", "optimized", "native", "optimized", "native", "native", "optimized", "optimized", "optimized", "native",
+           "optimized", "optimized"]
+    xs = [siggen.xs_u8(7200 + k, G * n) for k in range(len(seq))]
+    dev = [torch.from_numpy(x).cuda() for x in xs]
+    torch.cuda.synchronize()
+    for k, variant in enumerate(seq):  # no sync in between: the host runs as far ahead as the queues allow
+        eng.process_device_group(dev[k].data_ptr(), n, G, variant, "engine")
+    eng.sync()
+    eng.fetch()
+    for cid in keep:
+        o = oracles[cid]
+        for x in xs:
+            want = np.concatenate([o.process("cu8", bl) for bl in np.split(x, G)])
+        assert rel_err(eng.output(cid), want) <= REL_TOL, cid
+        assert tuple(np.float32(v).tobytes() for v in eng.phase(cid)) == tuple(np.float32(v).tobytes() for v in o.phase), cid
     eng.close()

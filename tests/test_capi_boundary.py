@@ -38,6 +38,20 @@ def test_every_declared_symbol_is_exported(header):
         C.c_char_p.in_dll(L, "SIMD_STATUS")
 
 
+@pytest.mark.parametrize("header,libname", [("xlating_sinks.h", "hip"), ("xlating_wire.h", "hip"), ("xlating_multi.h", "multi")])
+def test_every_declared_symbol_is_defined_nm(header, libname):
+    """The remaining headers, by symbol table (libxlating_multi.so links librccl: not dlopen'ed on a GPU-less box)."""
+    path = xl.library_path() if libname == "hip" else xl.multi_library_path()
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    defined = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    decl = _declared_functions(header)
+    assert decl, header
+    for name in decl:
+        assert name in defined, f"{name} declared in include/{header} but not defined in {os.path.basename(path)}"
+    if libname == "multi":
+        assert set(xl.MULTI_SYMBOLS) <= defined
+
+
 def test_exported_list_matches_nm():
     out = subprocess.run(["nm", "-D", "--defined-only", xl.library_path()], capture_output=True, text=True).stdout
     defined = {l.split()[-1] for l in out.splitlines() if l.strip()}
