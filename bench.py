@@ -13,20 +13,26 @@ lpf_cutoff_rate=5 -> 505 taps (the BASELINE "~84-tap" figure is not reachable wi
 SURVEY D3).  The engine is driven as sdr_callback would drive it with a super-block: calls
 of 8 consecutive blocks (xlating_batch_process_device_group) -- results identical to 8 successive process calls.
 
-A "step" = one pass of the hot path over one batch of synthetic input = BLOCKS_PER_STEP consecutive blocks (40 calls of
-8 blocks, 41.9 M samples of the stream) for every client of every GPU; ms_per_step x steps = the timed seconds.
+A "step" = one pass of the hot path over one batch of synthetic input = BLOCKS_PER_STEP consecutive blocks (240 calls of
+8 blocks, 252 M samples of the stream) for every client of every GPU.  The timed region (exactly `--steps` steps between
+barrier + synchronize on both sides, max over ranks) is repeated REPEATS = 3 times; `value` / `ms_per_step` are the
+MEDIAN repeat, all three are printed ("repeats").  20 steps ~ 1.1 s per repeat at 1024 clients.
     N > 1: rank 0's blocks are broadcast over RCCL/xGMI, 8 blocks per broadcast, on a side stream (the path's only
     exchange step), then each rank runs its own clients on them -- no further communication.
 Inputs are synthetic (xorshift bytes), already resident in HBM when the timed region starts.
 
 Prints ONE JSON line (rank 0): value = input IQ Msamples/s summed over all clients and GPUs.
-"roofline":     per-client-read model of SURVEY 8(d): algorithmic bytes per call = clients x samples x (2 B in + 8/D B
-                out), divided by the mean duration of a call's launches measured with HIP events on the launch stream
-                inside the timed region ("frac").  "traffic" = HBM bytes per call from the PMC counters (separate
-                rocprofv3 passes; "traffic_source" says where they were measured) and "hbm_counter_frac" = traffic /
-                that duration / peak: what the launches really move.
-"parity_spot":  after the timed region 16 sampled clients are fetched and compared with the oracle (whose stream state
-                is fast-forwarded over the run: phase recurrence only, then real blocks).
+"roofline":     PHYSICAL: "traffic" = HBM bytes one call's launches move by the PMC counters (FETCH_SIZE / WRITE_SIZE in
+                separate rocprofv3 passes over `bench.py --replay-calls`, run as subprocesses right after the timed region
+                -- "traffic_source" says "measured in this run", or names the committed file it fell back to), "achieved" =
+                traffic / the mean duration of a call's launches (HIP events on the launch stream inside the timed region),
+                "frac" = achieved / 8 TB/s: <= 1 by construction.  "per_kernel": duration, bytes, HBM and FP32 fractions and
+                the ceiling that binds each launch.  The per-client-read MODEL of SURVEY 8(d) (2 B in + 8/D B out per
+                (client, sample): every client "reads" the block the engine reads once) is kept as "model_frac" -- it is
+                not traffic and can exceed 1.
+"parity_spot":  after the timed region EVERY client of this GPU is fetched and compared with a population of oracle filters
+                run on the host cores (oracle/population.c; stream state fast-forwarded over the run: phase recurrence
+                only, then one real super-block to load the history, the next one compared).
 "native":       the same workload with the reference's default arithmetic (cpu_optimization NATIVE_CF32,
                 src/config.c:252-264): bit-exact scalar order, direct FIR kernel.
 "cpu_baseline": the reference itself (oracle/_ref, unmodified sources, -O3 -ffast-math AVX2) -- or the repo's CPU
@@ -52,11 +58,12 @@ D = FS // RATE
 BLOCK_BYTES = 262144            # server default buffer_size (src/resources/config.conf:13)
 S = BLOCK_BYTES // 2            # complex samples per block
 GROUP = 8                       # blocks per engine call and per RCCL broadcast (8-block super-block)
-BLOCKS_PER_STEP = 320           # blocks per bench step (40 calls): 20 steps ~ 0.2 s of GPU time at 1024 clients
+BLOCKS_PER_STEP = 1920          # blocks per bench step (240 calls): 20 steps ~ 1.1 s of GPU time at 1024 clients
+REPEATS = 3                     # the timed region is repeated; value = the median repeat
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 TIMING_STRIDE = 5               # HIP events bracket every 5th call of the timed region (an event pair costs ~6 us of stream time; odd, so that both calls of a chain launch's pair are sampled)
-SPOT_CLIENTS = 16
+PMC_REPLAY_CALLS = 12           # calls of the counter passes (rocprofv3 serialises the dispatches; the first 3 per kernel are dropped)
 
 
 def shard_clients(total_clients, world_size, rank):
@@ -245,12 +252,12 @@ class CHost:
     stream and the event plumbing all live in the C library (north_star: host code stays in C).  torch.distributed is
     used by bench.py only to hand rank 0's RCCL id to the other ranks and for the barrier / max-over-ranks of the timing."""
 
-    name = "xlating_multi (C host: ncclBroadcast per super-block on a side stream) + xlating_batch"
-
     def __init__(self, ctx, group):
         xl, torch, dist = ctx["xl"], ctx["torch"], ctx["dist"]
         self.ctx = ctx
         rank, world = ctx["rank"], ctx["world"]
+        self.name = ("xlating_multi (C host: ncclBroadcast of every super-block on a communication stream) + xlating_batch" if world > 1
+                     else "xlating_multi (C host; one GPU: no communicator, the resident super-block is filtered in place) + xlating_batch")
         uid = None
         if world > 1:
             t = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -284,8 +291,9 @@ class CHost:
 
 
 def make_host(ctx, group):
-    """The C host unless `--feed torch`; if any rank cannot create it (e.g. an RCCL set-up problem) every rank falls back
-    to the torch.distributed feeder -- the JSON line says which one ran ("feed")."""
+    """The C host (include/xlating_multi.h) unless `--feed torch` asks for the torch.distributed feeder.  If any rank cannot
+    create the C host (e.g. an RCCL set-up problem) EVERY rank stops with an error: a multi-GPU run that silently measured
+    the Python feeder instead would be mistaken for the C host's number."""
     torch, dist, world = ctx["torch"], ctx["dist"], ctx["world"]
     if not ctx["cuda"] or ctx["feed"] == "torch":
         return TorchHost(ctx, group)
@@ -313,7 +321,7 @@ def make_host(ctx, group):
     else:
         try:
             host = CHost(ctx, group)
-        except Exception as e:  # noqa: BLE001 -- reported, then the fallback runs
+        except Exception as e:  # noqa: BLE001 -- reported below
             err = e
     ok = 1 if host is not None else 0
     if world > 1:
@@ -322,18 +330,18 @@ def make_host(ctx, group):
         ok = int(t.item())
     if ok:
         return host
-    sys.stderr.write(f"bench.py: the C multi-GPU host is unavailable on rank {ctx['rank']} ({err}); falling back to the torch feeder\n")
     if host is not None:
         host.close()
-    ctx["feed"] = "torch"
-    return TorchHost(ctx, group)
+    raise SystemExit(f"bench.py: the C multi-GPU host (xlating_multi) could not be created on rank {ctx['rank']} ({err}); "
+                     "nothing was measured.  `--feed torch` runs the torch.distributed feeder instead (and says so in config.feed).")
 
 
 def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROUP, options=None, staggered=False,
-                 spot=False, poly3=True):
-    """Build this rank's engine with its shard of clients and time `steps` steps.  Returns dict of measurements.
+                 spot=False, poly3=True, blocks_per_step=BLOCKS_PER_STEP, repeats=1, replay_calls=0):
+    """Build this rank's engine with its shard of clients and time `repeats` x `steps` steps.  Returns dict of measurements.
     options: engine plan options (xlating_batch_set_option); staggered: the clients join over 21 consecutive blocks
-    before the warm-up (every join lands on another output grid) instead of all before block 0."""
+    before the warm-up (every join lands on another output grid) instead of all before block 0.
+    replay_calls > 0: no timing at all -- warm up, run that many calls, return (the PMC passes profile this)."""
     xl, torch, dist, rank, world = ctx["xl"], ctx["torch"], ctx["dist"], ctx["rank"], ctx["world"]
     cuda = ctx["cuda"]
     code, taps = ctx["lpf"](1.0, FS, RATE // 2, RATE // ntaps_rate)
@@ -344,7 +352,7 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
     if cuda:
         for k, v in (options or {}).items():
             eng.set_option(k, v)
-    calls_per_step = BLOCKS_PER_STEP // GROUP
+    calls_per_step = blocks_per_step // GROUP
     ids = {}
 
     def call(nblocks=group):
@@ -360,26 +368,37 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
         for c in mine:
             ids[c] = host.add_client(c, taps)
 
+    if replay_calls:
+        for _ in range(4 + replay_calls):
+            call()
+        host.sync()
+        host.close()
+        return None
+
     for _ in range(warmup * calls_per_step if warmup else 2):
         call()
     host.sync()
     eng.timing_stride(TIMING_STRIDE)
     eng.timing(True)
-    if world > 1:
-        dist.barrier()
-    host.sync()
-    t0 = time.perf_counter()
-    for _ in range(steps * calls_per_step):
-        call()
-    host.sync()
-    if world > 1:
-        dist.barrier()
-    host.sync()
-    dt = time.perf_counter() - t0
+    secs = []
+    for _ in range(repeats):
+        if world > 1:
+            dist.barrier()
+        host.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps * calls_per_step):
+            call()
+        host.sync()
+        if world > 1:
+            dist.barrier()
+        host.sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            dt = reduce_max_seconds(dist, torch, dt, "cuda" if cuda else "cpu")
+        secs.append(dt)
     nt, fir_ms, nco_ms = eng.timing_read(reset=True)
     eng.timing(False)
-    if world > 1:
-        dt = reduce_max_seconds(dist, torch, dt, "cuda" if cuda else "cpu")
+    dt = sorted(secs)[len(secs) // 2]
     plan = eng.describe()
     polyphase = mode == "optimized" and "polyphase: none" not in plan
     klen = eng.output_len(ids[mine[0]]) if mine else 0
@@ -392,7 +411,7 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
     if polyphase and poly3 and cuda:  # separate durations of the three launches: a short extra pass, OUTSIDE the timed region
         eng.timing_stride(1)
         eng.timing(2)
-        for _ in range(8):
+        for _ in range(16):
             call()
         host.sync()
         n3, ms3 = eng.timing_polyphase(reset=True)
@@ -402,54 +421,49 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
                           "xlp_inverse_kernel": round(ms3[2] / n3, 4)}
     feed_name = host.name
     host.close()
-    return {"feed": feed_name, "ntaps": int(taps.size), "seconds": dt, "call_ms_avg": fir_ms / max(nt, 1), "nco_ms_avg": nco_ms / max(nt, 1),
+    return {"feed": feed_name, "ntaps": int(taps.size), "seconds": dt, "repeat_seconds": secs, "call_ms_avg": fir_ms / max(nt, 1),
+            "nco_ms_avg": nco_ms / max(nt, 1), "blocks_per_step": blocks_per_step,
             "timed_calls": nt, "clients_this_rank": len(mine), "total_clients": total_clients, "K_call": int(klen),
             "plan": plan, "polyphase": polyphase, "kernels_ms": kernels_ms, "group": group, "steps": steps,
             "parity_spot": spot_res}
 
 
 def parity_spot(ctx, eng, ids, mine, taps, mode, calls_done, call):
-    """16 sampled clients of the engine the timed region just ran, vs the oracle.  The oracle's stream state (phase
+    """EVERY client of the engine the timed region just ran, vs a population of oracle filters on the host cores
+    (oracle/population.c, one reference-model filter per client over pthreads).  The oracles' stream state (phase
     recurrence with per-block renormalisation, history counter) is fast-forwarded over the blocks processed so far
-    without filtering, then it filters the next super-block for real to load its sample history, and the one after is
-    compared (native: bit-exact; optimized: max|d| / max|y| <= 1e-5)."""
+    without filtering; then they filter the next super-block for real to load their sample history, and the one after is
+    compared (native: bit-exact; optimized: max|d| / max|y| <= 1e-5 per client)."""
     odir = os.path.join(ROOT, "oracle")  # the checker (test infrastructure): never on the timed path
     if odir not in sys.path:
         sys.path.insert(0, odir)
-    from pyoracle import Oracle
+    from pyoracle import population
 
     t0 = time.perf_counter()
-    n = len(mine)
-    sample = sorted({mine[(i * (n - 1)) // (SPOT_CLIENTS - 1)] for i in range(SPOT_CLIENTS)}) if n > 1 else list(mine)
-    ors = {}
-    for c in sample:
-        o = Oracle(D, taps, client_center_freq(c), FS, BLOCK_BYTES)
-        o.skip_calls(S, calls_done * GROUP)
-        ors[c] = o
-    worst, exact, want_len = 0.0, True, 0
-    for rnd in range(2):
-        g = make_group((calls_done + rnd) % NSRC_GROUPS)
-        call()
-        if rnd == 1:
-            eng.fetch()
-        for c, o in ors.items():
-            want = np.concatenate([o.process("cu8", bl) for bl in np.split(g, GROUP)])
-            if rnd == 0:
-                continue
-            got = eng.output(ids[c])
-            if got.shape != want.shape:
-                worst, exact = float("inf"), False
-                continue
-            want_len = len(want)
-            worst = max(worst, float(np.abs(got.astype(np.complex128) - want).max() / np.abs(want).max()))
-            exact = exact and np.array_equal(got.view(np.uint8), want.view(np.uint8))
-    for o in ors.values():
-        o.close()
-    return {"clients": len(sample), "blocks_before": calls_done * GROUP, "outputs_compared_per_client": want_len,
+    x = np.concatenate([make_group((calls_done + rnd) % NSRC_GROUPS) for rnd in range(2)])
+    call()
+    call()
+    eng.fetch()
+    want = population(D, taps, [client_center_freq(c) for c in mine], FS, BLOCK_BYTES, "cu8", x, GROUP, nwarm=GROUP,
+                      skip_fresh=S, skip_calls=calls_done * GROUP)
+    t_oracle = time.perf_counter() - t0
+    worst, exact, want_len, bad = 0.0, True, 0, 0
+    for c, w in zip(mine, want):
+        got = eng.output(ids[c])
+        if got.shape != w.shape:
+            worst, exact, bad = float("inf"), False, bad + 1
+            continue
+        want_len = len(w)
+        e = float(np.abs(got.astype(np.complex128) - w).max() / np.abs(w).max())
+        same = np.array_equal(got.view(np.uint8), w.view(np.uint8))
+        worst, exact = max(worst, e), exact and same
+        bad += 0 if (same if mode == "native" else e <= 1e-5) else 1
+    return {"clients": len(mine), "clients_failing": bad, "blocks_before": calls_done * GROUP, "outputs_compared_per_client": want_len,
             "max_rel": worst, "bit_exact": bool(exact), "tolerance": 0.0 if mode == "native" else 1e-5,
             "ok": bool(exact if mode == "native" else worst <= 1e-5), "seconds": round(time.perf_counter() - t0, 2),
-            "how": "oracle fast-forwarded over the run's blocks (phase recurrence + per-block renormalisation only), one "
-                   "super-block filtered to load its history, the next one compared"}
+            "oracle_seconds": round(t_oracle, 2),
+            "how": "every client of this GPU vs oracle/population.c on the host cores: oracles fast-forwarded over the run's blocks "
+                   "(phase recurrence + per-block renormalisation only), one super-block filtered to load the history, the next one compared"}
 
 
 def cpu_baseline(ntaps_rate, seconds=12.0):
@@ -517,8 +531,8 @@ def polyphase_traffic_model(nclients, K_call, ntaps, group, M=128):
 
 
 def summarize(m):
-    """value and roofline figures from the timed region of `m` (HIP-event duration of the calls' launches in it)."""
-    blocks = m["steps"] * BLOCKS_PER_STEP
+    """value and model figures from the timed region of `m` (HIP-event duration of the calls' launches in it)."""
+    blocks = m["steps"] * m["blocks_per_step"]
     value = m["total_clients"] * S * blocks / m["seconds"] / 1e6
     units_per_call = m["clients_this_rank"] * S * m["group"]
     bpu = algorithmic_bytes_per_unit(D)
@@ -532,15 +546,87 @@ def summarize(m):
 def variant_entry(m, note=None):
     v, g, t, _, f = summarize(m)
     e = {"value": round(v, 1), "ms_per_step": round(m["seconds"] / m["steps"] * 1e3, 4),
-         "us_per_block": round(m["seconds"] / (m["steps"] * BLOCKS_PER_STEP) * 1e6, 3),
+         "us_per_block": round(m["seconds"] / (m["steps"] * m["blocks_per_step"]) * 1e6, 3),
          "launches_ms_per_call": round(m["call_ms_avg"], 4), "blocks_per_call": m["group"],
          "path": "polyphase" if m["polyphase"] else "direct FIR kernel",
-         "roofline_hbm_frac": round(g / HBM_PEAK_GBS, 4),
+         "model_hbm_frac": round(g / HBM_PEAK_GBS, 4),
          "fp32_frac": None if m["polyphase"] else round(t / FP32_PEAK_TFLOPS, 4),
          "achieved_TFLOPs": None if m["polyphase"] else round(t, 2), "plan": m["plan"]}
     if note:
         e["note"] = note
     return e
+
+
+PMC_KERNEL_PREFIXES = ("xlp_forward", "xlp_mix", "xlp_inverse", "xl_fir_kernel", "xl_nco_chain", "xl_nco_table", "xl_update_history")
+
+
+def measure_traffic(args):
+    """HBM bytes per call of THIS workload on THIS box: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: the guide's
+    HBM section asks for separate passes) over `bench.py --replay-calls N`, run as subprocesses after the timed region.
+    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of wide coalesced reads ->
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB.  Returns (result dict | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="xl_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    tail = [sys.executable, os.path.abspath(__file__), "--replay-calls", str(PMC_REPLAY_CALLS), "--clients", str(args.clients),
+            "--mode", args.mode, "--lpf-cutoff-rate", str(args.lpf_cutoff_rate)]
+    vals = {}  # kernel -> counter -> [per dispatch]
+    t0 = time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            r = subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + tail,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=float(os.environ.get("XL_BENCH_PMC_TIMEOUT", "240")))
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+            for row in csv.DictReader(open(files[0])):
+                k = row["Kernel_Name"].split("(")[0]
+                k = k[5:] if k.startswith("void ") else k
+                if k.startswith(PMC_KERNEL_PREFIXES) and row["Counter_Name"] == counter:
+                    vals.setdefault(k, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 --pmc pass timed out"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    main_k = next((k for k in vals if k.startswith("xlp_inverse")), None) or next((k for k in vals if k.startswith("xl_fir_kernel")), None)
+    if main_k is None:
+        return None, "no engine kernel in the counter output"
+    per, total = {}, 0.0
+    ncalls = max(len(vals[main_k].get("FETCH_SIZE", [])), 1)
+    for k, d in vals.items():
+        f, w = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
+        n = max(len(f), len(w), 1)
+        drop = 3 if n > 6 else 0  # (the first calls: stand-alone NCO tabulation, cold caches)
+        fm = sum(f[drop:]) / max(len(f[drop:]), 1)
+        wm = sum(w[drop:]) / max(len(w[drop:]), 1)
+        per_dispatch = (2.0 * fm + wm) * 1024.0
+        per_call = per_dispatch * n / ncalls  # (a chain launch covers several calls; every other kernel is once per call)
+        per[k] = {"hbm_bytes_per_dispatch": int(per_dispatch), "dispatches_per_call": round(n / ncalls, 3), "hbm_bytes_per_call": int(per_call),
+                  "FETCH_SIZE_KiB": round(fm, 1), "WRITE_SIZE_KiB": round(wm, 1)}
+        total += per_call
+    return {"bytes_per_call": int(total), "per_kernel": per, "calls_profiled": ncalls, "seconds": round(time.perf_counter() - t0, 1),
+            "correction": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM): "
+                          "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
+            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --replay-calls %d (two passes)" % PMC_REPLAY_CALLS}, \
+        "measured in this run"
+
+
+# DESIGN.md section 7: the curve this workload is EXPECTED to follow (per-GPU step times measured on one GPU; the 2 MB
+# broadcast per call hides behind a 200+ us call).  Strong scaling saturates at once: below ~1000 clients per GPU every GPU
+# is bound by the float32 phase recurrence (3121 sequential steps per block and client).
+EXPECTED_STRONG = {"clients_total": 1024, "Msamples_per_s": {"1": 3.90e6, "2": 5.52e6, "4": 5.83e6, "8": 5.94e6},
+                   "speedup": {"1": 1.0, "2": 1.42, "4": 1.49, "8": 1.52},
+                   "why": "DESIGN.md section 7: 1024 clients IN TOTAL leave 512 / 256 / 128 per GPU, all bound by the NCO phase recurrence "
+                          "(~22.5 us per block whatever the client count); adding GPUs pays with MORE clients (weak scaling)"}
+EXPECTED_WEAK = {"clients_per_gpu": 1024, "Msamples_per_s_per_gpu": "4.0e6 - 4.6e6", "efficiency": "~1.0 (no data-path collective besides one 2 MB broadcast per call)"}
 
 
 def main():
@@ -555,8 +641,10 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spot", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (traffic falls back to profiles/pmc_latest.json)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--feed", default="c", choices=["c", "torch"], help="c: include/xlating_multi.h (C host, RCCL); torch: torch.distributed feeder")
+    ap.add_argument("--replay-calls", type=int, default=0, help=argparse.SUPPRESS)  # the counter passes profile this: no timing, N calls
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_launch.py only
     args = ap.parse_args()
 
@@ -606,34 +694,51 @@ def main():
            "feed": args.feed}
 
     total_clients = args.clients if args.scaling == "strong" else args.clients * world
+    if args.replay_calls:  # what the counter passes profile: this workload, no timing
+        run_workload(ctx, total_clients, args.lpf_cutoff_rate, 0, 0, args.mode, replay_calls=args.replay_calls)
+        return
+    bps = BLOCKS_PER_STEP if cuda else 64
     m = run_workload(ctx, total_clients, args.lpf_cutoff_rate, args.steps, args.warmup, args.mode,
-                     spot=not args.no_spot)
-    value, ach_gbs, ach_tf, bpu, fpu = summarize(m)
+                     spot=not args.no_spot, blocks_per_step=bps, repeats=REPEATS)
+    value, model_gbs, ach_tf, bpu, fpu = summarize(m)
 
     variants = {}
     native = None
+    VB = 320  # blocks per step of the variants (their number is context, not the headline)
     if not args.no_variants and cuda:
         vs = max(2, args.steps // 4)
         other_mode = "native" if args.mode == "optimized" else "optimized"
-        mn = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, other_mode, spot=not args.no_spot, poly3=False)
+        mn = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, other_mode, spot=not args.no_spot, poly3=False, blocks_per_step=VB)
         native = variant_entry(mn, "the reference's default arithmetic (cpu_optimization NATIVE_CF32, src/config.c:252-264): bit-exact "
                                    "scalar tap order, 4 packed unfused ops per complex MAC, direct FIR kernel")
         native["parity_spot"] = mn["parity_spot"]
-        other_rate = 1 if args.lpf_cutoff_rate != 1 else 5
-        mv = run_workload(ctx, total_clients, other_rate, vs, 1, args.mode, poly3=False)
-        variants[f"lpf_cutoff_rate={other_rate} ({mv['ntaps']} taps)"] = variant_entry(mv)
-        m1 = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, group=1, poly3=False)
-        variants["one block per call (the reference's call granularity)"] = variant_entry(m1)
-        ms = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, staggered=True, poly3=False)
-        variants["staggered joins (clients joined over 21 consecutive blocks: 21 output grids, one polyphase class)"] = variant_entry(ms)
-        if world == 1 and total_clients >= 8 * 64:  # what each GPU of an 8-GPU strong-scaling run holds (c mod 8)
-            m8 = run_workload(ctx, total_clients // 8, args.lpf_cutoff_rate, vs, 1, args.mode, poly3=False)
-            variants[f"one GPU's share at 8 GPUs ({total_clients // 8} clients): aggregate = 8 x this value minus the feed"] = variant_entry(m8)
-        if m["polyphase"]:  # the same workload through the direct FIR kernels: the FP32-bound design
-            md = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, options={"polyphase": 0}, poly3=False)
-            variants[f"process_{args.mode}_cu8_cf32 through the direct FIR kernel ({md['ntaps']} taps)"] = variant_entry(
-                md, "FP32-bound: 96 flop per (client, sample) caps the HBM fraction at "
-                    f"{min(1.0, FP32_PEAK_TFLOPS * 1e12 / fpu * bpu / (HBM_PEAK_GBS * 1e9)):.3f}")
+        if world > 1:  # the other way to use N GPUs, next to the strong-scaling headline (or vice versa)
+            other = "weak" if args.scaling == "strong" else "strong"
+            mw = run_workload(ctx, args.clients * world if other == "weak" else args.clients, args.lpf_cutoff_rate, vs, 1, args.mode,
+                              poly3=False, blocks_per_step=VB)
+            variants[f"{other} scaling ({args.clients} clients {'per GPU' if other == 'weak' else 'in total'})"] = variant_entry(mw)
+        else:
+            other_rate = 1 if args.lpf_cutoff_rate != 1 else 5
+            mv = run_workload(ctx, total_clients, other_rate, vs, 1, args.mode, poly3=False, blocks_per_step=VB)
+            variants[f"lpf_cutoff_rate={other_rate} ({mv['ntaps']} taps)"] = variant_entry(mv)
+            m1 = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, group=1, poly3=False, blocks_per_step=VB)
+            variants["one block per call (the reference's call granularity)"] = variant_entry(m1)
+            ms = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, staggered=True, poly3=False, blocks_per_step=VB)
+            variants["staggered joins (clients joined over 21 consecutive blocks: 21 output grids, one polyphase class)"] = variant_entry(ms)
+            if total_clients >= 8 * 64:  # what each GPU of an 8-GPU strong-scaling run holds (c mod 8)
+                m8 = run_workload(ctx, total_clients // 8, args.lpf_cutoff_rate, vs, 1, args.mode, poly3=False, blocks_per_step=VB)
+                variants[f"one GPU's share at 8 GPUs ({total_clients // 8} clients): aggregate = 8 x this value minus the feed"] = variant_entry(m8)
+            for big in (2048, 4096):  # where the launches, not the NCO recurrence, bound the engine
+                if total_clients == 1024:
+                    mb = run_workload(ctx, big, args.lpf_cutoff_rate, 2, 1, args.mode, blocks_per_step=VB)
+                    e = variant_entry(mb)
+                    e["kernels_ms_per_call"] = mb["kernels_ms"]
+                    variants[f"{big} clients on this GPU (kernel-bound regime)"] = e
+            if m["polyphase"]:  # the same workload through the direct FIR kernels: the FP32-bound design
+                md = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, options={"polyphase": 0}, poly3=False, blocks_per_step=VB)
+                variants[f"process_{args.mode}_cu8_cf32 through the direct FIR kernel ({md['ntaps']} taps)"] = variant_entry(
+                    md, "FP32-bound: 96 flop per (client, sample) caps the per-client-read model fraction at "
+                        f"{min(1.0, FP32_PEAK_TFLOPS * 1e12 / fpu * bpu / (HBM_PEAK_GBS * 1e9)):.3f}")
 
     if rank != 0:
         if world > 1:
@@ -641,50 +746,95 @@ def main():
             dist.destroy_process_group()
         return
 
-    traffic, traffic_source = None, None
+    # ---- HBM traffic of one call: counters measured now, on this box; else the committed digest, and the line says so
+    pmc, traffic, traffic_source, per_kernel_bytes = None, None, None, {}
+    if cuda and world == 1 and not args.no_pmc:
+        pmc, note = measure_traffic(args)
+        if pmc:
+            traffic, traffic_source = pmc["bytes_per_call"], note
+            per_kernel_bytes = {k: v["hbm_bytes_per_call"] for k, v in pmc["per_kernel"].items()}
+        else:
+            traffic_source = f"in-run counter passes failed ({note}); "
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path) and world == 1 and args.clients == 1024:
+    if traffic is None and os.path.exists(pmc_path) and world == 1 and args.clients == 1024:
         try:
             pj = json.load(open(pmc_path))
             traffic = pj.get("hbm_bytes_per_call_polyphase" if m["polyphase"] else "hbm_bytes_per_call_direct")
-            traffic_source = ("replayed from profiles/pmc_latest.json, NOT measured in this run: " + pj.get("source", "?"))
+            per_kernel_bytes = dict(pj.get("hbm_bytes_kernels_polyphase" if m["polyphase"] else "hbm_bytes_kernels_direct", {}))
+            traffic_source = (traffic_source or "") + "replayed from profiles/pmc_latest.json, NOT measured in this run: " + pj.get("source", "?")
         except Exception:
             traffic = None
 
     call_s = m["call_ms_avg"] * 1e-3
     nloc = m["clients_this_rank"]
-    roofline = {
-        "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-        "hbm_counter_frac": round(traffic / call_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and call_s > 0 else None,
-        "kernel_ms": round(m["call_ms_avg"], 4),
-        "kernel_ms_note": f"mean HIP-event duration of one call's launches ({m['group']} blocks per call), every {TIMING_STRIDE}th call of the timed region, on the launch stream",
-        "bytes_per_unit": round(bpu, 4), "units_per_launch": nloc * S * m["group"],
-        "model": "per-client-read (SURVEY 8(d)): 2 B in + 8/D B out per (client, input sample); the block is in fact read once per GPU "
-                 "and shared, so this 'frac' is a model number that can exceed what HBM moves -- see hbm_counter_frac",
-        "shared_read_model": {"bytes_per_unit": round(2.0 / max(nloc, 1) + 8.0 / D, 5),
-                              "achieved_GBs": round(nloc * S * m["group"] * (2.0 / max(nloc, 1) + 8.0 / D) / call_s / 1e9, 1) if call_s > 0 else None,
-                              "note": "the blocks are read once per GPU and shared through L2/LDS: 2/N + 8/D B per unit (SURVEY 8(d))"},
-    }
+    calls_per_step = m["blocks_per_step"] // GROUP
+    period_ms = m["seconds"] / args.steps / calls_per_step * 1e3
+    tm = None
     if m["polyphase"]:
         import re
         mm = re.search(r"polyphase: cls0 .*? M(\d+)", m["plan"])
         tm = polyphase_traffic_model(nloc, m["K_call"], m["ntaps"], m["group"], int(mm.group(1)) if mm else 256)
-        roofline["kernel"] = ("xlp_forward_kernel + xlp_mix_kernel (dominant) + xlp_inverse_kernel: the three launches of one "
-                              "call on the polyphase overlap-save path (each also carries a slice of the next call's NCO "
-                              "phase recurrence; the forward launch rolls the raw history)")
-        roofline["kernels_ms"] = m["kernels_ms"]
-        roofline["kernels_ms_note"] = "separate HIP-event durations of the three launches, 8 extra calls after the timed region"
-        roofline["design_traffic"] = dict(tm, achieved_GBs=round(tm["bytes_per_call"] / call_s / 1e9, 1) if call_s > 0 else None,
-                                          frac_of_peak=round(tm["bytes_per_call"] / call_s / 1e9 / HBM_PEAK_GBS, 4) if call_s > 0 else None,
-                                          note="bytes the path moves through HBM per call by design (xl_polyphase.h); compare with 'traffic'")
-        roofline["direct_equivalent_TFLOPs"] = round(ach_tf, 2)
+    phys_bytes = traffic if traffic else (tm["bytes_per_call"] if tm else None)
+    ach = phys_bytes / call_s / 1e9 if phys_bytes and call_s > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+        "frac_is": ("HBM bytes of one call's launches by the PMC counters / the HIP-event duration of those launches / peak" if traffic else
+                    "NO counter value available: bytes the path moves by design (design_traffic) / launch duration / peak"),
+        "kernel_ms": round(m["call_ms_avg"], 4),
+        "kernel_ms_note": f"mean HIP-event duration of one call's launches ({m['group']} blocks per call), every {TIMING_STRIDE}th call of the "
+                          "timed region, on the launch stream.  A bracketed call also pays for its two event records (~3 us each of stream "
+                          "time) and includes the wait for the side-stream phase table when that is late, so this can exceed call_period_ms "
+                          "(= timed seconds / calls: what an un-bracketed call occupies) by 1-3 %",
+        "call_period_ms": round(period_ms, 4),
+        "units_per_launch": nloc * S * m["group"],
+        "algorithmic": {"bytes_per_unit": round(bpu, 4), "model": "per-client-read (SURVEY 8(d)): 2 B in + 8/D B out per (client, input sample)",
+                        "model_GBs": round(model_gbs, 1), "model_frac": round(model_gbs / HBM_PEAK_GBS, 4),
+                        "note": "a MODEL, not traffic: it counts one read of the block per client while the engine reads the block once per GPU "
+                                "(shared through L2), so it can exceed 1; shared-read minimum below",
+                        "shared_read_bytes_per_unit": round(2.0 / max(nloc, 1) + 8.0 / D, 5),
+                        "shared_read_bytes_per_call": int(nloc * S * m["group"] * (2.0 / max(nloc, 1) + 8.0 / D)),
+                        "traffic_over_shared_read_minimum": round(traffic / (nloc * S * m["group"] * (2.0 / max(nloc, 1) + 8.0 / D)), 2) if traffic else None},
+    }
+    if pmc:
+        roofline["pmc"] = {k: pmc[k] for k in ("calls_profiled", "seconds", "correction", "command")}
+    if m["polyphase"]:
+        A = -(-m["ntaps"] // D)
+        M = tm["transform_length_M"]
+        nseg = -(-(m["K_call"] + 2) // (M - A + 1))
+        lg = 7 if M == 128 else 8
+        flops = {"xlp_forward_kernel": 5.0 * M * lg * D * nseg, "xlp_mix_kernel": 8.0 * nloc * nseg * M * D,
+                 "xlp_inverse_kernel": nloc * nseg * (5.0 * M * lg + 8.0 * (M - A + 1))}
+        binding = {"xlp_forward_kernel": "latency (a few % of the call; shared by all clients)",
+                   "xlp_mix_kernel": "fp32 vector issue: 2 packed FMAs per complex MAC, D per (client, bin, segment)",
+                   "xlp_inverse_kernel": "hbm (reads the mixed spectra, writes the outputs)"}
+        pk = {}
+        for kname, ms_k in (m["kernels_ms"] or {}).items():
+            b = next((v for k, v in per_kernel_bytes.items() if k.startswith(kname)), None)
+            pk[kname] = {"ms": ms_k, "hbm_bytes": b, "frac_hbm": round(b / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b and ms_k else None,
+                         "frac_fp32": round(flops[kname] / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if ms_k else None,
+                         "binding": binding[kname]}
+        chain = next((v for k, v in per_kernel_bytes.items() if k.startswith("xl_nco_chain")), None)
+        if chain is not None:
+            pk["xl_nco_chain_kernel"] = {"ms": None, "hbm_bytes": chain, "binding": "a dependent float32 recurrence on a side stream (reserved CUs), "
+                                         "concurrent with the three launches; bounds the engine below ~1500 clients",
+                                         "note": "bytes per CALL (one launch tabulates the phase tables of four calls)"}
+        roofline["kernel"] = ("xlp_forward_kernel + xlp_mix_kernel + xlp_inverse_kernel: the three launches of one call on the polyphase "
+                              "overlap-save path (the next call's NCO phase recurrence runs beside them on a side stream)")
+        roofline["per_kernel"] = pk
+        roofline["per_kernel_note"] = "ms: separate HIP-event durations of the three launches, 16 extra calls after the timed region"
+        roofline["design_traffic"] = dict(tm, note="bytes the path moves through HBM per call by design (xl_polyphase.h); compare with 'traffic'")
     else:
+        kname = next((k for k in per_kernel_bytes if k.startswith("xl_fir_kernel")), "xl_fir_kernel")
         roofline["kernel"] = (f"xl_fir_kernel<H,{1 if args.mode == 'optimized' else 0},wide> (H = register-tile height chosen by the "
                               "engine; one launch per call: history roll + FIR + next call's NCO phase table)")
+        roofline["per_kernel"] = {kname: {"ms": round(m["call_ms_avg"], 4), "hbm_bytes": per_kernel_bytes.get(kname),
+                                          "frac_hbm": round(ach / HBM_PEAK_GBS, 4), "frac_fp32": round(ach_tf / FP32_PEAK_TFLOPS, 4),
+                                          "binding": "fp32 vector issue (native: 4 packed unfused ops per complex MAC -> ceiling 0.5; optimized: 2 packed FMAs)"}}
         roofline["fp32"] = {"achieved": round(ach_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(ach_tf / FP32_PEAK_TFLOPS, 4), "flop_per_unit": round(fpu, 2)}
 
+    rep_ms = [round(sec / args.steps * 1e3, 4) for sec in m["repeat_seconds"]]
     out = {
         "metric": "input IQ Msamples/s processed (all clients), 2.016 Msps->48 kHz xlating FIR",
         "value": round(value, 1),
@@ -698,13 +848,16 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if cuda else "cpu-plumbing-test",
+        "repeats": {"n": len(rep_ms), "ms_per_step": rep_ms, "min": min(rep_ms), "median": sorted(rep_ms)[len(rep_ms) // 2], "max": max(rep_ms),
+                    "value_is": "the median repeat; each repeat = exactly `steps` steps between barrier + synchronize, max over ranks",
+                    "values": [round(total_clients * S * args.steps * m["blocks_per_step"] / sec / 1e6, 1) for sec in m["repeat_seconds"]]},
         "config": {
             "workload": f"{total_clients} clients x 48 kHz off one 2.016 Msps cu8 stream ({nloc} on this GPU), {BLOCK_BYTES}-byte blocks, "
                         f"D={D}, {m['ntaps']} taps (lpf_cutoff_rate={args.lpf_cutoff_rate}), process_{args.mode}_cu8_cf32 semantics, "
                         f"{GROUP} blocks per engine call (BASELINE configs[3]; N=1: the >=1000-client single-GPU target)",
-            "step": f"{BLOCKS_PER_STEP} consecutive blocks = {BLOCKS_PER_STEP // GROUP} calls = {BLOCKS_PER_STEP * S} stream samples per client",
+            "step": f"{m['blocks_per_step']} consecutive blocks = {calls_per_step} calls = {m['blocks_per_step'] * S} stream samples per client",
             "clients_total": total_clients, "block_samples": S, "blocks_per_call": GROUP,
-            "outputs_per_client_per_call": m["K_call"], "us_per_block": round(m["seconds"] / (args.steps * BLOCKS_PER_STEP) * 1e6, 3),
+            "outputs_per_client_per_call": m["K_call"], "us_per_block": round(m["seconds"] / (args.steps * m["blocks_per_step"]) * 1e6, 3),
             "parallelism": (f"clients sharded c%{world}; one RCCL broadcast per {GROUP} raw IQ blocks ({GROUP * BLOCK_BYTES} bytes) "
                             "on a separate stream (overlaps the previous call's filtering), no other collective") if world > 1 else "single GPU",
             "rccl_ranks": rccl_ranks, "rank0_device": (f"cuda:{local_rank}" if cuda else "cpu"), "feed": m["feed"],
@@ -714,6 +867,8 @@ def main():
         "plan": m["plan"],
         "native": native,
         "variants": variants,
+        "expected_scaling": {"strong": EXPECTED_STRONG, "weak": EXPECTED_WEAK,
+                             "note": "what DESIGN.md section 7 predicts for --gpus 1/2/4/8, to judge a measured curve against"},
         "device": xl.device_info() if cuda else "none (plumbing test)",
     }
     if world == 1 and not args.no_cpu_baseline and cuda:

@@ -171,6 +171,36 @@ class Oracle:
         return np.ctypeslib.as_array(self.lib().orc_xlating_rtaps_q15(self.h), shape=(T, 2)).copy()
 
 
+def population(decimation, taps, center_freqs, sampling_freq, max_input, fmt, blocks, nblocks, nwarm=0, skip_fresh=0,
+               skip_calls=0, sum_mode=0, threads=0):
+    """oracle/population.c: len(center_freqs) independent filters over the same blocks on the host cores.
+    blocks: 1-D array holding (nwarm + nblocks) equal blocks back to back (scalar elements, I,Q interleaved); the outputs
+    of the last nblocks are returned as a list of complex64 arrays, one per client (the concatenation of its calls)."""
+    L = Oracle.lib()
+    fn = L.orc_population_cf32
+    fn.argtypes = [C.c_uint32, _c_float_p, C.c_size_t, C.POINTER(C.c_int32), C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, C.c_size_t,
+                   C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_int, _c_float_p, C.c_size_t, C.POINTER(C.c_size_t),
+                   C.c_int]
+    fn.restype = C.c_int
+    npdt, _ = Oracle.IN_FMTS[fmt]
+    blocks = np.ascontiguousarray(blocks, dtype=npdt)
+    total = nwarm + nblocks
+    assert total > 0 and blocks.size % total == 0
+    block_len = blocks.size // total
+    taps = np.ascontiguousarray(taps, dtype=np.float32)
+    fcs = np.ascontiguousarray(center_freqs, dtype=np.int32)
+    n = fcs.size
+    cap = nblocks * (block_len // 2 // decimation + 1)
+    out = np.zeros((n, cap), np.complex64)
+    lens = np.zeros(n, np.uintp)
+    code = fn(decimation, taps.ctypes.data_as(_c_float_p), taps.size, fcs.ctypes.data_as(C.POINTER(C.c_int32)), n, sampling_freq,
+              max_input, list(Oracle.IN_FMTS).index(fmt), skip_fresh, skip_calls, blocks.ctypes.data, block_len, nwarm, nblocks,
+              sum_mode, out.ctypes.data_as(_c_float_p), cap, lens.ctypes.data_as(C.POINTER(C.c_size_t)), threads)
+    if code != 0:
+        raise RuntimeError("orc_population_cf32 failed")
+    return [out[c, :int(lens[c])] for c in range(n)]
+
+
 # --------------------------------------------------------------------------- reference build
 
 

@@ -1103,3 +1103,70 @@ def test_side_and_fused_calls_mixed_while_the_host_runs_ahead(ncalls):
         assert rel_err(eng.output(cid), want) <= REL_TOL, cid
         assert tuple(np.float32(v).tobytes() for v in eng.phase(cid)) == tuple(np.float32(v).tobytes() for v in o.phase), cid
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Full-population parity: EVERY client of a shape against a population of oracle filters run on the host cores
+# (oracle/population.c: one reference-model filter per client, spread over pthreads).
+def _engine_outputs(eng, ids):
+    eng.fetch()
+    return [eng.output(i) for i in ids]
+
+
+@pytest.mark.parametrize("variant", ["native", "optimized"])
+def test_group_bench_shape_1024_clients_all(variant):
+    """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
+    server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
+    the oracle population, after a first call that loads every filter's history and phase: native bit for bit,
+    optimized max|d| / max|y| <= 1e-5 per client (fixture semantics: test/test_xlating.c:24-61, test/utils.c:176-196)."""
+    from pyoracle import population
+
+    t48 = lpf(FS, 24000, 9600)
+    G, nb = 8, 262144
+    fcs = [-984000 + 1920 * c for c in range(1024)]
+    eng = xl.BatchEngine(FS, "cu8", nb, group_blocks=G)
+    ids = [eng.add_client(42, t48, fc) for fc in fcs]
+    x = siggen.xs_u8(8100, 2 * G * nb)
+    for k in range(2):
+        eng.process_host_group(x[k * G * nb:(k + 1) * G * nb], G, variant)
+    got = _engine_outputs(eng, ids)
+    if variant == "optimized":
+        assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
+    want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
+    worst = 0.0
+    for c in range(1024):
+        assert len(got[c]) == len(want[c]) == 24966, (c, len(got[c]), len(want[c]))
+        if variant == "native":
+            assert bits_equal(got[c], want[c]), c
+        else:
+            worst = max(worst, rel_err(got[c], want[c]))
+    assert worst <= REL_TOL, worst
+    eng.close()
+
+
+@pytest.mark.parametrize("nclients", [64, 256])
+def test_config5_cf32_10msps_all_clients(nclients):
+    """BASELINE config 5 at the client counts SURVEY 8(d) lists (N = 64, 256; N = 1 runs in
+    test_config5_cf32_10msps_257_taps's family): cf32 input at 10 Msps, D = 100, 257 explicit taps, S = 131072; every
+    client of two consecutive blocks vs the oracle population, native bit-exact and optimized <= 1e-5 (at 256 clients the
+    optimized call takes the polyphase path)."""
+    from pyoracle import population
+
+    taps = siggen.hamming_sinc(257, 0.004)
+    nsamp = 131072
+    fcs = [-4900000 + (9800000 // nclients) * c for c in range(nclients)]
+    x = np.concatenate([siggen.sin_f32(0, 2 * nsamp), (siggen.xs_s16(91, 2 * nsamp).astype(np.float32) / np.float32(32768))]).astype(np.float32)
+    want = population(100, taps, fcs, 10000000, 2 * nsamp, "cf32", x, 1, nwarm=1)
+    for variant in ("native", "optimized"):
+        eng = xl.BatchEngine(10000000, "cf32", 2 * nsamp)
+        ids = [eng.add_client(100, taps, fc) for fc in fcs]
+        for k in range(2):
+            eng.process_host(x[k * 2 * nsamp:(k + 1) * 2 * nsamp], variant)
+        got = _engine_outputs(eng, ids)
+        for c in range(nclients):
+            assert len(got[c]) == len(want[c]), c
+            if variant == "native":
+                assert bits_equal(got[c], want[c]), c
+            else:
+                assert rel_err(got[c], want[c]) <= REL_TOL, (c, rel_err(got[c], want[c]))
+        eng.close()

@@ -31,7 +31,12 @@ def test_self_launch_two_ranks_strong_scaling():
     assert j["config"]["rccl_ranks"] == 2
     assert "512 on this GPU" in j["config"]["workload"]
     assert j["data"] == "cpu-plumbing-test" and j["value"] > 0
-    assert abs(j["ms_per_step"] * j["steps"] / 1e3 - j["config"]["us_per_block"] * 320 * j["steps"] / 1e6) < 1e-3
+    blocks_per_step = int(j["config"]["step"].split()[0])
+    assert abs(j["ms_per_step"] * j["steps"] / 1e3 - j["config"]["us_per_block"] * blocks_per_step * j["steps"] / 1e6) < 1e-3
+    # the timed region is repeated; the line reports the median repeat and shows all of them
+    assert j["repeats"]["n"] == 3 and j["repeats"]["median"] == j["ms_per_step"] and len(j["repeats"]["values"]) == 3
+    assert j["roofline"]["frac"] <= 1.0 and "model_frac" in j["roofline"]["algorithmic"]
+    assert set(j["expected_scaling"]["strong"]["Msamples_per_s"]) == {"1", "2", "4", "8"}
 
 
 def test_self_launch_weak_scaling_and_single_rank():

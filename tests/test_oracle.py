@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import scenarios
+import siggen
 import os
 
 from conftest import GOLDEN, assert_ref_cf32, bits_equal, load_live, trunc1e4
@@ -224,3 +225,28 @@ def test_reference_builds_diverge_beyond_tolerance_later():
 
     d = json.load(open(os.path.join(GOLDEN, "fast_divergence.json")))["block"]
     assert d["9"] < 1e-5 < d["49"] < d["399"]  # the documented reason why only the first blocks are pinned to the AVX build
+
+
+def test_population_driver_equals_single_filters():
+    """oracle/population.c (threaded, one filter per client) == the same filters run one by one: warm blocks, compared
+    blocks, the fast-forward, two input formats."""
+    from pyoracle import population
+
+    code, taps = Oracle.lpf(1.0, 2016000, 24000, 9600)
+    fcs = [-984000 + 1920 * c for c in range(19)]
+    x = siggen.xs_u8(5, 3 * 60002)
+    res = population(42, taps, fcs, 2016000, 60002, "cu8", x, 2, nwarm=1, skip_fresh=30001, skip_calls=5, threads=3)
+    for c in (0, 7, 18):
+        o = Oracle(42, taps, fcs[c], 2016000, 60002)
+        o.skip_calls(30001, 5)
+        bl = np.split(x, 3)
+        o.process("cu8", bl[0])
+        want = np.concatenate([o.process("cu8", bl[1]), o.process("cu8", bl[2])])
+        assert bits_equal(res[c], want), c
+        o.close()
+    y = siggen.xs_s16(6, 2 * 4000)
+    res = population(42, taps, fcs[:3], 2016000, 8000, "cs16", y, 2)
+    o = Oracle(42, taps, fcs[2], 2016000, 8000)
+    want = np.concatenate([o.process("cs16", b) for b in np.split(y, 2)])
+    assert bits_equal(res[2], want)
+    o.close()
