@@ -592,6 +592,19 @@ def measure_traffic(args):
                 k = k[5:] if k.startswith("void ") else k
                 if k.startswith(PMC_KERNEL_PREFIXES) and row["Counter_Name"] == counter:
                     vals.setdefault(k, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+        # third pass, no counters: the kernels' own durations as the profiler sees them in the production arrangement (the chain
+        # kernel running beside the three launches on its side stream) -- what `rocprofv3 --kernel-trace --stats` prints
+        durs = {}
+        d = os.path.join(out, "trace")
+        r = subprocess.run([rocprof, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + tail,
+                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=float(os.environ.get("XL_BENCH_PMC_TIMEOUT", "240")))
+        files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode == 0 and files:
+            for row in csv.DictReader(open(files[0])):
+                k = row["Kernel_Name"].split("(")[0]
+                k = k[5:] if k.startswith("void ") else k
+                if k.startswith(PMC_KERNEL_PREFIXES):
+                    durs.setdefault(k, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
     except subprocess.TimeoutExpired:
         return None, "rocprofv3 --pmc pass timed out"
     finally:
@@ -611,11 +624,16 @@ def measure_traffic(args):
         per_call = per_dispatch * n / ncalls  # (a chain launch covers several calls; every other kernel is once per call)
         per[k] = {"hbm_bytes_per_dispatch": int(per_dispatch), "dispatches_per_call": round(n / ncalls, 3), "hbm_bytes_per_call": int(per_call),
                   "FETCH_SIZE_KiB": round(fm, 1), "WRITE_SIZE_KiB": round(wm, 1)}
+        dk = durs.get(k, [])
+        dk = dk[3:] if len(dk) > 6 else dk
+        if dk:
+            per[k]["ms_per_dispatch_kernel_trace"] = round(sum(dk) / len(dk), 4)
         total += per_call
     return {"bytes_per_call": int(total), "per_kernel": per, "calls_profiled": ncalls, "seconds": round(time.perf_counter() - t0, 1),
             "correction": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM): "
                           "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
-            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --replay-calls %d (two passes)" % PMC_REPLAY_CALLS}, \
+            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --replay-calls %d (two passes) + one "
+                       "rocprofv3 --kernel-trace pass without counters for the kernels' durations" % PMC_REPLAY_CALLS}, \
         "measured in this run"
 
 
@@ -809,20 +827,26 @@ def main():
                    "xlp_mix_kernel": "fp32 vector issue: 2 packed FMAs per complex MAC, D per (client, bin, segment)",
                    "xlp_inverse_kernel": "hbm (reads the mixed spectra, writes the outputs)"}
         pk = {}
-        for kname, ms_k in (m["kernels_ms"] or {}).items():
+        trace_ms = {k: v.get("ms_per_dispatch_kernel_trace") for k, v in (pmc["per_kernel"] if pmc else {}).items()}
+        for kname, ms_ev in (m["kernels_ms"] or {}).items():
             b = next((v for k, v in per_kernel_bytes.items() if k.startswith(kname)), None)
-            pk[kname] = {"ms": ms_k, "hbm_bytes": b, "frac_hbm": round(b / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b and ms_k else None,
+            ms_k = next((v for k, v in trace_ms.items() if k.startswith(kname) and v), None) or ms_ev
+            pk[kname] = {"ms": ms_k, "ms_source": "rocprofv3 --kernel-trace, this run" if ms_k is not ms_ev else "HIP events around the launch",
+                         "ms_hip_events": ms_ev, "hbm_bytes": b,
+                         "frac_hbm": round(b / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b and ms_k else None,
                          "frac_fp32": round(flops[kname] / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if ms_k else None,
                          "binding": binding[kname]}
         chain = next((v for k, v in per_kernel_bytes.items() if k.startswith("xl_nco_chain")), None)
         if chain is not None:
-            pk["xl_nco_chain_kernel"] = {"ms": None, "hbm_bytes": chain, "binding": "a dependent float32 recurrence on a side stream (reserved CUs), "
+            pk["xl_nco_chain_kernel"] = {"ms": next((v for k, v in trace_ms.items() if k.startswith("xl_nco_chain") and v), None), "hbm_bytes": chain, "binding": "a dependent float32 recurrence on a side stream (reserved CUs), "
                                          "concurrent with the three launches; bounds the engine below ~1500 clients",
-                                         "note": "bytes per CALL (one launch tabulates the phase tables of four calls)"}
+                                         "note": "bytes per CALL, ms per LAUNCH (one launch tabulates the phase tables of four calls)"}
         roofline["kernel"] = ("xlp_forward_kernel + xlp_mix_kernel + xlp_inverse_kernel: the three launches of one call on the polyphase "
                               "overlap-save path (the next call's NCO phase recurrence runs beside them on a side stream)")
         roofline["per_kernel"] = pk
-        roofline["per_kernel_note"] = "ms: separate HIP-event durations of the three launches, 16 extra calls after the timed region"
+        roofline["per_kernel_note"] = ("ms: the kernel's own duration from a rocprofv3 --kernel-trace pass of this run (ms_hip_events: event pairs around "
+                                       "each launch, 16 extra calls after the timed region -- they include the event records and forbid the overlap "
+                                       "of one launch's tail with the next one's head, so their sum exceeds kernel_ms)")
         roofline["design_traffic"] = dict(tm, note="bytes the path moves through HBM per call by design (xl_polyphase.h); compare with 'traffic'")
     else:
         kname = next((k for k in per_kernel_bytes if k.startswith("xl_fir_kernel")), "xl_fir_kernel")

@@ -517,17 +517,20 @@ def test_polyphase_plan_switches_transform_length_mid_stream():
         cid = eng.add_client(42, taps, 111000 + 7000 * j)
         oracles[cid] = Oracle(42, taps, 111000 + 7000 * j, FS, 262144)
         joiners.append(cid)
-    assert "classes 2" in eng.describe() and "cols767 V244 M256" in eng.describe(), eng.describe()
+    # (with calls behind it a changed engine keeps the plan -- and the rows -- of the latest call until the next one:
+    # describe() says so instead of re-planning)
+    assert "re-plan pending" in eng.describe() and "cols767 V244 M256" in eng.describe(), eng.describe()
     block(2)
+    assert "classes 2" in eng.describe() and "cols767 V244 M256" in eng.describe(), eng.describe()
     eng.remove_client(ids[1])  # (a re-plan: the joiners' class now equals the old one -> 768 clients -> 128-point plan)
-    assert "classes 1" in eng.describe() and "cols768 V116 M128" in eng.describe(), eng.describe()
     block(3)
+    assert "classes 1" in eng.describe() and "cols768 V116 M128" in eng.describe(), eng.describe()
     block(4, 131070)
     for cid in joiners:  # 766 clients: back to the 256-point plan
         eng.remove_client(cid)
         oracles.pop(cid).close()
-    assert "cols766 V244 M256" in eng.describe(), eng.describe()
     block(5)
+    assert "cols766 V244 M256" in eng.describe(), eng.describe()
     eng.close()
 
 
