@@ -166,6 +166,7 @@ struct xlating_batch_t {
   int poly_mode = -1;        // option "polyphase": 0 never, 1 whenever the shape allows, -1 (default) by the size rule
   uint32_t poly_min_clients = 128;  // measured at 505 taps, D = 42: x1.10 at 128 clients, x0.96 at 64 (profiles/r01_polyphase_vs_direct.txt)
   uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
+  uint32_t inv_reg = 1;       // option "inverse_kernel": M = 128 classes: 1 = register transform (xlp_inverse_reg_kernel), 0 = LDS transform
   uint32_t mix_skip_at = 0;   // position of the mix launch's skipped workgroups; 0 = 1024
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
   uint32_t poly_exp = 0;     // XL_TUNING builds: tuning switches of the mix kernel
@@ -358,6 +359,9 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
   } else if (n == "polyphase_m") {
     if (value != 0 && value != 128 && value != 256) return -EINVAL;
     b->poly_m = (uint32_t)value;
+  } else if (n == "inverse_kernel") {
+    if (value != 0 && value != 1) return -EINVAL;
+    b->inv_reg = (uint32_t)value;
   } else if (n == "polyphase_min_clients") {
     if (value < 1) return -EINVAL;
     b->poly_min_clients = (uint32_t)value;
@@ -431,6 +435,7 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
   if (getenv("XL_EXP_POLY")) (void)xlating_batch_set_option(b, "polyphase", atol(getenv("XL_EXP_POLY")));
   if (getenv("XL_EXP_POLY_M")) (void)xlating_batch_set_option(b, "polyphase_m", atol(getenv("XL_EXP_POLY_M")));
   if (getenv("XL_EXP_POLY_MIN")) (void)xlating_batch_set_option(b, "polyphase_min_clients", atol(getenv("XL_EXP_POLY_MIN")));
+  if (getenv("XL_EXP_INV")) (void)xlating_batch_set_option(b, "inverse_kernel", atol(getenv("XL_EXP_INV")));
   if (getenv("XL_EXP_CHAIN_STATS")) (void)hipMalloc((void **)&b->d_chain_stats, 4096 * 4 * sizeof(unsigned long long));
   if (getenv("XL_EXP_NCO_SIDE")) (void)xlating_batch_set_option(b, "nco_side_stream", atol(getenv("XL_EXP_NCO_SIDE")));
   if (getenv("XL_EXP_CHAIN_CALLS")) (void)xlating_batch_set_option(b, "nco_calls_per_launch", atol(getenv("XL_EXP_CHAIN_CALLS")));
@@ -1423,6 +1428,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           }
           pa.ncg = pc.ncg;
           pa.exp = b->poly_exp;
+          pa.inv_reg = b->inv_reg;
           pa.W = b->d_W;
           pa.X = pc.d_X;
           pa.R = pc.d_R;

@@ -14,6 +14,7 @@
 #include "xl_polyphase.h"
 
 #include "xl_dev_inline.h"
+#include "xl_fft64.h"
 
 #include <hip/hip_ext.h>
 
@@ -513,6 +514,207 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------- inverse, register transform
+// The M = 128 inverse launch with the transform in REGISTERS (xl_fft64.h): a wave = one Y tile = (segment, 32 client
+// columns, all 128 bins); a PAIR of lanes owns a column, 64 bins each.  What the LDS version above pays for -- the tile
+// transposed into LDS, three exchange passes per transform (44 % of its LDS cycles were bank conflicts), twiddles fetched
+// from a table, phases expanded through LDS -- is gone:
+//   * the tile is loaded straight into registers: 64 x 8-byte loads per lane, all in flight at once (lane (c, hf) reads
+//     bin 2 i + hf of column c: every load instruction covers two adjacent 256-byte rows of the tile, 512 bytes back to back);
+//   * the same in-place 64-point transform in both lanes (compile-time twiddles as scalar operands), then ONE exchange
+//     with the partner lane (DPP quad_perm [1,0,3,2], no LDS): lane hf ends up with the shared points n = 64 hf + k of
+//     its column;
+//   * the NCO phases are walked in the lane itself, one step per output (the producer's own three IEEE operations per
+//     step, renormalised at block ends);
+//   * LDS is used once: the rotated outputs are transposed 2 x 32 shared points at a time through a wave-private
+//     [32 columns][2 halves][33] buffer (odd row stride: the sixteen rows of a write group hit 16 distinct bank pairs), so
+//     that the stores leave as 256-byte runs of one client's row.
+// grid = nco_blocks + nseg * ncg workgroups of 256 threads; workgroup = (segment, column group), wave = sub-tile.
+// v * (cs.x + j cs.y): two packed instructions, the swap and the sign in the operand modifiers
+//   t = (v.x, v.y) * (c, c);   r = (-v.y, v.x) * (s, s) + t
+XL_DEV v2f xlp_cmul_s(const v2f v, const v2f cs) {  // twiddle in a scalar register pair
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+      : "=&v"(r)
+      : "v"(v), "s"(cs));
+  return r;
+}
+XL_DEV v2f xlp_cmul_v(const v2f v, const v2f cs) {  // factor in a vector register pair (the NCO phase)
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+      : "=&v"(r)
+      : "v"(v), "v"(cs));
+  return r;
+}
+struct XlpFftOps {
+  template <int N>
+  static XL_MEM v2f twiddle(const v2f v) {
+    return xlp_cmul_s(v, (v2f){xl_w128_cos(N), xl_w128_sin(N)});
+  }
+  static XL_MEM v2f add_j(const v2f a, const v2f d) {  // (a.x - d.y, a.y + d.x)
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+  }
+  static XL_MEM v2f sub_j(const v2f a, const v2f d) {  // (a.x + d.y, a.y - d.x)
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+  }
+};
+XL_DEV float xlp_dpp_pair(const float f) {  // the value of lane ^ 1 (quad_perm [1,0,3,2])
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, false));
+}
+struct XlpPairExchange {
+  bool odd;  // hf == 1
+  XL_MEM v2f select(const v2f z, const v2f own) const { return (v2f){odd ? z.x : own.x, odd ? z.y : own.y}; }
+  // (built as an initialiser list on purpose: with `v2f r; r.x = dpp(v.x); r.y = dpp(v.y);` this compiler emitted ONE
+  // DPP move per complex value and used it for both components)
+  template <int K>
+  XL_MEM v2f partner(const v2f v) const {
+    return (v2f){xlp_dpp_pair(v.x), xlp_dpp_pair(v.y)};
+  }
+};
+
+// u[xl_fft64_slot(t)] (shared point n = 64 hf + t of the lane's column) <- u * 2^-7 * phase, t < 64; p = the phase of
+// the lane's first output, advancing one output per t.  valid0 false: the lane's first point is nobody's output (shared
+// point 0 of a column whose grid lies one step behind): p already belongs to the second one and stays at t = 0.
+// Plain walk: no block of the call ends inside the lane's range (the common case; the caller has checked).
+template <int T = 0>
+XL_DEV void xlp_rotate_plain(v2f (&u)[64], v2f &p, const v2f inc, const bool valid0) {
+  constexpr int slot = xl_fft64_slot(T);
+  u[slot] = xlp_cmul_v(u[slot] * (1.0f / 128.0f), p);  // exact scaling by 2^-7, then xlating.c:70 `out = temp * phase`
+  XL_FFT_PIN(u[slot]);  // (before the chain moves on: the recurrence steps are volatile asm, this product is not, and 64
+                        // phases waiting for their products are 128 registers)
+  const v2f q = xl_nco_next(p, inc);
+  if (T == 0) p = (v2f){valid0 ? q.x : p.x, valid0 ? q.y : p.y};
+  else p = q;
+  if constexpr (T % 4 == 3) XL_FFT_FENCE();
+  if constexpr (T + 1 < 64) xlp_rotate_plain<T + 1>(u, p, inc, valid0);
+}
+
+// Checked walk (a block of the call ends inside the range: the phase is renormalised there, xlating.c:73): the phases
+// of 16 points at a time go through the wave's staging buffer (`pl`: 17 slots per lane) from a compact run-time loop
+// that compares every step with the next block start; m = output index of p.
+template <int CH = 0>
+XL_DEV void xlp_rotate_checked(v2f (&u)[64], v2f &p, uint32_t &m, uint32_t &nb, const v2f inc, const XlBnd bnd, const bool valid0,
+                               v2f *__restrict__ pl) {
+#pragma unroll 1
+  for (uint32_t tt = 0; tt < 16u; ++tt) {
+    pl[tt] = p;
+    if (CH == 0 && tt == 0u && !valid0) continue;
+    p = xl_nco_next(p, inc);
+    if (++m == nb) {
+      p = xl_nco_renorm(p);
+      nb = xl_bnd_next(bnd, m);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int tt = 0; tt < 16; ++tt) {
+    const int slot = xl_fft64_slot(CH * 16 + tt);  // (a constant after unrolling)
+    u[slot] = xlp_cmul_v(u[slot] * (1.0f / 128.0f), pl[tt]);
+    XL_FFT_PIN(u[slot]);
+    if (tt % 4 == 3) XL_FFT_FENCE();
+  }
+  __builtin_amdgcn_wave_barrier();
+  if constexpr (CH + 1 < 4) xlp_rotate_checked<CH + 1>(u, p, m, nb, inc, bnd, valid0, pl);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void xlp_inverse_reg_kernel(const XlpArgs a) {
+  constexpr uint32_t M = 128u, CW = 32u, NSUB = XLP_COLS / CW, PR = 33u;
+  __shared__ v2f stage[NSUB][CW][2][PR];   // 67584 bytes: two workgroups per CU
+  __shared__ uint32_t cinfo[NSUB][CW][4];  // per column: out row, k of shared point 0 (may be -1), outputs owned, pad
+  if (blockIdx.x < a.nco_blocks) {
+    xlp_nco_role(a);
+    return;
+  }
+  if (blockIdx.x >= a.nco_skip_at && blockIdx.x < a.nco_skip_at + a.nco_skip) return;
+  const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
+  const uint32_t cg = bid % a.ncg, s = bid / a.ncg;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = threadIdx.x & 63u;
+  const uint32_t c = j >> 1, hf = j & 1u;
+  // ---- the tile, straight into registers: u[i] = Y[bin 2 i + hf][column c]
+  v2f u[64];
+  {
+    // (wave-uniform tile pointer + one 32-bit lane offset: the loads address as scalar base + vector offset; 64 separate
+    // 64-bit lane addresses would cost 128 registers before the first value arrives)
+    const v2f *__restrict__ tile = reinterpret_cast<const v2f *>(a.Y) + (((size_t)cg * a.nseg_cap + s) * NSUB + w) * M * CW;
+    const uint32_t lane_off = hf * CW + c;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) u[i] = __builtin_nontemporal_load(tile + (size_t)i * 2u * CW + lane_off);
+  }
+  // ---- the column of this lane pair on the class's shared grid (xl_grid.h)
+  const uint32_t N = a.pos.S * a.pos.G;
+  const uint32_t Ka = N / a.D, Nr = N - Ka * a.D;
+  const XlpCol col = a.cols[cg * XLP_COLS + w * CW + c];
+  XlBnd bnd;
+  bnd.j0 = xl_merge_j0(a.j0_ref, col.delta, a.D), bnd.D = a.D, bnd.S = a.pos.S, bnd.G = a.pos.G;
+  bnd.K = Ka + (bnd.j0 < Nr ? 1u : 0u);
+  const uint32_t shift = xl_merge_shift(a.j0_ref, col.delta, a.D);
+  const int32_t k0 = (int32_t)(s * a.V) - (int32_t)shift;  // output index of shared point n = 0 of this segment
+  const bool live = col.out_off != 0xFFFFFFFFu;
+  if (hf == 0u) {
+    cinfo[w][c][0] = col.out_off;
+    cinfo[w][c][1] = (uint32_t)k0;
+    cinfo[w][c][2] = live ? bnd.K : 0u;
+  }
+  // the lane's first output: k0 + 64 hf, or -- when that is -1 -- the next one
+  const int32_t kf = k0 + (int32_t)(64u * hf);
+  const bool valid0 = kf >= 0;
+  const uint32_t mb = valid0 ? (uint32_t)kf : 0u;
+  const bool walk = live && mb < bnd.K;
+  const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
+  v2f p = ph[walk ? (col.out_off >> XL_PH_SHIFT) + (mb >> XL_PH_SHIFT) : 0u];  // (requested before the transform)
+  // ---- transform
+  XL_FFT_FENCE();
+  xl_fft64_inverse<v2f, XlpFftOps>(u);
+  {
+    const XlpPairExchange ex{hf != 0u};
+    xl_fft128_combine<v2f, XlpFftOps>(u, hf ? -1.0f : 1.0f, ex);
+  }
+  // ---- phases: from the table entry at mb rounded down to the stride up to mb, then one step per output
+  const v2f inc = {col.incr.x, col.incr.y};
+  uint32_t m = mb & ~(XL_PH_STRIDE - 1u);
+  uint32_t nb = xl_bnd_next(bnd, m);
+  if (walk) {
+    for (; m < mb; ++m) {
+      p = xl_nco_next(p, inc);
+      if (m + 1u == nb) {
+        p = xl_nco_renorm(p);
+        nb = xl_bnd_next(bnd, m + 1u);
+      }
+    }
+  }
+  // (a block of the call ends inside this lane's 64 outputs: rare -- 8 of 216 segments of the bench call -- and wave
+  // uniform for all practical purposes; the checked walk does the per-step comparison the plain one leaves out)
+  const bool crosses = walk && nb <= mb + 64u;
+  if (__builtin_amdgcn_ballot_w64(crosses) != 0ull)
+    xlp_rotate_checked(u, p, m, nb, inc, bnd, valid0, &stage[w][0][0][0] + 17u * j);
+  else
+    xlp_rotate_plain(u, p, inc, valid0);
+  // ---- transpose through LDS, 2 x 32 shared points at a time, and store 256-byte runs of the clients' rows
+  v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
+  const uint32_t rh = j >> 5, rn = j & 31u;  // read-back duty: half rh, point rn of the chunk, one column per trip
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+    for (int tt = 0; tt < 32; ++tt) stage[w][c][hf][tt] = u[xl_fft64_slot(ch * 32 + tt)];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n = 64u * rh + (uint32_t)(ch * 32) + rn;
+#pragma unroll
+    for (int cc = 0; cc < (int)CW; ++cc) {
+      const v2f v = stage[w][cc][rh][rn];
+      const uint32_t off = cinfo[w][cc][0];
+      const int32_t kk = (int32_t)cinfo[w][cc][1] + (int32_t)n;
+      if (n < a.V && kk >= 0 && (uint32_t)kk < cinfo[w][cc][2]) out[(size_t)off + (uint32_t)kk] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------------- branch spectra
 // R[cg][m][b][col] = sum_{a<A} r'_col[D a + b] e^{+2 pi j a m / M}, r' = the column's taps delayed by its grid offset
 // (xl_grid.h), in double, rounded once.  One-time per plan.
@@ -590,14 +792,17 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
 // `done` (optional): recorded with the launch's own completion signal -- one queue packet instead of launch + event record
 hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done) {
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
-  const uint32_t work = a0.nseg * a0.ncg * (a0.M == 256u ? 8u : 4u);
+  const bool reg = a0.M == 128u && a0.inv_reg != 0u;  // workgroup = (segment, column group): all four sub-tiles
+  const uint32_t work = a0.nseg * a0.ncg * (reg ? 1u : (a0.M == 256u ? 8u : 4u));
   const XlpArgs a = xlp_checked_skip(a0, work);
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
   if (done) {
-    if (a.M == 256u) hipExtLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, nullptr, done, 0, a);
+    if (reg) hipExtLaunchKernelGGL(xlp_inverse_reg_kernel, grid, dim3(256), 0, s, nullptr, done, 0, a);
+    else if (a.M == 256u) hipExtLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, nullptr, done, 0, a);
     else hipExtLaunchKernelGGL(xlp_inverse_kernel<128>, grid, dim3(256), 0, s, nullptr, done, 0, a);
   } else {
-    if (a.M == 256u) hipLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, a);
+    if (reg) hipLaunchKernelGGL(xlp_inverse_reg_kernel, grid, dim3(256), 0, s, a);
+    else if (a.M == 256u) hipLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(xlp_inverse_kernel<128>, grid, dim3(256), 0, s, a);
   }
   return hipGetLastError();

@@ -30,8 +30,11 @@ for n in (128, 1024, 4096):
         t0 = time.perf_counter()
         cid = eng.add_client(D, taps, 12345 + trial)
         t1 = time.perf_counter()
-        call(); eng.sync()      # plan with the newcomer (its own direct class)
+        call()                  # plan with the newcomer (its own direct class)
+        t1b = time.perf_counter()
+        eng.sync()
         t2 = time.perf_counter()
+        print(f"   trial {trial}: call after join: host {1e3*(t1b-t1):.3f} ms + sync {1e3*(t2-t1b):.3f} ms", file=sys.stderr)
         call(); eng.sync()      # the newcomer is mature: re-plan, it joins the polyphase class
         t3 = time.perf_counter()
         call(); eng.sync()
