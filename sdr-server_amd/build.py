@@ -6,7 +6,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path():
-    return os.path.join(HERE, "lib", "libxlating_hip.so")
+    # XL_LIBRARY_PATH: test infrastructure only (tools/sanitize.sh points the host-code tests at an instrumented build)
+    return os.environ.get("XL_LIBRARY_PATH") or os.path.join(HERE, "lib", "libxlating_hip.so")
 
 
 def build_library(verbose=False):

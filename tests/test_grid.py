@@ -44,7 +44,8 @@ def grid(tmp_path_factory):
     src = d / "shim.c"
     src.write_text(SHIM)
     so = d / "libgrid.so"
-    subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-shared", "-fPIC", "-I", CSRC, str(src), "-o", str(so)], check=True)
+    extra = os.environ.get("XL_SANITIZE_CFLAGS", "").split()  # (tools/sanitize.sh: -fsanitize=address,undefined)
+    subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-shared", "-fPIC"] + extra + ["-I", CSRC, str(src), "-o", str(so)], check=True)
     L = C.CDLL(str(so))
     for n in ("g_mstart", "g_bnd_next", "g_merge_j0", "g_merge_shift", "g_merge_points"):
         getattr(L, n).restype = C.c_uint32
