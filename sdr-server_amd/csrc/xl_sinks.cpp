@@ -32,6 +32,35 @@
 #include "../../include/xlating_sinks.h"
 #include "xl_common.h"
 
+// ThreadSanitizer (tools/sanitize.sh) learns a mutex's lifetime from pthread_mutex_init / _destroy; libstdc++'s std::mutex
+// calls neither (constexpr constructor, trivial destructor), so a mutex living in heap memory that once held another
+// object's mutex looks "already destroyed" to the tool, which then ignores its ordering and reports every pair of
+// correctly locked accesses as a race.  These annotations tell it where a mutex starts and ends; they compile to nothing
+// outside -fsanitize=thread builds.
+#if defined(__SANITIZE_THREAD__)
+extern "C" void __tsan_mutex_create(void *addr, unsigned flags);
+extern "C" void __tsan_mutex_destroy(void *addr, unsigned flags);
+#define XL_TSAN_MUTEX_CREATE(m) __tsan_mutex_create((m)->native_handle(), 0)
+#define XL_TSAN_MUTEX_DESTROY(m) __tsan_mutex_destroy((m)->native_handle(), 0)
+#else
+#define XL_TSAN_MUTEX_CREATE(m) ((void)0)
+#define XL_TSAN_MUTEX_DESTROY(m) ((void)0)
+#endif
+
+// Timed wait with a predicate.  condition_variable::wait_for measures on the steady clock, which glibc implements with
+// pthread_cond_clockwait -- a call this image's libtsan (GCC 11) does not intercept: it misses the unlock / relock inside
+// the wait, believes the waiter still holds the mutex and reports "double lock" plus a race for every access the other
+// side makes meanwhile.  The instrumented build waits on the system clock instead (pthread_cond_timedwait, intercepted);
+// production keeps the steady clock (immune to clock steps).
+template <class Rep, class Period, class Pred>
+static bool xl_wait_for(std::condition_variable &cv, std::unique_lock<std::mutex> &lk, std::chrono::duration<Rep, Period> d, Pred pred) {
+#if defined(__SANITIZE_THREAD__)
+  return cv.wait_until(lk, std::chrono::system_clock::now() + d, pred);
+#else
+  return cv.wait_for(lk, d, pred);
+#endif
+}
+
 namespace {
 
 enum Kind { K_FD = 0, K_FILE = 1, K_GZ = 2 };
@@ -57,6 +86,8 @@ struct Sink {
 };
 
 struct Worker {
+  Worker() { XL_TSAN_MUTEX_CREATE(&m); }
+  ~Worker() { XL_TSAN_MUTEX_DESTROY(&m); }
   std::mutex m;
   std::condition_variable cv_work, cv_done;
   std::map<int, std::unique_ptr<Sink>> sinks;  // the sinks this thread serves (id % nthreads)
@@ -69,6 +100,8 @@ struct Worker {
 }  // namespace
 
 struct xlating_sinks_t {
+  xlating_sinks_t() { XL_TSAN_MUTEX_CREATE(&stats_m); }
+  ~xlating_sinks_t() { XL_TSAN_MUTEX_DESTROY(&stats_m); }
   std::vector<std::unique_ptr<Worker>> workers;
   size_t queue_bytes = 0;
   std::mutex stats_m;
@@ -424,7 +457,7 @@ extern "C" int xlating_sinks_detach(xlating_sinks *S, int client_id) {
     Sink *p = it->second.get();
     if (p->failed) p->cancel.store(true);
     // a healthy peer gets two seconds to take what is queued; one that has stopped reading is cut off
-    if (!w->cv_done.wait_for(lk, std::chrono::seconds(2), [&] { return !p->busy && (p->used == 0 || p->failed); })) {
+    if (!xl_wait_for(w->cv_done, lk, std::chrono::seconds(2), [&] { return !p->busy && (p->used == 0 || p->failed); })) {
       p->cancel.store(true);
       p->failed = true;
       p->used = 0;
@@ -454,7 +487,7 @@ extern "C" void xlating_sinks_destroy(xlating_sinks *S) {
     {
       // give queued bytes two seconds to drain, then abandon whatever a stuck peer still holds up
       std::unique_lock<std::mutex> lk(w->m);
-      (void)w->cv_done.wait_for(lk, std::chrono::seconds(2), [&] {
+      (void)xl_wait_for(w->cv_done, lk, std::chrono::seconds(2), [&] {
         for (auto &kv : w->sinks) {
           Sink *s = kv.second.get();
           if (s->busy || (s->used > 0 && !s->failed)) return false;
