@@ -64,7 +64,9 @@ struct Client {
   float incr[2] = {1.0f, 0.0f};
   int16_t qincr[2] = {0, 0};  // Q15 phase increment (xlating.c:548-549)
   uint64_t consumed = 0;
-  uint32_t out_off = 0, out_cap = 0;
+  uint32_t out_off = 0, out_cap = 0;  // the client's row in the output / phase-table images: assigned when it joins, kept for its lifetime
+  uint32_t row_len = 0;               // elements reserved for the row (out_cap rounded up to the table-entry pair)
+  uint64_t uid = 0;                   // unique over the engine's life (client ids are recycled, their taps are not)
   uint32_t last_K = 0;
   std::vector<uint32_t> last_Kg;  // outputs per block of the latest call
   bool planned_mature = false;
@@ -101,6 +103,15 @@ struct PolyClass {
   uint32_t hv0 = XL_HCAP;    // plan-time valid history of the members (XL_HCAP: mature)
   uint32_t dmax = 0;         // largest grid offset of a member
   std::vector<int> members;
+  // The class outlives re-plans (incremental planning): a member keeps its column for its lifetime, a column that a leaving
+  // member frees is handed to the next joiner, and the branch spectra are computed for NEW columns only -- a join costs
+  // one column of R (8 D M bytes), not the class's whole image.
+  std::vector<int> col_client;        // column -> client id, -1 = free
+  std::vector<uint32_t> col_delta;    // delay the column's spectra were built with
+  std::vector<uint64_t> col_uid;      // ... and for whom (Client::uid)
+  std::map<int, uint32_t> col_of;     // client id -> column
+  uint32_t ncg_cap = 0;               // column groups the R / Y / cols buffers hold
+  bool keep = false;                  // (planning scratch: the class was taken over by the new plan)
   float2 *d_R = nullptr;     // branch spectra [ncg][M][Dpad][128] (+ XLP_BSTEP rows of tail padding)
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
   float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
@@ -157,7 +168,14 @@ struct xlating_batch_t {
   uint32_t plan_maxD = 1;
   std::vector<DirectClass> classes;       // direct classes over ALL clients (native mode)
   std::vector<DirectClass> classes_rest;  // direct classes over the clients outside `poly` (optimized mode)
-  Launch launches[XL_NLAUNCH];       // one per register-tile height 12, 10, 9, 8, 4, 2, 1: ALL clients (native mode)
+  Launch launches[XL_NLAUNCH];       // one per register-tile height 12, 10, 9, 8, 4, 2, 1: ALL clients (native mode).  Built on
+                                     // demand (xl_batch_build_all_set): an engine that only ever runs optimized calls on the polyphase
+                                     // path never pays for the all-clients tap image (4 MB and 1.4 ms per re-plan at 1024 clients)
+  bool all_built = false;            // launches[] / d_taps / d_qtaps match the current plan
+  int big_h = 8;                     // register-tile height of the large direct classes (chosen per plan)
+  uint64_t next_uid = 1;
+  std::map<uint32_t, uint32_t> free_rows;  // output rows: free extents (offset -> length) below rows_end
+  uint32_t rows_end = 0;
   Launch launches_rest[XL_NLAUNCH];  // same, over classes_rest (optimized mode)
   std::vector<PolyClass> poly;       // classes on the polyphase overlap-save path in optimized mode
   float2 *d_W = nullptr;             // e^{-2 pi j n/256}
@@ -182,7 +200,8 @@ struct xlating_batch_t {
   int hcur = 0;  // d_hist[hcur] = history in front of the next call
   void *d_block = nullptr;
   void *h_block = nullptr;  // pinned staging
-  float2 *d_taps = nullptr;
+  float2 *d_taps = nullptr;       // tap image of the all-clients launch set
+  float2 *d_taps_rest = nullptr;  // tap image of the optimized-mode launch set (the clients outside the polyphase classes)
   double *d_qtaps = nullptr;   // Q15 taps as doubles, same indexing as d_taps (XL_MODE_Q15)
   uint32_t *d_qinc = nullptr;  // per nco entry: packed Q15 phase increment
   short2 *d_qphase = nullptr;  // per slot: running Q15 phase (xlating.c:546-547: starts at 32767 + 0j)
@@ -294,24 +313,38 @@ static void xl_plan_trim(xlating_batch *b) {
   b->plan_spare.clear();
 }
 
-static void xl_batch_free_plan(xlating_batch *b) {
-  for (Launch *set : {b->launches, b->launches_rest})
-    for (int i = 0; i < XL_NLAUNCH; ++i) {
-      Launch &l = set[i];
-      xl_plan_release(b, l.d_groups);
-      l.d_groups = nullptr;
-      l.groups.clear();
-    }
-  for (PolyClass &pc : b->poly) {
-    void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_cols};
-    for (void *q : dev) xl_plan_release(b, q);
+static void xl_poly_release(xlating_batch *b, PolyClass &pc) {
+  void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_cols};
+  for (void *q : dev) xl_plan_release(b, q);
+  pc.d_R = pc.d_X = pc.d_Y = nullptr;
+  pc.d_cols = nullptr;
+}
+
+static void xl_release_launch_set(xlating_batch *b, Launch *set) {
+  for (int i = 0; i < XL_NLAUNCH; ++i) {
+    Launch &l = set[i];
+    xl_plan_release(b, l.d_groups);
+    l.d_groups = nullptr;
+    l.groups.clear();
   }
-  b->poly.clear();
+}
+
+// Drops what a plan builds from scratch every time (launch sets, tap images, NCO records).  The polyphase classes
+// survive re-plans (xl_batch_plan takes over the ones that still fit); `all` releases them too.
+static void xl_batch_free_plan(xlating_batch *b, bool all) {
+  xl_release_launch_set(b, b->launches);
+  xl_release_launch_set(b, b->launches_rest);
+  b->all_built = false;
+  if (all) {
+    for (PolyClass &pc : b->poly) xl_poly_release(b, pc);
+    b->poly.clear();
+  }
   xl_plan_release(b, b->d_taps);
+  xl_plan_release(b, b->d_taps_rest);
   xl_plan_release(b, b->d_qtaps);
   xl_plan_release(b, b->d_qinc);
   xl_plan_release(b, b->d_nco);
-  b->d_taps = nullptr;
+  b->d_taps = b->d_taps_rest = nullptr;
   b->d_qtaps = nullptr;
   b->d_qinc = nullptr;
   b->d_nco = nullptr;
@@ -321,7 +354,7 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   if (b == nullptr) return;
   if (b->device >= 0) (void)hipSetDevice(b->device);
   xl_batch_sync_all(b);
-  xl_batch_free_plan(b);
+  xl_batch_free_plan(b, true);
   xl_plan_trim(b);
   void *dev[] = {b->d_hist[0], b->d_hist[1], b->d_block, b->d_out[0], b->d_out[1], b->d_W, b->d_phase_run, b->d_qphase, b->d_qphtab};
   for (void *p : dev)
@@ -469,6 +502,43 @@ extern "C" int xlating_batch_create(uint32_t sampling_freq, int input_format, ui
 
 extern "C" int xlating_batch_num_clients(const xlating_batch *b) { return b ? b->nalive : 0; }
 
+// Output rows.  A client's row (its outputs of a call, and 1/16 of that in the phase tables) is reserved when it joins and
+// stays where it is until it leaves: re-plans never move anybody's outputs.  First fit over the free extents, else the end.
+static uint32_t xl_row_alloc(xlating_batch *b, uint32_t len) {
+  for (auto it = b->free_rows.begin(); it != b->free_rows.end(); ++it) {
+    if (it->second < len) continue;
+    const uint32_t off = it->first, rest = it->second - len;
+    b->free_rows.erase(it);
+    if (rest) b->free_rows[off + len] = rest;
+    return off;
+  }
+  const uint32_t off = b->rows_end;
+  b->rows_end += len;
+  return off;
+}
+
+static void xl_row_free(xlating_batch *b, uint32_t off, uint32_t len) {
+  if (len == 0) return;
+  auto it = b->free_rows.emplace(off, len).first;
+  auto nx = std::next(it);
+  if (nx != b->free_rows.end() && it->first + it->second == nx->first) {
+    it->second += nx->second;
+    b->free_rows.erase(nx);
+  }
+  if (it != b->free_rows.begin()) {
+    auto pv = std::prev(it);
+    if (pv->first + pv->second == it->first) {
+      pv->second += it->second;
+      b->free_rows.erase(it);
+      it = pv;
+    }
+  }
+  if (it->first + it->second == b->rows_end) {  // the last extent gives the space back
+    b->rows_end = it->first;
+    b->free_rows.erase(it);
+  }
+}
+
 extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, const float *taps, size_t taps_len,
                                         int32_t center_freq) {
   if (taps_len == 0) return -1;  // like create_frequency_xlating_filter (xlating.c:496-498)
@@ -496,6 +566,7 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
   Client &c = b->clients[id];
   c = Client();
   c.alive = true;
+  c.uid = b->next_uid++;
   c.D = decimation;
   c.T = (uint32_t)taps_len;
   c.Tpad = Tpad;
@@ -503,6 +574,9 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
   c.rtq.assign(2 * taps_len, 0);
   xl_prepare_taps(taps, taps_len, center_freq, b->fs, decimation, c.rt.data(), c.rtq.data(), c.incr, c.qincr);
   c.out_cap = b->gcap * (b->max_samples / decimation + 1);  // xlating.c:568 per block
+  c.row_len = xl_roundup(c.out_cap, 2 * XL_PH_STRIDE);  // rows start at multiples of 2 strides: the NCO role stores pairs of
+                                                        // table entries as 16 bytes
+  c.out_off = xl_row_alloc(b, c.row_len);
   b->nalive++;
   b->dirty = true;
   // The running phase of a new client starts at 1 + 0j (xlating.c:543); slot = client id.  Any phase table
@@ -515,6 +589,8 @@ extern "C" int xlating_batch_add_client(xlating_batch *b, uint32_t decimation, c
   auto rollback = [&](int code) {
     c.alive = false;
     c.rt.clear();
+    xl_row_free(b, c.out_off, c.row_len);
+    c.row_len = 0;
     b->nalive--;
     return code;
   };
@@ -556,6 +632,8 @@ extern "C" int xlating_batch_remove_client(xlating_batch *b, int id) {
   if (b == nullptr || id < 0 || (size_t)id >= b->clients.size() || !b->clients[id].alive) return -EINVAL;
   b->clients[id].alive = false;
   b->clients[id].rt.clear();
+  xl_row_free(b, b->clients[id].out_off, b->clients[id].row_len);
+  b->clients[id].row_len = 0;
   b->nalive--;
   b->dirty = true;
   return 0;
@@ -733,6 +811,165 @@ static int xl_build_launches(xlating_batch *b, Launch *Ls, const std::vector<Dir
 // 1024 x 505 native (1615 M) 203 -> 227.
 static bool xl_direct_is_light(double macs_per_block) { return macs_per_block < 250e6; }
 
+// Uploads one launch set: its tap image (+ the Q15 image) and its group descriptors.
+static int xl_upload_launch_set(xlating_batch *b, Launch *set, const std::vector<float> &image, float2 **d_image,
+                                const std::vector<double> *imageq) {
+  if (!image.empty()) {
+    XL_TRY(xl_plan_alloc(b, (void **)d_image, image.size() * sizeof(float) + 256));
+    XL_TRY(hipMemcpy(*d_image, image.data(), image.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (imageq && !imageq->empty()) {
+    XL_TRY(xl_plan_alloc(b, (void **)&b->d_qtaps, imageq->size() * sizeof(double) + 256));
+    XL_TRY(hipMemcpy(b->d_qtaps, imageq->data(), imageq->size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  for (int i = 0; i < XL_NLAUNCH; ++i) {
+    Launch &L = set[i];
+    if (L.groups.empty()) continue;
+    XL_TRY(xl_plan_alloc(b, (void **)&L.d_groups, L.groups.size() * sizeof(XlGroup)));
+    XL_TRY(hipMemcpy(L.d_groups, L.groups.data(), L.groups.size() * sizeof(XlGroup), hipMemcpyHostToDevice));
+  }
+  return 0;
+fail:
+  return xl_errno_of_last_hip_error();
+}
+
+// The all-clients launch set (native and Q15 calls, optimized calls too small for the polyphase path): built when a call
+// first needs it after the client set changed.  Its tap image is the one thing of a plan whose cost grows with every
+// client (T x 8 bytes each, gathered tap-major on the host and uploaded).
+static int xl_batch_build_all_set(xlating_batch *b) {
+  if (b->all_built) return 0;
+  xl_batch_sync_all(b);  // (launches in flight may still read the previous image)
+  xl_release_launch_set(b, b->launches);
+  xl_plan_release(b, b->d_taps);
+  xl_plan_release(b, b->d_qtaps);
+  xl_plan_release(b, b->d_qinc);
+  b->d_taps = nullptr;
+  b->d_qtaps = nullptr;
+  b->d_qinc = nullptr;
+  std::vector<float> image;
+  std::vector<double> imageq;
+  const bool has_q15 = b->fmt != XL_FMT_CF32 && b->want_q15;
+  int rc = xl_build_launches(b, b->launches, b->classes, b->big_h, &image, has_q15 ? &imageq : nullptr);
+  if (rc != 0) return rc;
+  rc = xl_upload_launch_set(b, b->launches, image, &b->d_taps, has_q15 ? &imageq : nullptr);
+  if (rc != 0) return rc;
+  if (has_q15) {
+    std::vector<uint32_t> qinc;
+    for (const XlNcoClient &nc : b->nco) {
+      const Client &c = b->clients[nc.slot];
+      qinc.push_back((uint32_t)(uint16_t)c.qincr[0] | ((uint32_t)(uint16_t)c.qincr[1] << 16));
+    }
+    XL_TRY(xl_plan_alloc(b, (void **)&b->d_qinc, qinc.size() * sizeof(uint32_t)));
+    XL_TRY(hipMemcpy(b->d_qinc, qinc.data(), qinc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  xl_plan_trim(b);
+  b->all_built = true;
+  return 0;
+fail:
+  return xl_errno_of_last_hip_error();
+}
+
+// Transform length of a polyphase class: the mix launch streams D x M branch-spectrum values per client and call from HBM,
+// which is what bounds it with many clients and one block per call; M = 128 halves that for ~5-10 % more arithmetic
+// (valid outputs per segment M - A + 1) while the filter is short against the segment.  Measured at D = 42, 505 taps, one
+// block per call: x1.17 at 4096 clients, x1.08 at 2048, x1.015 at 1024, x0.99 at 512 and below.
+static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t A, size_t members) {
+  return A > 64 ? 256u : (b->poly_m ? b->poly_m : (A <= 32 && members >= 768 ? 128u : 256u));
+}
+
+// Brings the device images of a polyphase class in line with its member list: columns, branch spectra of the NEW columns.
+static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vector<uint32_t> &new_cols, bool fresh, uint32_t cap_samples) {
+  // ---- capacity: column groups (R, Y, cols) and segments (Y, X)
+  const uint32_t need_cg = ((uint32_t)pc.col_client.size() + XLP_COLS - 1) / XLP_COLS;
+  const uint32_t nseg_cap = (cap_samples / pc.D + 2 + pc.V - 1) / pc.V + 1;
+  const uint32_t passes = (nseg_cap + XLP_SEG - 1) / XLP_SEG;
+  if (fresh || need_cg > pc.ncg_cap || nseg_cap != pc.nseg_cap) {
+    // grow by an eighth (at least one group) so that the next joins find room; the old spectra move over on the device
+    const uint32_t cap = fresh ? need_cg : std::max(need_cg, pc.ncg_cap + std::max(1u, pc.ncg_cap / 8u));
+    float2 *nR = nullptr, *nY = nullptr;
+    XlpCol *ncols = nullptr;
+    const size_t rrows = (size_t)cap * pc.Dpad + 1;  // (+1 x M rows: covers the XLP_BSTEP rows of tail padding)
+    XL_TRY(xl_plan_alloc(b, (void **)&nR, rrows * pc.M * XLP_COLS * sizeof(float2)));
+    // (R rows are [cg][m][b][col]: a group's image is contiguous -- the old groups are one copy, the new ones and the tail
+    // padding start as zeros: empty columns and padding branches are multiplied into sums that are never stored, but must
+    // be finite)
+    const size_t old_elems = fresh ? 0 : (size_t)pc.ncg_cap * pc.Dpad * pc.M * XLP_COLS;
+    if (old_elems) XL_TRY(hipMemcpyAsync(nR, pc.d_R, old_elems * sizeof(float2), hipMemcpyDeviceToDevice, b->own_stream));
+    XL_TRY(hipMemsetAsync(nR + old_elems, 0, (rrows * pc.M * XLP_COLS - old_elems) * sizeof(float2), b->own_stream));
+    XL_TRY(xl_plan_alloc(b, (void **)&nY, (size_t)cap * nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
+    XL_TRY(xl_plan_alloc(b, (void **)&ncols, (size_t)cap * XLP_COLS * sizeof(XlpCol)));
+    XL_TRY(hipStreamSynchronize(b->own_stream));
+    xl_plan_release(b, pc.d_R);
+    xl_plan_release(b, pc.d_Y);
+    xl_plan_release(b, pc.d_cols);
+    pc.d_R = nR, pc.d_Y = nY, pc.d_cols = ncols;
+    pc.ncg_cap = cap;
+    if (fresh || nseg_cap != pc.nseg_cap || pc.d_X == nullptr) {
+      xl_plan_release(b, pc.d_X);
+      pc.d_X = nullptr;
+      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_X, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2)));
+      // (X: the padding branches and the unused segment slots of the last pass must be finite: cleared once)
+      XL_TRY(hipMemsetAsync(pc.d_X, 0, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2), b->own_stream));
+    }
+    pc.nseg_cap = nseg_cap;
+  }
+  pc.ncg = need_cg;
+  // ---- per-column records (16 bytes each: all of them, every plan)
+  {
+    std::vector<XlpCol> cols((size_t)pc.ncg_cap * XLP_COLS);
+    for (XlpCol &cc : cols) {
+      cc.out_off = 0xFFFFFFFFu;
+      cc.delta = 0;
+      cc.incr = make_float2(0.0f, 0.0f);
+    }
+    for (size_t j = 0; j < pc.col_client.size(); ++j) {
+      if (pc.col_client[j] < 0) continue;
+      const Client &c = b->clients[pc.col_client[j]];
+      cols[j].out_off = c.out_off;
+      cols[j].delta = pc.col_delta[j];
+      cols[j].incr = make_float2(c.incr[0], c.incr[1]);
+    }
+    XL_TRY(hipMemcpy(pc.d_cols, cols.data(), cols.size() * sizeof(XlpCol), hipMemcpyHostToDevice));
+  }
+  // ---- branch spectra of the new columns (device kernel, double arithmetic)
+  if (!new_cols.empty()) {
+    const size_t nn = new_cols.size();
+    std::vector<float> rt(nn * pc.T * 2);  // [tap][new column]
+    std::vector<uint32_t> meta(2 * nn);    // [new column]: delay, then column index
+    for (size_t j = 0; j < nn; ++j) {
+      const Client &c = b->clients[pc.col_client[new_cols[j]]];
+      meta[j] = pc.col_delta[new_cols[j]];
+      meta[nn + j] = new_cols[j];
+      for (uint32_t i = 0; i < pc.T; ++i) {
+        rt[((size_t)i * nn + j) * 2] = c.rt[2 * i];
+        rt[((size_t)i * nn + j) * 2 + 1] = c.rt[2 * i + 1];
+      }
+    }
+    float2 *d_rt = nullptr;
+    uint32_t *d_meta = nullptr;
+    XL_TRY(xl_plan_alloc(b, (void **)&d_rt, rt.size() * sizeof(float)));
+    hipError_t e = xl_plan_alloc(b, (void **)&d_meta, meta.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_meta, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      e = xlp_launch_tables(d_rt, d_meta, d_meta + nn, (uint32_t)nn, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.d_R, b->own_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->own_stream);
+    xl_plan_release(b, d_rt);  // (scratch: spare again at once)
+    xl_plan_release(b, d_meta);
+    if (e != hipSuccess) {
+      xl_last_hip_error = e;
+      goto fail;
+    }
+  }
+  return 0;
+fail:
+  return xl_errno_of_last_hip_error();
+}
+
+// (Re)build the resident plan.  INCREMENTAL where it matters: clients keep their output rows, polyphase classes keep their
+// columns and branch spectra (a join computes one column), the all-clients launch set is built only when a call needs it;
+// rebuilt every time: the class lists, the optimized-mode direct set (the few clients outside the polyphase classes) and the
+// small per-client records.
 static int xl_batch_plan(xlating_batch *b) {
   // tuning: XL_EXP_PLAN_TIMING=1 prints where a re-plan spends its time
   static const bool plan_timing = getenv("XL_EXP_PLAN_TIMING") != nullptr;
@@ -746,7 +983,8 @@ static int xl_batch_plan(xlating_batch *b) {
   xl_batch_sync_all(b);
   lap("sync");
   b->spec_n = 0;
-  xl_batch_free_plan(b);
+  const uint32_t advanced = b->trel;  // samples since the previous plan: every plan-time stream record moves by this much
+  xl_batch_free_plan(b, false);
   b->classes.clear();
   b->classes_rest.clear();
   b->nco.clear();
@@ -755,16 +993,12 @@ static int xl_batch_plan(xlating_batch *b) {
   b->planned_immature = 0;
   b->plan_maxD = 1;
   const uint32_t cap_samples = b->max_samples * b->gcap;
-  uint32_t off = 0;
   for (size_t i = 0; i < b->clients.size(); ++i) {
     Client &c = b->clients[i];
     if (!c.alive) continue;
     c.planned_mature = xl_mature(c);
     if (!c.planned_mature) b->planned_immature++;
     b->plan_maxD = std::max(b->plan_maxD, c.D);
-    c.out_off = off;
-    off += xl_roundup(c.out_cap, 2 * XL_PH_STRIDE);  // rows start at multiples of 2 strides: the NCO role stores
-                                                      // pairs of table entries as 16 bytes
     XlNcoClient nc;
     memset(&nc, 0, sizeof(nc));
     nc.incr = make_float2(c.incr[0], c.incr[1]);
@@ -774,11 +1008,19 @@ static int xl_batch_plan(xlating_batch *b) {
     nc.rem0 = (uint32_t)(c.consumed % c.D);
     b->nco.push_back(nc);
   }
-  b->out_total = off;
+  b->out_total = b->rows_end;
 
   // ---- polyphase classes (optimized mode): all mature clients of one (D, T) -- many clients (its lanes are client
   // columns and its cost per client does not depend on the tap count) with a filter long enough to be worth it
   std::vector<bool> all_use(b->clients.size(), true), rest_use(b->clients.size(), true);
+  std::vector<PolyClass> next_poly;
+  struct Pending {
+    size_t idx;
+    std::vector<uint32_t> new_cols;
+    bool fresh;
+  };
+  std::vector<Pending> pending;
+  for (PolyClass &pc : b->poly) pc.keep = false;
   {
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<int>> by_shape;
     for (size_t i = 0; i < b->clients.size(); ++i) {
@@ -788,45 +1030,116 @@ static int xl_batch_plan(xlating_batch *b) {
     for (auto &kv : by_shape) {
       const uint32_t D = std::get<0>(kv.first), T = std::get<1>(kv.first), hv0 = std::get<2>(kv.first);
       const std::vector<int> &m = kv.second;
-      // the shared grid's reference: the member offset that keeps the largest delay of a member smallest
       std::vector<uint32_t> rems;
       for (int id : m) rems.push_back((uint32_t)(b->clients[id].consumed % D));
       std::vector<uint32_t> distinct(rems);
       std::sort(distinct.begin(), distinct.end());
       distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
-      uint32_t best_ref = distinct[0], best_dmax = 0xFFFFFFFFu;
-      for (uint32_t ref : distinct) {
-        uint32_t dm = 0;
-        for (uint32_t r : distinct) dm = std::max(dm, (ref + D - r) % D);  // delta = (j0_c - j0_ref) mod D = (rem_ref - rem_c) mod D
-        if (dm < best_dmax) best_dmax = dm, best_ref = ref;
+      // An existing class of this shape whose members are (mostly) still here: same (D, T), same kind (mature), or the
+      // immature class these very clients formed when they joined together.  Its shared grid moved with the stream.
+      PolyClass *old = nullptr;
+      for (PolyClass &oc : b->poly) {
+        if (oc.keep || oc.D != D || oc.T != T) continue;
+        const bool same_kind = oc.hv0 == hv0 || (hv0 == XL_HCAP && oc.hv0 != XL_HCAP && !m.empty() && oc.col_of.count(m[0]));
+        if (same_kind) {
+          old = &oc;
+          break;
+        }
       }
-      const uint32_t A = (T + best_dmax + D - 1) / D;
-      // transform length: the mix launch streams D x M branch-spectrum values per client and call from HBM, which is
-      // what bounds it with many clients and one block per call; M = 128 halves that for ~5-10 % more arithmetic
-      // (valid outputs per segment M - A + 1) while the filter is short against the segment.  Measured at D = 42,
-      // 505 taps, one block per call: x1.17 at 4096 clients, x1.08 at 2048, x1.015 at 1024, x0.99 at 512 and below.
-      const uint32_t M = A > 64 ? 256u : (b->poly_m ? b->poly_m : (A <= 32 && m.size() >= 768 ? 128u : 256u));
+      uint32_t ref = 0, dmax = 0;
+      bool reuse = false;
+      if (old != nullptr) {
+        ref = (old->rem_ref0 + advanced % D) % D;
+        for (uint32_t r : distinct) dmax = std::max(dmax, (ref + D - r) % D);
+        const uint32_t A = (T + dmax + D - 1) / D;
+        reuse = A == old->A && xl_poly_pick_m(b, A, m.size()) == old->M;
+      }
+      if (!reuse) {
+        // the shared grid's reference: the member offset that keeps the largest delay of a member smallest
+        uint32_t best_ref = distinct[0], best_dmax = 0xFFFFFFFFu;
+        for (uint32_t cand : distinct) {
+          uint32_t dm = 0;
+          for (uint32_t r : distinct) dm = std::max(dm, (cand + D - r) % D);  // delta = (j0_c - j0_ref) mod D = (rem_ref - rem_c) mod D
+          if (dm < best_dmax) best_dmax = dm, best_ref = cand;
+        }
+        ref = best_ref, dmax = best_dmax;
+      }
+      const uint32_t A = (T + dmax + D - 1) / D;
+      const uint32_t M = xl_poly_pick_m(b, A, m.size());
       const bool fits = A >= 2 && A <= M / 2 && D <= 504;  // (the mix kernel stages D rows of 128 bytes in <= 64 KB of LDS)
       const bool pays = m.size() >= b->poly_min_clients && 2 * T >= 9 * D;  // crossover ~4.5 taps per branch
       if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
       PolyClass pc;
-      pc.D = D;
-      pc.Dpad = xl_roundup(D, XLP_BSTEP);
-      pc.T = T;
-      pc.A = A;
-      pc.M = M;
-      pc.V = M - A + 1;
-      pc.rem_ref0 = best_ref;
+      Pending pd;
+      pd.fresh = !reuse;
+      if (reuse) {
+        pc = std::move(*old);
+        old->keep = true;
+        old->d_R = old->d_X = old->d_Y = nullptr;
+        old->d_cols = nullptr;
+        // members that left give their columns back
+        std::vector<bool> here(b->clients.size(), false);
+        for (int id : m) here[id] = true;
+        for (auto it = pc.col_of.begin(); it != pc.col_of.end();) {
+          if (!here[it->first]) {
+            pc.col_client[it->second] = -1;
+            it = pc.col_of.erase(it);
+          } else {
+            ++it;
+          }
+        }
+        while (!pc.col_client.empty() && pc.col_client.back() < 0) {  // (trailing free columns shrink the class)
+          pc.col_client.pop_back();
+          pc.col_delta.pop_back();
+          pc.col_uid.pop_back();
+        }
+      } else {
+        pc.D = D;
+        pc.Dpad = xl_roundup(D, XLP_BSTEP);
+        pc.T = T;
+        pc.A = A;
+        pc.M = M;
+        pc.V = M - A + 1;
+      }
+      pc.keep = false;
+      pc.rem_ref0 = ref;
       pc.hv0 = hv0;
-      pc.dmax = best_dmax;
+      pc.dmax = dmax;
       pc.members = m;
-      pc.ncols = (uint32_t)m.size();
-      pc.ncg = (pc.ncols + XLP_COLS - 1) / XLP_COLS;
-      pc.nseg_cap = (cap_samples / D + 2 + pc.V - 1) / pc.V + 1;
-      b->poly.push_back(pc);
+      // newcomers (and, for a recycled client id, a changed delay) take the free columns first, then new ones
+      size_t next_free = 0;
+      for (int id : m) {
+        const uint32_t delta = (ref + D - (uint32_t)(b->clients[id].consumed % D)) % D;
+        auto it = pc.col_of.find(id);
+        if (it != pc.col_of.end() && pc.col_delta[it->second] == delta && pc.col_uid[it->second] == b->clients[id].uid) continue;
+        uint32_t col;
+        if (it != pc.col_of.end()) {
+          col = it->second;
+        } else {
+          while (next_free < pc.col_client.size() && pc.col_client[next_free] >= 0) ++next_free;
+          if (next_free == pc.col_client.size()) {
+            pc.col_client.push_back(-1);
+            pc.col_delta.push_back(0);
+            pc.col_uid.push_back(0);
+          }
+          col = (uint32_t)next_free;
+          pc.col_client[col] = id;
+          pc.col_of[id] = col;
+        }
+        pc.col_delta[col] = delta;
+        pc.col_uid[col] = b->clients[id].uid;
+        pd.new_cols.push_back(col);
+      }
+      pc.ncols = (uint32_t)pc.col_client.size();
+      pd.idx = next_poly.size();
+      next_poly.push_back(std::move(pc));
+      pending.push_back(std::move(pd));
       for (int id : m) rest_use[id] = false;
     }
   }
+  for (PolyClass &oc : b->poly)
+    if (!oc.keep) xl_poly_release(b, oc);
+  b->poly = std::move(next_poly);
   xl_direct_classes(b, all_use, &b->classes);
   if (!b->poly.empty()) xl_direct_classes(b, rest_use, &b->classes_rest);
   lap("classes");
@@ -867,12 +1180,10 @@ static int xl_batch_plan(xlating_batch *b) {
     }
     if (b->exp_h == 8 || b->exp_h == 9 || b->exp_h == 10 || b->exp_h == 12) big_h = b->exp_h;
   }
-  std::vector<float> image;  // tap image, floats (shared by both launch sets)
-  std::vector<double> imageq;  // Q15 taps of the all-clients launch set (input formats that have a Q15 family)
-  const bool has_q15 = b->fmt != XL_FMT_CF32 && b->want_q15;
-  {
-    int rc = xl_build_launches(b, b->launches, b->classes, big_h, &image, has_q15 ? &imageq : nullptr);
-    if (rc == 0 && !b->poly.empty()) rc = xl_build_launches(b, b->launches_rest, b->classes_rest, big_h, &image, nullptr);
+  b->big_h = big_h;
+  std::vector<float> image_rest;  // tap image of the optimized-mode launch set
+  if (!b->poly.empty()) {
+    int rc = xl_build_launches(b, b->launches_rest, b->classes_rest, big_h, &image_rest, nullptr);
     if (rc != 0) return rc;
   }
   lap("tiles + tap images (host)");
@@ -926,30 +1237,13 @@ static int xl_batch_plan(xlating_batch *b) {
     b->dirty = false;
     return 0;
   }
-  XL_TRY(xl_plan_alloc(b, (void **)&b->d_taps, image.size() * sizeof(float) + 256));
-  XL_TRY(hipMemcpy(b->d_taps, image.data(), image.size() * sizeof(float), hipMemcpyHostToDevice));
   XL_TRY(xl_plan_alloc(b, (void **)&b->d_nco, b->nco.size() * sizeof(XlNcoClient)));
   XL_TRY(hipMemcpy(b->d_nco, b->nco.data(), b->nco.size() * sizeof(XlNcoClient), hipMemcpyHostToDevice));
-  if (has_q15) {
-    std::vector<uint32_t> qinc;
-    for (const XlNcoClient &nc : b->nco) {
-      const Client &c = b->clients[nc.slot];
-      qinc.push_back((uint32_t)(uint16_t)c.qincr[0] | ((uint32_t)(uint16_t)c.qincr[1] << 16));
-    }
-    XL_TRY(xl_plan_alloc(b, (void **)&b->d_qinc, qinc.size() * sizeof(uint32_t)));
-    XL_TRY(hipMemcpy(b->d_qinc, qinc.data(), qinc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    XL_TRY(xl_plan_alloc(b, (void **)&b->d_qtaps, imageq.size() * sizeof(double) + 256));
-    XL_TRY(hipMemcpy(b->d_qtaps, imageq.data(), imageq.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (!b->poly.empty()) {
+    if (xl_upload_launch_set(b, b->launches_rest, image_rest, &b->d_taps_rest, nullptr) != 0) goto fail;
   }
-  for (Launch *set : {b->launches, b->launches_rest})
-    for (int i = 0; i < XL_NLAUNCH; ++i) {
-      Launch &L = set[i];
-      if (L.groups.empty()) continue;
-      XL_TRY(xl_plan_alloc(b, (void **)&L.d_groups, L.groups.size() * sizeof(XlGroup)));
-      XL_TRY(hipMemcpy(L.d_groups, L.groups.data(), L.groups.size() * sizeof(XlGroup), hipMemcpyHostToDevice));
-    }
   lap("uploads (taps, groups, nco)");
-  // ---- polyphase classes: images and the per-client branch spectra (device kernel, double arithmetic)
+  // ---- polyphase classes: images and the branch spectra of the new columns
   if (!b->poly.empty()) {
     if (b->d_W == nullptr) {
       std::vector<float> w(2 * 256);
@@ -972,55 +1266,8 @@ static int xl_batch_plan(xlating_batch *b) {
       XL_TRY(hipMalloc((void **)&b->d_phase_run, b->phase_cap * sizeof(float2)));
       b->phase_run_cap = b->phase_cap;
     }
-    for (PolyClass &pc : b->poly) {
-      const std::vector<int> &m = pc.members;
-      const size_t rows = (size_t)pc.ncg * pc.Dpad + 1;  // (+1 x M rows: covers the XLP_BSTEP rows of tail padding)
-      const uint32_t passes = (pc.nseg_cap + XLP_SEG - 1) / XLP_SEG;
-      // (R: the tables kernel writes every entry of the image proper, zeros included; its tail padding rows are only ever
-      // loaded, never used.  X: the padding branches and the unused segment slots of the last pass are multiplied by zeros
-      // / accumulated into segments that are never stored, but must be finite: cleared here, on the engine's stream.)
-      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_R, rows * pc.M * XLP_COLS * sizeof(float2)));
-      XL_TRY(hipMemsetAsync(pc.d_R + ((size_t)pc.ncg * pc.Dpad) * pc.M * XLP_COLS, 0, (size_t)pc.M * XLP_COLS * sizeof(float2), b->own_stream));
-      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_X, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2)));
-      XL_TRY(hipMemsetAsync(pc.d_X, 0, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2), b->own_stream));
-      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_Y, (size_t)pc.ncg * pc.nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
-      std::vector<XlpCol> cols((size_t)pc.ncg * XLP_COLS);
-      for (XlpCol &cc : cols) {
-        cc.out_off = 0xFFFFFFFFu;
-        cc.delta = 0;
-        cc.incr = make_float2(0.0f, 0.0f);
-      }
-      std::vector<float> rt((size_t)pc.ncols * pc.T * 2);
-      std::vector<uint32_t> delta(pc.ncols);
-      for (size_t j = 0; j < m.size(); ++j) {
-        const Client &c = b->clients[m[j]];
-        const uint32_t rem = (uint32_t)(c.consumed % pc.D);
-        cols[j].out_off = c.out_off;
-        cols[j].delta = delta[j] = (pc.rem_ref0 + pc.D - rem) % pc.D;
-        cols[j].incr = make_float2(c.incr[0], c.incr[1]);
-        for (uint32_t i = 0; i < pc.T; ++i) {  // [tap][column]
-          rt[((size_t)i * pc.ncols + j) * 2] = c.rt[2 * i];
-          rt[((size_t)i * pc.ncols + j) * 2 + 1] = c.rt[2 * i + 1];
-        }
-      }
-      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_cols, cols.size() * sizeof(XlpCol)));
-      XL_TRY(hipMemcpy(pc.d_cols, cols.data(), cols.size() * sizeof(XlpCol), hipMemcpyHostToDevice));
-      float2 *d_rt = nullptr;
-      uint32_t *d_delta = nullptr;
-      XL_TRY(xl_plan_alloc(b, (void **)&d_rt, rt.size() * sizeof(float)));
-      hipError_t e = xl_plan_alloc(b, (void **)&d_delta, delta.size() * sizeof(uint32_t));
-      if (e == hipSuccess) e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = hipMemcpy(d_delta, delta.data(), delta.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-      if (e == hipSuccess)
-        e = xlp_launch_tables(d_rt, d_delta, pc.ncols, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.ncg, pc.d_R, b->own_stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(b->own_stream);
-      xl_plan_release(b, d_rt);  // (scratch: spare again at once)
-      xl_plan_release(b, d_delta);
-      if (e != hipSuccess) {
-        xl_last_hip_error = e;
-        goto fail;
-      }
-    }
+    for (const Pending &pd : pending)
+      if (xl_poly_sync_device(b, b->poly[pd.idx], pd.new_cols, pd.fresh, cap_samples) != 0) goto fail;
   }
   lap("polyphase images + R kernel");
   if (b->out_total > b->out_alloc) {
@@ -1049,7 +1296,7 @@ static int xl_batch_plan(xlating_batch *b) {
   return 0;
 fail:
   // a half-built plan must not be used: drop it and stay dirty, the next call plans again (or fails again)
-  xl_batch_free_plan(b);
+  xl_batch_free_plan(b, true);
   b->dirty = true;
   return xl_errno_of_last_hip_error();
 }
@@ -1107,7 +1354,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     return -EINVAL;
   if (mode == XL_MODE_Q15 && !b->want_q15) {  // (the Q15 tap image is built from the first Q15 call on)
     b->want_q15 = true;
-    b->dirty = true;
+    b->all_built = false;
   }
   if (b->poisoned) return -EIO;
   // a client that was still inside its zero-history when the plan was built may be mature by now: it then joins
@@ -1137,6 +1384,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
   uint32_t maxK = 0;  // the most outputs any client produces in this call
   for (const DirectClass &cs : b->classes) maxK = std::max(maxK, xl_grid_dyn(cs.D, cs.T, cs.rem0, cs.hv0, pos).K);
   const bool use_poly = mode == XL_MODE_OPTIMIZED && !b->poly.empty() && maxK >= 2 * XLP_M_MAX;
+  if (!use_poly && !b->nco.empty()) {  // this call runs the all-clients launch set: build it if the plan has not yet
+    int rc = xl_batch_build_all_set(b);
+    if (rc != 0) return rc;
+  }
   const bool light = xl_direct_is_light((use_poly ? b->macs_rest : b->macs_all) * (double)S);
   const bool side_call = mode != XL_MODE_Q15 && (b->nco_side > 0 || (b->nco_side < 0 && G >= 2 && (use_poly || (light && b->cs_masked && s == XL_STREAM_ENGINE_P))));  // (a caller's own, unmasked stream would keep filling the chain's CUs)
   if (s == XL_STREAM_ENGINE_P) s = (side_call && b->cs_masked) ? b->cs_masked : b->own_stream;
@@ -1343,7 +1594,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
         const size_t cap = 256 * std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(L.lds, 1), 7));
         const bool flat = (b->exp_flags & 2u) || wgs > 2 * cap;
         a.flags = (L.all_wide ? 1u : 0u) | (flat ? 2u : 0u) | 4u | ((b->nco_prio & 3u) << 4);
-        a.taps = b->d_taps;
+        a.taps = use_poly ? b->d_taps_rest : b->d_taps;
         a.phtab = b->d_phtab[tab];
         a.out = b->d_out[p];
         if (!rolled) {
@@ -1606,6 +1857,7 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
     if (rc != 0) return rc;
   }
   std::string d = "clients " + std::to_string(b->nalive) + " classes " + std::to_string(b->classes.size()) + " | direct:";
+  if (!b->all_built && !b->nco.empty()) d += " (built by the first call that runs all clients on the direct kernel)";
   for (const Launch &L : b->launches)
     if (!L.groups.empty()) d += " h" + std::to_string(L.ct) + " x " + std::to_string(L.groups.size()) + " groups";
   d += " | polyphase:";
@@ -1613,7 +1865,7 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
   for (size_t k = 0; k < b->poly.size(); ++k) {
     const PolyClass &pc = b->poly[k];
     d += " cls" + std::to_string(k) + " D" + std::to_string(pc.D) + " T" + std::to_string(pc.T) + " cols" +
-         std::to_string(pc.ncols) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
+         std::to_string(pc.members.size()) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
     if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
   }
   if (!b->poly.empty()) {

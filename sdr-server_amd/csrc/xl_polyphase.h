@@ -84,11 +84,11 @@ struct XlpArgs {
   float2 *nco_tab;
 };
 
-// reversed band-pass taps of every column -> branch spectra R (double arithmetic, rounded once to float)
-//   rt: [T][ncols] float2 (tap-major), ncols <= ncg * XLP_COLS; columns >= ncols and branches >= D get 0
-//   delta: [ncols] delay of every column's taps in samples (xl_grid.h: merged classes); A = ceil((T + max delta) / D)
-hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, uint32_t ncols, uint32_t T, uint32_t D,
-                             uint32_t Dpad, uint32_t A, uint32_t M, uint32_t ncg, float2 *R, hipStream_t s);
+// reversed band-pass taps of a LIST of columns -> their branch spectra in R (double arithmetic, rounded once to float)
+//   rt: [T][nlist] float2 (tap-major); delta[j]: delay of entry j's taps in samples (xl_grid.h: merged classes);
+//   colidx[j]: the column of R the entry goes to; A = ceil((T + max delta) / D); branches >= D get 0
+hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, uint32_t nlist, uint32_t T,
+                             uint32_t D, uint32_t Dpad, uint32_t A, uint32_t M, float2 *R, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);

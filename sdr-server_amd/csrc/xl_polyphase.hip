@@ -717,44 +717,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // ------------------------------------------------------------------------------------------- branch spectra
 // R[cg][m][b][col] = sum_{a<A} r'_col[D a + b] e^{+2 pi j a m / M}, r' = the column's taps delayed by its grid offset
-// (xl_grid.h), in double, rounded once.  One-time per plan.
+// (xl_grid.h), in double, rounded once.  For a LIST of columns (all of them when a class is built, the newcomers' when a
+// client joins): thread j of block (m, b) handles list entry j -- column colidx[j], taps rt[.][j], delay delta[j].
 __global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__restrict__ rt,
-                                                              const uint32_t *__restrict__ delta, uint32_t ncols,
+                                                              const uint32_t *__restrict__ delta,
+                                                              const uint32_t *__restrict__ colidx, uint32_t nlist,
                                                               uint32_t T, uint32_t D, uint32_t Dpad, uint32_t A,
                                                               uint32_t M, float2 *__restrict__ R) {
   __shared__ double wc[256], ws[256];  // e^{+2 pi j n / M} in double
   for (uint32_t n = threadIdx.x; n < M; n += blockDim.x) sincospi(2.0 * (double)n / (double)M, &ws[n], &wc[n]);
   __syncthreads();
   const uint32_t m = blockIdx.x % M;
-  const uint32_t q = blockIdx.x / M;
-  const uint32_t b = q % Dpad, cg = q / Dpad;
-  const uint32_t col = cg * XLP_COLS + threadIdx.x;
+  const uint32_t b = blockIdx.x / M;
+  const uint32_t j = blockIdx.y * XLP_COLS + threadIdx.x;
+  if (j >= nlist) return;
+  const uint32_t col = colidx[j];
   double sr = 0.0, si = 0.0;
-  if (col < ncols && b < D) {
-    const uint32_t dl = delta[col];  // the column's taps are delayed by dl samples: r'[i] = r[i - dl]
+  if (b < D) {
+    const uint32_t dl = delta[j];  // the column's taps are delayed by dl samples: r'[i] = r[i - dl]
     for (uint32_t aa = 0; aa < A; ++aa) {
       if (D * aa + b < dl) continue;
       const uint32_t i = D * aa + b - dl;
       if (i >= T) break;
       const uint32_t n = (aa * m) & (M - 1u);
       const double cs = wc[n], sn = ws[n];
-      const float2 tv = rt[(size_t)i * ncols + col];  // [tap][column]: coalesced across the columns of the block
+      const float2 tv = rt[(size_t)i * nlist + j];  // [tap][list entry]: coalesced across the entries of the block
       const double tr = tv.x, ti = tv.y;
       sr += tr * cs - ti * sn;
       si += tr * sn + ti * cs;
     }
   }
-  R[(((size_t)cg * M + m) * Dpad + b) * XLP_COLS + threadIdx.x] = make_float2((float)sr, (float)si);
+  const uint32_t cg = col / XLP_COLS, cl = col % XLP_COLS;
+  R[(((size_t)cg * M + m) * Dpad + b) * XLP_COLS + cl] = make_float2((float)sr, (float)si);
 }
 
 // ------------------------------------------------------------------------------------------- launchers
 static bool xlp_valid_m(uint32_t M) { return M == 128u || M == 256u; }
 
-hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, uint32_t ncols, uint32_t T, uint32_t D,
-                             uint32_t Dpad, uint32_t A, uint32_t M, uint32_t ncg, float2 *R, hipStream_t s) {
-  if (!xlp_valid_m(M)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(xlp_tables_kernel, dim3(M * Dpad * ncg), dim3(XLP_COLS), 0, s, rt, delta, ncols, T, D, Dpad, A, M,
-                     R);
+hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, uint32_t nlist, uint32_t T,
+                             uint32_t D, uint32_t Dpad, uint32_t A, uint32_t M, float2 *R, hipStream_t s) {
+  if (!xlp_valid_m(M) || nlist == 0u) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(xlp_tables_kernel, dim3(M * Dpad, (nlist + XLP_COLS - 1u) / XLP_COLS), dim3(XLP_COLS), 0, s, rt, delta, colidx,
+                     nlist, T, D, Dpad, A, M, R);
   return hipGetLastError();
 }
 

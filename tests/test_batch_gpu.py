@@ -1181,3 +1181,44 @@ def test_config5_cf32_10msps_all_clients(nclients):
             else:
                 assert rel_err(got[c], want[c]) <= REL_TOL, (c, rel_err(got[c], want[c]))
         eng.close()
+
+
+def test_churn_one_join_and_one_leave_per_block():
+    """Incremental re-planning under churn: 1024 x 48 kHz clients, and for 200 blocks one client joins AND one leaves before
+    every block (dsp_worker_start / dsp_worker_destroy while the stream runs, src/dsp_worker.c:90-108, 172-197).  A joiner
+    spends its first block in a direct class of its own, then takes a column of the polyphase class -- the column a leaver
+    freed when there is one -- and only that column's branch spectra are computed.  Checked against the oracle: six clients
+    that stay for the whole run, every joiner over its first six blocks (alone, merged, settled), recycled client ids, and a
+    native block every 16th (bit-exact; it rebuilds the all-clients launch set after the churn)."""
+    t48 = lpf(FS, 24000, 9600)
+    nb = 262144
+    eng = xl.BatchEngine(FS, "cu8", nb)
+    fcs = {eng.add_client(42, t48, -984000 + 1920 * c): -984000 + 1920 * c for c in range(1024)}
+    stay = [0, 1, 511, 640, 1000, 1023]
+    oracles = {cid: Oracle(42, t48, fcs[cid], FS, nb) for cid in stay}
+    watch = {}  # cid -> blocks left to watch
+    rng = np.random.default_rng(11)
+    leavable = [cid for cid in fcs if cid not in stay]
+    for k in range(200):
+        gone = leavable.pop(int(rng.integers(len(leavable))))
+        eng.remove_client(gone)
+        if gone in oracles:
+            oracles.pop(gone).close()
+            watch.pop(gone, None)
+        fc = int(rng.integers(-980000, 980000))
+        cid = eng.add_client(42, t48, fc)  # (reuses the id that just left, half of the time)
+        oracles[cid] = Oracle(42, t48, fc, FS, nb)
+        watch[cid] = 6
+        leavable.append(cid)
+        x = siggen.xs_u8(9300 + k, nb if k % 5 else 200004)
+        variant = "native" if k % 16 == 15 else "optimized"
+        check_clients(eng, oracles, "cu8", x, variant)
+        for c in list(watch):
+            watch[c] -= 1
+            if watch[c] == 0:
+                del watch[c]
+                oracles.pop(c).close()
+    check_clients(eng, oracles, "cu8", siggen.xs_u8(9999, nb), "optimized")  # (the last joiner merges)
+    d = eng.describe()
+    assert "clients 1024 " in d and "polyphase: cls0 D42 T505 cols1024" in d and "cls1" not in d, d
+    eng.close()
