@@ -76,6 +76,15 @@ void destroy_xlating(xlating *filter);
 void process_native_cf32_cf32(const float *input, size_t input_len, XL_CF32 **output, size_t *output_len, xlating *filter);
 void process_optimized_cf32_cf32(const float *input, size_t input_len, XL_CF32 **output, size_t *output_len, xlating *filter);
 
+/* ---- extension, not in the reference: which build of the reference process_optimized_* follows.
+ * The reference's scalar and NEON paths renormalise the NCO phase once per call (src/xlating.c:73, :255); its x86 AVX path
+ * never does (:338-339), so an x86 OPTIMIZED_CF32 server's long streams drift in amplitude (about 1e-3 after 400
+ * server-default blocks).  on = 0 (default): renormalise, like native.  on = 1: never renormalise -- the x86 build's streams.
+ * on = 2: the same for an x86 build compiled with FMA (-mfma / -march=native), whose phase step is contracted to
+ * re = fma(pr, ir, -(pi ii)), im = fma(pr, ii, pi ir) and rounds differently.  The environment variable
+ * XLATING_OPTIMIZED_X86=<0|1|2> sets the default of filters created afterwards.  0 or -EINVAL. */
+int xlating_set_optimized_x86(xlating *filter, int on);
+
 #ifdef __cplusplus
 }
 #endif

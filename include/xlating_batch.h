@@ -35,7 +35,20 @@ enum { XL_MODE_NATIVE = 0, XL_MODE_OPTIMIZED = 1,
         * cf32 family (dsp_worker.c:110-124); a client stream should stay in one family (the reference keeps separate sample
         * buffers per family behind one history counter, a quirk the single-filter API reproduces and this engine -- one raw
         * history -- does not). */
-       XL_MODE_Q15 = 2 };
+       XL_MODE_Q15 = 2,
+       /* process_optimized_* as the reference's x86 AVX build runs it: the optimized arithmetic, but the NCO phase is
+        * NEVER renormalised (xlating.c:338-339; the scalar and NEON paths renormalise once per call, :73, :255, and so do
+        * XL_MODE_NATIVE and XL_MODE_OPTIMIZED).  The float32 phase recurrence itself is the same unfused multiply; only
+        * the per-call division by |phase| is left out, so the amplitude drifts like the x86 server's (about 1e-3 after 400
+        * server-default blocks).  For deployments that must reproduce an x86 OPTIMIZED_CF32 server's long streams; the
+        * running phase is shared with the other cf32 modes. */
+       XL_MODE_OPTIMIZED_X86 = 3,
+       /* the same, for reference builds compiled with FMA enabled (-mfma, -march=native on an AVX2 host): gcc -ffast-math
+        * contracts the phase step `phase * phase_incr` to re = fma(pr, ir, -(pi * ii)), im = fma(pr, ii, pi * ir), which
+        * walks away from the plain step's rounding by ~1e-5 within a few blocks at some offsets; this mode takes that
+        * step (and never renormalises).  Found by matching the phase sequence of the unmodified reference, built both
+        * ways, bit for bit (oracle/_ref/libref_avx.so, libref_fast.so; tests/golden/x86_*.npz, fast_*.npz). */
+       XL_MODE_OPTIMIZED_X86_FMA = 4 };
 
 /* Create an engine for one input stream on one GPU.
  *   sampling_freq             band sampling rate (server_config->band_sampling_rate)

@@ -55,6 +55,8 @@ class Oracle:
             L.orc_xlating_create.restype = C.c_int
             L.orc_xlating_destroy.argtypes = [C.c_void_p]
             L.orc_xlating_set_sum_mode.argtypes = [C.c_void_p, C.c_int]
+            L.orc_xlating_set_renorm.argtypes = [C.c_void_p, C.c_int]
+            L.orc_xlating_set_fma_step.argtypes = [C.c_void_p, C.c_int]
             L.orc_xlating_history.argtypes = [C.c_void_p]
             L.orc_xlating_history.restype = C.c_size_t
             L.orc_xlating_taps_len.argtypes = [C.c_void_p]
@@ -92,7 +94,7 @@ class Oracle:
         C.CDLL(None).free(p)
         return 0, taps
 
-    def __init__(self, decimation, taps, center_freq, sampling_freq, max_input, sum_mode=0):
+    def __init__(self, decimation, taps, center_freq, sampling_freq, max_input, sum_mode=0, renorm=True, fma_step=False):
         L = self.lib()
         taps = np.ascontiguousarray(taps, dtype=np.float32)
         h = C.c_void_p()
@@ -103,6 +105,10 @@ class Oracle:
         self.D = decimation
         if sum_mode:
             L.orc_xlating_set_sum_mode(h, sum_mode)
+        if not renorm:  # process_optimized_* of the reference's x86 AVX build (xlating.c:338-339)
+            L.orc_xlating_set_renorm(h, 0)
+        if fma_step:    # ... of a build with FMA enabled
+            L.orc_xlating_set_fma_step(h, 1)
 
     def close(self):
         if self.h:

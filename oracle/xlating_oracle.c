@@ -84,6 +84,8 @@ struct orc_xlating {
   uint32_t D;
   size_t T;
   int sum_mode;
+  int fma_step;   /* 1: the phase step as gcc -ffast-math -mfma contracts it (see orc_xlating_set_fma_step) */
+  int renorm;     /* 1: renormalise the phase once per call (xlating.c:73, scalar / NEON paths); 0: never (AVX path, :338-339) */
   float *rt;      /* reversed band-pass taps, interleaved re,im (T pairs) */
   int16_t *rt_q;  /* the same in Q15, interleaved */
   /* streaming state.  `hist` is SHARED by the cf32 and cs16 families exactly
@@ -114,6 +116,7 @@ int orc_xlating_create(uint32_t decimation, const float *taps, size_t taps_len,
   f->D = decimation;
   f->T = taps_len;
   f->sum_mode = ORC_SUM_SEQ_F32;
+  f->renorm = 1;
   f->rt = malloc(sizeof(float) * 2 * taps_len);
   f->rt_q = malloc(sizeof(int16_t) * 2 * taps_len);
   float complex *bp = malloc(sizeof(float complex) * taps_len);
@@ -197,6 +200,13 @@ void orc_xlating_destroy(orc_xlating *f) {
 }
 
 void orc_xlating_set_sum_mode(orc_xlating *f, int mode) { f->sum_mode = mode; }
+/* xlating.c:338-339: the x86 AVX path never renormalises (process_optimized_* of an x86 build) */
+void orc_xlating_set_renorm(orc_xlating *f, int on) { f->renorm = on != 0; }
+/* A reference build with FMA enabled (-O3 -ffast-math -mfma) contracts `phase * phase_incr` (xlating.c:338) to
+ * re = fma(pr, ir, -(pi * ii)), im = fma(pr, ii, pi * ir): established by matching the phase sequence of the unmodified
+ * reference built that way (oracle/_ref/libref_fast.so) bit for bit; the plain step matches the build without FMA
+ * (libref_avx.so) the same way (tests/test_oracle.py). */
+void orc_xlating_set_fma_step(orc_xlating *f, int on) { f->fma_step = on != 0; }
 size_t orc_xlating_history(const orc_xlating *f) { return f->hist; }
 size_t orc_xlating_taps_len(const orc_xlating *f) { return f->T; }
 const float *orc_xlating_rtaps(const orc_xlating *f) { return f->rt; }
@@ -252,15 +262,23 @@ static void run_cf32(orc_xlating *f, size_t fresh, float **output, size_t *outpu
       f->out_f[2 * made] = yr * f->ph_re - yi * f->ph_im;
       f->out_f[2 * made + 1] = yr * f->ph_im + yi * f->ph_re;
       /* xlating.c:71: phase *= phase_incr (float32 recurrence) */
-      float nr = f->ph_re * f->inc_re - f->ph_im * f->inc_im;
-      float ni = f->ph_re * f->inc_im + f->ph_im * f->inc_re;
+      float nr, ni;
+      if (f->fma_step) {
+        nr = fmaf(f->ph_re, f->inc_re, -(f->ph_im * f->inc_im));
+        ni = fmaf(f->ph_re, f->inc_im, f->ph_im * f->inc_re);
+      } else {
+        nr = f->ph_re * f->inc_re - f->ph_im * f->inc_im;
+        ni = f->ph_re * f->inc_im + f->ph_im * f->inc_re;
+      }
       f->ph_re = nr;
       f->ph_im = ni;
     }
-    /* xlating.c:73: one renormalisation per call that could produce output */
-    float mag = hypotf(f->ph_re, f->ph_im);
-    f->ph_re = f->ph_re / mag;
-    f->ph_im = f->ph_im / mag;
+    /* xlating.c:73: one renormalisation per call that could produce output (not on the AVX path, :338-339) */
+    if (f->renorm) {
+      float mag = hypotf(f->ph_re, f->ph_im);
+      f->ph_re = f->ph_re / mag;
+      f->ph_im = f->ph_im / mag;
+    }
   }
   /* xlating.c:76-79: keep the unconsumed tail as history */
   f->hist = avail - pos;
@@ -281,14 +299,22 @@ void orc_xlating_skip_calls_cf32(orc_xlating *f, size_t fresh, size_t ncalls) {
     if (avail > T - 1) {
       const size_t limit = avail - (T - 1);
       for (; pos < limit; pos += f->D) {
-        float nr = f->ph_re * f->inc_re - f->ph_im * f->inc_im;
-        float ni = f->ph_re * f->inc_im + f->ph_im * f->inc_re;
+        float nr, ni;
+        if (f->fma_step) {
+          nr = fmaf(f->ph_re, f->inc_re, -(f->ph_im * f->inc_im));
+          ni = fmaf(f->ph_re, f->inc_im, f->ph_im * f->inc_re);
+        } else {
+          nr = f->ph_re * f->inc_re - f->ph_im * f->inc_im;
+          ni = f->ph_re * f->inc_im + f->ph_im * f->inc_re;
+        }
         f->ph_re = nr;
         f->ph_im = ni;
       }
-      float mag = hypotf(f->ph_re, f->ph_im);
-      f->ph_re = f->ph_re / mag;
-      f->ph_im = f->ph_im / mag;
+      if (f->renorm) {
+        float mag = hypotf(f->ph_re, f->ph_im);
+        f->ph_re = f->ph_re / mag;
+        f->ph_im = f->ph_im / mag;
+      }
     }
     f->hist = avail - pos;
   }

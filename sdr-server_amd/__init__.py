@@ -34,7 +34,7 @@ _c_float_p = C.POINTER(C.c_float)
 _c_i16_p = C.POINTER(C.c_int16)
 
 FMT = {"cu8": 0, "cs8": 1, "cs16": 2, "cf32": 3}
-MODE = {"native": 0, "optimized": 1, "q15": 2}
+MODE = {"native": 0, "optimized": 1, "q15": 2, "optimized_x86": 3, "optimized_x86_fma": 4}
 _NP = {"cu8": np.uint8, "cs8": np.int8, "cs16": np.int16, "cf32": np.float32}
 _CT = {"cu8": C.c_uint8, "cs8": C.c_int8, "cs16": C.c_int16, "cf32": C.c_float}
 
@@ -42,7 +42,7 @@ _CT = {"cu8": C.c_uint8, "cs8": C.c_int8, "cs16": C.c_int16, "cf32": C.c_float}
 EXPORTED_SYMBOLS = (
     ["SIMD_STATUS", "create_frequency_xlating_filter", "destroy_xlating", "create_low_pass_filter"]
     + [f"process_{v}_{i}_{o}" for v in ("native", "optimized") for i in ("cu8", "cs8", "cs16") for o in ("cf32", "cs16")]
-    + ["process_native_cf32_cf32", "process_optimized_cf32_cf32"]
+    + ["process_native_cf32_cf32", "process_optimized_cf32_cf32", "xlating_set_optimized_x86"]
     + ["xlating_batch_create", "xlating_batch_create_grouped", "xlating_batch_set_option", "xlating_batch_process_host_group",
        "xlating_batch_process_device_group", "xlating_batch_process_device_group_ev", "xlating_batch_output_len_block", "xlating_batch_add_client", "xlating_batch_remove_client", "xlating_batch_num_clients",
        "xlating_batch_process_host", "xlating_batch_process_device", "xlating_batch_output_len", "xlating_batch_fetch",
@@ -133,6 +133,8 @@ def lib():
     L.create_frequency_xlating_filter.restype = C.c_int
     L.destroy_xlating.argtypes = [C.c_void_p]
     L.destroy_xlating.restype = None
+    L.xlating_set_optimized_x86.argtypes = [C.c_void_p, C.c_int]
+    L.xlating_set_optimized_x86.restype = C.c_int
     for v in ("native", "optimized"):
         for i in ("cu8", "cs8", "cs16", "cf32"):
             fn = getattr(L, f"process_{v}_{i}_cf32")
@@ -302,6 +304,13 @@ class XlatingFilter:
         if n.value == 0:
             return np.zeros((0, 2), np.int16)
         return np.ctypeslib.as_array(p, shape=(n.value, 2)).copy()
+
+    def set_optimized_x86(self, on=1):
+        """process_optimized_* follows the reference's x86 AVX build: the phase is never renormalised (xlating.c:338-339);
+        on = 2: the build compiled with FMA (its contracted phase step)."""
+        code = lib().xlating_set_optimized_x86(self.h, int(on))
+        if code != 0:
+            raise XlatingError("xlating_set_optimized_x86", code)
 
     def close(self):
         if getattr(self, "h", None):

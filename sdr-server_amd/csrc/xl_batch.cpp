@@ -226,7 +226,7 @@ struct xlating_batch_t {
   // spec_G blocks each (the phases after them: d_phase[pcur + 1 ..]); produced by the latest call's launches (spec_n = 1)
   // or by one chain launch on the side stream (spec_n <= 2), whose completion is ev_chain[spec_ev].
   int spec_n = 0;
-  uint32_t spec_S = 0, spec_G = 0;
+  uint32_t spec_S = 0, spec_G = 0, spec_flags = 0;
   int spec_ev = 0;
   bool waited_valid = false;  // stream waited_stream has waited for ev_chain[waited_ev] since that event was last recorded
   int waited_ev = 0;
@@ -1349,9 +1349,16 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
                         hipEvent_t wait_ev = nullptr, hipEvent_t record_ev = nullptr) {
   const size_t S = input_len / 2;
   hipStream_t s = s_in;
-  if (S > b->max_samples || G < 1 || G > b->gcap || (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED && mode != XL_MODE_Q15) ||
+  if (S > b->max_samples || G < 1 || G > b->gcap ||
+      (mode != XL_MODE_NATIVE && mode != XL_MODE_OPTIMIZED && mode != XL_MODE_Q15 && mode != XL_MODE_OPTIMIZED_X86 &&
+       mode != XL_MODE_OPTIMIZED_X86_FMA) ||
       (mode == XL_MODE_Q15 && b->fmt == XL_FMT_CF32))
     return -EINVAL;
+  // the x86 AVX build's optimized variant = the optimized arithmetic with the phase never renormalised (xlating.c:338-339):
+  // the stream position carries the flag to every kernel that walks phases (xl_grid.h: XL_POS_NORENORM)
+  const uint32_t pos_flags = mode == XL_MODE_OPTIMIZED_X86 ? XL_POS_NORENORM
+                             : (mode == XL_MODE_OPTIMIZED_X86_FMA ? (XL_POS_NORENORM | XL_POS_FMA_STEP) : 0u);
+  if (mode == XL_MODE_OPTIMIZED_X86 || mode == XL_MODE_OPTIMIZED_X86_FMA) mode = XL_MODE_OPTIMIZED;
   if (mode == XL_MODE_Q15 && !b->want_q15) {  // (the Q15 tap image is built from the first Q15 call on)
     b->want_q15 = true;
     b->all_built = false;
@@ -1378,7 +1385,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
   pos.trel = b->trel;
   pos.S = (uint32_t)S;
   pos.G = G;
-  pos.pad = 0;
+  pos.pad = pos_flags;
   // optimized mode: the polyphase classes leave the direct launches (tiny calls stay direct: a segment is 128 or 256
   // branch samples whatever the call holds)
   uint32_t maxK = 0;  // the most outputs any client produces in this call
@@ -1487,7 +1494,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     int spec_left = 0;  // look-ahead calls that stay valid behind this one (a chain launch covers up to two)
     const int chain_ev = b->spec_ev;
     bool tab_from_s = true;
-    if (b->spec_n > 0 && b->spec_S == S && b->spec_G == G) {
+    if (b->spec_n > 0 && b->spec_S == S && b->spec_G == G && b->spec_flags == pos_flags) {
       tab_from_s = !b->spec_on_side;
       // (the second call of a chain launch's pair: this stream has already waited for that launch)
       chain_wait = b->spec_on_side && !(b->waited_valid && b->waited_ev == chain_ev && b->waited_stream == s);
@@ -1839,6 +1846,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     }
     b->spec_S = (uint32_t)S;
     b->spec_G = G;
+    b->spec_flags = pos_flags;
   }
   return 0;
 fail:

@@ -127,6 +127,24 @@ XL_DEV v2f xl_nco_next(const v2f p, const v2f inc) {
   return r;
 }
 
+// The same step as a reference build with FMA contraction computes it (gcc -O3 -ffast-math -mfma turns xlating.c:338
+// `phase * phase_incr` into  re = fma(pr, ir, -(pi * ii)),  im = fma(pr, ii, pi * ir): found by matching the unmodified
+// reference's phase sequence bit for bit, oracle/_ref/libref_fast.so; tests/test_oracle.py): one packed multiply, one
+// packed FMA.
+XL_DEV v2f xl_nco_next_fma(const v2f p, const v2f inc) {
+  v2f t, r;
+  asm volatile(
+      "v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %1, %2, %3, %0 op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+      : "=&v"(t), "=&v"(r)
+      : "v"(p), "v"(inc));
+  return r;
+}
+// the step a call's flags ask for (xl_grid.h: XL_POS_FMA_STEP); wave-uniform choice
+XL_DEV v2f xl_nco_next_any(const v2f p, const v2f inc, const uint32_t flags) {
+  return (flags & XL_POS_FMA_STEP) ? xl_nco_next_fma(p, inc) : xl_nco_next(p, inc);
+}
+
 // xlating.c:73 `phase /= hypotf(re, im)`: glibc's hypotf evaluates sqrt(x*x + y*y) in double and narrows; restated with
 // IEEE double operations (equal to libm on 2e8 inputs, tests/test_oracle.py) and correctly rounded float divisions.
 XL_DEV v2f xl_nco_renorm(const v2f p) {
@@ -161,10 +179,10 @@ XL_DEV void xl_nco_client_chain(const XlNcoClient k, const XlBnd bnd, const uint
     const uint32_t me = nb < ke ? nb : ke;
     for (; m < me && (m & (2u * XL_PH_STRIDE - 1u)) != 0u; ++m) {  // head: up to the next pair boundary
       if (tab != nullptr && (m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
-      p = xl_nco_next(p, inc);
+      p = xl_nco_next_any(p, inc, bnd.flags);
     }
-    // 2 * XL_PH_STRIDE steps and ONE store (two entries) per trip
-    for (; m + 2u * XL_PH_STRIDE <= me; m += 2u * XL_PH_STRIDE) {
+    // 2 * XL_PH_STRIDE steps and ONE store (two entries) per trip (plain step; FMA-step calls take the loops around it)
+    for (; !(bnd.flags & XL_POS_FMA_STEP) && m + 2u * XL_PH_STRIDE <= me; m += 2u * XL_PH_STRIDE) {
       const v2f q0 = p;
       for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
 #pragma unroll
@@ -179,7 +197,7 @@ XL_DEV void xl_nco_client_chain(const XlNcoClient k, const XlBnd bnd, const uint
     }
     for (; m < me; ++m) {
       if (tab != nullptr && (m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
-      p = xl_nco_next(p, inc);
+      p = xl_nco_next_any(p, inc, bnd.flags);
     }
     if (me == nb) p = xl_nco_renorm(p);  // a block of the call ends here
   }
@@ -197,6 +215,7 @@ XL_DEV XlBnd xl_nco_bnd(const XlNcoClient k, const XlPos pos, const uint32_t exp
     const XlDyn d = xl_grid_dyn(k.D, 1u, k.rem0, 0u, pos);
     b.j0 = d.j0, b.D = k.D, b.S = pos.S, b.G = pos.G, b.K = d.K;
   }
+  b.flags = pos.pad;
   return b;
 }
 
@@ -211,7 +230,7 @@ XL_DEV void xl_phase_walk(v2f p, const uint32_t m0, const uint32_t count, const 
   const uint32_t end = m0 + count;
   for (; m < end; ++m) {
     if (m >= m0) store(m - m0, p);
-    p = xl_nco_next(p, inc);
+    p = xl_nco_next_any(p, inc, bnd.flags);
     if (m + 1u == nb) {
       p = xl_nco_renorm(p);
       nb = xl_bnd_next(bnd, m + 1u);

@@ -34,6 +34,9 @@ struct xlating_t {
   size_t out_cap = 0;
   int16_t qinc[2] = {0, 0};
   bool warned = false;
+  int x86 = 0;             // process_optimized_*: 1 = never renormalise the phase (the reference's x86 AVX build, xlating.c:338-339),
+                           // 2 = and take the FMA-contracted phase step of an -mfma build (xl_grid.h: XL_POS_FMA_STEP)
+  uint32_t spec_flags = 0; // XlPos flags the look-ahead table was tabulated with
   uint32_t ota = 64;       // outputs per wave (64 unless the window image would not fit the LDS)
 
   void *d_raw = nullptr;
@@ -147,6 +150,8 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XL_TRY(hipStreamCreateWithFlags(&f->stream_nco, hipStreamNonBlocking));
   XL_TRY(hipEventCreateWithFlags(&f->ev_nco, hipEventDisableTiming));
   f->lookahead = getenv("XL_EXP_NOLOOKAHEAD") == nullptr;
+  f->x86 = getenv("XLATING_OPTIMIZED_X86") != nullptr ? atoi(getenv("XLATING_OPTIMIZED_X86")) : 0;
+  if (f->x86 < 0 || f->x86 > 2) f->x86 = 0;
   f->zero_copy = getenv("XL_EXP_DROPIN_COPY") == nullptr;
   XL_TRY(hipMalloc(&f->d_raw, f->max_samples * 8 + 16));
   XL_TRY(hipMalloc((void **)&f->d_work_f, work_n * sizeof(float2)));
@@ -191,6 +196,13 @@ fail:
 }
 
 extern "C" void destroy_xlating(xlating *filter) { xl_filter_free(filter); }
+
+// include/xlating.h extension: which build of the reference process_optimized_* follows (see the header)
+extern "C" int xlating_set_optimized_x86(xlating *filter, int on) {
+  if (filter == nullptr || on < 0 || on > 2) return -EINVAL;
+  filter->x86 = on;
+  return 0;
+}
 
 // Output count and consumed samples for `fresh` new samples (xlating.c:53-60,76): W = hist + fresh;
 // outputs at window starts 0, D, 2D, ... < W - (T-1).
@@ -238,6 +250,7 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
   const size_t bytes = n * xl_bytes_per_sample(fmt);
   size_t W, K, pos;
   bool ahead = false;  // the next call's table is requested during this call (else after the sync, if at all)
+  const uint32_t pflags = (mode == 1 && f->x86) ? (XL_POS_NORENORM | (f->x86 == 2 ? XL_POS_FMA_STEP : 0u)) : 0u;
   xl_counts(f, n, &W, &K, &pos);
   XL_TRY(hipSetDevice(f->device));
   if (n > 0) {
@@ -252,11 +265,12 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
     memset(&pos, 0, sizeof(pos));
     pos.S = (uint32_t)n;
     pos.G = 1;
+    pos.pad = pflags;
     // The phases of this call: tabulated ahead on stream_nco after the previous call if that call guessed this one's
     // output count (the recurrence is data independent: xlating.c:70-73), else now.  The chain is ~30 us of pure
     // latency; ahead of time it overlaps the host's work between calls, the upload and the convert kernel.
     ahead = false;
-    if (f->spec_valid && f->spec_K == K) {
+    if (f->spec_valid && f->spec_K == K && f->spec_flags == pflags) {
       XL_TRY(hipStreamWaitEvent(f->stream, f->ev_nco, 0));
       std::swap(f->d_phtab, f->d_phtab_next);
       std::swap(f->d_phase, f->d_phase_next);
@@ -309,10 +323,12 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
       memset(&pn, 0, sizeof(pn));
       pn.S = (uint32_t)n;
       pn.G = 1;
+      pn.pad = pflags;
       XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase_next, f->d_phtab_next, pn, (uint32_t)Kn, 0, f->stream_nco));
       XL_TRY(hipEventRecord(f->ev_nco, f->stream_nco));
       f->spec_valid = true;
       f->spec_K = Kn;
+      f->spec_flags = pflags;
     }
   }
   if (trace_us >= 0) ts2 = xl_now_us();
@@ -329,10 +345,12 @@ static void xl_run_cf32(xlating *f, const void *input, size_t input_len, int fmt
       memset(&pn, 0, sizeof(pn));
       pn.S = (uint32_t)n;
       pn.G = 1;
+      pn.pad = pflags;
       XL_TRY(xl_launch_nco_table(f->d_nco, 1, f->d_phase, f->d_phase_next, f->d_phtab_next, pn, (uint32_t)Kn, 0, f->stream_nco));
       XL_TRY(hipEventRecord(f->ev_nco, f->stream_nco));
       f->spec_valid = true;
       f->spec_K = Kn;
+      f->spec_flags = pflags;
     }
   }
   if (trace_us >= 0) {

@@ -31,8 +31,11 @@ typedef struct XlPos {
   uint32_t trel; /* samples the engine consumed between the plan and the start of this call (< 2^31; the engine re-plans before it overflows) */
   uint32_t S;    /* samples per block of this call */
   uint32_t G;    /* blocks in this call (>= 1) */
-  uint32_t pad;
+  uint32_t pad;  /* flags: XL_POS_NORENORM = the call never renormalises the NCO phase (the reference's x86 AVX build, xlating.c:338-339) */
 } XlPos;
+#define XL_POS_NORENORM 1u
+#define XL_POS_FMA_STEP 2u /* the phase recurrence step as gcc -ffast-math -mfma contracts `phase * phase_incr`: re = fma(pr, ir, -(pi*ii)),
+                              im = fma(pr, ii, pi*ir) -- reference builds with FMA enabled (e.g. -march=native on an AVX2 host) */
 
 typedef struct XlDyn {
   uint32_t base;       /* sample index in [history | blocks] coordinates of the first tap of output 0 */
@@ -72,12 +75,14 @@ XL_HD uint32_t xl_grid_mstart(uint32_t j0, uint32_t D, uint32_t S, uint32_t g) {
 /* Block boundaries of a call on one client's output index (NCO renormalisation points, xlating.c:73). */
 typedef struct XlBnd {
   uint32_t j0, D, S, G, K;
+  uint32_t flags; /* XL_POS_NORENORM: no renormalisation point exists */
 } XlBnd;
 
 /* smallest block-start index > m, or K when m lies in the last block: the phase is renormalised between
  * outputs xl_bnd_next(m) - 1 and xl_bnd_next(m).  Needs every block of a multi-block call to hold an output (S >= D). */
 XL_HD uint32_t xl_bnd_next(const XlBnd b, uint32_t m) {
   uint32_t g, nb;
+  if (b.flags & XL_POS_NORENORM) return 0xFFFFFFFFu; /* never reached: nobody renormalises */
   if (b.G <= 1u) return b.K;
   g = (b.j0 + m * b.D) / b.S;
   if (g + 1u >= b.G) return b.K;

@@ -202,6 +202,8 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
         // entries e .. e_stop - 1: their steps hold no block end for anybody ((e + 1) * 16 < evs)
         uint32_t e_stop = evs == 0u ? 0u : (evs - 1u) >> XL_PH_SHIFT;
         e_stop = e_stop < Emax ? e_stop : Emax;
+        if (pos.pad & XL_POS_FMA_STEP) e_stop = e;  // (the hand-scheduled blocks are the plain step: a call with the FMA-contracted
+                                                    // step of an -mfma reference build takes the per-step path throughout)
         if ((e << XL_PH_SHIFT) < K) {  // (a lane whose call has ended sits the region out; the others' mask is constant in it)
           uint32_t ee = e;
           while (ee < e_stop) {
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void xl_nco_chain_kernel(const XlNcoClient *__
           if (m0 < K) xl_lds_post64(a_ring + (e & (XLC_RING - 1u)) * 64u * (uint32_t)sizeof(v2f), p);
           xl_lds_post(a_prod, e + 1u);
           for (uint32_t m = m0; m < m0 + XL_PH_STRIDE && m < K; ++m) {
-            p = xl_nco_next(p, inc);
+            p = xl_nco_next_any(p, inc, bnd.flags);
             if (m + 1u == nb) {
               p = xl_nco_renorm(p);
               nb = xl_bnd_next(bnd, m + 1u);
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(64 * XL_NW_MAX) __attribute__((amdgpu_num_sgpr(96))
         const float2 ci = reinterpret_cast<const float2 *>(tg + 2 + XL_CT_MAX)[c];
         const uint32_t left = K - m0, span = OT < XL_PH_STRIDE ? OT : XL_PH_STRIDE;
         XlBnd bnd;
-        bnd.j0 = d.j0, bnd.D = D, bnd.S = a.pos.S, bnd.G = a.explicit_dyn ? 1u : a.pos.G, bnd.K = K;
+        bnd.j0 = d.j0, bnd.D = D, bnd.S = a.pos.S, bnd.G = a.explicit_dyn ? 1u : a.pos.G, bnd.K = K, bnd.flags = a.pos.pad;
         v2f *__restrict__ dst = pl + c * 64u + e * XL_PH_STRIDE;
         xl_phase_walk((reinterpret_cast<const v2f *>(a.phtab) + (off >> XL_PH_SHIFT))[m0 >> XL_PH_SHIFT], m0,
                       left < span ? left : span, (v2f){ci.x, ci.y}, bnd, [&](uint32_t i, v2f ph) { dst[i] = ph; });

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
   const uint32_t en = j / GQ, gq = j % GQ;  // expansion duty: column en of the wave, shared points s V + gq*XL_PH_STRIDE ..
   const XlpCol ce = a.cols[colbase + en];
   XlBnd ebnd;
-  ebnd.j0 = xl_merge_j0(a.j0_ref, ce.delta, a.D), ebnd.D = a.D, ebnd.S = a.pos.S, ebnd.G = a.pos.G;
+  ebnd.j0 = xl_merge_j0(a.j0_ref, ce.delta, a.D), ebnd.D = a.D, ebnd.S = a.pos.S, ebnd.G = a.pos.G, ebnd.flags = a.pos.pad;
   ebnd.K = Ka + (ebnd.j0 < Nr ? 1u : 0u);
   const uint32_t esh = xl_merge_shift(a.j0_ref, ce.delta, a.D);
   const uint32_t q0 = s * a.V + gq * XL_PH_STRIDE;
@@ -605,7 +605,7 @@ XL_DEV void xlp_rotate_checked(v2f (&u)[64], v2f &p, uint32_t &m, uint32_t &nb, 
   for (uint32_t tt = 0; tt < 16u; ++tt) {
     pl[tt] = p;
     if (CH == 0 && tt == 0u && !valid0) continue;
-    p = xl_nco_next(p, inc);
+    p = xl_nco_next_any(p, inc, bnd.flags);
     if (++m == nb) {
       p = xl_nco_renorm(p);
       nb = xl_bnd_next(bnd, m);
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const uint32_t Ka = N / a.D, Nr = N - Ka * a.D;
   const XlpCol col = a.cols[cg * XLP_COLS + w * CW + c];
   XlBnd bnd;
-  bnd.j0 = xl_merge_j0(a.j0_ref, col.delta, a.D), bnd.D = a.D, bnd.S = a.pos.S, bnd.G = a.pos.G;
+  bnd.j0 = xl_merge_j0(a.j0_ref, col.delta, a.D), bnd.D = a.D, bnd.S = a.pos.S, bnd.G = a.pos.G, bnd.flags = a.pos.pad;
   bnd.K = Ka + (bnd.j0 < Nr ? 1u : 0u);
   const uint32_t shift = xl_merge_shift(a.j0_ref, col.delta, a.D);
   const int32_t k0 = (int32_t)(s * a.V) - (int32_t)shift;  // output index of shared point n = 0 of this segment
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   uint32_t nb = xl_bnd_next(bnd, m);
   if (walk) {
     for (; m < mb; ++m) {
-      p = xl_nco_next(p, inc);
+      p = xl_nco_next_any(p, inc, bnd.flags);
       if (m + 1u == nb) {
         p = xl_nco_renorm(p);
         nb = xl_bnd_next(bnd, m + 1u);
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // (a block of the call ends inside this lane's 64 outputs: rare -- 8 of 216 segments of the bench call -- and wave
   // uniform for all practical purposes; the checked walk does the per-step comparison the plain one leaves out)
   const bool crosses = walk && nb <= mb + 64u;
-  if (__builtin_amdgcn_ballot_w64(crosses) != 0ull)
+  if (__builtin_amdgcn_ballot_w64(crosses) != 0ull || (a.pos.pad & XL_POS_FMA_STEP))  // (the plain walk is the plain step)
     xlp_rotate_checked(u, p, m, nb, inc, bnd, valid0, &stage[w][0][0][0] + 17u * j);
   else
     xlp_rotate_plain(u, p, inc, valid0);

@@ -17,6 +17,8 @@ Outputs (data only -- numbers, never reference source text):
                                        process_optimized_* of xlating.c:271-348, which does NOT renormalise the phase,
                                        :338-339) for blocks 0-9 of the g9 / g10 / g11 shapes: what an x86 server's
                                        "optimized" setting computes.  Head and tail of every block + block 9 in full.
+  tests/golden/avx_g11_t101.npz        blocks 0-9 of the g11 shape from the reference built with -mavx but WITHOUT FMA (libref_avx.so).
+  tests/golden/x86_long_g9.npz         the same AVX build over 400 blocks of the g9 shape, sampled (pins the no-renormalisation mode).
   tests/golden/fast_divergence.json    how far the reference's own two builds drift apart over a long stream
                                        (canonical native vs AVX optimized; max |d| / max |y| per block).
 """
@@ -136,6 +138,56 @@ def make_fast():
                            "blocks); both are the UNMODIFIED reference, oracle/_ref/libref_canon.so vs libref_fast.so",
                "block": div}, open(os.path.join(HERE, "fast_divergence.json"), "w"), indent=1)
     print("reference canon-vs-fast divergence:", div)
+    make_x86_long()
+    make_avx_g11()
+
+
+def make_avx_g11():
+    """tests/golden/avx_g11_t101.npz: blocks 0-9 of the g11 shape from the reference built WITHOUT FMA (oracle/_ref/libref_avx.so:
+    the reference's own Release flags -O3 -ffast-math, + -mavx) -- the shape on which the FMA build's contracted phase step
+    (fast_g11_t101.npz) and the plain one part ways within a few blocks.  Pins XL_MODE_OPTIMIZED_X86 (plain step)."""
+    if not RefLib.available("avx"):
+        return
+    sc = scenarios.BY_NAME["g11_t101"]
+    taps = scenarios.make_taps(sc, lpf=lambda *a: RefLib.lpf(*a)[1])
+    avx = RefLib(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"], flavour="avx", variant="optimized")
+    assert RefLib.simd_status("avx") == "AVX"
+    arrays = {"taps": taps}
+    for k in range(FAST_BLOCKS):
+        y = avx.process(sc["fmt"], fast_block(sc, k), "cf32")
+        arrays[f"n{k}"] = np.int64(len(y))
+        if k == FAST_BLOCKS - 1:
+            arrays[f"y{k}"] = y
+        else:
+            arrays[f"head{k}"] = y[:FAST_HEAD]
+            arrays[f"tail{k}"] = y[-FAST_TAIL:]
+    avx.close()
+    p = os.path.join(HERE, "avx_g11_t101.npz")
+    np.savez_compressed(p, **arrays)
+    print(f"avx_g11_t101 -> {os.path.getsize(p)/1024:.1f} KiB")
+
+
+def make_x86_long():
+    """tests/golden/x86_long_g9.npz: the reference's AVX process_optimized_cu8_cf32 (oracle/_ref/libref_fast.so) over a LONG
+    stream -- 400 server-default blocks, where its never-renormalised phasor has drifted by 1.5e-3 in amplitude -- sampled at
+    a few blocks.  Pins XL_MODE_OPTIMIZED_X86 / xlating_set_optimized_x86 outright (<= 1e-5, no scale factor)."""
+    sc = scenarios.BY_NAME["g9_default"]
+    taps = scenarios.make_taps(sc, lpf=lambda *a: RefLib.lpf(*a)[1])
+    fast = RefLib(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"], flavour="fast", variant="optimized")
+    arrays = {"taps": taps}
+    for k in range(scenarios.X86_LONG_BLOCKS):
+        y = fast.process(sc["fmt"], fast_block(sc, k % 16), "cf32")
+        if k in scenarios.X86_LONG_SAMPLED:
+            arrays[f"n{k}"] = np.int64(len(y))
+            if k == scenarios.X86_LONG_BLOCKS - 1:
+                arrays[f"y{k}"] = y
+            else:
+                arrays[f"head{k}"] = y[:scenarios.X86_HEAD]
+                arrays[f"tail{k}"] = y[-scenarios.X86_TAIL:]
+    fast.close()
+    p = os.path.join(HERE, "x86_long_g9.npz")
+    np.savez_compressed(p, **arrays)
+    print(f"x86_long_g9 -> {os.path.getsize(p)/1024:.1f} KiB")
 
 
 if __name__ == "__main__":

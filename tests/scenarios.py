@@ -91,6 +91,11 @@ def fast_block(sc, k):
     return make_input(sc, dict(gen="xs", a=SEED + 7000 + 16 * FAST_SHAPES.index(sc["name"]) + k, n=c0["n"]))
 
 
+# the long stream of the x86 build (tests/golden/x86_long_g9.npz): 400 blocks of the g9 shape cycling through the 16 fast-fixture
+# blocks; sampled blocks keep their first X86_HEAD and last X86_TAIL outputs, the last block is kept whole
+X86_LONG_BLOCKS, X86_LONG_SAMPLED, X86_HEAD, X86_TAIL = 400, (0, 9, 49, 99, 199, 299, 399), 128, 64
+
+
 def make_taps(sc, lpf):
     """lpf(gain, fs, cutoff, tw) -> float32 taps (reference, oracle or HIP-side designer: they must agree)."""
     kind = sc["taps"][0]

@@ -157,3 +157,44 @@ def test_create_process_destroy_cycle_is_leak_clean():
     free1, rss1 = torch.cuda.mem_get_info()[0], proc.memory_info().rss
     assert free0 - free1 <= 8 << 20, f"device memory leaked: {free0 - free1} bytes"
     assert rss1 - rss0 <= 48 << 20, f"host memory leaked: {rss1 - rss0} bytes"
+
+
+# ---- latency of the drop-in call as dsp_worker.c:49-86 makes it: one thread, one filter, one synchronous call per block
+LAT_SRC = os.path.join(ROOT, "tests", "c", "dropin_latency.c")
+LAT_EXE = os.path.join(ROOT, "sdr-server_amd", "build", "dropin_latency")
+
+
+def build_latency():
+    os.makedirs(os.path.dirname(LAT_EXE), exist_ok=True)
+    libdir = os.path.dirname(xl.library_path())
+    cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), LAT_SRC, "-o", LAT_EXE,
+           "-L", libdir, "-lxlating_hip", f"-Wl,-rpath,{libdir}", "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return LAT_EXE
+
+
+def test_latency_harness_compiles():
+    build_latency()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["native", "optimized"])
+def test_ten_thousand_consecutive_calls_stay_under_a_millisecond(variant):
+    """Round 2 reported "about one call in a thousand takes 1-35 ms" for the drop-in filter.  Root cause (round 3,
+    tools/dropin_python_stall.py): the MEASURING process -- CPython's cyclic garbage collector stopping the interpreter in
+    the middle of the timed wrapper call (37 ms once in 10 000 with gc enabled, never with gc disabled, never around the bare
+    ctypes call).  From C, the way dsp_worker.c calls the filter, 10 000 consecutive 262144-byte calls show no call over
+    0.2 ms.  This test keeps it that way: max < 1 ms (one retry: the box is shared with other jobs' host threads)."""
+    import json
+
+    exe = build_latency()
+    last = None
+    for attempt in range(2):
+        r = subprocess.run([exe, variant, "10000"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        last = json.loads(r.stdout.strip().splitlines()[-1])
+        if last["calls_over_1ms"] == 0:
+            break
+    assert last["calls_over_1ms"] == 0 and last["max_us"] < 1000.0, last
+    assert last["median_us"] < 120.0, last

@@ -324,3 +324,62 @@ def test_optimized_vs_reference_avx_build_fixtures(name, path):
     if path == "batch_polyphase":
         assert "polyphase: cls0" in eng.describe(), eng.describe()
     eng.close()
+
+
+# ---- the x86 build's semantics as a selectable mode: never renormalise (xlating.c:338-339), pinned OUTRIGHT to the reference's
+# AVX build: all ten blocks of the three fast_*.npz shapes and the sampled blocks of a 400-block stream (x86_long_g9.npz)
+@pytest.mark.parametrize("flavour", ["fma", "plain"])
+@pytest.mark.parametrize("path", ["dropin", "batch_direct", "batch_polyphase"])
+def test_optimized_x86_mode_vs_reference_avx_build_long_stream(path, flavour):
+    from test_oracle import check_x86_fixtures
+
+    mode = "optimized_x86_fma" if flavour == "fma" else "optimized_x86"
+
+    def make(sc, taps):
+        if path == "dropin":
+            f = xl.XlatingFilter(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"])
+            f.set_optimized_x86(2 if flavour == "fma" else 1)
+            return (lambda x: f.process("optimized", sc["fmt"], "cf32", x)), f.close
+        eng = xl.BatchEngine(sc["fs"], sc["fmt"], sc["max_input"])
+        eng.set_option("polyphase", 0 if path == "batch_direct" else 1)
+        cid = [eng.add_client(sc["D"], taps, sc["fc"]) for _ in range(3)][1]
+
+        def process(x):
+            eng.process_host(x, mode)
+            eng.fetch()
+            return eng.output(cid)
+
+        return process, eng.close
+
+    assert check_x86_fixtures(make, flavour) <= 1e-5
+
+
+@pytest.mark.parametrize("flavour", ["plain", "fma"])
+def test_optimized_x86_mode_groups_of_blocks(flavour):
+    """XL_MODE_OPTIMIZED_X86 / _X86_FMA in calls of four blocks (polyphase launches + the side-stream chain kernel, which must not
+    renormalise at the block ends inside a call either), a class of 160 clients; sampled clients vs the oracle with the
+    renormalisation switched off, over 24 blocks; then a renormalising call in between keeps working (shared phase)."""
+    from pyoracle import Oracle
+    import siggen
+
+    code, t48 = xl.create_low_pass_filter(1.0, 2016000, 24000, 9600)
+    n, G = 100002, 4
+    eng = xl.BatchEngine(2016000, "cu8", n, group_blocks=G)
+    fcs = [-900000 + 11000 * c for c in range(160)]
+    ids = [eng.add_client(42, t48, fc) for fc in fcs]
+    sample = [0, 63, 64, 159]
+    ors = {c: Oracle(42, t48, fcs[c], 2016000, n, renorm=False, fma_step=flavour == "fma") for c in sample}
+    for k in range(6):
+        x = siggen.xs_u8(9500 + k, G * n)
+        eng.process_host_group(x, G, "optimized_x86_fma" if flavour == "fma" else "optimized_x86")
+        eng.fetch()
+        for c, o in ors.items():
+            want = np.concatenate([o.process("cu8", bl) for bl in np.split(x, G)])
+            got = eng.output(ids[c])
+            assert len(got) == len(want) and rel_err(got, want) <= REL_TOL, (k, c, rel_err(got, want))
+    assert "polyphase: cls0 D42 T505 cols160" in eng.describe(), eng.describe()
+    # the phase drifted away from 1 in amplitude by now and both engines agree on it
+    for c, o in ors.items():
+        got, want = eng.phase(ids[c]), o.phase
+        assert tuple(np.float32(v).tobytes() for v in got) == tuple(np.float32(v).tobytes() for v in want), c
+    eng.close()

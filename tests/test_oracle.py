@@ -220,6 +220,102 @@ def test_oracle_vs_the_reference_avx_build(name):
         assert res[1][0] > 1e-5 and abs(res[9][2] - 1.0) > 1e-4, res
 
 
+def _x86_block_error(y, fx, k, head, tail):
+    if f"y{k}" in fx:
+        pairs = [(y, fx[f"y{k}"])]
+    else:
+        pairs = [(y[:head], fx[f"head{k}"]), (y[-tail:], fx[f"tail{k}"])]
+    scale = max(np.abs(b).max() for _, b in pairs)
+    return max(float(np.abs(a.astype(np.complex128) - b).max() / scale) for a, b in pairs)
+
+
+def check_x86_fixtures(make_process, flavour, tol=1e-5):
+    """The x86 AVX build's process_optimized_* (phase never renormalised, xlating.c:338-339) pinned OUTRIGHT -- max|d| /
+    max|y| <= tol per block, no scale factor -- to outputs of the UNMODIFIED reference:
+      flavour "fma":   the build with FMA enabled (oracle/_ref/libref_fast.so: -O3 -ffast-math -mavx2 -mfma): all ten blocks of
+                       the three fast_*.npz shapes and the sampled blocks of the 400-block stream x86_long_g9.npz
+      flavour "plain": the build without FMA (libref_avx.so: the reference's Release flags + -mavx): all ten blocks of
+                       avx_g11_t101.npz -- the shape on which the two builds' phase steps part ways within a few blocks.
+    make_process(sc, taps) -> (process(x) -> complex64[K], close())."""
+    worst = 0.0
+    files = [(n, f"fast_{n}.npz") for n in scenarios.FAST_SHAPES] if flavour == "fma" else [("g11_t101", "avx_g11_t101.npz")]
+    for name, fname in files:
+        sc = scenarios.BY_NAME[name]
+        fx = np.load(os.path.join(GOLDEN, fname))
+        process, close = make_process(sc, fx["taps"])
+        for k in range(scenarios.FAST_BLOCKS):
+            y = process(scenarios.fast_block(sc, k))
+            assert len(y) == int(fx[f"n{k}"]), (name, k)
+            err = _x86_block_error(y, fx, k, scenarios.FAST_HEAD, scenarios.FAST_TAIL)
+            assert err <= tol, (fname, k, err)
+            worst = max(worst, err)
+        close()
+    if flavour != "fma":
+        return worst
+    sc = scenarios.BY_NAME["g9_default"]
+    fx = np.load(os.path.join(GOLDEN, "x86_long_g9.npz"))
+    process, close = make_process(sc, fx["taps"])
+    for k in range(scenarios.X86_LONG_BLOCKS):
+        y = process(scenarios.fast_block(sc, k % 16))
+        if k not in scenarios.X86_LONG_SAMPLED:
+            continue
+        assert len(y) == int(fx[f"n{k}"]), k
+        err = _x86_block_error(y, fx, k, scenarios.X86_HEAD, scenarios.X86_TAIL)
+        assert err <= tol, ("x86_long", k, err)
+        worst = max(worst, err)
+    close()
+    return worst
+
+
+@pytest.mark.parametrize("flavour", ["fma", "plain"])
+def test_oracle_without_renormalisation_is_the_x86_build(flavour):
+    """orc_xlating_set_renorm(f, 0) (+ set_fma_step for the FMA build) == the reference's AVX process_optimized_* over short
+    AND long streams, outright -- and the WRONG step does not pass (the two builds really differ)."""
+
+    def make(fma):
+        def mk(sc, taps):
+            o = Oracle(sc["D"], taps, sc["fc"], sc["fs"], sc["max_input"], renorm=False, fma_step=fma)
+            return (lambda x: o.process(sc["fmt"], x)), o.close
+        return mk
+
+    assert check_x86_fixtures(make(flavour == "fma"), flavour) <= 2e-6
+    with pytest.raises(AssertionError):
+        check_x86_fixtures(make(flavour != "fma"), flavour)
+
+
+def test_renormalising_semantics_leave_the_x86_stream():
+    """WITH the per-call renormalisation the same stream is 1.5e-3 away from the x86 build's by block 399 (why the mode exists)."""
+    sc = scenarios.BY_NAME["g9_default"]
+    fx = np.load(os.path.join(GOLDEN, "x86_long_g9.npz"))
+    o = Oracle(sc["D"], fx["taps"], sc["fc"], sc["fs"], sc["max_input"])
+    for k in range(scenarios.X86_LONG_BLOCKS):
+        y = o.process(sc["fmt"], scenarios.fast_block(sc, k % 16))
+    o.close()
+    assert float(np.abs(y - fx["y399"]).max() / np.abs(fx["y399"]).max()) > 1e-3
+
+
+@pytest.mark.skipif(not (RefLib.available("fast") and RefLib.available("avx")), reason="oracle/_ref not built")
+def test_phase_step_of_both_reference_builds_bit_for_bit():
+    """How the two steps were established.  A one-tap filter at decimation 1 fed a constant 0.5 + 0j returns 0.5 * phase[k]
+    exactly, so the unmodified reference hands out its phase sequence: the build without FMA follows the plain product, the
+    build with FMA follows re = fma(pr, ir, -(pi * ii)), im = fma(pr, ii, pi * ir) -- 4000 steps, bit for bit."""
+    taps = np.array([1.0], np.float32)
+    fs, fc, n = 2016000, -500000, 4000
+    x = np.zeros(2 * n, np.int16)
+    x[0::2] = 16384
+    for flav, fma in (("avx", False), ("fast", True)):
+        r = RefLib(1, taps, fc, fs, 4 * n, flavour=flav, variant="optimized")
+        want = r.process("cs16", x, "cf32")
+        r.close()
+        o = Oracle(1, taps, fc, fs, 4 * n, renorm=False, fma_step=fma)
+        got = o.process("cs16", x)
+        o.close()
+        assert bits_equal(got, want), flav
+        o = Oracle(1, taps, fc, fs, 4 * n, renorm=False, fma_step=not fma)
+        assert not bits_equal(o.process("cs16", x), want), flav
+        o.close()
+
+
 def test_reference_builds_diverge_beyond_tolerance_later():
     import json
 
