@@ -137,11 +137,12 @@ hipError_t xl_launch_move_down(void *buf, uint32_t from, uint32_t count, uint32_
 // new_hist[j] = concat(hist[0..h), block[0..n))[n + j], j < h   (raw samples, `bps` bytes each)
 hipError_t xl_launch_update_history(const void *hist, const void *block, uint32_t h, uint32_t n, uint32_t bps,
                                     void *new_hist, hipStream_t s);
-// Q15 family (xlating.c:92-140): one filter
-hipError_t xl_launch_nco_table_q15(int16_t incr_re, int16_t incr_im, short2 *phase_state, short2 *phtab, uint32_t K,
-                                   hipStream_t s);
-hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T, uint32_t D, uint32_t K,
-                             const short2 *phtab, short2 *out, hipStream_t s);
+// Q15 family (xlating.c:92-140): one filter.  The phase table holds every XL_PH_STRIDE-th phase (the FIR kernel steps
+// the rest); state_in -> state_out: the running phase before / after the call (may alias)
+hipError_t xl_launch_nco_table_q15(int16_t incr_re, int16_t incr_im, const short2 *state_in, short2 *state_out, short2 *phtab,
+                                   uint32_t K, hipStream_t s);
+hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T, uint32_t D, uint32_t K, int16_t incr_re,
+                             int16_t incr_im, const short2 *phtab, short2 *out, hipStream_t s);
 
 // Q15 family on the batched boundary (xlating.c:92-140 per client): phase table (every XL_PH_STRIDE-th phase of the
 // truncating int16 recurrence, never renormalised) and the FIR launch -- exact integer arithmetic carried in float64 FMAs.

@@ -52,7 +52,12 @@ struct xlating_t {
   bool spec_valid = false;        // d_phtab_next / d_phase_next hold a call of spec_K outputs
   bool lookahead = true;          // XL_EXP_NOLOOKAHEAD disables (tuning)
   size_t spec_K = 0;
-  short2 *d_qphtab = nullptr;
+  short2 *d_qphtab = nullptr;       // Q15 phase table of the current call (every XL_PH_STRIDE-th phase)
+  short2 *d_qphtab_next = nullptr;  // look-ahead (as for the float family): the NEXT Q15 call's table and the phase after it
+  short2 *d_qphase_next = nullptr;
+  hipEvent_t ev_qnco = nullptr;
+  bool qspec_valid = false;
+  size_t qspec_K = 0;
   float2 *d_phase = nullptr;
   short2 *d_qphase = nullptr;
   float2 *d_taps = nullptr;
@@ -71,7 +76,7 @@ static void xl_filter_free(xlating *f) {
   if (f->device >= 0) (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
   if (f->stream_nco) (void)hipStreamSynchronize(f->stream_nco);
-  void *dev[] = {f->d_phtab_next, f->d_phase_next,
+  void *dev[] = {f->d_phtab_next, f->d_phase_next, f->d_qphtab_next, f->d_qphase_next,
                  f->d_raw,   f->d_work_f, f->d_work_q, f->d_out_f, f->d_out_q, f->d_phtab, f->d_qphtab,
                  f->d_phase, f->d_qphase, f->d_taps,   f->d_qtaps, f->d_group, f->d_nco};
   for (void *p : dev)
@@ -80,6 +85,7 @@ static void xl_filter_free(xlating *f) {
   for (void *p : host)
     if (p) (void)hipHostFree(p);
   if (f->ev_nco) (void)hipEventDestroy(f->ev_nco);
+  if (f->ev_qnco) (void)hipEventDestroy(f->ev_qnco);
   if (f->stream_nco) (void)hipStreamDestroy(f->stream_nco);
   if (f->stream) (void)hipStreamDestroy(f->stream);
   if (f->original_taps) free(f->original_taps);  // xlating.c:600-602
@@ -149,6 +155,7 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XL_TRY(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
   XL_TRY(hipStreamCreateWithFlags(&f->stream_nco, hipStreamNonBlocking));
   XL_TRY(hipEventCreateWithFlags(&f->ev_nco, hipEventDisableTiming));
+  XL_TRY(hipEventCreateWithFlags(&f->ev_qnco, hipEventDisableTiming));
   f->lookahead = getenv("XL_EXP_NOLOOKAHEAD") == nullptr;
   f->x86 = getenv("XLATING_OPTIMIZED_X86") != nullptr ? atoi(getenv("XLATING_OPTIMIZED_X86")) : 0;
   if (f->x86 < 0 || f->x86 > 2) f->x86 = 0;
@@ -159,7 +166,9 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XL_TRY(hipMalloc((void **)&f->d_out_f, f->out_cap * sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_out_q, f->out_cap * sizeof(short2)));
   XL_TRY(hipMalloc((void **)&f->d_phtab, (f->out_cap / XL_PH_STRIDE + 8) * sizeof(float2)));  // every XL_PH_STRIDE-th phase
-  XL_TRY(hipMalloc((void **)&f->d_qphtab, f->out_cap * sizeof(short2)));
+  XL_TRY(hipMalloc((void **)&f->d_qphtab, (f->out_cap / XL_PH_STRIDE + 8) * sizeof(short2)));
+  XL_TRY(hipMalloc((void **)&f->d_qphtab_next, (f->out_cap / XL_PH_STRIDE + 8) * sizeof(short2)));
+  XL_TRY(hipMalloc((void **)&f->d_qphase_next, sizeof(short2)));
   XL_TRY(hipMalloc((void **)&f->d_phase, sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_phtab_next, (f->out_cap / XL_PH_STRIDE + 8) * sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_phase_next, sizeof(float2)));
@@ -382,8 +391,18 @@ static void xl_run_q15(xlating *f, const void *input, size_t input_len, int fmt,
                                  f->stream));
   }
   if (K > 0) {
-    XL_TRY(xl_launch_nco_table_q15(f->qinc[0], f->qinc[1], f->d_qphase, f->d_qphtab, (uint32_t)K, f->stream));
-    XL_TRY(xl_launch_fir_q15(f->d_work_q, f->d_qtaps, (uint32_t)f->T, f->D, (uint32_t)K, f->d_qphtab,
+    // The Q15 phases of this call (truncating int16 recurrence, xlating.c:126-129: data independent): tabulated ahead on
+    // stream_nco after the previous Q15 call if that call guessed this one's output count, else now (~30 us of pure latency)
+    if (f->qspec_valid && f->qspec_K == K) {
+      XL_TRY(hipStreamWaitEvent(f->stream, f->ev_qnco, 0));
+      std::swap(f->d_qphtab, f->d_qphtab_next);
+      std::swap(f->d_qphase, f->d_qphase_next);  // (d_qphase now holds the phase AFTER this call)
+    } else {
+      if (f->qspec_valid) XL_TRY(hipStreamWaitEvent(f->stream, f->ev_qnco, 0));  // (its buffers are reused below)
+      XL_TRY(xl_launch_nco_table_q15(f->qinc[0], f->qinc[1], f->d_qphase, f->d_qphase, f->d_qphtab, (uint32_t)K, f->stream));
+    }
+    f->qspec_valid = false;
+    XL_TRY(xl_launch_fir_q15(f->d_work_q, f->d_qtaps, (uint32_t)f->T, f->D, (uint32_t)K, f->qinc[0], f->qinc[1], f->d_qphtab,
                              f->zero_copy ? f->h_out_q : f->d_out_q, f->stream));
     if (!f->zero_copy) XL_TRY(hipMemcpyAsync(f->h_out_q, f->d_out_q, K * sizeof(short2), hipMemcpyDeviceToHost, f->stream));
   }
@@ -393,6 +412,19 @@ static void xl_run_q15(xlating *f, const void *input, size_t input_len, int fmt,
     f->hist = keep;
   }
   XL_TRY(hipStreamSynchronize(f->stream));
+  if (K > 0 && f->lookahead) {
+    // look-ahead: the next Q15 call's table if it brings the same number of samples (the shared history counter decides its
+    // output count: a cf32-family call in between changes it, and the guess is then simply redone)
+    size_t Wn, Kn, posn;
+    xl_counts(f, n, &Wn, &Kn, &posn);
+    if (Kn > 0) {
+      XL_TRY(xl_launch_nco_table_q15(f->qinc[0], f->qinc[1], f->d_qphase, f->d_qphase_next, f->d_qphtab_next, (uint32_t)Kn,
+                                     f->stream_nco));
+      XL_TRY(hipEventRecord(f->ev_qnco, f->stream_nco));
+      f->qspec_valid = true;
+      f->qspec_K = Kn;
+    }
+  }
   *output_len = K;
   return;
 fail:

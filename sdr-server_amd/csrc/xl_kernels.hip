@@ -753,59 +753,92 @@ hipError_t xl_launch_update_history(const void *hist, const void *block, uint32_
 XL_DEV int32_t xl_sat16(int32_t v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }  // xlating.c:85-90
 
 // xlating.c:126-129: truncating Q15 phase recurrence, never renormalised.  One thread (one filter).
-__global__ void xl_nco_table_q15_kernel(int32_t ir, int32_t ii, short2 *__restrict__ state,
-                                        short2 *__restrict__ tab, uint32_t K) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int32_t pr = state->x, pi = state->y;
-  for (uint32_t m = 0; m < K; ++m) {
-    tab[m] = make_short2((short)pr, (short)pi);
-    const int32_t tr = pr * ir - pi * ii;
-    const int32_t ti = pr * ii + pi * ir;
-    pr = xl_sat16(tr >> 15);
-    pi = xl_sat16(ti >> 15);
-  }
-  *state = make_short2((short)pr, (short)pi);
+// One step of the Q15 phase recurrence (xlating.c:126-129): (pr + j pi) * (ir + j ii) >> 15, truncating, saturated --
+// two packed dot products (v_dot2_i32_i16: p . (ir, -ii) and p . (ii, ir); |sum| <= 2 * 32767^2 < 2^31) instead of four
+// multiplies and two adds.  p, a, b: int16 pairs in one register (low = real part).
+XL_DEV uint32_t xl_q15_step(const uint32_t p, const uint32_t a, const uint32_t b) {
+  typedef short s2 __attribute__((ext_vector_type(2)));
+  const int32_t tr = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, p), __builtin_bit_cast(s2, a), 0, false);
+  const int32_t ti = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, p), __builtin_bit_cast(s2, b), 0, false);
+  const int32_t nr = xl_sat16(tr >> 15), ni = xl_sat16(ti >> 15);
+  return ((uint32_t)nr & 0xFFFFu) | ((uint32_t)ni << 16);
 }
 
-hipError_t xl_launch_nco_table_q15(int16_t incr_re, int16_t incr_im, short2 *phase_state, short2 *phtab, uint32_t K,
-                                   hipStream_t s) {
+// Single filter: every XL_PH_STRIDE-th phase of a call's K outputs into tab, the phase after the call into state_out
+// (state_in / state_out may alias).  A dependent chain on one lane (~20 cycles per step); a store per step -- the first
+// version -- blocked the lane ~60 ns each and made this kernel 190 of the Q15 call's 275 us.
+__global__ void xl_nco_table_q15_kernel(int32_t ir, int32_t ii, const short2 *state_in, short2 *state_out,
+                                        uint32_t *__restrict__ tab, uint32_t K) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint32_t a = ((uint32_t)ir & 0xFFFFu) | ((uint32_t)(-ii) << 16), b = ((uint32_t)ii & 0xFFFFu) | ((uint32_t)ir << 16);
+  uint32_t p = ((uint32_t)(uint16_t)state_in->x) | ((uint32_t)(uint16_t)state_in->y << 16);
+  uint32_t m = 0;
+  for (; m + XL_PH_STRIDE <= K; m += XL_PH_STRIDE) {
+    tab[m >> XL_PH_SHIFT] = p;
+#pragma unroll
+    for (uint32_t i = 0; i < XL_PH_STRIDE; ++i) p = xl_q15_step(p, a, b);
+  }
+  if (m < K) tab[m >> XL_PH_SHIFT] = p;
+  for (; m < K; ++m) p = xl_q15_step(p, a, b);
+  *state_out = make_short2((short)(p & 0xFFFFu), (short)(p >> 16));
+}
+
+hipError_t xl_launch_nco_table_q15(int16_t incr_re, int16_t incr_im, const short2 *state_in, short2 *state_out, short2 *phtab,
+                                   uint32_t K, hipStream_t s) {
   if (K == 0) return hipSuccess;
-  hipLaunchKernelGGL(xl_nco_table_q15_kernel, dim3(1), dim3(64), 0, s, (int32_t)incr_re, (int32_t)incr_im, phase_state,
-                     phtab, K);
+  hipLaunchKernelGGL(xl_nco_table_q15_kernel, dim3(1), dim3(64), 0, s, (int32_t)incr_re, (int32_t)incr_im, state_in, state_out,
+                     reinterpret_cast<uint32_t *>(phtab), K);
   return hipGetLastError();
 }
 
 // xlating.c:100-124: int16 x int16 products accumulated in int64, >>15, saturate, rotate by the Q15 phase.
-// Lane = output; taps wave-uniform (scalar loads of packed int16 pairs); window read straight from L2.
-__global__ __launch_bounds__(256) void xl_fir_q15_kernel(const int32_t *__restrict__ work, const int32_t *taps,
-                                                         uint32_t T, uint32_t D, uint32_t K,
-                                                         const short2 *__restrict__ phtab, short2 *__restrict__ out) {
+// Lane = output; taps wave-uniform (scalar loads of packed int16 pairs); window read straight from L2, two samples per
+// load.  Per sample two packed dot products ((xr, xi) . (hr, -hi) and (xr, xi) . (hi, hr): each < 2^31) added into
+// 64-bit sums.  The lane's phase: the tabulated one at m rounded down to the stride, stepped m mod 16 times.
+__global__ __launch_bounds__(256) void xl_fir_q15_kernel(const uint32_t *__restrict__ work, const uint32_t *taps,
+                                                         uint32_t T, uint32_t D, uint32_t K, int32_t ir, int32_t ii,
+                                                         const uint32_t *__restrict__ phtab, short2 *__restrict__ out) {
+  typedef short s2 __attribute__((ext_vector_type(2)));
   const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= K) return;
-  const int32_t *__restrict__ w = work + (size_t)m * D;
+  const uint32_t *__restrict__ w = work + (size_t)m * D;
   const cu32_p tq = (cu32_p)(uintptr_t)taps;
   long long sr = 0, si = 0;
-  for (uint32_t i = 0; i < T; ++i) {
-    const int32_t xv = w[i];
-    const int32_t hv = (int32_t)tq[i];
-    const int32_t xr = (int16_t)(xv & 0xFFFF), xi = xv >> 16;
-    const int32_t hr = (int16_t)(hv & 0xFFFF), hi = hv >> 16;
+  auto mac = [&](const uint32_t xv, const uint32_t hv) {
+    // (hr, -hi): -hi of hi = -32768 would not fit an int16 -- the taps are (int16)(x * 32768) of |x| < 1 values scaled by a
+    // window, the reference's designer never produces -32768; guarded all the same by doing that product in 32 bits)
+    const int32_t hr = (int16_t)(hv & 0xFFFFu), hi = (int32_t)hv >> 16;
+    const int32_t xr = (int16_t)(xv & 0xFFFFu), xi = (int32_t)xv >> 16;
+    const uint32_t swp = (hv >> 16) | (hv << 16);  // (hi, hr)
+    si += (long long)__builtin_amdgcn_sdot2(__builtin_bit_cast(s2, xv), __builtin_bit_cast(s2, swp), 0, false);
     sr += (long long)(xr * hr - xi * hi);
-    si += (long long)(xr * hi + xi * hr);
+  };
+  uint32_t i = 0;
+  if ((((uintptr_t)w) & 7u) == 0u) {
+    for (; i + 2u <= T; i += 2u) {
+      const uint2 xv = *reinterpret_cast<const uint2 *>(w + i);
+      mac(xv.x, tq[i]);
+      mac(xv.y, tq[i + 1u]);
+    }
   }
+  for (; i < T; ++i) mac(w[i], tq[i]);
   const int32_t ar = xl_sat16((int32_t)(sr >> 15));
   const int32_t ai = xl_sat16((int32_t)(si >> 15));
-  const short2 p = phtab[m];
-  const int32_t tr = ar * p.x - ai * p.y;
-  const int32_t ti = ar * p.y + ai * p.x;
+  const uint32_t a = ((uint32_t)ir & 0xFFFFu) | ((uint32_t)(-ii) << 16), b = ((uint32_t)ii & 0xFFFFu) | ((uint32_t)ir << 16);
+  uint32_t p = phtab[m >> XL_PH_SHIFT];
+  for (uint32_t k = m & (XL_PH_STRIDE - 1u); k > 0u; --k) p = xl_q15_step(p, a, b);
+  const int32_t pr = (int16_t)(p & 0xFFFFu), pi = (int32_t)p >> 16;
+  const int32_t tr = ar * pr - ai * pi;
+  const int32_t ti = ar * pi + ai * pr;
   out[m] = make_short2((short)xl_sat16(tr >> 15), (short)xl_sat16(ti >> 15));
 }
 
-hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T, uint32_t D, uint32_t K,
-                             const short2 *phtab, short2 *out, hipStream_t s) {
+hipError_t xl_launch_fir_q15(const short2 *work, const short2 *taps, uint32_t T, uint32_t D, uint32_t K, int16_t incr_re,
+                             int16_t incr_im, const short2 *phtab, short2 *out, hipStream_t s) {
   if (K == 0) return hipSuccess;
-  hipLaunchKernelGGL(xl_fir_q15_kernel, dim3((K + 255) / 256), dim3(256), 0, s, reinterpret_cast<const int32_t *>(work),
-                     reinterpret_cast<const int32_t *>(taps), T, D, K, phtab, out);
+  hipLaunchKernelGGL(xl_fir_q15_kernel, dim3((K + 63) / 64), dim3(64), 0, s, reinterpret_cast<const uint32_t *>(work),
+                     reinterpret_cast<const uint32_t *>(taps), T, D, K, (int32_t)incr_re, (int32_t)incr_im,
+                     reinterpret_cast<const uint32_t *>(phtab), out);
   return hipGetLastError();
 }
 
