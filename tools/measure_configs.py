@@ -33,6 +33,17 @@ import subprocess  # noqa: E402
 
 _r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "measure_dropin.py")], capture_output=True, text=True, timeout=300)
 out["config1_single_client_dropin_process_cu8_cf32"] = json.loads(_r.stdout.strip().splitlines()[-1]) if _r.returncode == 0 else {"error": _r.stderr[-300:]}
+# ... and from C, the way dsp_worker.c:49-86 calls the filter: 10 000 consecutive calls, no Python in the process
+# (tests/c/dropin_latency.c; the 1-35 ms outliers of round 2's numbers were CPython's garbage collector in the measuring
+# process: tools/dropin_python_stall.py)
+_lat = os.path.join(ROOT, "sdr-server_amd", "build", "dropin_latency")
+if os.path.exists(_lat):
+    out["config1_dropin_latency_from_C_10000_calls"] = {}
+    for _v in ("native", "optimized"):
+        _r = subprocess.run([_lat, _v, "10000"], capture_output=True, text=True, timeout=300)
+        if _r.returncode == 0:
+            _j = json.loads(_r.stdout.strip().splitlines()[-1])
+            out["config1_dropin_latency_from_C_10000_calls"][_v] = {k: _j[k] for k in ("mean_us", "median_us", "p99_us", "p999_us", "max_us", "calls_over_1ms")}
 
 
 GROUP = 8  # blocks per engine call on the device-resident path (bench.py's super-block)
