@@ -74,8 +74,8 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                           always: the NCO phase recurrence of the following calls runs as a kernel of its own on a side
  *                           stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE)
  *   "nco_calls_per_launch"  1..4 (default 4): calls of the same shape one such kernel tabulates ahead
- *   "inverse_kernel"        128-point polyphase classes: 0 (default) = inverse launch with the transform staged in LDS,
- *                           1 = transform in registers (a lane pair per client column, one LDS pass for the stores)
+ *   "inverse_kernel"        128-point polyphase classes: the inverse launch's transform -- 0 = staged in LDS, 1 = in the
+ *                           registers of a lane pair per client column, 2 = of a lane quad (one LDS pass for the stores)
  * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call. */
 int xlating_batch_set_option(xlating_batch *batch, const char *name, long value);
 

@@ -81,8 +81,8 @@ struct XlFftPlainOps {
 };
 
 // one radix-4 butterfly of an INVERSE transform on slots i0 .. i3, followed by the twiddles e^{+2 pi j tw q / 128}, q = 1..3
-template <class V, class Ops, int I0, int I1, int I2, int I3, int TW>
-XL_FFT_FN void xl_fft_bfly4(V (&u)[64]) {
+template <class V, class Ops, int I0, int I1, int I2, int I3, int TW, int NN>
+XL_FFT_FN void xl_fft_bfly4(V (&u)[NN]) {
   const V a0 = u[I0], a1 = u[I1], a2 = u[I2], a3 = u[I3];
   const V t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
   const V b0 = t0 + t2, b1 = Ops::add_j(t1, d), b2 = t0 - t2, b3 = Ops::sub_j(t1, d);
@@ -103,7 +103,7 @@ template <class V, class Ops, int L, int G, int I>
 struct XlFftStage {
   XL_FFT_FN void run(V (&u)[64]) {
     constexpr int base = G * 4 * L + I;
-    xl_fft_bfly4<V, Ops, base, base + L, base + 2 * L, base + 3 * L, (L > 1 ? I * (32 / L) : 0)>(u);
+    xl_fft_bfly4<V, Ops, base, base + L, base + 2 * L, base + 3 * L, (L > 1 ? I * (32 / L) : 0), 64>(u);
     if constexpr ((G * L + I) % 2 == 1) XL_FFT_FENCE();  // two butterflies (8 slots, 14 temporaries) per scheduling window
     if constexpr (I + 1 < L) XlFftStage<V, Ops, L, G, I + 1>::run(u);
     else if constexpr ((G + 1) * 4 * L < 64) XlFftStage<V, Ops, L, G + 1, 0>::run(u);
@@ -133,4 +133,59 @@ XL_FFT_FN void xl_fft128_combine(V (&u)[64], const float sgn, const Ex &ex) {
   if constexpr (K + 1 < 64) xl_fft128_combine<V, Ops, Ex, K + 1>(u, sgn, ex);
 }
 
+// =====================================================================================================================
+// The same transform over a QUAD of lanes (32 points each): half the registers per lane, twice the waves per SIMD.
+//   lane q (0..3) holds   u[i] = Y[4 i + q], i < 32                (bins = q mod 4)
+//   F_q = the 32-point inverse transform of the lane's own values: radix-4 (span 8), radix-4 (span 2), radix-2, in place;
+//         output k ends up in slot xl_fft32_slot(k) = 8 (k & 3) + 2 ((k >> 2) & 3) + (k >> 4)
+//   x[k + 32 r] = sum_q j^{q r} W^{q k} F_q[k],  W = e^{+2 pi j / 128}  -> z = F_q[k] * W^{q k} (the lane's twiddle, handed in by
+//         the caller: device = a 4 x 32 table in LDS), then a radix-4 butterfly across the quad as two exchange stages:
+//           A (partner q ^ 2):  t = partner + sA * z                   sA = -1 in lanes 2, 3
+//           lane 3:             t = j t
+//           B (partner q ^ 1):  r = partner + sB * t                   sB = -1 in lanes 1, 3
+//         lane q ends up with x[k + XL_QUAD_NOFF(q)]: 0, 64, 32, 96 for q = 0, 1, 2, 3.
+constexpr int xl_fft32_slot(int k) { return 8 * (k & 3) + 2 * ((k >> 2) & 3) + (k >> 4); }
+#define XL_QUAD_NOFF(q) (32 * (2 * ((q) & 1) + ((q) >> 1)))
+
+template <class V, class Ops, int L, int G, int I>
+struct XlFft32Stage {  // radix-4 stage with span L (8 or 2) of a 32-point transform: twiddle W_{4L}^{i q} = W_128^{i q 32 / L}
+  XL_FFT_FN void run(V (&u)[32]) {
+    constexpr int base = G * 4 * L + I;
+    xl_fft_bfly4<V, Ops, base, base + L, base + 2 * L, base + 3 * L, I * (32 / L), 32>(u);
+    if constexpr ((G * L + I) % 2 == 1) XL_FFT_FENCE();
+    if constexpr (I + 1 < L) XlFft32Stage<V, Ops, L, G, I + 1>::run(u);
+    else if constexpr ((G + 1) * 4 * L < 32) XlFft32Stage<V, Ops, L, G + 1, 0>::run(u);
+  }
+};
+
+template <class V, int J = 0>
+XL_FFT_FN void xl_fft32_radix2(V (&u)[32]) {
+  const V a = u[2 * J], b = u[2 * J + 1];
+  u[2 * J] = a + b;
+  u[2 * J + 1] = a - b;
+  if constexpr (J + 1 < 16) xl_fft32_radix2<V, J + 1>(u);
+}
+
+template <class V, class Ops>
+XL_FFT_FN void xl_fft32_inverse(V (&u)[32]) {
+  XlFft32Stage<V, Ops, 8, 0, 0>::run(u);
+  XlFft32Stage<V, Ops, 2, 0, 0>::run(u);
+  xl_fft32_radix2(u);
+}
+
+// ex.template lane_twiddle<K>(v)  v * W^{q K} for THIS lane's q      ex.partner2(v) / ex.partner1(v)  the value of lane q ^ 2 / q ^ 1
+// ex.rot_lane3(t)  j t in lane 3, t elsewhere                      sA, sB: the lane's signs
+template <class V, class Ex, int K = 0>
+XL_FFT_FN void xl_fft128_combine_quad(V (&u)[32], const float sA, const float sB, const Ex &ex) {
+  constexpr int slot = xl_fft32_slot(K);
+  V z = u[slot];
+  if constexpr (K != 0) z = ex.template lane_twiddle<K>(u[slot]);
+  const V t = ex.rot_lane3(ex.partner2(z) + z * (V){sA, sA});
+  u[slot] = ex.partner1(t) + t * (V){sB, sB};
+  XL_FFT_PIN(u[slot]);
+  if constexpr (K % 4 == 3) XL_FFT_FENCE();
+  if constexpr (K + 1 < 32) xl_fft128_combine_quad<V, Ex, K + 1>(u, sA, sB, ex);
+}
+
 #endif  // XL_FFT64_H_
+

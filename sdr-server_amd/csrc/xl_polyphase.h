@@ -58,7 +58,7 @@ struct XlpArgs {
   uint32_t nseg_cap;   // segment capacity of the Y image
   uint32_t ncg;        // column groups of XLP_COLS client columns
   uint32_t exp;        // tuning switches (XL_TUNING builds only; 0 otherwise)
-  uint32_t inv_reg;    // M = 128: 1 = the inverse launch with the transform in registers (xlp_inverse_reg_kernel), 0 = in LDS
+  uint32_t inv_reg;    // M = 128: the inverse launch's transform: 0 = staged in LDS, 1 = registers of a lane pair, 2 = of a lane quad
   unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]

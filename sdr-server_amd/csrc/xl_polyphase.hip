@@ -564,14 +564,24 @@ struct XlpFftOps {
     return r;
   }
 };
-XL_DEV float xlp_dpp_pair(const float f) {  // the value of lane ^ 1 (quad_perm [1,0,3,2])
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, false));
+// The value of lane ^ 1 / lane ^ 2 of the own quad: DPP moves, written as inline assembly.  (Through the compiler's
+// __builtin_amdgcn_update_dpp, two moves of the two halves of a float2 written next to each other came out as ONE move
+// whose result was used for both halves -- seen twice with this toolchain, in two different spellings; the assembly leaves
+// nothing to merge.  The s_nop covers the wait states a DPP read needs after a VALU write of its source, which the
+// compiler only inserts for instructions it selected itself.)
+XL_DEV float xlp_dpp_pair(const float f) {  // quad_perm [1,0,3,2]
+  float r;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(f));
+  return r;
+}
+XL_DEV float xlp_dpp_cross(const float f) {  // quad_perm [2,3,0,1]
+  float r;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(f));
+  return r;
 }
 struct XlpPairExchange {
   bool odd;  // hf == 1
   XL_MEM v2f select(const v2f z, const v2f own) const { return (v2f){odd ? z.x : own.x, odd ? z.y : own.y}; }
-  // (built as an initialiser list on purpose: with `v2f r; r.x = dpp(v.x); r.y = dpp(v.y);` this compiler emitted ONE
-  // DPP move per complex value and used it for both components)
   template <int K>
   XL_MEM v2f partner(const v2f v) const {
     return (v2f){xlp_dpp_pair(v.x), xlp_dpp_pair(v.y)};
@@ -715,6 +725,159 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ------------------------------------------------------------------------------------------- inverse, register transform, quad
+// The same idea with FOUR lanes per client column (32 bins each; xl_fft64.h, quad variant): 64 data registers per lane
+// instead of 128, so four waves fit a SIMD (the lane-pair kernel above fits two and is latency-bound for it).
+// A wave = 16 columns x 128 bins = half a Y tile; lane (c, q) reads bins 4 i + q of column c (every load instruction covers
+// four 128-byte row halves), runs the 32-point transform in place, multiplies by its twiddles e^{+2 pi j q k / 128} (a
+// 4 x 32 table in LDS) and exchanges twice inside its quad (DPP) -- lane q ends up with the shared points
+// n = XL_QUAD_NOFF(q) + k, k < 32, of its column: a run of 32 outputs, walked with one phase step each, transposed
+// 16 at a time through a wave-private [64 rows][17] LDS buffer and stored as 128-byte runs.
+// grid = nco_blocks + nseg * ncg * 2 workgroups of 256 threads; workgroup = (segment, column group, half): 64 columns.
+struct XlpQuadExchange {
+  bool lane3;
+  const v2f *tw;  // LDS: the lane's 32 twiddles
+  template <int K>
+  XL_MEM v2f lane_twiddle(const v2f v) const {
+    return xlp_cmul_v(v, tw[K]);
+  }
+  XL_MEM v2f partner2(const v2f v) const { return (v2f){xlp_dpp_cross(v.x), xlp_dpp_cross(v.y)}; }  // lane ^ 2
+  XL_MEM v2f partner1(const v2f v) const { return (v2f){xlp_dpp_pair(v.x), xlp_dpp_pair(v.y)}; }
+  XL_MEM v2f rot_lane3(const v2f t) const { return (v2f){lane3 ? -t.y : t.x, lane3 ? t.x : t.y}; }
+};
+
+template <int T = 0>
+XL_DEV void xlp_rotate_plain32(v2f (&u)[32], v2f &p, const v2f inc, const bool valid0) {
+  constexpr int slot = xl_fft32_slot(T);
+  u[slot] = xlp_cmul_v(u[slot] * (1.0f / 128.0f), p);  // exact scaling by 2^-7, then xlating.c:70 `out = temp * phase`
+  XL_FFT_PIN(u[slot]);
+  const v2f q = xl_nco_next(p, inc);
+  if (T == 0) p = (v2f){valid0 ? q.x : p.x, valid0 ? q.y : p.y};
+  else p = q;
+  if constexpr (T % 4 == 3) XL_FFT_FENCE();
+  if constexpr (T + 1 < 32) xlp_rotate_plain32<T + 1>(u, p, inc, valid0);
+}
+
+template <int CH = 0>
+XL_DEV void xlp_rotate_checked32(v2f (&u)[32], v2f &p, uint32_t &m, uint32_t &nb, const v2f inc, const XlBnd bnd, const bool valid0,
+                                 v2f *__restrict__ pl) {
+#pragma unroll 1
+  for (uint32_t tt = 0; tt < 16u; ++tt) {
+    pl[tt] = p;
+    if (CH == 0 && tt == 0u && !valid0) continue;
+    p = xl_nco_next_any(p, inc, bnd.flags);
+    if (++m == nb) {
+      p = xl_nco_renorm(p);
+      nb = xl_bnd_next(bnd, m);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int tt = 0; tt < 16; ++tt) {
+    const int slot = xl_fft32_slot(CH * 16 + tt);  // (a constant after unrolling)
+    u[slot] = xlp_cmul_v(u[slot] * (1.0f / 128.0f), pl[tt]);
+    XL_FFT_PIN(u[slot]);
+    if (tt % 4 == 3) XL_FFT_FENCE();
+  }
+  __builtin_amdgcn_wave_barrier();
+  if constexpr (CH + 1 < 2) xlp_rotate_checked32<CH + 1>(u, p, m, nb, inc, bnd, valid0, pl);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void xlp_inverse_quad_kernel(const XlpArgs a) {
+  constexpr uint32_t M = 128u, CW = 32u, NSUB = XLP_COLS / CW, PR = 17u, WC = 16u;  // WC: columns per wave
+  __shared__ v2f stage[4][64][PR];        // 34816 bytes: four workgroups per CU
+  __shared__ v2f tw[4][32];               // e^{+2 pi j q k / 128}
+  __shared__ uint32_t cinfo[4][WC][4];    // per column: out row, k of shared point 0 (may be -1), outputs owned, pad
+  if (blockIdx.x < a.nco_blocks) {
+    xlp_nco_role(a);
+    return;
+  }
+  if (blockIdx.x >= a.nco_skip_at && blockIdx.x < a.nco_skip_at + a.nco_skip) return;
+  const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
+  const uint32_t hb = bid & 1u, cg = (bid >> 1) % a.ncg, s = (bid >> 1) / a.ncg;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = threadIdx.x & 63u;
+  const uint32_t sub = 2u * hb + (w >> 1), hw = w & 1u;  // sub-tile of 32 columns, and which 16 of them
+  const uint32_t c = j >> 2, q = j & 3u;
+  // ---- the wave's half tile, straight into registers: u[i] = Y[bin 4 i + q][column 16 hw + c]
+  v2f u[32];
+  {
+    const v2f *__restrict__ tile = reinterpret_cast<const v2f *>(a.Y) + (((size_t)cg * a.nseg_cap + s) * NSUB + sub) * M * CW;
+    const uint32_t lane_off = q * CW + WC * hw + c;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) u[i] = __builtin_nontemporal_load(tile + (size_t)i * 4u * CW + lane_off);
+  }
+  if (threadIdx.x < 128u) {
+    const uint32_t e = ((threadIdx.x >> 5) * (threadIdx.x & 31u)) & 127u;
+    tw[threadIdx.x >> 5][threadIdx.x & 31u] = (v2f){xl_w128_cos((int)e), xl_w128_sin((int)e)};
+  }
+  // ---- the column of this lane quad on the class's shared grid (xl_grid.h)
+  const uint32_t N = a.pos.S * a.pos.G;
+  const uint32_t Ka = N / a.D, Nr = N - Ka * a.D;
+  const XlpCol col = a.cols[cg * XLP_COLS + sub * CW + WC * hw + c];
+  XlBnd bnd;
+  bnd.j0 = xl_merge_j0(a.j0_ref, col.delta, a.D), bnd.D = a.D, bnd.S = a.pos.S, bnd.G = a.pos.G, bnd.flags = a.pos.pad;
+  bnd.K = Ka + (bnd.j0 < Nr ? 1u : 0u);
+  const uint32_t shift = xl_merge_shift(a.j0_ref, col.delta, a.D);
+  const int32_t k0 = (int32_t)(s * a.V) - (int32_t)shift;  // output index of shared point n = 0 of this segment
+  const bool live = col.out_off != 0xFFFFFFFFu;
+  if (q == 0u) {
+    cinfo[w][c][0] = col.out_off;
+    cinfo[w][c][1] = (uint32_t)k0;
+    cinfo[w][c][2] = live ? bnd.K : 0u;
+  }
+  const uint32_t noff = XL_QUAD_NOFF(q);
+  const int32_t kf = k0 + (int32_t)noff;  // the lane's first output, or -- when that is -1 -- the next one
+  const bool valid0 = kf >= 0;
+  const uint32_t mb = valid0 ? (uint32_t)kf : 0u;
+  const bool walk = live && mb < bnd.K;
+  const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
+  v2f p = ph[walk ? (col.out_off >> XL_PH_SHIFT) + (mb >> XL_PH_SHIFT) : 0u];  // (requested before the transform)
+  __syncthreads();  // (the twiddle table)
+  // ---- transform
+  XL_FFT_FENCE();
+  xl_fft32_inverse<v2f, XlpFftOps>(u);
+  {
+    const XlpQuadExchange ex{q == 3u, &tw[q][0]};
+    xl_fft128_combine_quad(u, (q & 2u) ? -1.0f : 1.0f, (q & 1u) ? -1.0f : 1.0f, ex);
+  }
+  // ---- phases: from the table entry at mb rounded down to the stride up to mb, then one step per output
+  const v2f inc = {col.incr.x, col.incr.y};
+  uint32_t m = mb & ~(XL_PH_STRIDE - 1u);
+  uint32_t nb = xl_bnd_next(bnd, m);
+  if (walk) {
+    for (; m < mb; ++m) {
+      p = xl_nco_next_any(p, inc, bnd.flags);
+      if (m + 1u == nb) {
+        p = xl_nco_renorm(p);
+        nb = xl_bnd_next(bnd, m + 1u);
+      }
+    }
+  }
+  const bool crosses = walk && nb <= mb + 32u;
+  if (__builtin_amdgcn_ballot_w64(crosses) != 0ull || (a.pos.pad & XL_POS_FMA_STEP))  // (the plain walk is the plain step)
+    xlp_rotate_checked32(u, p, m, nb, inc, bnd, valid0, &stage[w][0][0] + PR * j);
+  else
+    xlp_rotate_plain32(u, p, inc, valid0);
+  // ---- transpose through LDS, 16 points per lane at a time, and store 128-byte runs of the clients' rows
+  v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
+  const uint32_t rr = j >> 4, rk = j & 15u;  // read-back duty: row 4 it + rr (= column it, quad lane rr), point rk
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) stage[w][j][tt] = u[xl_fft32_slot(ch * 16 + tt)];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n = XL_QUAD_NOFF(rr) + (uint32_t)(ch * 16) + rk;
+#pragma unroll
+    for (int cc = 0; cc < (int)WC; ++cc) {
+      const v2f v = stage[w][4 * cc + rr][rk];
+      const uint32_t off = cinfo[w][cc][0];
+      const int32_t kk = (int32_t)cinfo[w][cc][1] + (int32_t)n;
+      if (n < a.V && kk >= 0 && (uint32_t)kk < cinfo[w][cc][2]) out[(size_t)off + (uint32_t)kk] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------------- branch spectra
 // R[cg][m][b][col] = sum_{a<A} r'_col[D a + b] e^{+2 pi j a m / M}, r' = the column's taps delayed by its grid offset
 // (xl_grid.h), in double, rounded once.  For a LIST of columns (all of them when a class is built, the newcomers' when a
@@ -796,18 +959,15 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
 // `done` (optional): recorded with the launch's own completion signal -- one queue packet instead of launch + event record
 hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done) {
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
-  const bool reg = a0.M == 128u && a0.inv_reg != 0u;  // workgroup = (segment, column group): all four sub-tiles
-  const uint32_t work = a0.nseg * a0.ncg * (reg ? 1u : (a0.M == 256u ? 8u : 4u));
+  // M = 128: 0 = transform staged in LDS (workgroup = one 32-column tile), 1 = registers, lane pair per column (workgroup
+  // = (segment, column group): four tiles), 2 = registers, lane quad per column (workgroup = two tiles)
+  const uint32_t kind = a0.M == 128u ? a0.inv_reg : 0u;
+  const uint32_t work = a0.nseg * a0.ncg * (kind == 1u ? 1u : (kind == 2u ? 2u : (a0.M == 256u ? 8u : 4u)));
   const XlpArgs a = xlp_checked_skip(a0, work);
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
-  if (done) {
-    if (reg) hipExtLaunchKernelGGL(xlp_inverse_reg_kernel, grid, dim3(256), 0, s, nullptr, done, 0, a);
-    else if (a.M == 256u) hipExtLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, nullptr, done, 0, a);
-    else hipExtLaunchKernelGGL(xlp_inverse_kernel<128>, grid, dim3(256), 0, s, nullptr, done, 0, a);
-  } else {
-    if (reg) hipLaunchKernelGGL(xlp_inverse_reg_kernel, grid, dim3(256), 0, s, a);
-    else if (a.M == 256u) hipLaunchKernelGGL(xlp_inverse_kernel<256>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(xlp_inverse_kernel<128>, grid, dim3(256), 0, s, a);
-  }
+  void (*kern)(const XlpArgs) = kind == 1u ? xlp_inverse_reg_kernel
+                                : (kind == 2u ? xlp_inverse_quad_kernel : (a.M == 256u ? xlp_inverse_kernel<256> : xlp_inverse_kernel<128>));
+  if (done) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, s, nullptr, done, 0, a);
+  else hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }
