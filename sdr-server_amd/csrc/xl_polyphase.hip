@@ -40,6 +40,21 @@ struct XlpTw {
 // lanes of a quarter-wave hit 16 distinct bank pairs in passes 0 and 1 and at most 2-way conflicts elsewhere.
 #define XLP_POS(i) ((i) + ((i) >> 2))
 #define XLP_ROW(M) ((M) + (M) / 4)  // padded row length in elements
+struct XlpPosPad {  // the padded layout above; `rs` (per-row constant) unused
+  static XL_MEM uint32_t pos(const uint32_t i, const uint32_t) { return XLP_POS(i); }
+};
+// Dense rows of 128 elements with an XOR swizzle instead of the pad (M = 128 inverse kernel, option "inverse_kernel" = 3):
+//   pos(i) = i ^ 5 a ^ rs,   a = (i >> 4) & 3,   rs = a per-row constant < 16
+// * gathers (32 lanes read elements l + 32 r of one row, 64 banks of 4 bytes = 32 elements): a depends on bit 4 of l and on r
+//   only, 5 a < 16 leaves bit 4 alone -> a bijection of the 32 elements: conflict-free;
+// * scatters (16-lane groups, 32 banks = 16 elements): pass 1 writes 4 l + r -> (4 (l & 3) + r) ^ 5 (l >> 2) =
+//   4 ((l & 3) ^ a) + (r ^ a): distinct; pass 4 writes 16 a + k + 4 r -> (k ^ a) + 4 (r ^ a): distinct; pass 16 writes
+//   l + 16 r: a constant XOR: distinct;
+// * the tile fill (16 lanes write the same bin of 16 different rows): rs = (row >> 1) & 15 separates them.
+// A workgroup's tile is then exactly 32 KB: five workgroups per CU instead of four.
+struct XlpPosSwz {
+  static XL_MEM uint32_t pos(const uint32_t i, const uint32_t rs) { return i ^ (5u * ((i >> 4) & 3u)) ^ rs; }
+};
 
 template <int SIGN, int M>
 XL_DEV XlpTw xlp_twiddles(const v2f *__restrict__ W, const uint32_t l) {
@@ -84,8 +99,8 @@ XL_DEV void xlp_dft_butterfly(v2f (&u)[4], const XlpTw &tw, const int pass) {
 }
 
 // NI independent transforms per lane interleaved (instruction-level parallelism for a wave that runs almost alone)
-template <int SIGN, int NI, int M>
-XL_DEV void xlp_dft(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, const uint32_t l) {
+template <int SIGN, int NI, int M, class P = XlpPosPad>
+XL_DEV void xlp_dft(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, const uint32_t l, const uint32_t (&rs)[NI]) {
   constexpr uint32_t L = M / 4;
   constexpr int NP4 = M == 256 ? 4 : 3;
 #pragma unroll
@@ -99,12 +114,12 @@ XL_DEV void xlp_dft(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, con
 #pragma unroll
       for (int n = 0; n < NI; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lds[n][XLP_POS(jo + r * p)] = u[n][r];
+        for (int r = 0; r < 4; ++r) lds[n][P::pos(jo + r * p, rs[n])] = u[n][r];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int n = 0; n < NI; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u[n][r] = lds[n][XLP_POS(l + L * r)];
+        for (int r = 0; r < 4; ++r) u[n][r] = lds[n][P::pos(l + L * r, rs[n])];
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -222,7 +237,8 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
     u[0][r] = ok ? v : (v2f){0.0f, 0.0f};
   }
   v2f *const bufs[1] = {lds[h]};
-  xlp_dft<-1, 1, M>(u, bufs, tw, l);
+  const uint32_t rs0[1] = {0u};
+  xlp_dft<-1, 1, M>(u, bufs, tw, l, rs0);
   // the transform's row, natural order (its own scratch: the LDS operations of a wave execute in order)
 #pragma unroll
   for (int r = 0; r < 4; ++r) lds[h][l + L * r] = u[0][r];
@@ -400,8 +416,10 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
 // grid = nco_blocks + nseg * ncg * (128 / CW) workgroups of 256 threads; workgroup = (segment, CW columns), CW = 16
 // (M = 256: a wave runs its four columns' transforms interleaved) or 32 (M = 128: each half-wave runs four).  The tile
 // rows double as the transforms' scratch.
-template <int M>
+template <int M, class P = XlpPosPad>
 __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
+  constexpr bool SWZ = !__is_same(P, XlpPosPad);
+  static_assert(!SWZ || M == 128, "the swizzled layout is written for rows of 128 elements");
   constexpr uint32_t L = M / 4;            // lanes per transform
   constexpr uint32_t CW = 16u * (256 / M);  // columns per workgroup
   constexpr uint32_t WPC = CW / 4;          // columns per wave
@@ -409,7 +427,7 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
   // [column][padded bin position].  Row length XLP_POS(M - 1) + 1 (319 / 159): 2 banks short of a multiple of 32, so
   // the lanes that fill different rows of one bin hit distinct bank pairs; and 16 x 319 x 8 B = 40832 B lets a CU hold
   // four workgroups (at 41.2 KB it held three: 768 slots for the 832 workgroups of a 1024-client block -> a second round)
-  __shared__ v2f tile[CW][XLP_ROW(M) - 1];
+  __shared__ v2f tile[CW][SWZ ? M : XLP_ROW(M) - 1];
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a);
     return;
@@ -436,8 +454,8 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t m = mrow + MR * i;
-      tile[2 * part][XLP_POS(m)] = (v2f){v[i].x, v[i].y};
-      tile[2 * part + 1][XLP_POS(m)] = (v2f){v[i].z, v[i].w};
+      tile[2 * part][P::pos(m, part & 15u)] = (v2f){v[i].x, v[i].y};  // (row r's constant: (r >> 1) & 15)
+      tile[2 * part + 1][P::pos(m, part & 15u)] = (v2f){v[i].z, v[i].w};
     }
   }
   // the epilogue's operands.  A column's client lies on the class's shared grid with its own offset (xl_grid.h):
@@ -478,19 +496,22 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
   v2f u[4][4];
   v2f *const rows[4] = {tile[WPC * w + 4u * h], tile[WPC * w + 4u * h + 1], tile[WPC * w + 4u * h + 2],
                         tile[WPC * w + 4u * h + 3]};
+  const uint32_t rbase = WPC * w + 4u * h;  // (the rows' swizzle constants: (row >> 1) & 15)
+  const uint32_t rs[4] = {(rbase >> 1) & 15u, ((rbase + 1u) >> 1) & 15u, ((rbase + 2u) >> 1) & 15u, ((rbase + 3u) >> 1) & 15u};
 #pragma unroll
   for (int n = 0; n < 4; ++n)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) u[n][r] = rows[n][XLP_POS(l + L * r)];
+    for (int r = 0; r < 4; ++r) u[n][r] = rows[n][P::pos(l + L * r, rs[n])];
   __builtin_amdgcn_wave_barrier();
-  xlp_dft<+1, 4, M>(u, rows, tw, l);
+  xlp_dft<+1, 4, M, P>(u, rows, tw, l, rs);
   __builtin_amdgcn_wave_barrier();
   if (eok) {
     v2f *__restrict__ row = tile[WPC * w + en];
+    const uint32_t ers = ((WPC * w + en) >> 1) & 15u;
     const uint32_t left = ebnd.K - m0, span = XL_PH_STRIDE - ibeg;
     const uint32_t p0 = gq * XL_PH_STRIDE + ibeg;
     xl_phase_walk(pe, m0, left < span ? left : span, (v2f){ce.incr.x, ce.incr.y}, ebnd,
-                  [&](uint32_t i, v2f phs) { row[XLP_POS(p0 + i)] = phs; });
+                  [&](uint32_t i, v2f phs) { row[P::pos(p0 + i, ers)] = phs; });
   }
   __builtin_amdgcn_wave_barrier();
   const unsigned long long t_xf = a.trace ? wall_clock64() : 0ull;
@@ -501,7 +522,7 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
       const uint32_t qo = l + L * r, qs = s * a.V + qo;  // shared point of this value
       if (off[n] != 0xFFFFFFFFu && qo < a.V && qs >= ksh[n] && qs - ksh[n] < kc[n]) {
         const v2f y = u[n][r] * (1.0f / (float)M);  // exact scaling by 2^-8 / 2^-7
-        out[off[n] + (qs - ksh[n])] = xl_rotate<1>(y, rows[n][XLP_POS(qo)]);
+        out[off[n] + (qs - ksh[n])] = xl_rotate<1>(y, rows[n][P::pos(qo, rs[n])]);
       }
     }
   }
@@ -961,12 +982,15 @@ hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done)
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
   // M = 128: 0 = transform staged in LDS (workgroup = one 32-column tile), 1 = registers, lane pair per column (workgroup
   // = (segment, column group): four tiles), 2 = registers, lane quad per column (workgroup = two tiles)
+  // 3 = staged in LDS like 0, dense rows with an XOR swizzle instead of the pad
   const uint32_t kind = a0.M == 128u ? a0.inv_reg : 0u;
   const uint32_t work = a0.nseg * a0.ncg * (kind == 1u ? 1u : (kind == 2u ? 2u : (a0.M == 256u ? 8u : 4u)));
   const XlpArgs a = xlp_checked_skip(a0, work);
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
-  void (*kern)(const XlpArgs) = kind == 1u ? xlp_inverse_reg_kernel
-                                : (kind == 2u ? xlp_inverse_quad_kernel : (a.M == 256u ? xlp_inverse_kernel<256> : xlp_inverse_kernel<128>));
+  void (*kern)(const XlpArgs) = kind == 1u   ? xlp_inverse_reg_kernel
+                                : kind == 2u ? xlp_inverse_quad_kernel
+                                : kind == 3u ? xlp_inverse_kernel<128, XlpPosSwz>
+                                             : (a.M == 256u ? xlp_inverse_kernel<256> : xlp_inverse_kernel<128>);
   if (done) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, s, nullptr, done, 0, a);
   else hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);
   return hipGetLastError();

@@ -293,7 +293,8 @@ def test_1000_clients_split_group_riders():
 # that the oracle can check every client.
 # The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
 # the forced-path tests run with both.
-@pytest.fixture(params=[(128, 0), (128, 1), (128, 2), (256, 0)], ids=["M128", "M128-register-inverse", "M128-quad-register-inverse", "M256"])
+@pytest.fixture(params=[(128, 0), (128, 1), (128, 2), (128, 3), (256, 0)],
+                ids=["M128", "M128-register-inverse", "M128-quad-register-inverse", "M128-swizzled-inverse", "M256"])
 def poly_m(request, monkeypatch):
     """Transform length of the forced polyphase plan; at M = 128 also with the inverse launch's transform in registers
     (option "inverse_kernel" = 1: xlp_inverse_reg_kernel, a lane pair per column; 2: xlp_inverse_quad_kernel, a lane quad)."""
@@ -747,7 +748,7 @@ def test_group_of_blocks_equals_successive_calls_direct(variant):
     eng.close()
 
 
-@pytest.mark.parametrize("m,inv", [(128, 0), (128, 1), (128, 2), (256, 0)])
+@pytest.mark.parametrize("m,inv", [(128, 0), (128, 1), (128, 2), (128, 3), (256, 0)])
 def test_group_of_blocks_polyphase(m, inv, monkeypatch):
     """Forced polyphase path, G = 4 server-default blocks per call (108 segments at M = 128): every client vs the
     oracle's four successive calls; a native group in between (shared history and phases); ragged group."""
@@ -1121,7 +1122,8 @@ def _engine_outputs(eng, ids):
     return [eng.output(i) for i in ids]
 
 
-@pytest.mark.parametrize("variant", ["native", "optimized", "optimized-register-inverse", "optimized-quad-register-inverse"])
+@pytest.mark.parametrize("variant", ["native", "optimized", "optimized-register-inverse", "optimized-quad-register-inverse",
+                                     "optimized-swizzled-inverse"])
 def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
     server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
@@ -1129,8 +1131,8 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     optimized max|d| / max|y| <= 1e-5 per client (fixture semantics: test/test_xlating.c:24-61, test/utils.c:176-196)."""
     from pyoracle import population
 
-    if variant.endswith("register-inverse"):
-        monkeypatch.setenv("XL_EXP_INV", "2" if "quad" in variant else "1")
+    if variant.endswith("-inverse"):
+        monkeypatch.setenv("XL_EXP_INV", "3" if "swizzled" in variant else ("2" if "quad" in variant else "1"))
         variant = "optimized"
     t48 = lpf(FS, 24000, 9600)
     G, nb = 8, 262144
