@@ -396,7 +396,7 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     if (value != 0 && value != 128 && value != 256) return -EINVAL;
     b->poly_m = (uint32_t)value;
   } else if (n == "inverse_kernel") {
-    if (value < 0 || value > 3) return -EINVAL;
+    if (value < 0 || value > 4) return -EINVAL;
     b->inv_reg = (uint32_t)value;
   } else if (n == "polyphase_min_clients") {
     if (value < 1) return -EINVAL;

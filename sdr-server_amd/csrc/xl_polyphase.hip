@@ -416,8 +416,8 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
 // grid = nco_blocks + nseg * ncg * (128 / CW) workgroups of 256 threads; workgroup = (segment, CW columns), CW = 16
 // (M = 256: a wave runs its four columns' transforms interleaved) or 32 (M = 128: each half-wave runs four).  The tile
 // rows double as the transforms' scratch.
-template <int M, class P = XlpPosPad>
-__global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
+template <int M, class P>
+XL_DEV void xlp_inverse_body(const XlpArgs &a) {
   constexpr bool SWZ = !__is_same(P, XlpPosPad);
   static_assert(!SWZ || M == 128, "the swizzled layout is written for rows of 128 elements");
   constexpr uint32_t L = M / 4;            // lanes per transform
@@ -533,6 +533,15 @@ __global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
     t[2] = t_loaded;
     t[3] = t_xf;
   }
+}
+
+template <int M, class P = XlpPosPad>
+__global__ __launch_bounds__(256) void xlp_inverse_kernel(const XlpArgs a) {
+  xlp_inverse_body<M, P>(a);
+}
+// the swizzled layout at five workgroups per CU: 32 KB of LDS each fit, 96 registers make the waves fit (4 spilled dwords)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void xlp_inverse_swz5_kernel(const XlpArgs a) {
+  xlp_inverse_body<128, XlpPosSwz>(a);
 }
 
 // ------------------------------------------------------------------------------------------- inverse, register transform
@@ -982,7 +991,7 @@ hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done)
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
   // M = 128: 0 = transform staged in LDS (workgroup = one 32-column tile), 1 = registers, lane pair per column (workgroup
   // = (segment, column group): four tiles), 2 = registers, lane quad per column (workgroup = two tiles)
-  // 3 = staged in LDS like 0, dense rows with an XOR swizzle instead of the pad
+  // 3 = staged in LDS like 0, dense rows with an XOR swizzle instead of the pad; 4 = the same built for five workgroups per CU
   const uint32_t kind = a0.M == 128u ? a0.inv_reg : 0u;
   const uint32_t work = a0.nseg * a0.ncg * (kind == 1u ? 1u : (kind == 2u ? 2u : (a0.M == 256u ? 8u : 4u)));
   const XlpArgs a = xlp_checked_skip(a0, work);
@@ -990,6 +999,7 @@ hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done)
   void (*kern)(const XlpArgs) = kind == 1u   ? xlp_inverse_reg_kernel
                                 : kind == 2u ? xlp_inverse_quad_kernel
                                 : kind == 3u ? xlp_inverse_kernel<128, XlpPosSwz>
+                                : kind == 4u ? xlp_inverse_swz5_kernel
                                              : (a.M == 256u ? xlp_inverse_kernel<256> : xlp_inverse_kernel<128>);
   if (done) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, s, nullptr, done, 0, a);
   else hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);

@@ -748,7 +748,7 @@ def test_group_of_blocks_equals_successive_calls_direct(variant):
     eng.close()
 
 
-@pytest.mark.parametrize("m,inv", [(128, 0), (128, 1), (128, 2), (128, 3), (256, 0)])
+@pytest.mark.parametrize("m,inv", [(128, 0), (128, 1), (128, 2), (128, 3), (128, 4), (256, 0)])
 def test_group_of_blocks_polyphase(m, inv, monkeypatch):
     """Forced polyphase path, G = 4 server-default blocks per call (108 segments at M = 128): every client vs the
     oracle's four successive calls; a native group in between (shared history and phases); ragged group."""
