@@ -74,8 +74,9 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                           always: the NCO phase recurrence of the following calls runs as a kernel of its own on a side
  *                           stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE)
  *   "nco_calls_per_launch"  1..4 (default 4): calls of the same shape one such kernel tabulates ahead
- *   "inverse_kernel"        128-point polyphase classes: the inverse launch's transform -- 0 = staged in LDS, 1 = in the
- *                           registers of a lane pair per client column, 2 = of a lane quad (one LDS pass for the stores)
+ *   "inverse_kernel"        128-point polyphase classes: the inverse launch's transform -- staged in LDS on padded rows (0),
+ *                           on dense XOR-swizzled rows (3, default; 4: built for five workgroups per CU), or in the registers
+ *                           of a lane pair (1) / lane quad (2) per client column with one LDS pass for the stores
  * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call. */
 int xlating_batch_set_option(xlating_batch *batch, const char *name, long value);
 

@@ -184,10 +184,10 @@ struct xlating_batch_t {
   int poly_mode = -1;        // option "polyphase": 0 never, 1 whenever the shape allows, -1 (default) by the size rule
   uint32_t poly_min_clients = 128;  // measured at 505 taps, D = 42: x1.10 at 128 clients, x0.96 at 64 (profiles/r01_polyphase_vs_direct.txt)
   uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
-  uint32_t inv_reg = 0;       // option "inverse_kernel": M = 128 classes: 1 = register transform (xlp_inverse_reg_kernel), 0 = LDS transform (default:
-                              // the register kernel holds 64 points per lane = 2 waves per SIMD, and with so few waves its serial
-                              // load -> transform -> store chain is latency-bound: 142 vs 113 us per 8-block call at 1024 clients,
-                              // profiles/r03_inverse_reg_vs_lds.txt)
+  uint32_t inv_reg = 3;       // option "inverse_kernel", M = 128 classes: 0 = LDS transform on padded rows (round 2), 3 = on dense rows with an XOR
+                              // swizzle (default: LDS bank-conflict cycles 0.44 -> 0.24 of the LDS cycles, -1 % time in two A/B sessions),
+                              // 4 = the same at five workgroups per CU (no gain), 1 / 2 = transform in registers of a lane pair / quad
+                              // (fewer instructions and LDS cycles, 25-30 % slower: profiles/r03_inverse_reg_vs_lds.txt)
   uint32_t mix_skip_at = 0;   // position of the mix launch's skipped workgroups; 0 = 1024
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
   uint32_t poly_exp = 0;     // XL_TUNING builds: tuning switches of the mix kernel
