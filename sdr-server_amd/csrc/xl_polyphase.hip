@@ -44,16 +44,21 @@ struct XlpPosPad {  // the padded layout above; `rs` (per-row constant) unused
   static XL_MEM uint32_t pos(const uint32_t i, const uint32_t) { return XLP_POS(i); }
 };
 // Dense rows of 128 elements with an XOR swizzle instead of the pad (M = 128 inverse kernel, option "inverse_kernel" = 3):
-//   pos(i) = i ^ 5 a ^ rs,   a = (i >> 4) & 3,   rs = a per-row constant < 16
-// * gathers (32 lanes read elements l + 32 r of one row, 64 banks of 4 bytes = 32 elements): a depends on bit 4 of l and on r
-//   only, 5 a < 16 leaves bit 4 alone -> a bijection of the 32 elements: conflict-free;
-// * scatters (16-lane groups, 32 banks = 16 elements): pass 1 writes 4 l + r -> (4 (l & 3) + r) ^ 5 (l >> 2) =
-//   4 ((l & 3) ^ a) + (r ^ a): distinct; pass 4 writes 16 a + k + 4 r -> (k ^ a) + 4 (r ^ a): distinct; pass 16 writes
-//   l + 16 r: a constant XOR: distinct;
-// * the tile fill (16 lanes write the same bin of 16 different rows): rs = (row >> 1) & 15 separates them.
-// A workgroup's tile is then exactly 32 KB: five workgroups per CU instead of four.
+//   pos(i) = i ^ g(a) ^ rs,   a = (i >> 4) & 7,   g(a) = 5 a mod 16 = {0, 5, 10, 15, 4, 9, 14, 3},   rs = a per-row constant < 16
+// * gathers (32 lanes read elements l + 32 r of one row; 64 banks of 4 bytes = 32 elements): a depends on bit 4 of l and on r
+//   only, and g < 16 leaves bit 4 alone -> a bijection of the 32 elements: conflict-free;
+// * scatters (16-lane groups; 32 banks = 16 elements): pass 1 writes 4 l + r, a = l >> 2: within one a the XOR permutes the
+//   four values 4 (l & 3) + r, and two a never meet because g(a) ^ g(a') is never a multiple of 4 inside a group of four
+//   (differences 5, 10, 15 / 13, 10, 7); pass 4 writes 16 a + k + 4 r: the same argument with differences never in
+//   {1, 2, 3}; pass 16 writes l + 16 r: one constant XOR per group;
+// * the phase expansion (a 16-lane group = 8 lanes x 2 rows writing element 16 gq + c): the eight g(gq) are distinct, and
+//   the two rows' constants differ by 8, which is no difference of two g values;
+// * the tile fill (16 lanes write the same bin of rows 2 part, then of rows 2 part + 1): the sixteen row constants of
+//   either set are distinct.    rs(row) = ((row >> 1) & 15) ^ ((row & 1) << 3)   (XLP_SWZ_ROW)
+// A workgroup's tile is then exactly 32 KB.
+#define XLP_SWZ_ROW(row) ((((row) >> 1) & 15u) ^ (((row) & 1u) << 3))
 struct XlpPosSwz {
-  static XL_MEM uint32_t pos(const uint32_t i, const uint32_t rs) { return i ^ (5u * ((i >> 4) & 3u)) ^ rs; }
+  static XL_MEM uint32_t pos(const uint32_t i, const uint32_t rs) { return i ^ ((5u * ((i >> 4) & 7u)) & 15u) ^ rs; }
 };
 
 template <int SIGN, int M>
@@ -454,8 +459,8 @@ XL_DEV void xlp_inverse_body(const XlpArgs &a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t m = mrow + MR * i;
-      tile[2 * part][P::pos(m, part & 15u)] = (v2f){v[i].x, v[i].y};  // (row r's constant: (r >> 1) & 15)
-      tile[2 * part + 1][P::pos(m, part & 15u)] = (v2f){v[i].z, v[i].w};
+      tile[2 * part][P::pos(m, XLP_SWZ_ROW(2u * part))] = (v2f){v[i].x, v[i].y};
+      tile[2 * part + 1][P::pos(m, XLP_SWZ_ROW(2u * part + 1u))] = (v2f){v[i].z, v[i].w};
     }
   }
   // the epilogue's operands.  A column's client lies on the class's shared grid with its own offset (xl_grid.h):
@@ -496,8 +501,8 @@ XL_DEV void xlp_inverse_body(const XlpArgs &a) {
   v2f u[4][4];
   v2f *const rows[4] = {tile[WPC * w + 4u * h], tile[WPC * w + 4u * h + 1], tile[WPC * w + 4u * h + 2],
                         tile[WPC * w + 4u * h + 3]};
-  const uint32_t rbase = WPC * w + 4u * h;  // (the rows' swizzle constants: (row >> 1) & 15)
-  const uint32_t rs[4] = {(rbase >> 1) & 15u, ((rbase + 1u) >> 1) & 15u, ((rbase + 2u) >> 1) & 15u, ((rbase + 3u) >> 1) & 15u};
+  const uint32_t rbase = WPC * w + 4u * h;  // (the rows' swizzle constants)
+  const uint32_t rs[4] = {XLP_SWZ_ROW(rbase), XLP_SWZ_ROW(rbase + 1u), XLP_SWZ_ROW(rbase + 2u), XLP_SWZ_ROW(rbase + 3u)};
 #pragma unroll
   for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -507,7 +512,7 @@ XL_DEV void xlp_inverse_body(const XlpArgs &a) {
   __builtin_amdgcn_wave_barrier();
   if (eok) {
     v2f *__restrict__ row = tile[WPC * w + en];
-    const uint32_t ers = ((WPC * w + en) >> 1) & 15u;
+    const uint32_t ers = XLP_SWZ_ROW(WPC * w + en);
     const uint32_t left = ebnd.K - m0, span = XL_PH_STRIDE - ibeg;
     const uint32_t p0 = gq * XL_PH_STRIDE + ibeg;
     xl_phase_walk(pe, m0, left < span ? left : span, (v2f){ce.incr.x, ce.incr.y}, ebnd,
