@@ -112,7 +112,13 @@ struct PolyClass {
   std::map<int, uint32_t> col_of;     // client id -> column
   uint32_t ncg_cap = 0;               // column groups the R / Y / cols buffers hold
   bool keep = false;                  // (planning scratch: the class was taken over by the new plan)
-  float2 *d_R = nullptr;     // branch spectra [ncg][M][Dpad][128] (+ XLP_BSTEP rows of tail padding)
+  float2 *d_R = nullptr;     // branch spectra [ncg][M][Dpad][128] (+ XLP_BSTEP rows of tail padding); mix_kind 0
+  // mix_kind 1 (the mix launch on the matrix cores, xlp_mix_mfma_kernel): the spectra scaled per column by a power of two and
+  // split in two halves, in the kernel's operand order, instead of d_R; per column the scale (host) and what undoes it (device)
+  uint32_t mix_kind = 0, nkb = 0;
+  void *d_Rh = nullptr;
+  std::vector<float> col_scale;
+  float *d_cscale = nullptr;
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
   float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
   XlpCol *d_cols = nullptr;  // per column: output row, grid offset, NCO increment
@@ -188,6 +194,9 @@ struct xlating_batch_t {
                               // swizzle (default: LDS bank-conflict cycles 0.44 -> 0.24 of the LDS cycles, -1 % time in two A/B sessions),
                               // 4 = the same at five workgroups per CU (no gain), 1 / 2 = transform in registers of a lane pair / quad
                               // (fewer instructions and LDS cycles, 25-30 % slower: profiles/r03_inverse_reg_vs_lds.txt)
+  uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = the mix launch on the matrix cores where the class allows it (integer input
+                              // format, D <= 64), 0 = packed FP32 FMAs everywhere
+  uint32_t mix_pp = 0;        // option "mix_passes_per_workgroup" (matrix-core mix): 0 = the launcher's default
   uint32_t mix_skip_at = 0;   // position of the mix launch's skipped workgroups; 0 = 1024
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
   uint32_t poly_exp = 0;     // XL_TUNING builds: tuning switches of the mix kernel
@@ -314,10 +323,12 @@ static void xl_plan_trim(xlating_batch *b) {
 }
 
 static void xl_poly_release(xlating_batch *b, PolyClass &pc) {
-  void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_cols};
+  void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_cols, pc.d_Rh, pc.d_cscale};
   for (void *q : dev) xl_plan_release(b, q);
   pc.d_R = pc.d_X = pc.d_Y = nullptr;
   pc.d_cols = nullptr;
+  pc.d_Rh = nullptr;
+  pc.d_cscale = nullptr;
 }
 
 static void xl_release_launch_set(xlating_batch *b, Launch *set) {
@@ -398,6 +409,13 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
   } else if (n == "inverse_kernel") {
     if (value < 0 || value > 4) return -EINVAL;
     b->inv_reg = (uint32_t)value;
+  } else if (n == "mix_kernel") {
+    if (value < 0 || value > 1) return -EINVAL;
+    b->mix_kernel = (uint32_t)value;
+  } else if (n == "mix_passes_per_workgroup") {
+    if (value < 0 || value > 64) return -EINVAL;
+    b->mix_pp = (uint32_t)value;
+    return 0;  // (a launch parameter: no re-plan)
   } else if (n == "polyphase_min_clients") {
     if (value < 1) return -EINVAL;
     b->poly_min_clients = (uint32_t)value;
@@ -472,6 +490,8 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
   if (getenv("XL_EXP_POLY_M")) (void)xlating_batch_set_option(b, "polyphase_m", atol(getenv("XL_EXP_POLY_M")));
   if (getenv("XL_EXP_POLY_MIN")) (void)xlating_batch_set_option(b, "polyphase_min_clients", atol(getenv("XL_EXP_POLY_MIN")));
   if (getenv("XL_EXP_INV")) (void)xlating_batch_set_option(b, "inverse_kernel", atol(getenv("XL_EXP_INV")));
+  if (getenv("XL_EXP_MIX")) (void)xlating_batch_set_option(b, "mix_kernel", atol(getenv("XL_EXP_MIX")));
+  if (getenv("XL_EXP_MIX_PP")) (void)xlating_batch_set_option(b, "mix_passes_per_workgroup", atol(getenv("XL_EXP_MIX_PP")));
   if (getenv("XL_EXP_CHAIN_STATS")) (void)hipMalloc((void **)&b->d_chain_stats, 4096 * 4 * sizeof(unsigned long long));
   if (getenv("XL_EXP_NCO_SIDE")) (void)xlating_batch_set_option(b, "nco_side_stream", atol(getenv("XL_EXP_NCO_SIDE")));
   if (getenv("XL_EXP_CHAIN_CALLS")) (void)xlating_batch_set_option(b, "nco_calls_per_launch", atol(getenv("XL_EXP_CHAIN_CALLS")));
@@ -877,6 +897,25 @@ static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t A, size_t member
   return A > 64 ? 256u : (b->poly_m ? b->poly_m : (A <= 32 && members >= 768 ? 128u : 256u));
 }
 
+// Which mix launch a class of (D) takes (PolyClass::mix_kind): the matrix-core kernel carries the spectra as pairs of halves
+// and needs them bounded -- integer input formats -- and at most XLP_NKB_MAX k-blocks of 8 branches.
+static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D) {
+  return (b->mix_kernel == 1u && b->fmt != XL_FMT_CF32 && D <= 8u * XLP_NKB_MAX) ? 1u : 0u;
+}
+
+// Power-of-two scale of a column's branch spectra for the matrix-core mix: every component of R_b[m] = sum_a r_b[a] e^{..} is at
+// most L = max_b sum_a |r_b[a]| (the same for the delayed taps: a delay permutes the branches); scale = 2^floor(log2(RMAX / L)).
+static float xl_poly_col_scale(const Client &c, uint32_t D, uint32_t T) {
+  std::vector<double> l1(D, 0.0);
+  for (uint32_t i = 0; i < T; ++i) l1[i % D] += hypot((double)c.rt[2 * i], (double)c.rt[2 * i + 1]);
+  double L = 0.0;
+  for (double v : l1) L = std::max(L, v);
+  if (!(L > 0.0) || !std::isfinite(L)) return 1.0f;
+  int e = (int)floor(log2((double)XLP_H_RMAX / L));
+  e = std::max(-100, std::min(100, e));
+  return (float)ldexp(1.0, e);
+}
+
 // Brings the device images of a polyphase class in line with its member list: columns, branch spectra of the NEW columns.
 static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vector<uint32_t> &new_cols, bool fresh, uint32_t cap_samples) {
   // ---- capacity: column groups (R, Y, cols) and segments (Y, X)
@@ -887,22 +926,36 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     // grow by an eighth (at least one group) so that the next joins find room; the old spectra move over on the device
     const uint32_t cap = fresh ? need_cg : std::max(need_cg, pc.ncg_cap + std::max(1u, pc.ncg_cap / 8u));
     float2 *nR = nullptr, *nY = nullptr;
+    void *nRh = nullptr;
+    float *ncs = nullptr;
     XlpCol *ncols = nullptr;
-    const size_t rrows = (size_t)cap * pc.Dpad + 1;  // (+1 x M rows: covers the XLP_BSTEP rows of tail padding)
-    XL_TRY(xl_plan_alloc(b, (void **)&nR, rrows * pc.M * XLP_COLS * sizeof(float2)));
-    // (R rows are [cg][m][b][col]: a group's image is contiguous -- the old groups are one copy, the new ones and the tail
-    // padding start as zeros: empty columns and padding branches are multiplied into sums that are never stored, but must
-    // be finite)
-    const size_t old_elems = fresh ? 0 : (size_t)pc.ncg_cap * pc.Dpad * pc.M * XLP_COLS;
-    if (old_elems) XL_TRY(hipMemcpyAsync(nR, pc.d_R, old_elems * sizeof(float2), hipMemcpyDeviceToDevice, b->own_stream));
-    XL_TRY(hipMemsetAsync(nR + old_elems, 0, (rrows * pc.M * XLP_COLS - old_elems) * sizeof(float2), b->own_stream));
+    if (pc.mix_kind == 1u) {
+      // operand-form image [cg][m][quarter][term][k-block][lane][8 halves]: a group's image is contiguous here too
+      const size_t per_cg = xlp_rh_bytes_per_group(pc.M, pc.nkb);
+      XL_TRY(xl_plan_alloc(b, &nRh, (size_t)cap * per_cg));
+      const size_t old_bytes = fresh ? 0 : (size_t)pc.ncg_cap * per_cg;
+      if (old_bytes) XL_TRY(hipMemcpyAsync(nRh, pc.d_Rh, old_bytes, hipMemcpyDeviceToDevice, b->own_stream));
+      XL_TRY(hipMemsetAsync((char *)nRh + old_bytes, 0, (size_t)cap * per_cg - old_bytes, b->own_stream));
+      XL_TRY(xl_plan_alloc(b, (void **)&ncs, (size_t)cap * XLP_COLS * sizeof(float)));
+    } else {
+      const size_t rrows = (size_t)cap * pc.Dpad + 1;  // (+1 x M rows: covers the XLP_BSTEP rows of tail padding)
+      XL_TRY(xl_plan_alloc(b, (void **)&nR, rrows * pc.M * XLP_COLS * sizeof(float2)));
+      // (R rows are [cg][m][b][col]: a group's image is contiguous -- the old groups are one copy, the new ones and the tail
+      // padding start as zeros: empty columns and padding branches are multiplied into sums that are never stored, but must
+      // be finite)
+      const size_t old_elems = fresh ? 0 : (size_t)pc.ncg_cap * pc.Dpad * pc.M * XLP_COLS;
+      if (old_elems) XL_TRY(hipMemcpyAsync(nR, pc.d_R, old_elems * sizeof(float2), hipMemcpyDeviceToDevice, b->own_stream));
+      XL_TRY(hipMemsetAsync(nR + old_elems, 0, (rrows * pc.M * XLP_COLS - old_elems) * sizeof(float2), b->own_stream));
+    }
     XL_TRY(xl_plan_alloc(b, (void **)&nY, (size_t)cap * nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
     XL_TRY(xl_plan_alloc(b, (void **)&ncols, (size_t)cap * XLP_COLS * sizeof(XlpCol)));
     XL_TRY(hipStreamSynchronize(b->own_stream));
     xl_plan_release(b, pc.d_R);
+    xl_plan_release(b, pc.d_Rh);
+    xl_plan_release(b, pc.d_cscale);
     xl_plan_release(b, pc.d_Y);
     xl_plan_release(b, pc.d_cols);
-    pc.d_R = nR, pc.d_Y = nY, pc.d_cols = ncols;
+    pc.d_R = nR, pc.d_Rh = nRh, pc.d_cscale = ncs, pc.d_Y = nY, pc.d_cols = ncols;
     pc.ncg_cap = cap;
     if (fresh || nseg_cap != pc.nseg_cap || pc.d_X == nullptr) {
       xl_plan_release(b, pc.d_X);
@@ -930,16 +983,28 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
       cols[j].incr = make_float2(c.incr[0], c.incr[1]);
     }
     XL_TRY(hipMemcpy(pc.d_cols, cols.data(), cols.size() * sizeof(XlpCol), hipMemcpyHostToDevice));
+    if (pc.mix_kind == 1u) {  // what the matrix-core mix multiplies a column's sums by: 1 / (its scale * the spectra's)
+      std::vector<float> cs((size_t)pc.ncg_cap * XLP_COLS, 1.0f);
+      pc.col_scale.resize(pc.col_client.size(), 1.0f);
+      for (uint32_t j : new_cols) pc.col_scale[j] = xl_poly_col_scale(b->clients[pc.col_client[j]], pc.D, pc.T);
+      for (size_t j = 0; j < pc.col_client.size(); ++j) {
+        if (pc.col_client[j] < 0) continue;
+        cs[j] = 1.0f / (pc.col_scale[j] * XLP_H_XSCALE);
+      }
+      XL_TRY(hipMemcpy(pc.d_cscale, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
   }
   // ---- branch spectra of the new columns (device kernel, double arithmetic)
   if (!new_cols.empty()) {
     const size_t nn = new_cols.size();
     std::vector<float> rt(nn * pc.T * 2);  // [tap][new column]
-    std::vector<uint32_t> meta(2 * nn);    // [new column]: delay, then column index
+    std::vector<uint32_t> meta(3 * nn);    // [new column]: delay, then column index, then (matrix-core mix) the column scale's bits
     for (size_t j = 0; j < nn; ++j) {
       const Client &c = b->clients[pc.col_client[new_cols[j]]];
       meta[j] = pc.col_delta[new_cols[j]];
       meta[nn + j] = new_cols[j];
+      const float sc = pc.mix_kind == 1u ? pc.col_scale[new_cols[j]] : 1.0f;
+      memcpy(&meta[2 * nn + j], &sc, sizeof(float));
       for (uint32_t i = 0; i < pc.T; ++i) {
         rt[((size_t)i * nn + j) * 2] = c.rt[2 * i];
         rt[((size_t)i * nn + j) * 2 + 1] = c.rt[2 * i + 1];
@@ -952,7 +1017,10 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     if (e == hipSuccess) e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_meta, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
-      e = xlp_launch_tables(d_rt, d_meta, d_meta + nn, (uint32_t)nn, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.d_R, b->own_stream);
+      e = pc.mix_kind == 1u
+              ? xlp_launch_tables_h(d_rt, d_meta, d_meta + nn, reinterpret_cast<const float *>(d_meta + 2 * nn), (uint32_t)nn, pc.T,
+                                    pc.D, pc.A, pc.M, pc.nkb, pc.d_Rh, b->own_stream)
+              : xlp_launch_tables(d_rt, d_meta, d_meta + nn, (uint32_t)nn, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.d_R, b->own_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->own_stream);
     xl_plan_release(b, d_rt);  // (scratch: spare again at once)
     xl_plan_release(b, d_meta);
@@ -1052,7 +1120,7 @@ static int xl_batch_plan(xlating_batch *b) {
         ref = (old->rem_ref0 + advanced % D) % D;
         for (uint32_t r : distinct) dmax = std::max(dmax, (ref + D - r) % D);
         const uint32_t A = (T + dmax + D - 1) / D;
-        reuse = A == old->A && xl_poly_pick_m(b, A, m.size()) == old->M;
+        reuse = A == old->A && xl_poly_pick_m(b, A, m.size()) == old->M && xl_poly_mix_kind(b, D) == old->mix_kind;
       }
       if (!reuse) {
         // the shared grid's reference: the member offset that keeps the largest delay of a member smallest
@@ -1077,6 +1145,8 @@ static int xl_batch_plan(xlating_batch *b) {
         old->keep = true;
         old->d_R = old->d_X = old->d_Y = nullptr;
         old->d_cols = nullptr;
+        old->d_Rh = nullptr;
+        old->d_cscale = nullptr;
         // members that left give their columns back
         std::vector<bool> here(b->clients.size(), false);
         for (int id : m) here[id] = true;
@@ -1093,6 +1163,7 @@ static int xl_batch_plan(xlating_batch *b) {
           pc.col_delta.pop_back();
           pc.col_uid.pop_back();
         }
+        pc.col_scale.resize(pc.col_client.size(), 1.0f);
       } else {
         pc.D = D;
         pc.Dpad = xl_roundup(D, XLP_BSTEP);
@@ -1100,6 +1171,8 @@ static int xl_batch_plan(xlating_batch *b) {
         pc.A = A;
         pc.M = M;
         pc.V = M - A + 1;
+        pc.mix_kind = xl_poly_mix_kind(b, D);
+        pc.nkb = (D + 7u) / 8u;
       }
       pc.keep = false;
       pc.rem_ref0 = ref;
@@ -1690,6 +1763,11 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           pa.ncg = pc.ncg;
           pa.exp = b->poly_exp;
           pa.inv_reg = b->inv_reg;
+          pa.mix_kind = pc.mix_kind;
+          pa.nkb = pc.nkb;
+          pa.mix_pp = b->mix_pp;
+          pa.Rh = pc.d_Rh;
+          pa.cscale = pc.d_cscale;
           pa.W = b->d_W;
           pa.X = pc.d_X;
           pa.R = pc.d_R;
@@ -1875,6 +1953,7 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
     d += " cls" + std::to_string(k) + " D" + std::to_string(pc.D) + " T" + std::to_string(pc.T) + " cols" +
          std::to_string(pc.members.size()) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
     if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
+    d += pc.mix_kind == 1u ? " mix=mfma" : " mix=fma";
   }
   if (!b->poly.empty()) {
     d += " | optimized-mode direct:";

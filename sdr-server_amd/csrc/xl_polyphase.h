@@ -29,6 +29,10 @@
 #define XLP_SEG 14u    // segments accumulated per lane in one pass of the mix kernel
 #define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: XLP_SEG padded to 128 bytes
 #define XLP_COLS 128u  // client columns per column group (= one mix workgroup: a wave with two columns per lane)
+#define XLP_NKB_MAX 8u // matrix-core mix: at most 8 k-blocks of 8 branches (D <= 64)
+#define XLP_H_XSCALE 128.0f  // matrix-core mix: the shared spectra are multiplied by this before the split in halves: integer input
+                             // formats give |X| <= M sqrt(2) <= 363, so the first half stays below 46 400 < 65 504
+#define XLP_H_RMAX 8192.0f   // ... and a column's spectra by the power of two that brings their bound max_b sum_a |r_b[a]| under this
 #define XLP_BSTEP 6u   // rows per trip of the mix kernel's row loop (even; the branch count is padded to a multiple in the images)
 
 // One client column of a class: 16 bytes, one load.
@@ -59,10 +63,16 @@ struct XlpArgs {
   uint32_t ncg;        // column groups of XLP_COLS client columns
   uint32_t exp;        // tuning switches (XL_TUNING builds only; 0 otherwise)
   uint32_t inv_reg;    // M = 128: the inverse launch's transform: 0 = staged in LDS, 1 = registers of a lane pair, 2 = of a lane quad
+  uint32_t mix_kind;   // the mix launch: 0 = packed FP32 FMAs (xlp_mix_kernel), 1 = matrix cores on two-term half splits (xlp_mix_mfma_kernel)
+  uint32_t nkb;        // mix_kind 1: k-blocks of 8 branches = ceil(D / 8), <= XLP_NKB_MAX
+  uint32_t mix_pp;     // mix_kind 1: passes per workgroup (0 = default)
   unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
   const float2 *R;     // branch spectra   [cg][M][Dpad][XLP_COLS] (+ XLP_BSTEP rows of tail padding)
+  const void *Rh;      // mix_kind 1: the same, scaled per column and split in two halves, in MFMA operand order
+                       //   [cg][M][32-column quarter][term 2][k-block nkb][lane 64][8 halves] (see xlp_mix_mfma_kernel)
+  const float *cscale; // mix_kind 1: per column, what the sums are multiplied by = 1 / (column scale * XLP_H_XSCALE)
   float2 *Y;           // mixed spectra    [cg][nseg_cap][sub][M][CW], CW = 32 (M = 128) / 16 (M = 256) columns: one inverse tile contiguous
   const XlpCol *cols;  // per column
   const float2 *phtab;
@@ -89,6 +99,12 @@ struct XlpArgs {
 //   colidx[j]: the column of R the entry goes to; A = ceil((T + max delta) / D); branches >= D get 0
 hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, uint32_t nlist, uint32_t T,
                              uint32_t D, uint32_t Dpad, uint32_t A, uint32_t M, float2 *R, hipStream_t s);
+// the same in the matrix-core mix's operand form (XlpArgs::Rh); scale[j]: the entry's power-of-two column scale
+hipError_t xlp_launch_tables_h(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, const float *scale,
+                               uint32_t nlist, uint32_t T, uint32_t D, uint32_t A, uint32_t M, uint32_t nkb, void *Rh,
+                               hipStream_t s);
+// bytes of the operand-form image per column group
+static inline size_t xlp_rh_bytes_per_group(uint32_t M, uint32_t nkb) { return (size_t)M * 4u * 2u * nkb * 64u * 16u; }
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);

@@ -417,6 +417,153 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
   xlp_trace_work(a, t_begin);
 }
 
+// ------------------------------------------------------------------------------------------- mix on the matrix cores
+// The same sums as xlp_mix_kernel, Y[c][s][m] = sum_b X[s][b][m] R[c][b][m], as one real matrix product per bin m:
+//
+//   rows   i = (segment s, component re / im)        A[i][k]   k = 2 b + {0, 1}:   re row: ( X.re, X.im )   im row: ( X.im, -X.re )
+//   cols   j = client column c                       B[k][j]                       ( R.re, -R.im )
+//   D[(s, re)][c] = sum_b X.re R.re - X.im R.im      D[(s, im)][c] = sum_b X.im R.re + X.re R.im
+//
+// on v_mfma_f32_32x32x16_f16 (32 rows = the 14 segments of a pass + 2 idle, 32 columns, 16 k = 8 branches per instruction; FP32
+// accumulation) with every float32 operand v carried as TWO halves, v * scale = h1 + h2 + O(2^-22 |v|):
+//
+//   X R ~ (X1 R1) + (X1 R2 + X2 R1)        three matrix instructions per k-block; the dropped X2 R2 is 2^-22 relative.
+//
+// Measured against the oracle this is as good as the FP32 FMA chain of xlp_mix_kernel (CPU model of the arithmetic:
+// 8e-8 of max|y| against 1.9e-7 for the chain: the products are exact in FP32 and the small terms are summed on their own) --
+// and costs 12 half-precision MACs per complex MAC on units 16 x faster than the packed FP32 FMAs the other kernel saturates.
+// The scales are powers of two: XLP_H_XSCALE for the spectra of the INTEGER input formats (bounded: |X| <= M sqrt 2; a cf32
+// stream has no bound, its classes keep xlp_mix_kernel) and per column the one that brings the bound of its branch spectra
+// under XLP_H_RMAX (xl_batch.cpp); the sums are multiplied by 1 / (both) before they are stored.  Halves in the subnormal
+// range only ever carry 2^-24 of the operand scale.
+//
+// Workgroup = 4 waves = (bin m, column group of 128 clients, a run of `pp` passes); wave w = the group's columns
+// 32 w .. 32 w + 31.  A wave keeps its B operands -- 2 terms x nkb k-blocks x 16 bytes per lane, read ONCE as whole 1 KB runs
+// from the operand-form image Rh -- in registers for all its passes.  Per pass the workgroup stages the bin's rows of the
+// shared spectra (the FP32 image the forward launch wrote: 128-byte rows X[pass][b][m][0..15]) into LDS in A-operand order,
+// scaled and split: wave w converts k-blocks w, w + 4, ..; lane = (branch of the block, pair of segments), one 16-byte load.
+// The next pass's rows are requested before this pass's products.  Lane (h, i) of an operand holds k = 8 h .. 8 h + 7 of
+// the k-block, A and B alike -- whatever the hardware's assignment of those eight slots to k is, it is the same for both
+// operands, which is all a dot product needs.  D: lane (h, c), register g = row (g & 3) + 8 (g >> 2) + 4 h, column c.
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+
+// v * scale as two halves; (lo, hi) of the returned pairs: first terms, second terms
+XL_DEV void xlp_split_h(const float v, _Float16 &h1, _Float16 &h2) {
+  h1 = (_Float16)v;
+  h2 = (_Float16)(v - (float)h1);
+}
+XL_DEV uint32_t xlp_pack_h(const _Float16 lo, const _Float16 hi) {
+  const v2h p = {lo, hi};
+  return __builtin_bit_cast(uint32_t, p);
+}
+
+template <int NKB>
+__global__ __launch_bounds__(256) void xlp_mix_mfma_kernel(const XlpArgs a) {
+  // A operands of one pass: [term][k-block][lane][8 halves]; two buffers (one barrier per pass: a buffer is rewritten two
+  // barriers after it was read)
+  __shared__ uint4 xs[2][2][NKB][64];
+  if (blockIdx.x < a.nco_blocks) {
+    xlp_nco_role(a);
+    return;
+  }
+  const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;
+  const uint32_t bid = blockIdx.x - a.nco_blocks;
+  const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+  const uint32_t M = a.M;
+  // the pass runs of one (bin, column group) sit 8 positions apart in the grid: same XCD, dispatched together -- the
+  // group's operands come from HBM once (as in xlp_mix_kernel)
+  const uint32_t pp = a.mix_pp, runs = (a.mix_passes + pp - 1u) / pp;
+  const uint32_t grp = bid / (8u * runs), rr = bid - grp * 8u * runs;
+  const uint32_t run = rr >> 3, pair = grp * 8u + (rr & 7u);
+  const uint32_t m = pair & (M - 1u), cg = pair / M;
+  const uint32_t p0 = run * pp, p1 = p0 + pp < a.mix_passes ? p0 + pp : a.mix_passes;
+  if (p0 >= p1) return;
+  // ---- B operands of this wave: 2 NKB runs of 1 KB
+  const uint4 *__restrict__ Rp =
+      reinterpret_cast<const uint4 *>(a.Rh) + ((((size_t)cg * M + m) * 4u + w) * 2u * NKB) * 64u + lane;
+  v8h r1[NKB], r2[NKB];
+#pragma unroll
+  for (int j = 0; j < NKB; ++j) {
+    r1[j] = __builtin_bit_cast(v8h, Rp[(size_t)j * 64u]);
+    r2[j] = __builtin_bit_cast(v8h, Rp[(size_t)(NKB + j) * 64u]);
+  }
+  const uint32_t h = lane >> 5, c = lane & 31u;
+  const float cs = a.cscale[cg * XLP_COLS + w * 32u + c];
+  // ---- staging role of this lane: branch 8 j + bb of k-block j = w + 4 round, segments 2 sp, 2 sp + 1 of the pass
+  constexpr int ROUNDS = (NKB + 3) / 4;
+  const uint32_t bb = lane >> 3, sp = lane & 7u;
+  const v4f *__restrict__ Xm = reinterpret_cast<const v4f *>(a.X) + (size_t)m * (XLP_XS / 2u) + sp;
+  const size_t xrow = (size_t)M * (XLP_XS / 2u);  // v4f per branch row
+  v4f g[ROUNDS];
+  auto request = [&](const uint32_t pass) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < ROUNDS; ++q) {
+      const uint32_t b = 8u * (w + 4u * (uint32_t)q) + bb;
+      // (rows D .. Dpad - 1 of the image are zeros; beyond Dpad there is nothing to read)
+      g[q] = (w + 4u * (uint32_t)q < (uint32_t)NKB && b < a.D) ? Xm[((size_t)pass * a.Dpad + b) * xrow] : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  };
+  auto stage = [&](const uint32_t buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < ROUNDS; ++q) {
+      const uint32_t j = w + 4u * (uint32_t)q;
+      if (j < (uint32_t)NKB) {  // (wave-uniform)
+        _Float16 f1[4], f2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xlp_split_h(g[q][e] * XLP_H_XSCALE, f1[e], f2[e]);
+        // lane slot (h' = bb >> 2, row) of k-block j, dword bb & 3 of its 16 bytes
+        uint32_t *__restrict__ d1 = reinterpret_cast<uint32_t *>(&xs[buf][0][j][(bb >> 2) * 32u + 4u * sp]) + (bb & 3u);
+        uint32_t *__restrict__ d2 = reinterpret_cast<uint32_t *>(&xs[buf][1][j][(bb >> 2) * 32u + 4u * sp]) + (bb & 3u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {  // segment 2 sp + u: rows 4 sp + 2 u (re) and 4 sp + 2 u + 1 (im)
+          d1[(2 * u) * 4] = xlp_pack_h(f1[2 * u], f1[2 * u + 1]);
+          d1[(2 * u + 1) * 4] = xlp_pack_h(f1[2 * u + 1], -f1[2 * u]);
+          d2[(2 * u) * 4] = xlp_pack_h(f2[2 * u], f2[2 * u + 1]);
+          d2[(2 * u + 1) * 4] = xlp_pack_h(f2[2 * u + 1], -f2[2 * u]);
+        }
+      }
+    }
+  };
+  // ---- Y image [cg][segment][sub][bin][CW columns] (the inverse workgroups' tiles): this lane's column of segment s
+  const uint32_t CW = M == 256u ? 16u : 32u, NSUB = XLP_COLS / CW;
+  const uint32_t col = w * 32u + c;
+  v2f *__restrict__ Yc = reinterpret_cast<v2f *>(a.Y) +
+                         ((((size_t)cg * a.nseg_cap) * NSUB + col / CW) * M + m) * CW + col % CW;
+  const size_t ystride = (size_t)NSUB * M * CW;  // v2f per segment
+  request(p0);
+  for (uint32_t pass = p0; pass < p1; ++pass) {
+    const uint32_t buf = (pass - p0) & 1u;
+    stage(buf);
+    __syncthreads();
+    if (pass + 1u < p1) request(pass + 1u);
+    v16f32 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hi[i] = lo[i] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) {
+      const v8h a1 = __builtin_bit_cast(v8h, xs[buf][0][j][lane]);
+      const v8h a2 = __builtin_bit_cast(v8h, xs[buf][1][j][lane]);
+      lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, r1[j], lo, 0, 0, 0);
+      hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r1[j], hi, 0, 0, 0);
+      lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r2[j], lo, 0, 0, 0);
+    }
+    // rows of this lane: registers 4 q + 2 u + {0, 1} = (re, im) of the pass's segment 4 q + 2 h + u
+    const uint32_t s0 = pass * XLP_SEG;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t sl = 4u * (uint32_t)q + 2u * h + (uint32_t)u;
+        const v2f y = {(hi[4 * q + 2 * u] + lo[4 * q + 2 * u]) * cs, (hi[4 * q + 2 * u + 1] + lo[4 * q + 2 * u + 1]) * cs};
+        if (sl < XLP_SEG && s0 + sl < a.nseg) __builtin_nontemporal_store(y, &Yc[(size_t)(s0 + sl) * ystride]);
+      }
+    }
+  }
+  xlp_trace_work(a, t_begin);
+}
+
 // ------------------------------------------------------------------------------------------- inverse + epilogue
 // grid = nco_blocks + nseg * ncg * (128 / CW) workgroups of 256 threads; workgroup = (segment, CW columns), CW = 16
 // (M = 256: a wave runs its four columns' transforms interleaved) or 32 (M = 128: each half-wave runs four).  The tile
@@ -917,6 +1064,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // R[cg][m][b][col] = sum_{a<A} r'_col[D a + b] e^{+2 pi j a m / M}, r' = the column's taps delayed by its grid offset
 // (xl_grid.h), in double, rounded once.  For a LIST of columns (all of them when a class is built, the newcomers' when a
 // client joins): thread j of block (m, b) handles list entry j -- column colidx[j], taps rt[.][j], delay delta[j].
+// (sr, si) = R_b[m] of list entry j; `wc`, `ws`: e^{+2 pi j n / M} in double
+XL_DEV void xlp_branch_spectrum(const float2 *__restrict__ rt, const uint32_t nlist, const uint32_t j, const uint32_t dl,
+                                const uint32_t T, const uint32_t D, const uint32_t A, const uint32_t M, const uint32_t m,
+                                const uint32_t b, const double *wc, const double *ws, double &sr, double &si) {
+  sr = 0.0, si = 0.0;
+  if (b >= D) return;
+  for (uint32_t aa = 0; aa < A; ++aa) {  // the column's taps are delayed by dl samples: r'[i] = r[i - dl]
+    if (D * aa + b < dl) continue;
+    const uint32_t i = D * aa + b - dl;
+    if (i >= T) break;
+    const uint32_t n = (aa * m) & (M - 1u);
+    const double cs = wc[n], sn = ws[n];
+    const float2 tv = rt[(size_t)i * nlist + j];  // [tap][list entry]: coalesced across the entries of the block
+    const double tr = tv.x, ti = tv.y;
+    sr += tr * cs - ti * sn;
+    si += tr * sn + ti * cs;
+  }
+}
+
 __global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__restrict__ rt,
                                                               const uint32_t *__restrict__ delta,
                                                               const uint32_t *__restrict__ colidx, uint32_t nlist,
@@ -930,23 +1096,40 @@ __global__ __launch_bounds__(XLP_COLS) void xlp_tables_kernel(const float2 *__re
   const uint32_t j = blockIdx.y * XLP_COLS + threadIdx.x;
   if (j >= nlist) return;
   const uint32_t col = colidx[j];
-  double sr = 0.0, si = 0.0;
-  if (b < D) {
-    const uint32_t dl = delta[j];  // the column's taps are delayed by dl samples: r'[i] = r[i - dl]
-    for (uint32_t aa = 0; aa < A; ++aa) {
-      if (D * aa + b < dl) continue;
-      const uint32_t i = D * aa + b - dl;
-      if (i >= T) break;
-      const uint32_t n = (aa * m) & (M - 1u);
-      const double cs = wc[n], sn = ws[n];
-      const float2 tv = rt[(size_t)i * nlist + j];  // [tap][list entry]: coalesced across the entries of the block
-      const double tr = tv.x, ti = tv.y;
-      sr += tr * cs - ti * sn;
-      si += tr * sn + ti * cs;
-    }
-  }
+  double sr, si;
+  xlp_branch_spectrum(rt, nlist, j, delta[j], T, D, A, M, m, b, wc, ws, sr, si);
   const uint32_t cg = col / XLP_COLS, cl = col % XLP_COLS;
   R[(((size_t)cg * M + m) * Dpad + b) * XLP_COLS + cl] = make_float2((float)sr, (float)si);
+}
+
+// The same values in the matrix-core mix's operand form (xlp_mix_mfma_kernel): (R.re, -R.im) * scale[j] -- a power of two, so the
+// float32 value is the one above with another exponent -- as two halves each; branch b of column cl = 32 w + c lands in
+// dword b & 3 of lane slot (h = (b >> 2) & 1, c) of k-block b >> 3, once per term.  Grid: 8 nkb branches (those >= D: zeros).
+__global__ __launch_bounds__(XLP_COLS) void xlp_tables_h_kernel(const float2 *__restrict__ rt,
+                                                                const uint32_t *__restrict__ delta,
+                                                                const uint32_t *__restrict__ colidx,
+                                                                const float *__restrict__ scale, uint32_t nlist, uint32_t T,
+                                                                uint32_t D, uint32_t A, uint32_t M, uint32_t nkb,
+                                                                uint32_t *__restrict__ Rh) {
+  __shared__ double wc[256], ws[256];
+  for (uint32_t n = threadIdx.x; n < M; n += blockDim.x) sincospi(2.0 * (double)n / (double)M, &ws[n], &wc[n]);
+  __syncthreads();
+  const uint32_t m = blockIdx.x % M;
+  const uint32_t b = blockIdx.x / M;
+  const uint32_t j = blockIdx.y * XLP_COLS + threadIdx.x;
+  if (j >= nlist) return;
+  const uint32_t col = colidx[j];
+  double sr, si;
+  xlp_branch_spectrum(rt, nlist, j, delta[j], T, D, A, M, m, b, wc, ws, sr, si);
+  const float sc = scale[j];
+  _Float16 r1, r2, i1, i2;
+  xlp_split_h((float)sr * sc, r1, r2);
+  xlp_split_h(-(float)si * sc, i1, i2);
+  const uint32_t cg = col / XLP_COLS, cl = col % XLP_COLS;
+  const uint32_t w = cl >> 5, c = cl & 31u, kb = b >> 3, h = (b >> 2) & 1u;
+  const size_t slot0 = ((((size_t)cg * M + m) * 4u + w) * 2u * nkb + kb) * 64u + h * 32u + c;  // term 0; term 1: + nkb * 64
+  Rh[slot0 * 4u + (b & 3u)] = xlp_pack_h(r1, i1);
+  Rh[(slot0 + (size_t)nkb * 64u) * 4u + (b & 3u)] = xlp_pack_h(r2, i2);
 }
 
 // ------------------------------------------------------------------------------------------- launchers
@@ -957,6 +1140,15 @@ hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, const uint
   if (!xlp_valid_m(M) || nlist == 0u) return hipErrorInvalidValue;
   hipLaunchKernelGGL(xlp_tables_kernel, dim3(M * Dpad, (nlist + XLP_COLS - 1u) / XLP_COLS), dim3(XLP_COLS), 0, s, rt, delta, colidx,
                      nlist, T, D, Dpad, A, M, R);
+  return hipGetLastError();
+}
+
+hipError_t xlp_launch_tables_h(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, const float *scale,
+                               uint32_t nlist, uint32_t T, uint32_t D, uint32_t A, uint32_t M, uint32_t nkb, void *Rh,
+                               hipStream_t s) {
+  if (!xlp_valid_m(M) || nlist == 0u || nkb == 0u || nkb > XLP_NKB_MAX || D > 8u * nkb) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(xlp_tables_h_kernel, dim3(M * 8u * nkb, (nlist + XLP_COLS - 1u) / XLP_COLS), dim3(XLP_COLS), 0, s, rt, delta,
+                     colidx, scale, nlist, T, D, A, M, nkb, reinterpret_cast<uint32_t *>(Rh));
   return hipGetLastError();
 }
 
@@ -979,9 +1171,37 @@ static XlpArgs xlp_checked_skip(const XlpArgs &a, uint32_t work_blocks) {
   return b;
 }
 
+template <int NKB>
+static void xlp_launch_mix_mfma_n(const XlpArgs &a, const dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL(xlp_mix_mfma_kernel<NKB>, grid, dim3(256), 0, s, a);
+}
+
 hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
   const uint32_t passes = (a0.nseg + XLP_SEG - 1) / XLP_SEG;
+  if (a0.mix_kind == 1u) {
+    if (a0.nkb == 0u || a0.nkb > XLP_NKB_MAX || a0.D > 8u * a0.nkb || a0.Rh == nullptr || a0.cscale == nullptr ||
+        a0.fmt == XLF_CF32)
+      return hipErrorInvalidValue;
+    XlpArgs a = a0;
+    a.nco_skip = 0u;  // (the skipped positions are the one-wave kernel's device)
+    a.nco_skip_at = 0xFFFFFFFFu;
+    a.mix_passes = passes;
+    if (a.mix_pp == 0u) a.mix_pp = 4u;
+    const uint32_t runs = (passes + a.mix_pp - 1u) / a.mix_pp;
+    const dim3 grid(a.nco_blocks + a.M * a.ncg * runs);
+    switch (a.nkb) {
+      case 1: xlp_launch_mix_mfma_n<1>(a, grid, s); break;
+      case 2: xlp_launch_mix_mfma_n<2>(a, grid, s); break;
+      case 3: xlp_launch_mix_mfma_n<3>(a, grid, s); break;
+      case 4: xlp_launch_mix_mfma_n<4>(a, grid, s); break;
+      case 5: xlp_launch_mix_mfma_n<5>(a, grid, s); break;
+      case 6: xlp_launch_mix_mfma_n<6>(a, grid, s); break;
+      case 7: xlp_launch_mix_mfma_n<7>(a, grid, s); break;
+      default: xlp_launch_mix_mfma_n<8>(a, grid, s); break;
+    }
+    return hipGetLastError();
+  }
   const uint32_t work = a0.M * a0.ncg * passes;
   XlpArgs a = xlp_checked_skip(a0, work);
   a.mix_passes = passes;

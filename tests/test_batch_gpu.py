@@ -293,14 +293,18 @@ def test_1000_clients_split_group_riders():
 # that the oracle can check every client.
 # The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
 # the forced-path tests run with both.
-@pytest.fixture(params=[(128, 0), (128, 1), (128, 2), (128, 3), (256, 0)],
-                ids=["M128", "M128-register-inverse", "M128-quad-register-inverse", "M128-swizzled-inverse", "M256"])
+@pytest.fixture(params=[(128, 0, 1), (128, 1, 1), (128, 2, 1), (128, 3, 1), (256, 0, 1), (128, 3, 0), (256, 0, 0)],
+                ids=["M128", "M128-register-inverse", "M128-quad-register-inverse", "M128-swizzled-inverse", "M256",
+                     "M128-fma-mix", "M256-fma-mix"])
 def poly_m(request, monkeypatch):
     """Transform length of the forced polyphase plan; at M = 128 also with the inverse launch's transform in registers
-    (option "inverse_kernel" = 1: xlp_inverse_reg_kernel, a lane pair per column; 2: xlp_inverse_quad_kernel, a lane quad)."""
-    m, inv = request.param
+    (option "inverse_kernel" = 1: xlp_inverse_reg_kernel, a lane pair per column; 2: xlp_inverse_quad_kernel, a lane quad);
+    the mix launch on the matrix cores (option "mix_kernel" = 1, the default where the class allows it: integer input, D <= 64)
+    or as packed FP32 FMAs (0)."""
+    m, inv, mix = request.param
     monkeypatch.setenv("XL_EXP_POLY_M", str(m))
     monkeypatch.setenv("XL_EXP_INV", str(inv))
+    monkeypatch.setenv("XL_EXP_MIX", str(mix))
     return m
 
 
@@ -416,6 +420,36 @@ def test_polyphase_forced_other_shapes(shape, monkeypatch, poly_m):
     assert "polyphase: cls0 D%d T%d cols5" % (D, len(taps)) in eng.describe(), eng.describe()
     for xb in x:
         check_clients(eng, oracles, fmt, xb, "optimized")
+    eng.close()
+
+
+@pytest.mark.parametrize("m", [128, 256])
+def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, monkeypatch):
+    """The matrix-core mix carries every operand as two halves after a power-of-two scale (per column for the branch
+    spectra, fixed for the shared spectra): one class whose members' taps differ by 10^8 in gain (column scales 2^-2 ..
+    2^25), a one-tap-dominated and an asymmetric filter among them, on full-scale inputs (constant +127:
+    the largest possible spectrum value, 128 x sqrt 2 x M / 128; a full-scale square wave; noise) -- each client within the
+    same 1e-5 of ITS output scale as on the FP32 path."""
+    monkeypatch.setenv("XL_EXP_POLY_M", str(m))
+    monkeypatch.setenv("XL_EXP_MIX", "1")
+    base = np.asarray(lpf(FS, 24000, 9600), dtype=np.float32)
+    T = len(base)
+    spike = base.copy()
+    spike[T // 2] += np.float32(40.0)  # one huge tap: the bound of its branch dominates the column scale
+    asym = (base * np.linspace(0.2, 1.8, T).astype(np.float32)).astype(np.float32)
+    variants = [base * np.float32(g) for g in (1e-4, 1.0, 37.5, 3000.0, 1e4)] + [spike, asym]
+    eng = _poly_engine(monkeypatch)
+    oracles = {}
+    for c, taps in enumerate(variants):
+        for fc in (-600000 + 170000 * c, 250000 - 31000 * c):
+            t = [float(v) for v in taps]
+            oracles[eng.add_client(42, t, fc)] = Oracle(42, t, fc, FS, 262144)
+    assert "mix=mfma" in eng.describe(), eng.describe()
+    n = 262144
+    full = np.full(n, 255, dtype=np.uint8)
+    square = np.where((np.arange(n) // 2) % 84 < 42, 255, 0).astype(np.uint8)
+    for x in (full, square, siggen.xs_u8(5100, n), full):
+        check_clients(eng, oracles, "cu8", x, "optimized")
     eng.close()
 
 
@@ -748,11 +782,14 @@ def test_group_of_blocks_equals_successive_calls_direct(variant):
     eng.close()
 
 
-@pytest.mark.parametrize("m,inv", [(128, 0), (128, 1), (128, 2), (128, 3), (128, 4), (256, 0)])
-def test_group_of_blocks_polyphase(m, inv, monkeypatch):
+@pytest.mark.parametrize("m,inv,mix", [(128, 0, 1), (128, 1, 1), (128, 2, 1), (128, 3, 1), (128, 4, 1), (256, 0, 1),
+                                       (128, 3, 0), (256, 0, 0)])
+def test_group_of_blocks_polyphase(m, inv, mix, monkeypatch):
     """Forced polyphase path, G = 4 server-default blocks per call (108 segments at M = 128): every client vs the
-    oracle's four successive calls; a native group in between (shared history and phases); ragged group."""
+    oracle's four successive calls; a native group in between (shared history and phases); ragged group.  mix = 1: the mix
+    launch on the matrix cores (8 passes of 14 segments = two runs of 4 per workgroup), 0: packed FP32 FMAs."""
     monkeypatch.setenv("XL_EXP_INV", str(inv))
+    monkeypatch.setenv("XL_EXP_MIX", str(mix))
     t48 = lpf(FS, 24000, 9600)
     clients = [(42, t48, -900000 + 61000 * c) for c in range(30)]
     eng, oracles = _group_engine("cu8", 262144, 4, clients, poly=1, m=m)
@@ -1123,7 +1160,7 @@ def _engine_outputs(eng, ids):
 
 
 @pytest.mark.parametrize("variant", ["native", "optimized", "optimized-register-inverse", "optimized-quad-register-inverse",
-                                     "optimized-swizzled-inverse"])
+                                     "optimized-swizzled-inverse", "optimized-fma-mix"])
 def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
     server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
@@ -1133,6 +1170,9 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
 
     if variant.endswith("-inverse"):
         monkeypatch.setenv("XL_EXP_INV", "3" if "swizzled" in variant else ("2" if "quad" in variant else "1"))
+        variant = "optimized"
+    if variant.endswith("-fma-mix"):
+        monkeypatch.setenv("XL_EXP_MIX", "0")
         variant = "optimized"
     t48 = lpf(FS, 24000, 9600)
     G, nb = 8, 262144
@@ -1145,6 +1185,7 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     got = _engine_outputs(eng, ids)
     if variant == "optimized":
         assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
+        assert ("mix=fma" if os.environ.get("XL_EXP_MIX") == "0" else "mix=mfma") in eng.describe(), eng.describe()
     want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
     worst = 0.0
     for c in range(1024):
