@@ -201,6 +201,7 @@ struct xlating_batch_t {
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
   uint32_t poly_exp = 0;     // XL_TUNING builds: tuning switches of the mix kernel
   uint32_t poly_slice1 = 8000, poly_slice2 = 50000;  // NCO slice boundaries in 1/65536 of the call (forward | mix | inverse)
+  uint32_t poly_slice1_m = 8000, poly_slice2_m = 50000;  // ... of classes whose mix launch runs on the matrix cores (a shorter launch)
   std::vector<XlNcoClient> nco;
   size_t out_total = 0;
   uint64_t ncalls = 0;  // calls processed
@@ -436,6 +437,7 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     b->poly_slice1 = (uint32_t)((value >> 16) & 0xFFFF);
     b->poly_slice2 = (uint32_t)(value & 0xFFFF);
     if (b->poly_slice1 > b->poly_slice2) return -EINVAL;
+    b->poly_slice1_m = b->poly_slice1, b->poly_slice2_m = b->poly_slice2;
   } else {
     return -ENOENT;
   }
@@ -496,6 +498,7 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
   if (getenv("XL_EXP_NCO_SIDE")) (void)xlating_batch_set_option(b, "nco_side_stream", atol(getenv("XL_EXP_NCO_SIDE")));
   if (getenv("XL_EXP_CHAIN_CALLS")) (void)xlating_batch_set_option(b, "nco_calls_per_launch", atol(getenv("XL_EXP_CHAIN_CALLS")));
   if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
+  if (getenv("XL_EXP_POLY_SLICES_M")) (void)sscanf(getenv("XL_EXP_POLY_SLICES_M"), "%u,%u", &b->poly_slice1_m, &b->poly_slice2_m);
   if (getenv("XL_EXP_MIXSKIP")) b->mix_skip_at = (uint32_t)atoi(getenv("XL_EXP_MIXSKIP"));
   if (getenv("XL_EXP_INVSKIP")) b->inv_skip_at = (uint32_t)atoi(getenv("XL_EXP_INVSKIP"));
   if (getenv("XL_EXP_NCOPRIO")) b->nco_prio = (uint32_t)atoi(getenv("XL_EXP_NCOPRIO")) & 3u;
@@ -1778,6 +1781,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           // the NEXT call's phase recurrence rides in these three launches as three slices (a direct launch
           // above carries all of it if there is one)
           const bool carry = fuse && !nco_fused;
+          const uint32_t sl1 = pc.mix_kind == 1u ? b->poly_slice1_m : b->poly_slice1;
+          const uint32_t sl2 = pc.mix_kind == 1u ? b->poly_slice2_m : b->poly_slice2;
           if (carry) {
             pa.nco_clients = b->d_nco;
             pa.nco_nclients = (uint32_t)b->nco.size();
@@ -1785,7 +1790,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
             pa.nco_tab = b->d_phtab[xl_nx(tab)];
             pa.nco_prio = b->nco_prio;
             pa.nco_k0 = 0;
-            pa.nco_k1 = b->poly_slice1;
+            pa.nco_k1 = sl1;
             pa.nco_state_src = b->d_phase[pcur];
             pa.nco_state_dst = b->d_phase_run;
           }
@@ -1801,8 +1806,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           if (pe[1]) XL_TRY(hipEventRecord(pe[1], s));
           pa.roll_blocks = 0;
           if (carry) {
-            pa.nco_k0 = b->poly_slice1;
-            pa.nco_k1 = b->poly_slice2;
+            pa.nco_k0 = sl1;
+            pa.nco_k1 = sl2;
             pa.nco_state_src = b->d_phase_run;
             if (!(b->poly_exp & 16u)) {  // keep the second wave slot of the chain SIMDs empty (1024 SIMDs, round-robin deal)
               pa.nco_skip_at = b->mix_skip_at ? b->mix_skip_at : 1024;
@@ -1833,7 +1838,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           if (carry) {
             pa.nco_tab = b->d_phtab[xl_nx(tab)];
             pa.nco_blocks = (pa.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
-            pa.nco_k0 = b->poly_slice2;
+            pa.nco_k0 = sl2;
             pa.nco_k1 = 65536;
             if (b->inv_skip_at > 0) {
               pa.nco_skip_at = b->inv_skip_at;

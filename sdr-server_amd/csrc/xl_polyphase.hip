@@ -459,8 +459,16 @@ XL_DEV uint32_t xlp_pack_h(const _Float16 lo, const _Float16 hi) {
   return __builtin_bit_cast(uint32_t, p);
 }
 
+// Built for 4 waves per SIMD WITHOUT accumulation registers (124 VGPRs, the products land in VGPRs).  The unconstrained build
+// (128 VGPRs + 32 AGPRs, 3 waves per SIMD) did something no other kernel of this library has shown: when its launch carried
+// a slice of the NCO recurrence (one-block calls), the phases of lanes 48..63 of a random role wave came out wrong from some
+// step on -- 20 % of 1024 clients hit within 120 calls, deterministic in nothing but the lane quarter; the role's
+// instructions AND registers are identical in both builds, table stores as two 8-byte stores or followed by 16 wait states
+// changed nothing, the role behind a function call (168 registers) or this build never failed.  Unexplained; guarded by
+// tests/test_batch_gpu.py::test_matrix_core_mix_role_phases_bit_exact (two engines, FMA and matrix-core mix, all phases
+// bit-equal after every one of 120 calls).
 template <int NKB>
-__global__ __launch_bounds__(256) void xlp_mix_mfma_kernel(const XlpArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void xlp_mix_mfma_kernel(const XlpArgs a) {
   // A operands of one pass: [term][k-block][lane][8 halves]; two buffers (one barrier per pass: a buffer is rewritten two
   // barriers after it was read)
   __shared__ uint4 xs[2][2][NKB][64];
@@ -1187,7 +1195,9 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
     a.nco_skip = 0u;  // (the skipped positions are the one-wave kernel's device)
     a.nco_skip_at = 0xFFFFFFFFu;
     a.mix_passes = passes;
-    if (a.mix_pp == 0u) a.mix_pp = 4u;
+    // (all passes of an 8-block call in one workgroup: the operands are fetched once; A/B at 4096 clients, passes per
+    // workgroup 4 / 8 / 16: 42.5 / 38.5 / 34.8 us per block, at 1024 clients 10.3 / 9.3 / 10.0)
+    if (a.mix_pp == 0u) a.mix_pp = 16u;
     const uint32_t runs = (passes + a.mix_pp - 1u) / a.mix_pp;
     const dim3 grid(a.nco_blocks + a.M * a.ncg * runs);
     switch (a.nkb) {

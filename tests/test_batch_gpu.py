@@ -453,6 +453,32 @@ def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, monkeypatc
     eng.close()
 
 
+def test_matrix_core_mix_role_phases_bit_exact(monkeypatch):
+    """One-block calls: each of the three polyphase launches carries a slice of the NEXT call's NCO recurrence, the mix
+    launch the longest.  Two engines on the same stream of 120 blocks, one with the FMA mix, one with the matrix-core mix:
+    the committed phases of all 1024 clients agree bit for bit after every call (the recurrence does not depend on the mix
+    kernel -- a first build of xlp_mix_mfma_kernel corrupted a fifth of them within 120 calls, see its header)."""
+    t48 = lpf(FS, 24000, 9600)
+    engs = []
+    for mix in (0, 1):
+        monkeypatch.setenv("XL_EXP_MIX", str(mix))
+        e = xl.BatchEngine(FS, "cu8", 262144)
+        ids = [e.add_client(42, t48, -984000 + 1920 * c) for c in range(1024)]
+        engs.append((e, ids))
+    assert "mix=fma" in engs[0][0].describe() and "mix=mfma" in engs[1][0].describe()
+    for k in range(120):
+        x = siggen.xs_u8(7000 + k, 262144)
+        ph = []
+        for e, ids in engs:
+            e.process_host(x, "optimized")
+            e.sync()
+            ph.append(np.array([e.phase(i) for i in ids], dtype=np.float32))
+        bad = np.flatnonzero((ph[0].view(np.uint32) != ph[1].view(np.uint32)).any(axis=1))
+        assert len(bad) == 0, (k, bad[:32])
+    for e, _ in engs:
+        e.close()
+
+
 def test_polyphase_class_next_to_direct_classes():
     """The size rule at work inside one engine: 200 x 48 kHz clients (505 taps) take the polyphase path, 9 x 96 kHz
     clients (253 taps, too few for it) stay on the direct kernel, whose launch then carries the NCO role for ALL
