@@ -62,6 +62,7 @@ BLOCKS_PER_STEP = 1920          # blocks per bench step (240 calls): 20 steps ~ 
 REPEATS = 3                     # the timed region is repeated; value = the median repeat
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
+MFMA_F16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16 / F16 MFMA peak
 TIMING_STRIDE = 5               # HIP events bracket every 5th call of the timed region (an event pair costs ~6 us of stream time; odd, so that both calls of a chain launch's pair are sampled)
 PMC_REPLAY_CALLS = 12           # calls of the counter passes (rocprofv3 serialises the dispatches; the first 3 per kernel are dropped)
 
@@ -417,7 +418,8 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
         n3, ms3 = eng.timing_polyphase(reset=True)
         eng.timing(False)
         if n3 > 0:
-            kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), "xlp_mix_kernel": round(ms3[1] / n3, 4),
+            mix_name = "xlp_mix_mfma_kernel" if "mix=mfma" in plan else "xlp_mix_kernel"
+            kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), mix_name: round(ms3[1] / n3, 4),
                           "xlp_inverse_kernel": round(ms3[2] / n3, 4)}
     feed_name = host.name
     host.close()
@@ -514,7 +516,7 @@ def cpu_baseline(ntaps_rate, seconds=12.0):
     }
 
 
-def polyphase_traffic_model(nclients, K_call, ntaps, group, M=128):
+def polyphase_traffic_model(nclients, K_call, ntaps, group, M=128, mfma=True):
     """HBM bytes one CALL of `group` blocks moves by design on the polyphase path (xl_polyphase.h), per GPU: branch
     spectra R read once per call (8 D M bytes per client), mixed spectra Y written and read back (8 M bytes per client
     and segment), outputs written, NCO phase table (every 16th phase) written and read; the shared spectra X and the
@@ -522,7 +524,8 @@ def polyphase_traffic_model(nclients, K_call, ntaps, group, M=128):
     A = -(-ntaps // D)
     V = M - A + 1
     nseg = -(-(K_call + 2) // V)
-    dpad = -(-D // 7) * 7
+    # (packed-FMA mix: float2 per branch padded to a multiple of 6; matrix-core mix: two halves per component, 8 branches per k-block)
+    dpad = -(-D // 8) * 8 if mfma else -(-D // 6) * 6
     per_client = 8 * dpad * M + 2 * 8 * M * nseg + 8 * K_call + 2 * 8 * (K_call // 16)
     return {"transform_length_M": M, "blocks_per_call": group, "bytes_per_call": int(nclients * per_client),
             "bytes_per_block": int(nclients * per_client / group), "bytes_per_client_per_block": int(per_client / group),
@@ -791,7 +794,7 @@ def main():
     if m["polyphase"]:
         import re
         mm = re.search(r"polyphase: cls0 .*? M(\d+)", m["plan"])
-        tm = polyphase_traffic_model(nloc, m["K_call"], m["ntaps"], m["group"], int(mm.group(1)) if mm else 256)
+        tm = polyphase_traffic_model(nloc, m["K_call"], m["ntaps"], m["group"], int(mm.group(1)) if mm else 256, mfma="mix=mfma" in m["plan"])
     phys_bytes = traffic if traffic else (tm["bytes_per_call"] if tm else None)
     ach = phys_bytes / call_s / 1e9 if phys_bytes and call_s > 0 else 0.0
     roofline = {
@@ -822,26 +825,36 @@ def main():
         nseg = -(-(m["K_call"] + 2) // (M - A + 1))
         lg = 7 if M == 128 else 8
         flops = {"xlp_forward_kernel": 5.0 * M * lg * D * nseg, "xlp_mix_kernel": 8.0 * nloc * nseg * M * D,
+                 "xlp_mix_mfma_kernel": 8.0 * nloc * nseg * M * D,
                  "xlp_inverse_kernel": nloc * nseg * (5.0 * M * lg + 8.0 * (M - A + 1))}
+        # matrix-core mix: half-precision flops the launch EXECUTES = 3 products x (32 rows x 32 columns x 16 k x 2) per k-block of
+        # 8 branches, per (bin, 32 columns, pass of 14 segments in 32 rows)
+        mfma_flops = 3.0 * 32 * 32 * 16 * 2 * -(-D // 8) * M * -(-nloc // 32) * -(-nseg // 14)
         binding = {"xlp_forward_kernel": "latency (a few % of the call; shared by all clients)",
                    "xlp_mix_kernel": "fp32 vector issue: 2 packed FMAs per complex MAC, D per (client, bin, segment)",
+                   "xlp_mix_mfma_kernel": "hbm (writes the mixed spectra once, reads the operand-form branch spectra once); the products run on the "
+                                          "matrix cores as two-term half-precision splits (3 v_mfma_f32_32x32x16_f16 per 8 branches)",
                    "xlp_inverse_kernel": "hbm (reads the mixed spectra, writes the outputs)"}
         pk = {}
         trace_ms = {k: v.get("ms_per_dispatch_kernel_trace") for k, v in (pmc["per_kernel"] if pmc else {}).items()}
         for kname, ms_ev in (m["kernels_ms"] or {}).items():
-            b = next((v for k, v in per_kernel_bytes.items() if k.startswith(kname)), None)
-            ms_k = next((v for k, v in trace_ms.items() if k.startswith(kname) and v), None) or ms_ev
+            kpre = kname[:-len("_kernel")]  # (the trace prints template arguments after the name)
+            b = next((v for k, v in per_kernel_bytes.items() if k.startswith(kpre) and ("mfma" in k) == ("mfma" in kname)), None)
+            ms_k = next((v for k, v in trace_ms.items() if k.startswith(kpre) and ("mfma" in k) == ("mfma" in kname) and v), None) or ms_ev
             pk[kname] = {"ms": ms_k, "ms_source": "rocprofv3 --kernel-trace, this run" if ms_k is not ms_ev else "HIP events around the launch",
                          "ms_hip_events": ms_ev, "hbm_bytes": b,
                          "frac_hbm": round(b / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b and ms_k else None,
                          "frac_fp32": round(flops[kname] / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if ms_k else None,
                          "binding": binding[kname]}
+            if kname == "xlp_mix_mfma_kernel" and ms_k:
+                pk[kname]["frac_fp32_note"] = "FP32-equivalent flops (8 per complex MAC) over the FP32 vector peak: what the packed-FMA kernel would need"
+                pk[kname]["frac_mfma_f16"] = round(mfma_flops / (ms_k * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
         chain = next((v for k, v in per_kernel_bytes.items() if k.startswith("xl_nco_chain")), None)
         if chain is not None:
             pk["xl_nco_chain_kernel"] = {"ms": next((v for k, v in trace_ms.items() if k.startswith("xl_nco_chain") and v), None), "hbm_bytes": chain, "binding": "a dependent float32 recurrence on a side stream (reserved CUs), "
                                          "concurrent with the three launches; bounds the engine below ~1500 clients",
                                          "note": "bytes per CALL, ms per LAUNCH (one launch tabulates the phase tables of four calls)"}
-        roofline["kernel"] = ("xlp_forward_kernel + xlp_mix_kernel + xlp_inverse_kernel: the three launches of one call on the polyphase "
+        roofline["kernel"] = ("xlp_forward_kernel + " + ("xlp_mix_mfma_kernel" if "mix=mfma" in m["plan"] else "xlp_mix_kernel") + " + xlp_inverse_kernel: the three launches of one call on the polyphase "
                               "overlap-save path (the next call's NCO phase recurrence runs beside them on a side stream)")
         roofline["per_kernel"] = pk
         roofline["per_kernel_note"] = ("ms: the kernel's own duration from a rocprofv3 --kernel-trace pass of this run (ms_hip_events: event pairs around "

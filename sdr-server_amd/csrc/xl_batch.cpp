@@ -201,7 +201,7 @@ struct xlating_batch_t {
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
   uint32_t poly_exp = 0;     // XL_TUNING builds: tuning switches of the mix kernel
   uint32_t poly_slice1 = 8000, poly_slice2 = 50000;  // NCO slice boundaries in 1/65536 of the call (forward | mix | inverse)
-  uint32_t poly_slice1_m = 8000, poly_slice2_m = 50000;  // ... of classes whose mix launch runs on the matrix cores (a shorter launch)
+  uint32_t poly_slice1_m = 6000, poly_slice2_m = 35000;  // ... of classes whose mix launch runs on the matrix cores (a shorter launch)
   std::vector<XlNcoClient> nco;
   size_t out_total = 0;
   uint64_t ncalls = 0;  // calls processed
