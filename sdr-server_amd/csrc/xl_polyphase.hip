@@ -540,12 +540,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   v2f *__restrict__ Yc = reinterpret_cast<v2f *>(a.Y) +
                          ((((size_t)cg * a.nseg_cap) * NSUB + col / CW) * M + m) * CW + col % CW;
   const size_t ystride = (size_t)NSUB * M * CW;  // v2f per segment
+  // Software pipeline: the rows of pass p + 1 are converted into the other buffer AFTER pass p's products and BEFORE its stores
+  // -- the wait for those rows (vmcnt counts loads and stores alike, and the two complete out of order: the only safe wait is
+  // "all") then finds nothing younger than the stores of pass p - 1, a whole pass old.  Waiting with pass p's stores just
+  // issued made every pass sit out a write latency.
   request(p0);
+  stage(0u);
+  if (p0 + 1u < p1) request(p0 + 1u);
+  __syncthreads();
   for (uint32_t pass = p0; pass < p1; ++pass) {
     const uint32_t buf = (pass - p0) & 1u;
-    stage(buf);
-    __syncthreads();
-    if (pass + 1u < p1) request(pass + 1u);
     v16f32 hi, lo;
 #pragma unroll
     for (int i = 0; i < 16; ++i) hi[i] = lo[i] = 0.0f;
@@ -557,6 +561,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r1[j], hi, 0, 0, 0);
       lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r2[j], lo, 0, 0, 0);
     }
+    if (pass + 1u < p1) stage(buf ^ 1u);
+    if (pass + 2u < p1) request(pass + 2u);
     // rows of this lane: registers 4 q + 2 u + {0, 1} = (re, im) of the pass's segment 4 q + 2 h + u
     const uint32_t s0 = pass * XLP_SEG;
 #pragma unroll
@@ -568,6 +574,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (sl < XLP_SEG && s0 + sl < a.nseg) __builtin_nontemporal_store(y, &Yc[(size_t)(s0 + sl) * ystride]);
       }
     }
+    __syncthreads();  // the other buffer is staged; everybody is done with this one
   }
   xlp_trace_work(a, t_begin);
 }
