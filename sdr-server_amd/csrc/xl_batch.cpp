@@ -95,6 +95,8 @@ struct Launch {
 // A class of clients evaluated by the polyphase overlap-save path (xl_polyphase.hip) in optimized mode: all mature
 // clients of one (D, T), whatever their grid offsets -- or clients of one (D, T) that joined together and are still
 // inside their zero history (one grid, one zero_below).
+#define XL_SIDE_ONE_BLOCK_MAX 2048u  // one-block polyphase calls: side-stream chain kernel up to this many clients
+
 struct PolyClass {
   uint32_t D = 0, Dpad = 0, T = 0, A = 0, V = 0;
   uint32_t M = 256;          // transform length (128 or 256), V = M - A + 1
@@ -1272,7 +1274,9 @@ static int xl_batch_plan(xlating_batch *b) {
     for (const DirectClass &cs : b->classes) b->macs_all += (double)cs.members.size() * cs.T / cs.D;
     for (const DirectClass &cs : b->classes_rest) b->macs_rest += (double)cs.members.size() * cs.T / cs.D;
     const bool light = xl_direct_is_light(b->macs_all * b->max_samples) || (!b->poly.empty() && xl_direct_is_light(b->macs_rest * b->max_samples));
-    uint32_t want = (b->gcap >= 2 && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? (nwg + 7u) / 8u : 0u;
+    // (one-block calls of a polyphase plan take the side stream too, up to XL_SIDE_ONE_BLOCK_MAX clients: see side_call)
+    const bool one_block_side = !b->poly.empty() && b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX;
+    uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? (nwg + 7u) / 8u : 0u;
     if (want > 16u) want = 0u;  // (more than half the chip for the chain: such engines are bound by the filtering anyway)
     if (getenv("XL_EXP_NOMASK")) want = 0u;
     // (creating a masked stream pair takes ~25 ms: grow at once, shrink only when two CUs per XCD too many are held, so that
@@ -1472,7 +1476,12 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     if (rc != 0) return rc;
   }
   const bool light = xl_direct_is_light((use_poly ? b->macs_rest : b->macs_all) * (double)S);
-  const bool side_call = mode != XL_MODE_Q15 && (b->nco_side > 0 || (b->nco_side < 0 && G >= 2 && (use_poly || (light && b->cs_masked && s == XL_STREAM_ENGINE_P))));  // (a caller's own, unmasked stream would keep filling the chain's CUs)
+  // One-block calls (the reference's call granularity) on the polyphase path: the three launches are short since the mix runs on
+  // the matrix cores, and a slice of the recurrence inside each made every one of them last as long as its slice (1024 clients:
+  // 50.2 us per block; the chain kernel beside them, four calls per launch: 47.7; 128 clients: 40.4 -> 29.2; 4096: 129 -> 134,
+  // hence the limit)
+  const bool one_block_side = G == 1 && use_poly && b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX;
+  const bool side_call = mode != XL_MODE_Q15 && (b->nco_side > 0 || (b->nco_side < 0 && (G >= 2 || one_block_side) && (use_poly || (light && b->cs_masked && s == XL_STREAM_ENGINE_P))));  // (a caller's own, unmasked stream would keep filling the chain's CUs)
   if (s == XL_STREAM_ENGINE_P) s = (side_call && b->cs_masked) ? b->cs_masked : b->own_stream;
   // Calls depend on each other through the engine's device state (history, phases, tables): a call on another
   // stream than the previous one is ordered behind it.

@@ -463,6 +463,7 @@ def test_matrix_core_mix_role_phases_bit_exact(monkeypatch):
     for mix in (0, 1):
         monkeypatch.setenv("XL_EXP_MIX", str(mix))
         e = xl.BatchEngine(FS, "cu8", 262144)
+        e.set_option("nco_side_stream", 0)  # the recurrence inside the launches (one-block calls default to the side stream now)
         ids = [e.add_client(42, t48, -984000 + 1920 * c) for c in range(1024)]
         engs.append((e, ids))
     assert "mix=fma" in engs[0][0].describe() and "mix=mfma" in engs[1][0].describe()
@@ -503,6 +504,8 @@ def test_polyphase_100_block_drift(monkeypatch, poly_m):
     block of 8 clients against the oracle, plus the committed phases at the end."""
     taps = lpf(FS, 24000, 9600)
     eng = _poly_engine(monkeypatch)
+    if os.environ.get("XL_EXP_INV") == "0":  # (fixtures "M128", "M256", "M256-fma-mix": the recurrence inside the launches, as three
+        eng.set_option("nco_side_stream", 0)  # slices per block; the others: on the side stream, the default for these calls now)
     oracles = {}
     for c in range(8):
         fc = -800000 + c * 213000 + 17
@@ -946,11 +949,11 @@ def test_set_option_and_unknown_option():
     eng.close()
 
 
-@pytest.mark.parametrize("side,G", [(1, 1), (0, 4), (1, 3)])
+@pytest.mark.parametrize("side,G", [(1, 1), (0, 1), (0, 4), (1, 3)])
 @pytest.mark.parametrize("poly", [0, 1])
 def test_nco_tabulation_side_stream_or_inside_the_launches(side, G, poly):
     """The next call's phase table comes either from the NCO role inside the launches or from xl_nco_chain_kernel on
-    the side stream (default for calls of >= 2 blocks): both forced here for both call shapes, native bit-exact incl.
+    the side stream (default for calls of >= 2 blocks and for one-block polyphase calls): both forced here for both call shapes, native bit-exact incl.
     the committed phases, a shape change in between (the look-ahead table is dropped and redone)."""
     t48 = lpf(FS, 24000, 9600)
     clients = [(42, t48, -700000 + 47000 * c) for c in range(70)]
