@@ -70,13 +70,20 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *   "polyphase_m"           0 by the size rule, 128, 256: its transform length
  *   "polyphase_min_clients" smallest class that takes it under the size rule (default 128)
  *   "riders" 0/1, "riders_min_workgroups" n, "tile_height" 0/8/9/10/12, "nco_slices" (a << 16 | b): launch shaping
- *   "nco_side_stream"       -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light), 0 never, 1
+ *   "nco_side_stream"       -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light, and one-block
+ *                           polyphase calls of up to 2048 clients), 0 never, 1
  *                           always: the NCO phase recurrence of the following calls runs as a kernel of its own on a side
  *                           stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE)
  *   "nco_calls_per_launch"  1..4 (default 4): calls of the same shape one such kernel tabulates ahead
  *   "inverse_kernel"        128-point polyphase classes: the inverse launch's transform -- staged in LDS on padded rows (0),
  *                           on dense XOR-swizzled rows (3, default; 4: built for five workgroups per CU), or in the registers
  *                           of a lane pair (1) / lane quad (2) per client column with one LDS pass for the stores
+ *   "mix_kernel"            polyphase classes: the mix launch (spectra x branch spectra, summed over the branches) on the matrix
+ *                           cores (1, default: every float32 operand as two halves, three v_mfma_f32_32x32x16_f16 per 8
+ *                           branches, FP32 accumulation; classes of an integer input format with decimation <= 64) or as
+ *                           packed FP32 FMAs (0; always for cf32 input and decimation > 64).  Same 1e-5 bar either way
+ *   "mix_passes_per_workgroup"  matrix-core mix: passes of 14 segments one workgroup runs with its operands in registers
+ *                           (0 = default 16; a launch parameter, no re-plan)
  * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call. */
 int xlating_batch_set_option(xlating_batch *batch, const char *name, long value);
 
