@@ -17,7 +17,8 @@
 //
 // DFT_M(x_b) is shared by ALL clients of the class (D transforms per segment, whatever the client count) and the
 // per-client work is D complex MACs per spectrum bin plus one inverse transform per segment: ~45 complex MACs per
-// output instead of T (= 505 at the server default).  The NCO derotation (exact float32 recurrence table) and the
+// output instead of T (= 505 at the server default) -- and those MACs are a matrix product per bin (clients x branches x
+// segments), which runs on the matrix cores with two-half operands where the input format bounds the spectra.  The NCO derotation (exact float32 recurrence table) and the
 // streaming rules (global output grid, history, late joiners) are those of the direct kernels.
 // Measured against the oracle: max|d|/max|y| <= 1e-6, which is the reference's own float32 summation noise (an
 // all-double evaluation of the same operator differs from the reference by the same amount).

@@ -4,7 +4,10 @@
 // Three launches per call and class (stream order is the only synchronisation):
 //   xlp_forward_kernel  one workgroup per (pass of 14 segments, branch): raw samples -> cf32 (xlating.c:357-378, exact)
 //                       -> M-point DFT of the branch per segment -> shared spectra X[pass][b][m][s], stored as whole rows.
-//   xlp_mix_kernel      Y[c][s][m] = sum_b X[s][b][m] * R[c][b][m].  lane = two client columns, the bin m is
+//   xlp_mix_mfma_kernel Y[c][s][m] = sum_b X[s][b][m] * R[c][b][m] on the matrix cores: one real matrix product per bin m (rows =
+//                       (segment, re / im), columns = clients, k = (branch, re / im)) with every float32 operand carried as two
+//                       halves, v_mfma_f32_32x32x16_f16, FP32 accumulation.  Integer input formats, D <= 64 (the default there).
+//   xlp_mix_kernel      the same sums as packed FP32 FMAs (cf32 input, D > 64, option): lane = two client columns, the bin m is
 //                       workgroup-uniform: its rows of X arrive through the scalar cache as SGPR operands of the FMAs,
 //                       R is streamed coalesced (16 bytes per lane and branch): 8 * D * M bytes per client and call.
 //   xlp_inverse_kernel  per (segment, 16 or 32 columns): Y tile -> LDS (transposed) -> M-point inverse DFT per column
