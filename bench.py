@@ -886,6 +886,10 @@ def main():
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
+        "dtype_note": ("float32 in, float32 out, float32 accumulation everywhere; on the polyphase path the per-client sums (mix launch) "
+                       "multiply float32 operands carried as two half-precision terms each (products exact in float32, 2^-22 per product "
+                       "dropped: as accurate as the float32 FMA chain, tests/test_mix_split_model.py) -- not a reduced-precision run: "
+                       "parity_spot holds every client to the 1e-5 bar against the float32 reference") if (m["polyphase"] and "mix=mfma" in m["plan"]) else "float32 throughout",
         "data": "synthetic" if cuda else "cpu-plumbing-test",
         "repeats": {"n": len(rep_ms), "ms_per_step": rep_ms, "min": min(rep_ms), "median": sorted(rep_ms)[len(rep_ms) // 2], "max": max(rep_ms),
                     "value_is": "the median repeat; each repeat = exactly `steps` steps between barrier + synchronize, max over ranks",

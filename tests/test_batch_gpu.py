@@ -453,6 +453,31 @@ def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, monkeypatc
     eng.close()
 
 
+@pytest.mark.parametrize("D,fs", [(12, 576000), (33, 1584000), (50, 2400000), (64, 3072000)])
+def test_polyphase_matrix_core_mix_other_branch_counts(D, fs, monkeypatch):
+    """The matrix-core mix is built per number of k-blocks of 8 branches (1..8): the server default is 6 (D = 42), the
+    fixture shapes cover 1 (D = 5) and 3 (D = 21); here 2, 5, 7 and 8 (the last two keep a few operand registers in
+    scratch) -- 48 kHz clients off other sample rates, 12 taps per branch, both transform lengths by the size rule's
+    forcing, every client vs the oracle."""
+    monkeypatch.setenv("XL_EXP_MIX", "1")
+    taps = lpf(fs, 24000, fs // 210)
+    assert len(taps) >= 9 * D // 2
+    n = 131072
+    for m in (128, 256):
+        monkeypatch.setenv("XL_EXP_POLY_M", str(m))
+        eng = _poly_engine(monkeypatch, max_input=2 * n, fs=fs)
+        oracles = {}
+        for c in range(37):
+            fc = int(-0.4 * fs + c * 0.021 * fs)
+            oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, fs, 2 * n)
+        assert "mix=mfma" in eng.describe() and " M%d " % m in eng.describe(), eng.describe()
+        for k in range(3):
+            check_clients(eng, oracles, "cu8", siggen.xs_u8(5300 + k, 2 * n if k != 1 else 2 * n - 1234), "optimized")
+        eng.close()
+        for o in oracles.values():
+            o.close()
+
+
 def test_matrix_core_mix_role_phases_bit_exact(monkeypatch):
     """One-block calls: each of the three polyphase launches carries a slice of the NEXT call's NCO recurrence, the mix
     launch the longest.  Two engines on the same stream of 120 blocks, one with the FMA mix, one with the matrix-core mix:
