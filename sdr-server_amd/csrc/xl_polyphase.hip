@@ -467,7 +467,9 @@ XL_DEV uint32_t xlp_pack_h(const _Float16 lo, const _Float16 hi) {
 // a slice of the NCO recurrence (one-block calls), the phases of lanes 48..63 of a random role wave came out wrong from some
 // step on -- 20 % of 1024 clients hit within 120 calls, deterministic in nothing but the lane quarter; the role's
 // instructions AND registers are identical in both builds, table stores as two 8-byte stores or followed by 16 wait states
-// changed nothing, the role behind a function call (168 registers) or this build never failed.  Unexplained; guarded by
+// changed nothing, the role behind a function call (168 registers) or this build never failed -- and neither did the
+// unconstrained build of the LATER, software-pipelined loop below (156 registers, 32 of them AGPRs): the trigger sits in the
+// first build's work waves' instruction stream (git 7991f21), not in AGPR use as such.  Unexplained; guarded by
 // tests/test_batch_gpu.py::test_matrix_core_mix_role_phases_bit_exact (two engines, FMA and matrix-core mix, all phases
 // bit-equal after every one of 120 calls).
 template <int NKB>
