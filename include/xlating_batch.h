@@ -68,7 +68,8 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *   "polyphase"             -1 by the size rule (default), 0 never, 1 whenever the shape allows: which classes take the
  *                           polyphase overlap-save path in XL_MODE_OPTIMIZED
  *   "polyphase_m"           0 by the size rule, 128, 256: its transform length
- *   "polyphase_min_clients" smallest class that takes it under the size rule (default 128)
+ *   "polyphase_min_clients" smallest class that takes it under the size rule (default: 32 where the class's mix launch runs
+ *                           on the matrix cores -- see "mix_kernel" --, 128 elsewhere; a given value holds for every class)
  *   "riders" 0/1, "riders_min_workgroups" n, "tile_height" 0/8/9/10/12, "nco_slices" (a << 16 | b): launch shaping
  *   "nco_side_stream"       -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light, and one-block
  *                           polyphase calls of up to 2048 clients), 0 never, 1

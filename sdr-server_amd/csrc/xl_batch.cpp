@@ -190,6 +190,7 @@ struct xlating_batch_t {
   float2 *d_phase_run = nullptr;     // running phases between the NCO slices of a call
   size_t phase_run_cap = 0;
   int poly_mode = -1;        // option "polyphase": 0 never, 1 whenever the shape allows, -1 (default) by the size rule
+  bool poly_min_set = false;        // "polyphase_min_clients" was given: it holds for every class (else 32 where the mix runs on the matrix cores)
   uint32_t poly_min_clients = 128;  // measured at 505 taps, D = 42: x1.10 at 128 clients, x0.96 at 64 (profiles/r01_polyphase_vs_direct.txt)
   uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
   uint32_t inv_reg = 3;       // option "inverse_kernel", M = 128 classes: 0 = LDS transform on padded rows (round 2), 3 = on dense rows with an XOR
@@ -422,6 +423,7 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
   } else if (n == "polyphase_min_clients") {
     if (value < 1) return -EINVAL;
     b->poly_min_clients = (uint32_t)value;
+    b->poly_min_set = true;
   } else if (n == "riders") {
     b->riders = value != 0;
   } else if (n == "riders_min_workgroups") {
@@ -1140,7 +1142,13 @@ static int xl_batch_plan(xlating_batch *b) {
       const uint32_t A = (T + dmax + D - 1) / D;
       const uint32_t M = xl_poly_pick_m(b, A, m.size());
       const bool fits = A >= 2 && A <= M / 2 && D <= 504;  // (the mix kernel stages D rows of 128 bytes in <= 64 KB of LDS)
-      const bool pays = m.size() >= b->poly_min_clients && 2 * T >= 9 * D;  // crossover ~4.5 taps per branch
+      // crossover, packed-FMA mix: ~4.5 taps per branch and 128 clients (x1.10 at 128, x0.96 at 64).  With the mix on the matrix
+      // cores the path costs the same whatever the filter length and little beside the recurrence in small classes (A/B at
+      // 8 blocks per call, direct kernel -> polyphase, us per block: 101 taps 37.3 -> 28.2 at 1024 clients, 124.8 -> 88.7 at
+      // 4096, 23.3 -> 22.9 at 128; 505 taps 24.8 -> 22.9 at 96 clients, 23.1 -> 22.7 at 32): 2 taps per branch, 32 clients
+      const bool mfma_class = xl_poly_mix_kind(b, D) == 1u;
+      const size_t min_clients = (mfma_class && !b->poly_min_set) ? 32u : b->poly_min_clients;
+      const bool pays = m.size() >= min_clients && (mfma_class ? T >= 2 * D : 2 * T >= 9 * D);
       if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
       PolyClass pc;
       Pending pd;
