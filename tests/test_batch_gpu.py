@@ -478,6 +478,38 @@ def test_polyphase_matrix_core_mix_other_branch_counts(D, fs, monkeypatch):
             o.close()
 
 
+def test_size_rule_of_matrix_core_classes():
+    """The engine's own plan (no forcing): classes whose mix launch runs on the matrix cores take the polyphase path from 32
+    clients and 2 taps per branch on (101 taps at D = 42: 3 per branch), cf32 streams keep round 1's rule (128 clients, 4.5
+    taps per branch), a given "polyphase_min_clients" holds for every class -- and the 101-tap class matches the oracle."""
+    t101 = lpf(FS, 24000, 48000)
+    assert len(t101) == 101
+    eng = xl.BatchEngine(FS, "cu8", 262144, group_blocks=2)
+    oracles = {}
+    for c in range(40):
+        fc = -800000 + 41000 * c
+        oracles[eng.add_client(42, t101, fc)] = Oracle(42, t101, fc, FS, 262144)
+    for c in range(20):  # (a class of 20: below the rule)
+        fc = -300000 + 29000 * c
+        oracles[eng.add_client(21, lpf(FS, 48000, 19200), fc)] = Oracle(21, lpf(FS, 48000, 19200), fc, FS, 262144)
+    for k in range(3):
+        x = siggen.xs_u8(5400 + k, 2 * 262144)
+        _check_group(eng, oracles, "cu8", x, 2, "optimized")
+    d = eng.describe()
+    assert "polyphase: cls0 D42 T101 cols40 " in d and "mix=mfma" in d and "cls1" not in d and "optimized-mode direct: h" in d, d
+    eng.set_option("polyphase_min_clients", 64)
+    _check_group(eng, oracles, "cu8", siggen.xs_u8(5410, 2 * 262144), 2, "optimized")
+    assert "polyphase: none" in eng.describe(), eng.describe()
+    eng.close()
+    eng = xl.BatchEngine(FS, "cf32", 8 * 65536)
+    taps = lpf(FS, 24000, 9600)
+    for c in range(40):
+        eng.add_client(42, taps, -800000 + 41000 * c)
+    eng.process_host((siggen.xs_s16(5420, 2 * 65536).astype(np.float32) / np.float32(32768)).astype(np.float32), "optimized")
+    assert "polyphase: none" in eng.describe(), eng.describe()
+    eng.close()
+
+
 def test_matrix_core_mix_role_phases_bit_exact(monkeypatch):
     """One-block calls: each of the three polyphase launches carries a slice of the NEXT call's NCO recurrence, the mix
     launch the longest.  Two engines on the same stream of 120 blocks, one with the FMA mix, one with the matrix-core mix:
