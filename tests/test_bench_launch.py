@@ -25,7 +25,7 @@ def _run(extra, env_extra=None, timeout=300):
 
 
 def test_self_launch_two_ranks_strong_scaling():
-    j = _run(["--gpus", "2"])
+    j = _run(["--gpus", "2", "--scaling", "strong"])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1
     assert j["scaling"] == "strong" and j["config"]["clients_total"] == 1024  # BASELINE configs[3]: 1024 clients in total
     assert j["config"]["rccl_ranks"] == 2
@@ -40,7 +40,7 @@ def test_self_launch_two_ranks_strong_scaling():
 
 
 def test_self_launch_weak_scaling_and_single_rank():
-    j = _run(["--gpus", "2", "--scaling", "weak", "--clients", "64"])
+    j = _run(["--gpus", "2", "--clients", "64"])  # (weak scaling is the default: 64 clients per GPU)
     assert j["scaling"] == "weak" and j["config"]["clients_total"] == 128
     j1 = _run(["--gpus", "1", "--clients", "64"])
     assert j1["n_gpus"] == 1 and j1["config"]["clients_total"] == 64 and j1["config"]["parallelism"] == "single GPU"
