@@ -18,6 +18,7 @@
 
 #include "xl_dev_inline.h"
 #include "xl_fft64.h"
+#include "xl_mix_layout.h"
 
 #include <hip/hip_ext.h>
 
@@ -494,47 +495,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const uint32_t p0 = run * pp, p1 = p0 + pp < a.mix_passes ? p0 + pp : a.mix_passes;
   if (p0 >= p1) return;
   // ---- B operands of this wave: 2 NKB runs of 1 KB
-  const uint4 *__restrict__ Rp =
-      reinterpret_cast<const uint4 *>(a.Rh) + ((((size_t)cg * M + m) * 4u + w) * 2u * NKB) * 64u + lane;
+  const uint4 *__restrict__ Rp = reinterpret_cast<const uint4 *>(a.Rh);
   v8h r1[NKB], r2[NKB];
 #pragma unroll
   for (int j = 0; j < NKB; ++j) {
-    r1[j] = __builtin_bit_cast(v8h, Rp[(size_t)j * 64u]);
-    r2[j] = __builtin_bit_cast(v8h, Rp[(size_t)(NKB + j) * 64u]);
+    r1[j] = __builtin_bit_cast(v8h, Rp[xlm_rh_slot(cg, M, m, w, 0u, NKB, (uint32_t)j, lane)]);
+    r2[j] = __builtin_bit_cast(v8h, Rp[xlm_rh_slot(cg, M, m, w, 1u, NKB, (uint32_t)j, lane)]);
   }
   const uint32_t h = lane >> 5, c = lane & 31u;
   const float cs = a.cscale[cg * XLP_COLS + w * 32u + c];
   // ---- staging role of this lane: branch 8 j + bb of k-block j = w + 4 round, segments 2 sp, 2 sp + 1 of the pass
   constexpr int ROUNDS = (NKB + 3) / 4;
-  const uint32_t bb = lane >> 3, sp = lane & 7u;
+  const uint32_t bb = xlm_stage_branch_in_block(lane), sp = xlm_stage_segment_pair(lane);
   const v4f *__restrict__ Xm = reinterpret_cast<const v4f *>(a.X) + (size_t)m * (XLP_XS / 2u) + sp;
   const size_t xrow = (size_t)M * (XLP_XS / 2u);  // v4f per branch row
   v4f g[ROUNDS];
   auto request = [&](const uint32_t pass) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < ROUNDS; ++q) {
-      const uint32_t b = 8u * (w + 4u * (uint32_t)q) + bb;
+      const uint32_t b = 8u * xlm_stage_kblock(w, (uint32_t)q) + bb;
       // (rows D .. Dpad - 1 of the image are zeros; beyond Dpad there is nothing to read)
-      g[q] = (w + 4u * (uint32_t)q < (uint32_t)NKB && b < a.D) ? Xm[((size_t)pass * a.Dpad + b) * xrow] : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+      g[q] = (xlm_stage_kblock(w, (uint32_t)q) < (uint32_t)NKB && b < a.D) ? Xm[((size_t)pass * a.Dpad + b) * xrow] : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
     }
   };
   auto stage = [&](const uint32_t buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < ROUNDS; ++q) {
-      const uint32_t j = w + 4u * (uint32_t)q;
+      const uint32_t j = xlm_stage_kblock(w, (uint32_t)q);
       if (j < (uint32_t)NKB) {  // (wave-uniform)
         _Float16 f1[4], f2[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) xlp_split_h(g[q][e] * XLP_H_XSCALE, f1[e], f2[e]);
-        // lane slot (h' = bb >> 2, row) of k-block j, dword bb & 3 of its 16 bytes
-        uint32_t *__restrict__ d1 = reinterpret_cast<uint32_t *>(&xs[buf][0][j][(bb >> 2) * 32u + 4u * sp]) + (bb & 3u);
-        uint32_t *__restrict__ d2 = reinterpret_cast<uint32_t *>(&xs[buf][1][j][(bb >> 2) * 32u + 4u * sp]) + (bb & 3u);
+        // branch bb of the k-block: dword xlm_dword(bb) of the lane slots (half xlm_half(bb), row) of its two segments' rows
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {  // segment 2 sp + u: rows 4 sp + 2 u (re) and 4 sp + 2 u + 1 (im)
-          d1[(2 * u) * 4] = xlp_pack_h(f1[2 * u], f1[2 * u + 1]);
-          d1[(2 * u + 1) * 4] = xlp_pack_h(f1[2 * u + 1], -f1[2 * u]);
-          d2[(2 * u) * 4] = xlp_pack_h(f2[2 * u], f2[2 * u + 1]);
-          d2[(2 * u + 1) * 4] = xlp_pack_h(f2[2 * u + 1], -f2[2 * u]);
+        for (int u = 0; u < 2; ++u) {  // segment 2 sp + u: (re, im) = f[2 u], f[2 u + 1]
+          const uint32_t sre = xlm_lane(xlm_half(bb), xlm_row(2u * sp + (uint32_t)u, 0u));
+          const uint32_t sim = xlm_lane(xlm_half(bb), xlm_row(2u * sp + (uint32_t)u, 1u));
+          reinterpret_cast<uint32_t *>(&xs[buf][0][j][sre])[xlm_dword(bb)] = xlp_pack_h(f1[2 * u], f1[2 * u + 1]);
+          reinterpret_cast<uint32_t *>(&xs[buf][0][j][sim])[xlm_dword(bb)] = xlp_pack_h(f1[2 * u + 1], -f1[2 * u]);
+          reinterpret_cast<uint32_t *>(&xs[buf][1][j][sre])[xlm_dword(bb)] = xlp_pack_h(f2[2 * u], f2[2 * u + 1]);
+          reinterpret_cast<uint32_t *>(&xs[buf][1][j][sim])[xlm_dword(bb)] = xlp_pack_h(f2[2 * u + 1], -f2[2 * u]);
         }
       }
     }
@@ -568,16 +568,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     if (pass + 1u < p1) stage(buf ^ 1u);
     if (pass + 2u < p1) request(pass + 2u);
-    // rows of this lane: registers 4 q + 2 u + {0, 1} = (re, im) of the pass's segment 4 q + 2 h + u
+    // this lane's rows: registers g, g + 1 (g even) = (re, im) of the pass's segment xlm_result_row(g, h) / 2
     const uint32_t s0 = pass * XLP_SEG;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const uint32_t sl = 4u * (uint32_t)q + 2u * h + (uint32_t)u;
-        const v2f y = {(hi[4 * q + 2 * u] + lo[4 * q + 2 * u]) * cs, (hi[4 * q + 2 * u + 1] + lo[4 * q + 2 * u + 1]) * cs};
-        if (sl < XLP_SEG && s0 + sl < a.nseg) __builtin_nontemporal_store(y, &Yc[(size_t)(s0 + sl) * ystride]);
-      }
+    for (int g2 = 0; g2 < 16; g2 += 2) {
+      const uint32_t sl = xlm_result_row((uint32_t)g2, h) >> 1;
+      const v2f y = {(hi[g2] + lo[g2]) * cs, (hi[g2 + 1] + lo[g2 + 1]) * cs};
+      if (sl < XLP_SEG && s0 + sl < a.nseg) __builtin_nontemporal_store(y, &Yc[(size_t)(s0 + sl) * ystride]);
     }
     __syncthreads();  // the other buffer is staged; everybody is done with this one
   }
@@ -1146,10 +1143,9 @@ __global__ __launch_bounds__(XLP_COLS) void xlp_tables_h_kernel(const float2 *__
   xlp_split_h((float)sr * sc, r1, r2);
   xlp_split_h(-(float)si * sc, i1, i2);
   const uint32_t cg = col / XLP_COLS, cl = col % XLP_COLS;
-  const uint32_t w = cl >> 5, c = cl & 31u, kb = b >> 3, h = (b >> 2) & 1u;
-  const size_t slot0 = ((((size_t)cg * M + m) * 4u + w) * 2u * nkb + kb) * 64u + h * 32u + c;  // term 0; term 1: + nkb * 64
-  Rh[slot0 * 4u + (b & 3u)] = xlp_pack_h(r1, i1);
-  Rh[(slot0 + (size_t)nkb * 64u) * 4u + (b & 3u)] = xlp_pack_h(r2, i2);
+  const uint32_t w = cl >> 5, ln = xlm_lane(xlm_half(b), cl & 31u);
+  Rh[xlm_rh_slot(cg, M, m, w, 0u, nkb, xlm_kblock(b), ln) * 4u + xlm_dword(b)] = xlp_pack_h(r1, i1);
+  Rh[xlm_rh_slot(cg, M, m, w, 1u, nkb, xlm_kblock(b), ln) * 4u + xlm_dword(b)] = xlp_pack_h(r2, i2);
 }
 
 // ------------------------------------------------------------------------------------------- launchers
