@@ -38,6 +38,19 @@ XLM_FN size_t xlm_rh_slot(uint32_t cg, uint32_t M, uint32_t m, uint32_t w, uint3
   return (((((size_t)cg * M + m) * 4u + w) * 2u + term) * nkb + kb) * 64u + lane;
 }
 
+// Where lane slot (h, row) of a staged A operand sits in LDS: the four slots of an aligned group of four rows are permuted by
+// (h, row bit 4).  The staging writes are 4 bytes per lane -- lane (branch-in-block bb, segment pair sp) writes dword bb & 3 of
+// slot (bb >> 2, 4 sp + r): dword address 128 h + 16 sp + 4 r + (bb & 3), i.e. 16 banks for 64 lanes -- and the two bits that (h,
+// sp >> 2) would waste go into the slot's low bits instead: 64 lanes, 64 banks.  The 16-byte operand reads do not care (a group
+// of four lanes still covers the same 64 bytes).
+XLM_FN uint32_t xlm_lds_slot(uint32_t lane_slot) {
+#ifdef XLM_NO_LDS_SWIZZLE  // (A/B builds only: tools/experiments/build_variant.sh)
+  return lane_slot;
+#else
+  return lane_slot ^ (((lane_slot >> 5) & 1u) | (((lane_slot >> 4) & 1u) << 1));
+#endif
+}
+
 // Staging role of a lane of wave w in round q: k-block w + 4 q, branch 8 (w + 4 q) + (lane >> 3), segments 2 (lane & 7) and + 1 of
 // the pass (one 16-byte load of the FP32 image row X[pass][branch][m][0..15])
 XLM_FN uint32_t xlm_stage_kblock(uint32_t w, uint32_t q) { return w + 4u * q; }

@@ -529,8 +529,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // branch bb of the k-block: dword xlm_dword(bb) of the lane slots (half xlm_half(bb), row) of its two segments' rows
 #pragma unroll
         for (int u = 0; u < 2; ++u) {  // segment 2 sp + u: (re, im) = f[2 u], f[2 u + 1]
-          const uint32_t sre = xlm_lane(xlm_half(bb), xlm_row(2u * sp + (uint32_t)u, 0u));
-          const uint32_t sim = xlm_lane(xlm_half(bb), xlm_row(2u * sp + (uint32_t)u, 1u));
+          const uint32_t sre = xlm_lds_slot(xlm_lane(xlm_half(bb), xlm_row(2u * sp + (uint32_t)u, 0u)));
+          const uint32_t sim = xlm_lds_slot(xlm_lane(xlm_half(bb), xlm_row(2u * sp + (uint32_t)u, 1u)));
           reinterpret_cast<uint32_t *>(&xs[buf][0][j][sre])[xlm_dword(bb)] = xlp_pack_h(f1[2 * u], f1[2 * u + 1]);
           reinterpret_cast<uint32_t *>(&xs[buf][0][j][sim])[xlm_dword(bb)] = xlp_pack_h(f1[2 * u + 1], -f1[2 * u]);
           reinterpret_cast<uint32_t *>(&xs[buf][1][j][sre])[xlm_dword(bb)] = xlp_pack_h(f2[2 * u], f2[2 * u + 1]);
@@ -560,8 +560,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int i = 0; i < 16; ++i) hi[i] = lo[i] = 0.0f;
 #pragma unroll
     for (int j = 0; j < NKB; ++j) {
-      const v8h a1 = __builtin_bit_cast(v8h, xs[buf][0][j][lane]);
-      const v8h a2 = __builtin_bit_cast(v8h, xs[buf][1][j][lane]);
+      const v8h a1 = __builtin_bit_cast(v8h, xs[buf][0][j][xlm_lds_slot(lane)]);
+      const v8h a2 = __builtin_bit_cast(v8h, xs[buf][1][j][xlm_lds_slot(lane)]);
       lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, r1[j], lo, 0, 0, 0);
       hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r1[j], hi, 0, 0, 0);
       lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r2[j], lo, 0, 0, 0);

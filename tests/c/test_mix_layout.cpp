@@ -49,7 +49,7 @@ static int run(uint32_t D, uint32_t M, uint32_t ncg, uint32_t nseg_pass) {
             for (uint32_t u = 0; u < 2; ++u) {
               const uint32_t sl = 2 * sp + u;
               const cd x = (b < D && sl < nseg_pass) ? Xat(b, m, sl) : cd(0, 0);
-              const uint32_t sre = xlm_lane(xlm_half(bb), xlm_row(sl, 0)), sim = xlm_lane(xlm_half(bb), xlm_row(sl, 1));
+              const uint32_t sre = xlm_lds_slot(xlm_lane(xlm_half(bb), xlm_row(sl, 0))), sim = xlm_lds_slot(xlm_lane(xlm_half(bb), xlm_row(sl, 1)));
               double *pre = &xs[((size_t)j * 64 + sre) * 8 + 2 * xlm_dword(bb)], *pim = &xs[((size_t)j * 64 + sim) * 8 + 2 * xlm_dword(bb)];
               pre[0] = x.real(), pre[1] = x.imag();
               pim[0] = x.imag(), pim[1] = -x.real();
@@ -69,7 +69,7 @@ static int run(uint32_t D, uint32_t M, uint32_t ncg, uint32_t nseg_pass) {
             for (uint32_t j = 0; j < nkb; ++j)
               for (uint32_t hh = 0; hh < 2; ++hh)
                 for (uint32_t e = 0; e < 8; ++e)
-                  acc[g] += xs[((size_t)j * 64 + xlm_lane(hh, row)) * 8 + e] *
+                  acc[g] += xs[((size_t)j * 64 + xlm_lds_slot(xlm_lane(hh, row))) * 8 + e] *
                             Rh[(xlm_rh_slot(cg, M, m, w, 0u, nkb, j, xlm_lane(hh, c))) * 8 + e];
           }
           // ---- the kernel's store loop
@@ -101,6 +101,17 @@ int main() {
       if (sl >= 16 || seen[sl]) bad |= printf("FAIL: segment %u twice or out of range\n", sl);
       seen[sl] = true;
     }
+  // the staging writes of one instruction (fixed segment-of-the-pair u and component): 64 lanes, 64 distinct banks of 4 bytes
+  for (uint32_t r2 = 0; r2 < 4; ++r2) {
+    bool bank[64] = {};
+    for (uint32_t lane = 0; lane < 64; ++lane) {
+      const uint32_t bb = xlm_stage_branch_in_block(lane), sp = xlm_stage_segment_pair(lane);
+      const uint32_t slot = xlm_lds_slot(xlm_lane(xlm_half(bb), xlm_row(2 * sp + (r2 >> 1), r2 & 1u)));
+      const uint32_t bk = (slot * 4 + xlm_dword(bb)) & 63u;
+      if (bank[bk]) bad |= printf("FAIL: staging write bank %u hit twice (rows +%u)\n", bk, r2);
+      bank[bk] = true;
+    }
+  }
   const uint32_t shapes[][2] = {{42, 3}, {5, 2}, {21, 2}, {8, 1}, {50, 2}, {64, 2}, {1, 1}};
   for (auto &sh : shapes) bad |= run(sh[0], sh[1], 2, 14);
   if (!bad) printf("matrix-core mix layout: ok\n");
