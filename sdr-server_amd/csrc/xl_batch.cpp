@@ -42,6 +42,7 @@
 #include "../../include/xlating_batch.h"
 #include "xl_common.h"
 #include "xl_device.h"
+#include "xl_fused_layout.h"
 #include "xl_polyphase.h"
 #include "xl_taps.h"
 
@@ -117,12 +118,14 @@ struct PolyClass {
   float2 *d_R = nullptr;     // branch spectra [ncg][M][Dpad][128] (+ XLP_BSTEP rows of tail padding); mix_kind 0
   // mix_kind 1 (the mix launch on the matrix cores, xlp_mix_mfma_kernel): the spectra scaled per column by a power of two and
   // split in two halves, in the kernel's operand order, instead of d_R; per column the scale (host) and what undoes it (device)
+  // mix_kind 2 (mix + inverse as one launch, xl_fused.hip): the same in THAT launch's operand order (xl_fused_layout.h), the
+  // shared spectra d_X in its A-operand form, and no Y image at all
   uint32_t mix_kind = 0, nkb = 0;
   void *d_Rh = nullptr;
   std::vector<float> col_scale;
   float *d_cscale = nullptr;
-  float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
-  float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
+  float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]; mix_kind 2: operand form (xlf_xh_slot)
+  float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]; mix_kind 2: none
   XlpCol *d_cols = nullptr;  // per column: output row, grid offset, NCO increment
 };
 
@@ -198,7 +201,9 @@ struct xlating_batch_t {
                               // 4 = the same at five workgroups per CU (no gain), 1 / 2 = transform in registers of a lane pair / quad
                               // (fewer instructions and LDS cycles, 25-30 % slower: profiles/r03_inverse_reg_vs_lds.txt)
   uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = the mix launch on the matrix cores where the class allows it (integer input
-                              // format, D <= 64), 0 = packed FP32 FMAs everywhere
+                              // format, D <= 64), 0 = packed FP32 FMAs everywhere, 2 = mix + inverse as ONE launch with the mixed spectra
+                              // on chip (xl_fused.hip) where the class allows it (integer input, D <= 64, <= 32 taps per branch)
+  int fus_split = -1;         // option "fused_split": the fused launch's tiles cover 8 segments (1) or 16 (0); -1 = by the call's size
   uint32_t mix_pp = 0;        // option "mix_passes_per_workgroup" (matrix-core mix): 0 = the launcher's default
   uint32_t mix_skip_at = 0;   // position of the mix launch's skipped workgroups; 0 = 1024
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
@@ -414,8 +419,12 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     if (value < 0 || value > 4) return -EINVAL;
     b->inv_reg = (uint32_t)value;
   } else if (n == "mix_kernel") {
-    if (value < 0 || value > 1) return -EINVAL;
+    if (value < 0 || value > 2) return -EINVAL;
     b->mix_kernel = (uint32_t)value;
+  } else if (n == "fused_split") {
+    if (value < -1 || value > 1) return -EINVAL;
+    b->fus_split = (int)value;
+    return 0;  // (a launch parameter: no re-plan)
   } else if (n == "mix_passes_per_workgroup") {
     if (value < 0 || value > 64) return -EINVAL;
     b->mix_pp = (uint32_t)value;
@@ -900,14 +909,20 @@ fail:
 // which is what bounds it with many clients and one block per call; M = 128 halves that for ~5-10 % more arithmetic
 // (valid outputs per segment M - A + 1) while the filter is short against the segment.  Measured at D = 42, 505 taps, one
 // block per call: x1.17 at 4096 clients, x1.08 at 2048, x1.015 at 1024, x0.99 at 512 and below.
-static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t A, size_t members) {
+static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D, uint32_t A);
+static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t D, uint32_t A, size_t members) {
+  if (xl_poly_mix_kind(b, D, A) == 2u) return XLF_M;  // (the fused launch is written for 128-point segments)
   return A > 64 ? 256u : (b->poly_m ? b->poly_m : (A <= 32 && members >= 768 ? 128u : 256u));
 }
 
 // Which mix launch a class of (D) takes (PolyClass::mix_kind): the matrix-core kernel carries the spectra as pairs of halves
 // and needs them bounded -- integer input formats -- and at most XLP_NKB_MAX k-blocks of 8 branches.
-static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D) {
-  return (b->mix_kernel == 1u && b->fmt != XL_FMT_CF32 && D <= 8u * XLP_NKB_MAX) ? 1u : 0u;
+// The fused launch (2) keeps a tile's mixed spectra in registers, 128 bins per segment: filters of up to 32 taps per branch
+// (longer ones waste too much of a 128-point segment: they take the three-launch path with 256-point segments).
+static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D, uint32_t A) {
+  if (b->mix_kernel == 0u || b->fmt == XL_FMT_CF32 || D > 8u * XLP_NKB_MAX) return 0u;
+  if (b->mix_kernel == 2u && A <= 32u && (b->poly_m == 0u || b->poly_m == XLF_M)) return 2u;
+  return 1u;
 }
 
 // Power-of-two scale of a column's branch spectra for the matrix-core mix: every component of R_b[m] = sum_a r_b[a] e^{..} is at
@@ -936,9 +951,10 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     void *nRh = nullptr;
     float *ncs = nullptr;
     XlpCol *ncols = nullptr;
-    if (pc.mix_kind == 1u) {
-      // operand-form image [cg][m][quarter][term][k-block][lane][8 halves]: a group's image is contiguous here too
-      const size_t per_cg = xlp_rh_bytes_per_group(pc.M, pc.nkb);
+    if (pc.mix_kind != 0u) {
+      // operand-form image [cg][m][quarter][term][k-block][lane][8 halves] (fused launch: [16-column group][m][k-block][term][lane]):
+      // a group's image is contiguous here too
+      const size_t per_cg = pc.mix_kind == 2u ? (XLP_COLS / XLF_COLS) * xlf_rh_bytes_per_cg16(pc.nkb) : xlp_rh_bytes_per_group(pc.M, pc.nkb);
       XL_TRY(xl_plan_alloc(b, &nRh, (size_t)cap * per_cg));
       const size_t old_bytes = fresh ? 0 : (size_t)pc.ncg_cap * per_cg;
       if (old_bytes) XL_TRY(hipMemcpyAsync(nRh, pc.d_Rh, old_bytes, hipMemcpyDeviceToDevice, b->own_stream));
@@ -954,7 +970,7 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
       if (old_elems) XL_TRY(hipMemcpyAsync(nR, pc.d_R, old_elems * sizeof(float2), hipMemcpyDeviceToDevice, b->own_stream));
       XL_TRY(hipMemsetAsync(nR + old_elems, 0, (rrows * pc.M * XLP_COLS - old_elems) * sizeof(float2), b->own_stream));
     }
-    XL_TRY(xl_plan_alloc(b, (void **)&nY, (size_t)cap * nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
+    if (pc.mix_kind != 2u) XL_TRY(xl_plan_alloc(b, (void **)&nY, (size_t)cap * nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
     XL_TRY(xl_plan_alloc(b, (void **)&ncols, (size_t)cap * XLP_COLS * sizeof(XlpCol)));
     XL_TRY(hipStreamSynchronize(b->own_stream));
     xl_plan_release(b, pc.d_R);
@@ -967,9 +983,11 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     if (fresh || nseg_cap != pc.nseg_cap || pc.d_X == nullptr) {
       xl_plan_release(b, pc.d_X);
       pc.d_X = nullptr;
-      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_X, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2)));
-      // (X: the padding branches and the unused segment slots of the last pass must be finite: cleared once)
-      XL_TRY(hipMemsetAsync(pc.d_X, 0, (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2), b->own_stream));
+      // (X: the padding branches and the unused segment slots of the last pass / group must be finite: cleared once)
+      const size_t xbytes = pc.mix_kind == 2u ? xlf_xh_slots((nseg_cap + XLF_SEGS - 1u) / XLF_SEGS, pc.nkb) * 16u
+                                              : (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2);
+      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_X, xbytes));
+      XL_TRY(hipMemsetAsync(pc.d_X, 0, xbytes, b->own_stream));
     }
     pc.nseg_cap = nseg_cap;
   }
@@ -990,7 +1008,7 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
       cols[j].incr = make_float2(c.incr[0], c.incr[1]);
     }
     XL_TRY(hipMemcpy(pc.d_cols, cols.data(), cols.size() * sizeof(XlpCol), hipMemcpyHostToDevice));
-    if (pc.mix_kind == 1u) {  // what the matrix-core mix multiplies a column's sums by: 1 / (its scale * the spectra's)
+    if (pc.mix_kind != 0u) {  // what the matrix-core mix multiplies a column's sums by: 1 / (its scale * the spectra's)
       std::vector<float> cs((size_t)pc.ncg_cap * XLP_COLS, 1.0f);
       pc.col_scale.resize(pc.col_client.size(), 1.0f);
       for (uint32_t j : new_cols) pc.col_scale[j] = xl_poly_col_scale(b->clients[pc.col_client[j]], pc.D, pc.T);
@@ -1010,7 +1028,7 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
       const Client &c = b->clients[pc.col_client[new_cols[j]]];
       meta[j] = pc.col_delta[new_cols[j]];
       meta[nn + j] = new_cols[j];
-      const float sc = pc.mix_kind == 1u ? pc.col_scale[new_cols[j]] : 1.0f;
+      const float sc = pc.mix_kind != 0u ? pc.col_scale[new_cols[j]] : 1.0f;
       memcpy(&meta[2 * nn + j], &sc, sizeof(float));
       for (uint32_t i = 0; i < pc.T; ++i) {
         rt[((size_t)i * nn + j) * 2] = c.rt[2 * i];
@@ -1024,7 +1042,10 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     if (e == hipSuccess) e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_meta, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
-      e = pc.mix_kind == 1u
+      e = pc.mix_kind == 2u
+              ? xlp_launch_tables_h16(d_rt, d_meta, d_meta + nn, reinterpret_cast<const float *>(d_meta + 2 * nn), (uint32_t)nn, pc.T,
+                                      pc.D, pc.A, pc.nkb, pc.d_Rh, b->own_stream)
+          : pc.mix_kind == 1u
               ? xlp_launch_tables_h(d_rt, d_meta, d_meta + nn, reinterpret_cast<const float *>(d_meta + 2 * nn), (uint32_t)nn, pc.T,
                                     pc.D, pc.A, pc.M, pc.nkb, pc.d_Rh, b->own_stream)
               : xlp_launch_tables(d_rt, d_meta, d_meta + nn, (uint32_t)nn, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.d_R, b->own_stream);
@@ -1127,7 +1148,7 @@ static int xl_batch_plan(xlating_batch *b) {
         ref = (old->rem_ref0 + advanced % D) % D;
         for (uint32_t r : distinct) dmax = std::max(dmax, (ref + D - r) % D);
         const uint32_t A = (T + dmax + D - 1) / D;
-        reuse = A == old->A && xl_poly_pick_m(b, A, m.size()) == old->M && xl_poly_mix_kind(b, D) == old->mix_kind;
+        reuse = A == old->A && xl_poly_pick_m(b, D, A, m.size()) == old->M && xl_poly_mix_kind(b, D, A) == old->mix_kind;
       }
       if (!reuse) {
         // the shared grid's reference: the member offset that keeps the largest delay of a member smallest
@@ -1140,13 +1161,13 @@ static int xl_batch_plan(xlating_batch *b) {
         ref = best_ref, dmax = best_dmax;
       }
       const uint32_t A = (T + dmax + D - 1) / D;
-      const uint32_t M = xl_poly_pick_m(b, A, m.size());
+      const uint32_t M = xl_poly_pick_m(b, D, A, m.size());
       const bool fits = A >= 2 && A <= M / 2 && D <= 504;  // (the mix kernel stages D rows of 128 bytes in <= 64 KB of LDS)
       // crossover, packed-FMA mix: ~4.5 taps per branch and 128 clients (x1.10 at 128, x0.96 at 64).  With the mix on the matrix
       // cores the path costs the same whatever the filter length and little beside the recurrence in small classes (A/B at
       // 8 blocks per call, direct kernel -> polyphase, us per block: 101 taps 37.3 -> 28.2 at 1024 clients, 124.8 -> 88.7 at
       // 4096, 23.3 -> 22.9 at 128; 505 taps 24.8 -> 22.9 at 96 clients, 23.1 -> 22.7 at 32): 2 taps per branch, 32 clients
-      const bool mfma_class = xl_poly_mix_kind(b, D) == 1u;
+      const bool mfma_class = xl_poly_mix_kind(b, D, A) != 0u;
       const size_t min_clients = (mfma_class && !b->poly_min_set) ? 32u : b->poly_min_clients;
       const bool pays = m.size() >= min_clients && (mfma_class ? T >= 2 * D : 2 * T >= 9 * D);
       if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
@@ -1184,8 +1205,8 @@ static int xl_batch_plan(xlating_batch *b) {
         pc.A = A;
         pc.M = M;
         pc.V = M - A + 1;
-        pc.mix_kind = xl_poly_mix_kind(b, D);
-        pc.nkb = (D + 7u) / 8u;
+        pc.mix_kind = xl_poly_mix_kind(b, D, A);
+        pc.nkb = pc.mix_kind == 2u ? xlf_nk(D) : (D + 7u) / 8u;
       }
       pc.keep = false;
       pc.rem_ref0 = ref;
@@ -1283,7 +1304,9 @@ static int xl_batch_plan(xlating_batch *b) {
     for (const DirectClass &cs : b->classes_rest) b->macs_rest += (double)cs.members.size() * cs.T / cs.D;
     const bool light = xl_direct_is_light(b->macs_all * b->max_samples) || (!b->poly.empty() && xl_direct_is_light(b->macs_rest * b->max_samples));
     // (one-block calls of a polyphase plan take the side stream too, up to XL_SIDE_ONE_BLOCK_MAX clients: see side_call)
-    const bool one_block_side = !b->poly.empty() && b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX;
+    bool plan_fused = !b->poly.empty();
+    for (const PolyClass &pc : b->poly) plan_fused = plan_fused && pc.mix_kind == 2u;
+    const bool one_block_side = !b->poly.empty() && (plan_fused || b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX);
     uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? (nwg + 7u) / 8u : 0u;
     if (want > 16u) want = 0u;  // (more than half the chip for the chain: such engines are bound by the filtering anyway)
     if (getenv("XL_EXP_NOMASK")) want = 0u;
@@ -1488,7 +1511,9 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
   // the matrix cores, and a slice of the recurrence inside each made every one of them last as long as its slice (1024 clients:
   // 50.2 us per block; the chain kernel beside them, four calls per launch: 47.7; 128 clients: 40.4 -> 29.2; 4096: 129 -> 134,
   // hence the limit)
-  const bool one_block_side = G == 1 && use_poly && b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX;
+  bool all_fused = use_poly;  // every polyphase class runs forward + fused: two short launches, neither a good host for the recurrence
+  for (const PolyClass &pc : b->poly) all_fused = all_fused && pc.mix_kind == 2u;
+  const bool one_block_side = G == 1 && use_poly && (all_fused || b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX);
   const bool side_call = mode != XL_MODE_Q15 && (b->nco_side > 0 || (b->nco_side < 0 && (G >= 2 || one_block_side) && (use_poly || (light && b->cs_masked && s == XL_STREAM_ENGINE_P))));  // (a caller's own, unmasked stream would keep filling the chain's CUs)
   if (s == XL_STREAM_ENGINE_P) s = (side_call && b->cs_masked) ? b->cs_masked : b->own_stream;
   // Calls depend on each other through the engine's device state (history, phases, tables): a call on another
@@ -1795,11 +1820,14 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           pa.cols = pc.d_cols;
           pa.phtab = b->d_phtab[tab];
           pa.out = b->d_out[p];
-          // the NEXT call's phase recurrence rides in these three launches as three slices (a direct launch
-          // above carries all of it if there is one)
+          // the NEXT call's phase recurrence rides in these launches (a direct launch above carries all of it if there is
+          // one): forward and inverse, never a launch that issues matrix instructions -- the first matrix-core mix build
+          // corrupted the phases of role waves riding in it, cause unknown, so no product launch mixes the two.
+          // Packed-FMA mix: three slices (forward | mix | inverse); matrix-core mix: two (forward | inverse); fused: the
+          // forward launch carries all of it (such calls take the side stream whenever there is one).
           const bool carry = fuse && !nco_fused;
-          const uint32_t sl1 = pc.mix_kind == 1u ? b->poly_slice1_m : b->poly_slice1;
-          const uint32_t sl2 = pc.mix_kind == 1u ? b->poly_slice2_m : b->poly_slice2;
+          const uint32_t sl1 = pc.mix_kind == 2u ? 65536u : (pc.mix_kind == 1u ? std::min(b->poly_slice2_m, 60000u) : b->poly_slice1);
+          const uint32_t sl2 = pc.mix_kind == 0u ? b->poly_slice2 : sl1;
           if (carry) {
             pa.nco_clients = b->d_nco;
             pa.nco_nclients = (uint32_t)b->nco.size();
@@ -1809,7 +1837,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
             pa.nco_k0 = 0;
             pa.nco_k1 = sl1;
             pa.nco_state_src = b->d_phase[pcur];
-            pa.nco_state_dst = b->d_phase_run;
+            pa.nco_state_dst = sl1 >= 65536u ? b->d_phase[xl_nx(pcur)] : b->d_phase_run;
           }
           hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
           if (b->timing == 2) {
@@ -1819,10 +1847,35 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
             }
             XL_TRY(hipEventRecord(pe[0], s));
           }
+          // the call's last launch carries the "table has been read" event the side stream waits for
+          const bool last_launch = side && rolled && &pc == &b->poly.back();
+          if (pc.mix_kind == 2u) {
+            // ---- two launches: spectra in operand form, then mix + inverse with the mixed spectra on chip
+            XL_TRY(xlp_launch_forward_h(pa, s));
+            if (pe[1]) XL_TRY(hipEventRecord(pe[1], s));
+            pa.roll_blocks = 0;
+            if (carry) nco_fused = true;
+            pa.nco_clients = nullptr;
+            pa.nco_nclients = pa.nco_blocks = 0;
+            pa.nco_tab = nullptr;
+            if (chain_wait) {  // (the forward launch does not read the table)
+              XL_TRY(hipStreamWaitEvent(s, b->ev_chain[chain_ev], 0));
+              chain_wait = false;
+              b->waited_valid = true, b->waited_ev = chain_ev, b->waited_stream = s;
+            }
+            // tiles of 16 segments, or of 8 when those would leave CUs idle (short calls)
+            const uint32_t tiles16 = ((pa.nseg + XLF_SEGS - 1u) / XLF_SEGS) * pc.ncg * (XLP_COLS / XLF_COLS);
+            pa.fus_split = b->fus_split >= 0 ? (uint32_t)b->fus_split : (tiles16 < 448u ? 1u : 0u);
+            XL_TRY(xlp_launch_fused(pa, s, last_launch ? b->ev_done[tab] : nullptr));
+            done_attached = last_launch;
+            if (pe[2]) XL_TRY(hipEventRecord(pe[2], s));
+            if (pe[3]) XL_TRY(hipEventRecord(pe[3], s));
+            continue;
+          }
           XL_TRY(xlp_launch_forward(pa, s));
           if (pe[1]) XL_TRY(hipEventRecord(pe[1], s));
           pa.roll_blocks = 0;
-          if (carry) {
+          if (carry && pc.mix_kind == 0u) {
             pa.nco_k0 = sl1;
             pa.nco_k1 = sl2;
             pa.nco_state_src = b->d_phase_run;
@@ -1834,6 +1887,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
             if (b->poly_exp & 4u) pa.nco_tab = nullptr;  // tuning: the mix launch's slice stores nothing (WRONG results)
             if (b->poly_exp & 8u) pa.nco_blocks = 0;     // tuning: the mix launch carries no slice at all (WRONG results)
 #endif
+          } else {
+            pa.nco_blocks = 0;  // (matrix-core mix: no role in this launch)
           }
 #ifdef XL_TUNING
           const bool trace_inv = b->poly_trace && getenv("XL_EXP_POLY_TRACE_INV");  // (the inverse launch instead)
@@ -1857,6 +1912,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
             pa.nco_blocks = (pa.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
             pa.nco_k0 = sl2;
             pa.nco_k1 = 65536;
+            pa.nco_state_src = b->d_phase_run;
             if (b->inv_skip_at > 0) {
               pa.nco_skip_at = b->inv_skip_at;
               pa.nco_skip = pa.nco_blocks;
@@ -1876,14 +1932,15 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
             chain_wait = false;
             b->waited_valid = true, b->waited_ev = chain_ev, b->waited_stream = s;
           }
-          // the call's last launch carries the "table has been read" event the side stream waits for
-          const bool last_launch = side && rolled && &pc == &b->poly.back()
+          {
+            const bool attach = last_launch
 #ifdef XL_TUNING
-                                   && !trace_inv
+                                && !trace_inv
 #endif
-              ;
-          XL_TRY(xlp_launch_inverse(pa, s, last_launch ? b->ev_done[tab] : nullptr));
-          done_attached = last_launch;
+                ;
+            XL_TRY(xlp_launch_inverse(pa, s, attach ? b->ev_done[tab] : nullptr));
+            done_attached = attach;
+          }
 #ifdef XL_TUNING
           if (trace_inv) {
             pa.trace = nullptr;
@@ -1975,7 +2032,7 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
     d += " cls" + std::to_string(k) + " D" + std::to_string(pc.D) + " T" + std::to_string(pc.T) + " cols" +
          std::to_string(pc.members.size()) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
     if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
-    d += pc.mix_kind == 1u ? " mix=mfma" : " mix=fma";
+    d += pc.mix_kind == 2u ? " mix=fused" : (pc.mix_kind == 1u ? " mix=mfma" : " mix=fma");
   }
   if (!b->poly.empty()) {
     d += " | optimized-mode direct:";

@@ -64,9 +64,11 @@ struct XlpArgs {
   uint32_t ncg;        // column groups of XLP_COLS client columns
   uint32_t exp;        // tuning switches (XL_TUNING builds only; 0 otherwise)
   uint32_t inv_reg;    // M = 128: the inverse launch's transform: 0 = staged in LDS, 1 = registers of a lane pair, 2 = of a lane quad
-  uint32_t mix_kind;   // the mix launch: 0 = packed FP32 FMAs (xlp_mix_kernel), 1 = matrix cores on two-term half splits (xlp_mix_mfma_kernel)
-  uint32_t nkb;        // mix_kind 1: k-blocks of 8 branches = ceil(D / 8), <= XLP_NKB_MAX
+  uint32_t mix_kind;   // the mix launch: 0 = packed FP32 FMAs (xlp_mix_kernel), 1 = matrix cores on two-term half splits (xlp_mix_mfma_kernel),
+                       // 2 = mix + inverse as ONE launch with the mixed spectra on chip (xl_fused.hip: no Y image, X and Rh in that launch's operand forms)
+  uint32_t nkb;        // mix_kind 1: k-blocks of 8 branches = ceil(D / 8), <= XLP_NKB_MAX; mix_kind 2: k-blocks of 16 branches, <= 4
   uint32_t mix_pp;     // mix_kind 1: passes per workgroup (0 = default)
+  uint32_t fus_split;  // mix_kind 2 (xl_fused.hip): 1 = the fused launch's tiles cover 8 segments instead of 16 (short calls)
   unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
@@ -106,6 +108,13 @@ hipError_t xlp_launch_tables_h(const float2 *rt, const uint32_t *delta, const ui
                                hipStream_t s);
 // bytes of the operand-form image per column group
 static inline size_t xlp_rh_bytes_per_group(uint32_t M, uint32_t nkb) { return (size_t)M * 4u * 2u * nkb * 64u * 16u; }
+// mix_kind 2 (xl_fused.hip; M = 128, integer input formats, D <= 64): the branch spectra in the fused launch's operand form
+// (xl_fused_layout.h: xlf_rh_slot), the forward launch that writes the shared spectra in its operand form (a.X = that image,
+// xlf_xh_slot) and the fused mix + inverse launch itself
+hipError_t xlp_launch_tables_h16(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, const float *scale,
+                                 uint32_t nlist, uint32_t T, uint32_t D, uint32_t A, uint32_t nk, void *Rh, hipStream_t s);
+hipError_t xlp_launch_forward_h(const XlpArgs &a, hipStream_t s);
+hipError_t xlp_launch_fused(const XlpArgs &a, hipStream_t s, hipEvent_t done);
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);

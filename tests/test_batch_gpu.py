@@ -293,14 +293,14 @@ def test_1000_clients_split_group_riders():
 # that the oracle can check every client.
 # The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
 # the forced-path tests run with both.
-@pytest.fixture(params=[(128, 0, 1), (128, 1, 1), (128, 2, 1), (128, 3, 1), (256, 0, 1), (128, 3, 0), (256, 0, 0)],
+@pytest.fixture(params=[(128, 0, 1), (128, 1, 1), (128, 2, 1), (128, 3, 1), (256, 0, 1), (128, 3, 0), (256, 0, 0), (128, 3, 2)],
                 ids=["M128", "M128-register-inverse", "M128-quad-register-inverse", "M128-swizzled-inverse", "M256",
-                     "M128-fma-mix", "M256-fma-mix"])
+                     "M128-fma-mix", "M256-fma-mix", "M128-fused"])
 def poly_m(request, monkeypatch):
     """Transform length of the forced polyphase plan; at M = 128 also with the inverse launch's transform in registers
     (option "inverse_kernel" = 1: xlp_inverse_reg_kernel, a lane pair per column; 2: xlp_inverse_quad_kernel, a lane quad);
     the mix launch on the matrix cores (option "mix_kernel" = 1, the default where the class allows it: integer input, D <= 64)
-    or as packed FP32 FMAs (0)."""
+    or as packed FP32 FMAs (0), or mix + inverse as ONE launch with the mixed spectra on chip (2: xl_fused.hip)."""
     m, inv, mix = request.param
     monkeypatch.setenv("XL_EXP_POLY_M", str(m))
     monkeypatch.setenv("XL_EXP_INV", str(inv))
@@ -423,15 +423,15 @@ def test_polyphase_forced_other_shapes(shape, monkeypatch, poly_m):
     eng.close()
 
 
-@pytest.mark.parametrize("m", [128, 256])
-def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, monkeypatch):
+@pytest.mark.parametrize("m,mix", [(128, 1), (256, 1), (128, 2)], ids=["M128", "M256", "M128-fused"])
+def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, mix, monkeypatch):
     """The matrix-core mix carries every operand as two halves after a power-of-two scale (per column for the branch
     spectra, fixed for the shared spectra): one class whose members' taps differ by 10^8 in gain (column scales 2^-2 ..
     2^25), a one-tap-dominated and an asymmetric filter among them, on full-scale inputs (constant +127:
     the largest possible spectrum value, 128 x sqrt 2 x M / 128; a full-scale square wave; noise) -- each client within the
     same 1e-5 of ITS output scale as on the FP32 path."""
     monkeypatch.setenv("XL_EXP_POLY_M", str(m))
-    monkeypatch.setenv("XL_EXP_MIX", "1")
+    monkeypatch.setenv("XL_EXP_MIX", str(mix))
     base = np.asarray(lpf(FS, 24000, 9600), dtype=np.float32)
     T = len(base)
     spike = base.copy()
@@ -444,7 +444,7 @@ def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, monkeypatc
         for fc in (-600000 + 170000 * c, 250000 - 31000 * c):
             t = [float(v) for v in taps]
             oracles[eng.add_client(42, t, fc)] = Oracle(42, t, fc, FS, 262144)
-    assert "mix=mfma" in eng.describe(), eng.describe()
+    assert ("mix=fused" if mix == 2 else "mix=mfma") in eng.describe(), eng.describe()
     n = 262144
     full = np.full(n, 255, dtype=np.uint8)
     square = np.where((np.arange(n) // 2) % 84 < 42, 255, 0).astype(np.uint8)
@@ -453,24 +453,26 @@ def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, monkeypatc
     eng.close()
 
 
+@pytest.mark.parametrize("mix", [1, 2], ids=["mfma", "fused"])
 @pytest.mark.parametrize("D,fs", [(12, 576000), (33, 1584000), (50, 2400000), (64, 3072000)])
-def test_polyphase_matrix_core_mix_other_branch_counts(D, fs, monkeypatch):
+def test_polyphase_matrix_core_mix_other_branch_counts(D, fs, mix, monkeypatch):
     """The matrix-core mix is built per number of k-blocks of 8 branches (1..8): the server default is 6 (D = 42), the
     fixture shapes cover 1 (D = 5) and 3 (D = 21); here 2, 5, 7 and 8 (the last two keep a few operand registers in
     scratch) -- 48 kHz clients off other sample rates, 12 taps per branch, both transform lengths by the size rule's
-    forcing, every client vs the oracle."""
-    monkeypatch.setenv("XL_EXP_MIX", "1")
+    forcing, every client vs the oracle.  The fused launch (mix = 2) is built per number of k-blocks of SIXTEEN branches (1..4;
+    128-point segments only): 1, 3, 4 and 4 here, 1 (D = 5), 2 (D = 21) and 3 (D = 42) in the fixture shapes."""
+    monkeypatch.setenv("XL_EXP_MIX", str(mix))
     taps = lpf(fs, 24000, fs // 210)
     assert len(taps) >= 9 * D // 2
     n = 131072
-    for m in (128, 256):
+    for m in ((128,) if mix == 2 else (128, 256)):
         monkeypatch.setenv("XL_EXP_POLY_M", str(m))
         eng = _poly_engine(monkeypatch, max_input=2 * n, fs=fs)
         oracles = {}
         for c in range(37):
             fc = int(-0.4 * fs + c * 0.021 * fs)
             oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, fs, 2 * n)
-        assert "mix=mfma" in eng.describe() and " M%d " % m in eng.describe(), eng.describe()
+        assert ("mix=fused" if mix == 2 else "mix=mfma") in eng.describe() and " M%d " % m in eng.describe(), eng.describe()
         for k in range(3):
             check_clients(eng, oracles, "cu8", siggen.xs_u8(5300 + k, 2 * n if k != 1 else 2 * n - 1234), "optimized")
         eng.close()
@@ -511,19 +513,20 @@ def test_size_rule_of_matrix_core_classes():
 
 
 def test_matrix_core_mix_role_phases_bit_exact(monkeypatch):
-    """One-block calls: each of the three polyphase launches carries a slice of the NEXT call's NCO recurrence, the mix
-    launch the longest.  Two engines on the same stream of 120 blocks, one with the FMA mix, one with the matrix-core mix:
-    the committed phases of all 1024 clients agree bit for bit after every call (the recurrence does not depend on the mix
-    kernel -- a first build of xlp_mix_mfma_kernel corrupted a fifth of them within 120 calls, see its header)."""
+    """One-block calls with the recurrence INSIDE the launches (option nco_side_stream = 0): with the FMA mix each of the three
+    polyphase launches carries a slice of the NEXT call's NCO recurrence; with the matrix-core mix only the forward and the
+    inverse launch do, with the fused launch only the forward launch (round 4: no launch that issues matrix instructions hosts
+    the role -- a first build of xlp_mix_mfma_kernel corrupted the phases of role waves riding in it, see its header).  Three
+    engines on the same stream of 120 blocks: the committed phases of all 1024 clients agree bit for bit after every call."""
     t48 = lpf(FS, 24000, 9600)
     engs = []
-    for mix in (0, 1):
+    for mix in (0, 1, 2):
         monkeypatch.setenv("XL_EXP_MIX", str(mix))
         e = xl.BatchEngine(FS, "cu8", 262144)
         e.set_option("nco_side_stream", 0)  # the recurrence inside the launches (one-block calls default to the side stream now)
         ids = [e.add_client(42, t48, -984000 + 1920 * c) for c in range(1024)]
         engs.append((e, ids))
-    assert "mix=fma" in engs[0][0].describe() and "mix=mfma" in engs[1][0].describe()
+    assert "mix=fma" in engs[0][0].describe() and "mix=mfma" in engs[1][0].describe() and "mix=fused" in engs[2][0].describe()
     for k in range(120):
         x = siggen.xs_u8(7000 + k, 262144)
         ph = []
@@ -531,8 +534,9 @@ def test_matrix_core_mix_role_phases_bit_exact(monkeypatch):
             e.process_host(x, "optimized")
             e.sync()
             ph.append(np.array([e.phase(i) for i in ids], dtype=np.float32))
-        bad = np.flatnonzero((ph[0].view(np.uint32) != ph[1].view(np.uint32)).any(axis=1))
-        assert len(bad) == 0, (k, bad[:32])
+        for other in (1, 2):
+            bad = np.flatnonzero((ph[0].view(np.uint32) != ph[other].view(np.uint32)).any(axis=1))
+            assert len(bad) == 0, (k, other, bad[:32])
     for e, _ in engs:
         e.close()
 
@@ -869,7 +873,7 @@ def test_group_of_blocks_equals_successive_calls_direct(variant):
 
 
 @pytest.mark.parametrize("m,inv,mix", [(128, 0, 1), (128, 1, 1), (128, 2, 1), (128, 3, 1), (128, 4, 1), (256, 0, 1),
-                                       (128, 3, 0), (256, 0, 0)])
+                                       (128, 3, 0), (256, 0, 0), (128, 3, 2)])
 def test_group_of_blocks_polyphase(m, inv, mix, monkeypatch):
     """Forced polyphase path, G = 4 server-default blocks per call (108 segments at M = 128): every client vs the
     oracle's four successive calls; a native group in between (shared history and phases); ragged group.  mix = 1: the mix
@@ -1246,7 +1250,7 @@ def _engine_outputs(eng, ids):
 
 
 @pytest.mark.parametrize("variant", ["native", "optimized", "optimized-register-inverse", "optimized-quad-register-inverse",
-                                     "optimized-swizzled-inverse", "optimized-fma-mix"])
+                                     "optimized-swizzled-inverse", "optimized-fma-mix", "optimized-fused", "optimized-fused-split"])
 def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
     server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
@@ -1260,18 +1264,25 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     if variant.endswith("-fma-mix"):
         monkeypatch.setenv("XL_EXP_MIX", "0")
         variant = "optimized"
+    split = None
+    if "-fused" in variant:
+        monkeypatch.setenv("XL_EXP_MIX", "2")
+        split = 1 if variant.endswith("-split") else 0
+        variant = "optimized"
     t48 = lpf(FS, 24000, 9600)
     G, nb = 8, 262144
     fcs = [-984000 + 1920 * c for c in range(1024)]
     eng = xl.BatchEngine(FS, "cu8", nb, group_blocks=G)
     ids = [eng.add_client(42, t48, fc) for fc in fcs]
+    if split is not None:
+        eng.set_option("fused_split", split)
     x = siggen.xs_u8(8100, 2 * G * nb)
     for k in range(2):
         eng.process_host_group(x[k * G * nb:(k + 1) * G * nb], G, variant)
     got = _engine_outputs(eng, ids)
     if variant == "optimized":
         assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
-        assert ("mix=fma" if os.environ.get("XL_EXP_MIX") == "0" else "mix=mfma") in eng.describe(), eng.describe()
+        assert {"0": "mix=fma", "2": "mix=fused"}.get(os.environ.get("XL_EXP_MIX"), "mix=mfma") in eng.describe(), eng.describe()
     want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
     worst = 0.0
     for c in range(1024):
@@ -1281,6 +1292,60 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
         else:
             worst = max(worst, rel_err(got[c], want[c]))
     assert worst <= REL_TOL, worst
+    eng.close()
+
+
+@pytest.mark.parametrize("mix", [1, 2], ids=["mfma-mix", "fused"])
+@pytest.mark.parametrize("variant", ["native", "optimized"])
+def test_group_2048_clients_all(variant, mix, monkeypatch):
+    """The shape the >= 50 % claim of DESIGN 6 rests on (the launches, not the recurrence, bound the call): 2048 x 48 kHz
+    clients (16 column groups), one whole 8-block call after a warm-up call, ALL clients against the oracle population --
+    native bit for bit, optimized <= 1e-5 per client (fixture semantics: test/test_xlating.c:24-61, test/utils.c:176-196)."""
+    from pyoracle import population
+
+    if variant == "native" and mix == 2:
+        pytest.skip("native calls do not depend on the mix kernel")
+    monkeypatch.setenv("XL_EXP_MIX", str(mix))
+    t48 = lpf(FS, 24000, 9600)
+    G, nb, n = 8, 262144, 2048
+    fcs = [-984000 + 960 * c for c in range(n)]
+    eng = xl.BatchEngine(FS, "cu8", nb, group_blocks=G)
+    ids = [eng.add_client(42, t48, fc) for fc in fcs]
+    x = siggen.xs_u8(8300, 2 * G * nb)
+    for k in range(2):
+        eng.process_host_group(x[k * G * nb:(k + 1) * G * nb], G, variant)
+    got = _engine_outputs(eng, ids)
+    if variant == "optimized":
+        assert "polyphase: cls0 D42 T505 cols2048" in eng.describe() and ("mix=fused" if mix == 2 else "mix=mfma") in eng.describe(), eng.describe()
+    want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
+    worst = 0.0
+    for c in range(n):
+        assert len(got[c]) == len(want[c]) == 24966, (c, len(got[c]), len(want[c]))
+        if variant == "native":
+            assert bits_equal(got[c], want[c]), c
+        else:
+            worst = max(worst, rel_err(got[c], want[c]))
+    assert worst <= REL_TOL, worst
+    eng.close()
+
+
+@pytest.mark.parametrize("mix", [1, 2], ids=["mfma-mix", "fused"])
+def test_group_4096_clients_sampled(mix, monkeypatch):
+    """4096 x 48 kHz clients (32 column groups), 8 blocks per call, optimized: every 16th column and the first and last column
+    of every group of 128 (and of 16: the fused launch's tiles) against oracle filters over two calls; a one-block call on the
+    same engine afterwards (the reference's call granularity)."""
+    monkeypatch.setenv("XL_EXP_MIX", str(mix))
+    t48 = lpf(FS, 24000, 9600)
+    G, nb, n = 8, 262144, 4096
+    fcs = [-984000 + 480 * c for c in range(n)]
+    eng = xl.BatchEngine(FS, "cu8", nb, group_blocks=G)
+    ids = [eng.add_client(42, t48, fc) for fc in fcs]
+    sample = sorted(set(range(0, n, 16)) | set(range(127, n, 128)) | set(range(15, n, 256)) | {n - 1})
+    oracles = {ids[c]: Oracle(42, t48, fcs[c], FS, nb) for c in sample}
+    for k in range(2):
+        _check_group(eng, oracles, "cu8", siggen.xs_u8(8400 + k, G * nb), G, "optimized")
+    assert "polyphase: cls0 D42 T505 cols4096" in eng.describe() and ("mix=fused" if mix == 2 else "mix=mfma") in eng.describe(), eng.describe()
+    check_clients(eng, oracles, "cu8", siggen.xs_u8(8410, nb), "optimized")
     eng.close()
 
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=320, help="blocks in the timed region")
     ap.add_argument("--poly3", action="store_true", help="also time the three polyphase launches separately")
     ap.add_argument("--slices", default="")
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable), e.g. mix_kernel=2")
     ap.add_argument("--engine-stream", type=int, default=1, help="1: XL_STREAM_ENGINE (the engine's own, CU-masked compute stream); 0: torch's stream")
     args = ap.parse_args()
     code, taps = xl.create_low_pass_filter(1.0, FS, 24000, 48000 // args.rate)
@@ -46,6 +47,9 @@ def main():
                     if args.slices:
                         a, b = (int(v) for v in args.slices.split(","))
                         eng.set_option("nco_slices", (a << 16) | b)
+                    for kv in args.opt:
+                        name, val = kv.split("=")
+                        eng.set_option(name, int(val))
                     for c in range(n):
                         eng.add_client(D, taps, -984000 + 1920 * (c % 1024) + 240 * (c // 1024))
                     calls = max(4, args.blocks // G)
