@@ -917,11 +917,11 @@ static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t D, uint32_t A, s
 
 // Which mix launch a class of (D) takes (PolyClass::mix_kind): the matrix-core kernel carries the spectra as pairs of halves
 // and needs them bounded -- integer input formats -- and at most XLP_NKB_MAX k-blocks of 8 branches.
-// The fused launch (2) keeps a tile's mixed spectra in registers, 128 bins per segment: filters of up to 32 taps per branch
-// (longer ones waste too much of a 128-point segment: they take the three-launch path with 256-point segments).
+// The fused launch (2) keeps a tile's mixed spectra in registers, 128 bins per segment: filters of up to 64 taps per branch
+// (the same bound the three-launch path puts on 128-point segments).
 static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D, uint32_t A) {
   if (b->mix_kernel == 0u || b->fmt == XL_FMT_CF32 || D > 8u * XLP_NKB_MAX) return 0u;
-  if (b->mix_kernel == 2u && A <= 32u && (b->poly_m == 0u || b->poly_m == XLF_M)) return 2u;
+  if (b->mix_kernel == 2u && A <= XLF_M / 2u && (b->poly_m == 0u || b->poly_m == XLF_M)) return 2u;
   return 1u;
 }
 

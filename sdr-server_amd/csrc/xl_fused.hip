@@ -187,12 +187,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // read the slot of a row the tile DOES own (the same cache lines: no extra traffic), not zeros.
     const uint32_t seg16 = a.fus_split ? ((xlf_row_seg(i16) & 7u) | (e0 << 2)) : xlf_row_seg(i16);
     // (uniform base pointer + 32-bit lane offset: the loads address as scalar base + vector offset)
+#ifdef XLF_EXP_SAME_OPERANDS  // (tools/experiments: every tile streams the SAME operands -- all L2 hits; WRONG results)
+    const uint4 *__restrict__ Xb = reinterpret_cast<const uint4 *>(a.X);
+    const uint4 *__restrict__ Rb = reinterpret_cast<const uint4 *>(a.Rh);
+#else
     const uint4 *__restrict__ Xb = reinterpret_cast<const uint4 *>(a.X) + xlf_xh_slot(sg, NK, 0u, 0u, 0u, 0u, 0u);
     const uint4 *__restrict__ Rb = reinterpret_cast<const uint4 *>(a.Rh) + xlf_rh_slot(cg16, NK, 0u, 0u, 0u, 0u);
+#endif
     const uint32_t xbyte = (uint32_t)xlf_xh_slot(0u, NK, 0u, kg, 0u, 0u, seg16) * 16u, rbyte = lane * 16u;  // (< 2^20)
     v8h a1[2][NK], a2[2][NK], b1[2][NK], b2[2][NK];
     auto ld = [](const uint4 *__restrict__ base, const uint32_t byte) __attribute__((always_inline)) {
+#ifdef XLF_EXP_NO_LOADS  // (tools/experiments: what the launch costs without its operand stream -- WRONG results)
+      const uint32_t v = (uint32_t)(uintptr_t)base + byte;
+      return __builtin_bit_cast(v8h, make_uint4(v & 0x03FF03FFu, (v >> 3) & 0x03FF03FFu, (v >> 5) & 0x03FF03FFu, (v >> 7) & 0x03FF03FFu));
+#else
       return __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(base) + byte));
+#endif
     };
     auto load = [&](const uint32_t m, const int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -240,6 +250,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+#ifdef XLF_EXP_NO_EPILOGUE  // (tools/experiments: the operand stream + products alone -- WRONG results)
+  {
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sum += d1[i][0] + d1[i][1] + d1[i][2] + d1[i][3] + d2[i][0] + d2[i][1] + d2[i][2] + d2[i][3];
+    if (sum == 12345.678f) reinterpret_cast<float *>(a.out)[0] = sum;
+    return;
+  }
+#endif
   // ---- epilogue, one quarter (result register e = segments 4 e .. 4 e + 3 of the group) at a time
   const uint32_t c = lane & 15u;  // as a result lane: client column c, segments 4 e + (lane >> 4)
   // what undoes the operand scales (a power of two) and the transform's 1 / M, applied before the transform (linear, exact)

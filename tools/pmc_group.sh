@@ -7,7 +7,7 @@ TAG=${1:-pmcg}; CLIENTS=${2:-1024}; G=${3:-8}; MODE=${4:-optimized}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $GRAFT_REPO_ROOT/tools/group_sweep.py --clients $CLIENTS --groups $G --modes $MODE --blocks 48"
+CMD="python $GRAFT_REPO_ROOT/tools/group_sweep.py --clients $CLIENTS --groups $G --modes $MODE --blocks 48 $EXTRA"  # EXTRA (env): more group_sweep options, e.g. "--opt mix_kernel=2"
 run() { n=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -o p -- $CMD > $OUT/$n.log 2>&1
 }
@@ -53,7 +53,7 @@ res = {"workload": f"{clients} clients x 48 kHz, 505 taps, {mode}, {G} blocks pe
        "correction": "gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
        "per_dispatch_mean": per, "hbm_bytes_per_call": tot, "hbm_bytes_per_block": int(tot / G)}
 json.dump(res, open(f"{out}/pmc_group.json", "w"), indent=1)
-if clients == 1024 and G == 8:
+if clients == 1024 and G == 8 and not __import__('os').environ.get('EXTRA'):
     key = "hbm_bytes_per_call_polyphase" if mode == "optimized" else "hbm_bytes_per_call_direct"
     latest = {}
     try:
