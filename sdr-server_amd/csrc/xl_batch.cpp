@@ -203,7 +203,6 @@ struct xlating_batch_t {
   uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = the mix launch on the matrix cores where the class allows it (integer input
                               // format, D <= 64), 0 = packed FP32 FMAs everywhere, 2 = mix + inverse as ONE launch with the mixed spectra
                               // on chip (xl_fused.hip) where the class allows it (integer input, D <= 64, <= 32 taps per branch)
-  int fus_split = -1;         // option "fused_split": the fused launch's tiles cover 8 segments (1) or 16 (0); -1 = by the call's size
   uint32_t mix_pp = 0;        // option "mix_passes_per_workgroup" (matrix-core mix): 0 = the launcher's default
   uint32_t mix_skip_at = 0;   // position of the mix launch's skipped workgroups; 0 = 1024
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
@@ -421,10 +420,6 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
   } else if (n == "mix_kernel") {
     if (value < 0 || value > 2) return -EINVAL;
     b->mix_kernel = (uint32_t)value;
-  } else if (n == "fused_split") {
-    if (value < -1 || value > 1) return -EINVAL;
-    b->fus_split = (int)value;
-    return 0;  // (a launch parameter: no re-plan)
   } else if (n == "mix_passes_per_workgroup") {
     if (value < 0 || value > 64) return -EINVAL;
     b->mix_pp = (uint32_t)value;
@@ -1863,9 +1858,6 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
               chain_wait = false;
               b->waited_valid = true, b->waited_ev = chain_ev, b->waited_stream = s;
             }
-            // tiles of 16 segments, or of 8 when those would leave CUs idle (short calls)
-            const uint32_t tiles16 = ((pa.nseg + XLF_SEGS - 1u) / XLF_SEGS) * pc.ncg * (XLP_COLS / XLF_COLS);
-            pa.fus_split = b->fus_split >= 0 ? (uint32_t)b->fus_split : (tiles16 < 448u ? 1u : 0u);
             XL_TRY(xlp_launch_fused(pa, s, last_launch ? b->ev_done[tab] : nullptr));
             done_attached = last_launch;
             if (pe[2]) XL_TRY(hipEventRecord(pe[2], s));

@@ -4,21 +4,25 @@
 //   xlp_forward_h_kernel   raw samples -> cf32 (xlating.c:357-378, exact) -> 128-point DFT of every polyphase branch per
 //                          segment -> the shared spectra in the matrix instruction's A-operand form, scaled and split in two
 //                          halves ("Xh", xl_fused_layout.h), stored as whole 128-byte lines.
-//   xlp_fused_kernel       workgroup = (16 segments x 16 client columns x all 128 bins).  Per bin the sums over the branches
+//   xlp_fused_kernel       workgroup = (8 segments x 16 client columns x all 128 bins), 4 waves at 256 registers: TWO workgroups
+//                          share a CU.  Per bin the sums over the branches
 //                              Y[c][s][m] = sum_b X[s][b][m] R[c][b][m]
-//                          are two 16 x 16 x 2D real matrix products on v_mfma_f32_16x16x32_f16 (Re Y and Im Y: the same A
-//                          rows (X.re, X.im) against (R.re, -R.im) and (R.im, R.re)), every float32 operand carried as two
+//                          are one 16 x 16 x 2D real matrix product on v_mfma_f32_16x16x32_f16 (rows = (segment, re / im):
+//                          (X.re, X.im) / (X.im, -X.re); columns = clients: (R.re, -R.im)), every float32 operand carried as two
 //                          halves (X R ~ X1 R1 + X1 R2 + X2 R1, FP32 accumulation, small terms first: see xlp_mix_mfma_kernel
 //                          in xl_polyphase.hip for the arithmetic and its error model).  The results NEVER leave the chip: wave
-//                          w keeps the bins m = 4 i + w of the whole tile in 256 accumulation registers per lane (the register
+//                          w keeps the bins m = 4 i + w of the whole tile in 128 accumulation registers per lane (the register
 //                          file is the largest memory of a CU: 512 KB against 160 KB of LDS), runs the 32-point inverse
 //                          transforms of its own bins in registers (xl_fft64.h), and the four waves combine their quarters
 //                          through LDS (one write + one read of the tile instead of the four of a staged transform) ->
 //                          scale -> NCO rotate (xlating.c:70) with the tabulated float32 phases -> out[k].
 // What the three-launch path moved through the memory system and this one does not: the mixed spectra Y, written and read back
 // once per call (8 M bytes per client and segment each way: 58 % of that path's traffic).  What it costs: the operands of a
-// tile (6 KB of spectra + 6 KB of branch spectra per bin) are streamed from L2 by every tile -- no workgroup can hold the
-// branch spectra of all bins of its columns -- so the launch is bound by L2 -> CU bandwidth, not by HBM.
+// tile (3 KB of spectra + 6 KB of branch spectra per bin) are streamed from L2 by every tile -- no workgroup can hold the
+// branch spectra of all bins of its columns -- so the launch is bound by L2 -> CU bandwidth, not by HBM; a tile's operand
+// stream (memory-bound) and its epilogue (vector-ALU-bound) overlap with the other workgroup's on the same CU.
+// (Round 4's first shape -- 16 x 16 tiles, one wave per SIMD at 512 registers, profiles/r04_fused_designA_timesplit.txt -- had
+// two thirds of the operand traffic per client and nothing to overlap its epilogue with: 2.4 x slower than the three launches.)
 #include "xl_poly_dev.h"
 
 #include "xl_fused_layout.h"
@@ -90,11 +94,10 @@ __global__ __launch_bounds__(1024) void xlp_forward_h_kernel(const XlpArgs a) {
     t0[q] = xlp_pack_h(r1, i1);
     t1[q] = xlp_pack_h(r2, i2);
   }
-  const uint32_t seg = s8 * 8u + so;
   uint4 *__restrict__ Xh = reinterpret_cast<uint4 *>(a.X);
   const uint32_t nk = xlf_nk(a.D);
-  Xh[xlf_xh_slot(seg >> 4, nk, bq >> 2, bq & 3u, m, 0u, seg & 15u)] = make_uint4(t0[0], t0[1], t0[2], t0[3]);
-  Xh[xlf_xh_slot(seg >> 4, nk, bq >> 2, bq & 3u, m, 1u, seg & 15u)] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+  Xh[xlf_xh_slot(s8, nk, bq >> 2, bq & 3u, m, 0u, so)] = make_uint4(t0[0], t0[1], t0[2], t0[3]);
+  Xh[xlf_xh_slot(s8, nk, bq >> 2, bq & 3u, m, 1u, so)] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
 }
 
 // ------------------------------------------------------------------------------------------- branch spectra, operand form
@@ -125,11 +128,11 @@ __global__ __launch_bounds__(XLP_COLS) void xlp_tables_h16_kernel(const float2 *
 }
 
 // ------------------------------------------------------------------------------------------- mix + inverse + epilogue, fused
-// B' = (R.im, R.re) from B = (R.re, -R.im), per dword (lo, hi) -> (-hi, lo): ONE packed half-precision multiply by (-1, +1)
-// with the source halves crossed (op_sel); exact.
-XL_DEV v8h xlf_bprime(const v8h b) {
-  uint4 x = __builtin_bit_cast(uint4, b);
-  const uint32_t pm = 0x3C00BC00u;  // (lo, hi) = (-1.0h, +1.0h)
+// A row (s, im) from the slot of row (s, re), per dword (lo, hi) = (X.re, X.im) -> (X.im, -X.re): ONE packed half-precision
+// multiply by (+1, -1) with the source halves crossed (op_sel); exact.
+XL_DEV v8h xlf_imrow(const v8h v) {
+  uint4 x = __builtin_bit_cast(uint4, v);
+  const uint32_t pm = 0xBC003C00u;  // (lo, hi) = (+1.0h, -1.0h)
   asm("v_pk_mul_f16 %0, %0, %4 op_sel:[1,0] op_sel_hi:[0,1]\n\t"
       "v_pk_mul_f16 %1, %1, %4 op_sel:[1,0] op_sel_hi:[0,1]\n\t"
       "v_pk_mul_f16 %2, %2, %4 op_sel:[1,0] op_sel_hi:[0,1]\n\t"
@@ -139,31 +142,41 @@ XL_DEV v8h xlf_bprime(const v8h b) {
   return __builtin_bit_cast(v8h, x);
 }
 
-#define XLF_PH_ROW 528u  // phases staged per client column and quarter: 4 segments x V <= 508 outputs + alignment to the table stride
+// One table entry's worth of NCO phases (xlating.c:70-73) into a staging row: row[i] = phase of output m0 + i, i < count <= 16,
+// p = the tabulated phase of output m0 (a multiple of the table stride).  Straight line when no block of the call ends inside
+// the run (the common case); else the checked walk of the other consumers (xl_phase_walk), bit-identical to the producer's chain.
+XL_DEV void xlf_stage_phases(v2f p, const uint32_t m0, const uint32_t count, const v2f inc, const XlBnd bnd, v2f *__restrict__ row) {
+  if (xl_bnd_next(bnd, m0) >= m0 + XL_PH_STRIDE && !(bnd.flags & XL_POS_FMA_STEP)) {
+#pragma unroll
+    for (uint32_t i = 0; i < XL_PH_STRIDE; ++i) {
+      if (i < count) row[i] = p;
+      if (i + 1u < XL_PH_STRIDE) p = xl_nco_next(p, inc);
+    }
+  } else {
+    xl_phase_walk(p, m0, count, inc, bnd, [&](uint32_t i, v2f phs) { row[i] = phs; });
+  }
+}
 
 // Tile order.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each with a private 4 MB L2: XCD x owns the
-// 16-column groups cg16 = x mod 8 and walks them against the segment tiles four at a time, so that the ~32 tiles in flight on
-// an XCD share 8 column groups' branch spectra and 4 segment groups' spectra -- which they stream bin by bin, roughly in step:
-// the L2 needs to hold a window of bins, not the images.
-// grid = 8 * (ncg16 / 8) * roundup(nst, 4) workgroups of 256 threads; nst segment tiles = 16-segment groups, or their halves
-// (fus_split: short calls, so that the tiles still cover the chip).
+// 16-column groups cg16 = x mod 8 and walks them against the segment tiles four at a time, so that the tiles in flight on an
+// XCD share a few column groups' branch spectra and a few segment groups' spectra -- which they stream bin by bin, roughly in
+// step: the L2 needs to hold a window of bins, not the images.
+// grid = 8 * (ncg16 / 8) * roundup(nst, 4) workgroups of 256 threads, nst = ceil(nseg / 8) segment tiles.
 template <int NK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void xlp_fused_kernel(const XlpArgs a) {
-  __shared__ v2f exch[4u * 64u * 32u];     // 64 KB: Z'_w[pair][k] of one quarter (xlf_exch)
-  __shared__ v2f phl[XLF_COLS][XLF_PH_ROW];  // 66 KB: the quarter's NCO phases per client column
-  __shared__ v2f twl[4][32];               // e^{+2 pi j w k / 128}
-  __shared__ uint4 cinfo[XLF_COLS];        // per client column: out row, grid shift, outputs owned, first staged output of the quarter
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void xlp_fused_kernel(const XlpArgs a) {
+  __shared__ v2f exch[4u * 32u * 32u];        // 32 KB: Z'_w[pair][k] of one sub-step (xlf_exch)
+  __shared__ v2f phl[XLF_COLS][XLF_PH_ROW];   // 36 KB: the sub-step's NCO phases per client column
+  __shared__ v2f twl[4][32];                  // e^{+2 pi j w k / 128}
+  __shared__ uint4 cinfo[XLF_COLS];           // per client column: out row, grid shift, outputs owned, first staged output of the sub-step
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   // ---- which tile
   const uint32_t ncgl = a.ncg;  // 16-column groups per XCD = ncg * 8 / 8
   const uint32_t x = blockIdx.x & 7u, r = blockIdx.x >> 3;
-  const uint32_t nst = a.fus_split ? (a.nseg + 7u) >> 3 : (a.nseg + 15u) >> 4;
+  const uint32_t nst = (a.nseg + XLF_SEGS - 1u) / XLF_SEGS;
   const uint32_t cg16 = ((r >> 2) % ncgl) * 8u + x;
-  const uint32_t st = (r / (4u * ncgl)) * 4u + (r & 3u);
-  if (st >= nst) return;
-  const uint32_t sg = a.fus_split ? st >> 1 : st;
-  const uint32_t e0 = a.fus_split ? 2u * (st & 1u) : 0u, e1 = a.fus_split ? e0 + 2u : 4u;  // quarters of the group this tile covers
+  const uint32_t sg = (r / (4u * ncgl)) * 4u + (r & 3u);
+  if (sg >= nst) return;
   // ---- the client column whose phase chains this thread walks (tid & 15: the same in every round), and is anybody here?
   const uint32_t cc = tid & 15u;
   const XlpCol colc = a.cols[cg16 * XLF_COLS + cc];
@@ -178,14 +191,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t e = ((tid >> 5) * (tid & 31u)) & 127u;
     twl[tid >> 5][tid & 31u] = (v2f){xl_w128_cos((int)e), xl_w128_sin((int)e)};
   }
+  if (tid < XLF_COLS) cinfo[tid] = make_uint4(colc.out_off, shiftc, bndc.K, 0u);
   // ---- the sums over the branches: wave w, bins m = 4 i + w
-  v4f d1[32], d2[32];  // Re Y / Im Y of (client column lane & 15, segments 4 (lane >> 4) + e of the group's ... see xlf_row_seg), per bin
+  v4f d[32];  // per bin: (re, im) of Y of (client column lane & 15, segment lane >> 4), then of segment 4 + (lane >> 4)
   {
     const uint32_t i16 = lane & 15u, kg = lane >> 4;
-    // A rows are independent of each other (row i of D depends on row i of A alone), and the rows this tile does not own --
-    // the other half of the group (fus_split), segments past the call's last -- end in sums nobody stores: their lanes
-    // read the slot of a row the tile DOES own (the same cache lines: no extra traffic), not zeros.
-    const uint32_t seg16 = a.fus_split ? ((xlf_row_seg(i16) & 7u) | (e0 << 2)) : xlf_row_seg(i16);
     // (uniform base pointer + 32-bit lane offset: the loads address as scalar base + vector offset)
 #ifdef XLF_EXP_SAME_OPERANDS  // (tools/experiments: every tile streams the SAME operands -- all L2 hits; WRONG results)
     const uint4 *__restrict__ Xb = reinterpret_cast<const uint4 *>(a.X);
@@ -194,7 +204,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint4 *__restrict__ Xb = reinterpret_cast<const uint4 *>(a.X) + xlf_xh_slot(sg, NK, 0u, 0u, 0u, 0u, 0u);
     const uint4 *__restrict__ Rb = reinterpret_cast<const uint4 *>(a.Rh) + xlf_rh_slot(cg16, NK, 0u, 0u, 0u, 0u);
 #endif
-    const uint32_t xbyte = (uint32_t)xlf_xh_slot(0u, NK, 0u, kg, 0u, 0u, seg16) * 16u, rbyte = lane * 16u;  // (< 2^20)
+    const uint32_t xbyte = (uint32_t)xlf_xh_slot(0u, NK, 0u, kg, 0u, 0u, xlf_row_seg(i16)) * 16u, rbyte = lane * 16u;  // (< 2^20)
+    const bool imrow = xlf_row_comp(i16) != 0u;
     v8h a1[2][NK], a2[2][NK], b1[2][NK], b2[2][NK];
     auto ld = [](const uint4 *__restrict__ base, const uint32_t byte) __attribute__((always_inline)) {
 #ifdef XLF_EXP_NO_LOADS  // (tools/experiments: what the launch costs without its operand stream -- WRONG results)
@@ -207,11 +218,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto load = [&](const uint32_t m, const int buf) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < NK; ++j) {
-        // (slot strides: k-block 4 * 128 * 2 * 16, bin 2 * 16, term 16)
-        const uint4 *__restrict__ xp = Xb + ((size_t)j * 4u * XLF_M + m) * 32u;
+        // (slot strides: k-block 4 * 128 * 2 * 8, bin 2 * 8, term 8)
+        const uint4 *__restrict__ xp = Xb + ((size_t)j * 4u * XLF_M + m) * 16u;
         const uint4 *__restrict__ rp = Rb + ((size_t)m * NK + j) * 128u;
         a1[buf][j] = ld(xp, xbyte);
-        a2[buf][j] = ld(xp + 16, xbyte);
+        a2[buf][j] = ld(xp + 8, xbyte);
         b1[buf][j] = ld(rp, rbyte);
         b2[buf][j] = ld(rp + 64, rbyte);
       }
@@ -222,31 +233,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int cur = i & 1, nxt = cur ^ 1;
       if (i + 1 < 32) load(xlf_bin(w, (uint32_t)i + 1u), nxt);  // one bin ahead: requested before this bin's products
       __builtin_amdgcn_sched_barrier(0);
-      v8h p1[NK], p2[NK];
+      if (imrow) {
 #pragma unroll
-      for (int j = 0; j < NK; ++j) {
-        p1[j] = xlf_bprime(b1[cur][j]);
-        p2[j] = xlf_bprime(b2[cur][j]);
+        for (int j = 0; j < NK; ++j) {
+          a1[cur][j] = xlf_imrow(a1[cur][j]);
+          a2[cur][j] = xlf_imrow(a2[cur][j]);
+        }
       }
-      v4f re = {0.0f, 0.0f, 0.0f, 0.0f}, im = {0.0f, 0.0f, 0.0f, 0.0f};
-      // small terms first (X2 R1, X1 R2), then X1 R1 on top of them: one accumulator per component
+      v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      // small terms first (X2 R1, X1 R2), then X1 R1 on top of them: one accumulator
 #pragma unroll
-      for (int j = 0; j < NK; ++j) {
-        re = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[cur][j], b1[cur][j], re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[cur][j], p1[j], im, 0, 0, 0);
-      }
+      for (int j = 0; j < NK; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[cur][j], b1[cur][j], acc, 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < NK; ++j) {
-        re = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[cur][j], b2[cur][j], re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[cur][j], p2[j], im, 0, 0, 0);
-      }
+      for (int j = 0; j < NK; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[cur][j], b2[cur][j], acc, 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < NK; ++j) {
-        re = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[cur][j], b1[cur][j], re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[cur][j], p1[j], im, 0, 0, 0);
-      }
-      d1[i] = re;
-      d2[i] = im;
+      for (int j = 0; j < NK; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[cur][j], b1[cur][j], acc, 0, 0, 0);
+      d[i] = acc;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -254,96 +256,101 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   {
     float sum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) sum += d1[i][0] + d1[i][1] + d1[i][2] + d1[i][3] + d2[i][0] + d2[i][1] + d2[i][2] + d2[i][3];
+    for (int i = 0; i < 32; ++i) sum += d[i][0] + d[i][1] + d[i][2] + d[i][3];
     if (sum == 12345.678f) reinterpret_cast<float *>(a.out)[0] = sum;
     return;
   }
 #endif
-  // ---- epilogue, one quarter (result register e = segments 4 e .. 4 e + 3 of the group) at a time
-  const uint32_t c = lane & 15u;  // as a result lane: client column c, segments 4 e + (lane >> 4)
+  // ---- epilogue: half h = result registers (2 h, 2 h + 1) = segments 4 h .. 4 h + 3 of the tile; sub-step ab = the lanes
+  // 32 ab .. 32 ab + 31 of every wave = segments 4 h + 2 ab, + 1
+  const uint32_t c = lane & 15u;  // as a result lane: client column c, segment 4 h + (lane >> 4)
   // what undoes the operand scales (a power of two) and the transform's 1 / M, applied before the transform (linear, exact)
   const float scl = a.cscale[cg16 * XLF_COLS + c] * (1.0f / (float)XLF_M);
-  if (tid < XLF_COLS) cinfo[tid] = make_uint4(colc.out_off, shiftc, bndc.K, 0u);
   const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
   v2f *__restrict__ out = reinterpret_cast<v2f *>(a.out);
-  const uint32_t hp = lane >> 5, k = lane & 31u;  // as a consumer lane: point k of the pairs 16 w + 2 pp + hp
-  auto quarter = [&](const int e) __attribute__((always_inline)) {
-    const uint32_t S0 = sg * XLF_SEGS + 4u * (uint32_t)e;  // first segment of the quarter
-    if ((uint32_t)e < e0 || (uint32_t)e >= e1 || S0 >= a.nseg) return;  // (workgroup-uniform)
-    // -- this thread's phase chains: the outputs of column cc inside the quarter's (live) segments, table entry by table entry
-    const uint32_t Se = S0 + 4u < a.nseg ? S0 + 4u : a.nseg;
-    const uint32_t qlo = S0 * a.V > shiftc ? S0 * a.V : shiftc;
-    const uint32_t klo = qlo - shiftc;
-    const uint32_t khi = Se * a.V - shiftc < bndc.K ? Se * a.V - shiftc : bndc.K;  // (Se V >= V >= 2 > shiftc)
-    const uint32_t base = klo & ~(XL_PH_STRIDE - 1u);
-    const uint32_t nent = khi > base ? (khi - base + XL_PH_STRIDE - 1u) >> XL_PH_SHIFT : 0u;
-    if (tid < XLF_COLS) cinfo[tid].w = base;
-    v2f pe[3];
+  const v2f incc = {colc.incr.x, colc.incr.y};
+  const uint32_t hp = lane >> 5, k = lane & 31u;  // as a consumer lane: point k of the client columns 8 (w & 1) + 2 pp + hp
+  __syncthreads();  // (cinfo, twl)
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {  // (requested before the transform)
-      const uint32_t te = (tid >> 4) + 16u * (uint32_t)rr;
-      pe[rr] = ph[te < nent ? (colc.out_off >> XL_PH_SHIFT) + (base >> XL_PH_SHIFT) + te : 0u];
+  for (int h = 0; h < 2; ++h) {
+    if (sg * XLF_SEGS + 4u * (uint32_t)h >= a.nseg) break;  // (workgroup-uniform)
+    // -- the lane's sequence of this half -> 32-point inverse transform -> twiddle: z[k] in slot xl_fft32_slot(k)
+    v2f u[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) u[i] = (v2f){d[i][2 * h], d[i][2 * h + 1]} * scl;
+    XL_FFT_FENCE();
+    xl_fft32_inverse<v2f, XlpFftOps>(u);
+#pragma unroll
+    for (int kk = 1; kk < 32; ++kk) {
+      u[xl_fft32_slot(kk)] = xlp_cmul_v(u[xl_fft32_slot(kk)], twl[w][kk]);
+      if (kk % 4 == 3) XL_FFT_FENCE();
     }
-    // -- producer: the lane's sequence of this quarter -> 32-point inverse transform -> twiddle -> exchange buffer
-    {
-      v2f u[32];
+#pragma unroll 1
+    for (uint32_t ab = 0; ab < 2u; ++ab) {
+      const uint32_t S0 = sg * XLF_SEGS + 4u * (uint32_t)h + 2u * ab;  // first of the sub-step's two segments
+      if (S0 >= a.nseg) break;
+      // -- this thread's phase chains: the outputs of column cc inside the sub-step's (live) segments, table entry by entry
+      const uint32_t Se = S0 + 2u < a.nseg ? S0 + 2u : a.nseg;
+      const uint32_t qlo = S0 * a.V > shiftc ? S0 * a.V : shiftc;
+      const uint32_t klo = qlo - shiftc;
+      const uint32_t khi = Se * a.V - shiftc < bndc.K ? Se * a.V - shiftc : bndc.K;  // (Se V >= V >= 2 > shiftc)
+      const uint32_t base = klo & ~(XL_PH_STRIDE - 1u);
+      const uint32_t nent = khi > base ? (khi - base + XL_PH_STRIDE - 1u) >> XL_PH_SHIFT : 0u;
+      if (tid < XLF_COLS) cinfo[tid].w = base;
+      v2f pe[2];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) u[i] = (v2f){d1[i][e], d2[i][e]} * scl;
-      XL_FFT_FENCE();
-      xl_fft32_inverse<v2f, XlpFftOps>(u);
-#pragma unroll
-      for (int kk = 0; kk < 32; ++kk) {
-        const v2f z = kk == 0 ? u[xl_fft32_slot(kk)] : xlp_cmul_v(u[xl_fft32_slot(kk)], twl[w][kk]);
-        exch[xlf_exch(w, lane, (uint32_t)kk)] = z;
-        if (kk % 4 == 3) XL_FFT_FENCE();
+      for (int rr = 0; rr < 2; ++rr) {  // (requested before the exchange writes)
+        const uint32_t te = (tid >> 4) + 16u * (uint32_t)rr;
+        pe[rr] = ph[te < nent ? (colc.out_off >> XL_PH_SHIFT) + (base >> XL_PH_SHIFT) + te : 0u];
       }
-    }
-    // -- the phases
+      // -- producers: the lanes of this sub-step hand their sequences to the exchange buffer
+      if (hp == ab) {
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-      const uint32_t te = (tid >> 4) + 16u * (uint32_t)rr;
-      if (te < nent) {
-        const uint32_t m0 = base + te * XL_PH_STRIDE;
-        const uint32_t left = khi - m0;
-        v2f *__restrict__ row = &phl[cc][te * XL_PH_STRIDE];
-        xl_phase_walk(pe[rr], m0, left < XL_PH_STRIDE ? left : XL_PH_STRIDE, (v2f){colc.incr.x, colc.incr.y}, bndc,
-                      [&](uint32_t i, v2f phs) { row[i] = phs; });
+        for (int kk = 0; kk < 32; ++kk) exch[xlf_exch(w, k, (uint32_t)kk)] = u[xl_fft32_slot(kk)];
       }
-    }
-    __syncthreads();
-    // -- consumer: wave w = segment S0 + w, all 16 columns; lane = point k of two columns at a time
-    const uint32_t seg = S0 + w;
-    if (seg < a.nseg) {
+      // -- the phases
 #pragma unroll
-      for (int pp = 0; pp < 8; ++pp) {
-        const uint32_t cl = 2u * (uint32_t)pp + hp, p = 16u * w + cl;
-        const v2f z0 = exch[xlf_exch(0u, p, k)], z1 = exch[xlf_exch(1u, p, k)];
-        const v2f z2 = exch[xlf_exch(2u, p, k)], z3 = exch[xlf_exch(3u, p, k)];
-        const uint4 ci = cinfo[cl];
-        // y[k + 32 q] = sum_w j^{w q} z_w
-        const v2f t0 = z0 + z2, t1 = z0 - z2, t2 = z1 + z3, t3 = z1 - z3;
-        v2f y[4];
-        y[0] = t0 + t2;
-        y[1] = XlpFftOps::add_j(t1, t3);
-        y[2] = t0 - t2;
-        y[3] = XlpFftOps::sub_j(t1, t3);
+      for (int rr = 0; rr < 2; ++rr) {
+        const uint32_t te = (tid >> 4) + 16u * (uint32_t)rr;
+        if (te < nent) {
+          const uint32_t m0 = base + te * XL_PH_STRIDE;
+          const uint32_t left = khi - m0;
+          xlf_stage_phases(pe[rr], m0, left < XL_PH_STRIDE ? left : XL_PH_STRIDE, incc, bndc, &phl[cc][te * XL_PH_STRIDE]);
+        }
+      }
+      __syncthreads();
+      // -- consumers: waves 0, 1 = segment S0, waves 2, 3 = S0 + 1; wave parity = which 8 of the 16 columns; lane = point k
+      // of two columns at a time
+      const uint32_t seg = S0 + (w >> 1);
+      if (seg < a.nseg) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t n = k + 32u * (uint32_t)q, qs = seg * a.V + n;  // shared point of this value
-          if (n < a.V && qs >= ci.y && qs - ci.y < ci.z) {
-            const uint32_t ko = qs - ci.y;
-            out[ci.x + ko] = xl_rotate<1>(y[q], phl[cl][ko - ci.w]);
+        for (int pp = 0; pp < 4; ++pp) {
+          const uint32_t cl = 8u * (w & 1u) + 2u * (uint32_t)pp + hp, p = 16u * (w >> 1) + cl;
+          const v2f z0 = exch[xlf_exch(0u, p, k)], z1 = exch[xlf_exch(1u, p, k)];
+          const v2f z2 = exch[xlf_exch(2u, p, k)], z3 = exch[xlf_exch(3u, p, k)];
+          const uint4 ci = cinfo[cl];
+          // y[k + 32 q] = sum_w j^{w q} z_w
+          const v2f t0 = z0 + z2, t1 = z0 - z2, t2 = z1 + z3, t3 = z1 - z3;
+          v2f y[4];
+          y[0] = t0 + t2;
+          y[1] = XlpFftOps::add_j(t1, t3);
+          y[2] = t0 - t2;
+          y[3] = XlpFftOps::sub_j(t1, t3);
+          // shared point of y[q]: seg V + k + 32 q; the column's output index is that - shift, staged phase index that - base
+          const uint32_t q0 = seg * a.V + k;
+          const bool inner = q0 >= ci.y + k && q0 - k + a.V <= ci.y + ci.z;  // every point of the segment is an output of the column
+          v2f *__restrict__ op = out + ci.x + (q0 - ci.y);                    // (wraps below the row only where nothing is stored)
+          const v2f *__restrict__ pp0 = &phl[cl][0] + (q0 - ci.y - ci.w);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t n = k + 32u * (uint32_t)q, qs = q0 + 32u * (uint32_t)q;
+            if (n < a.V && (inner || (qs >= ci.y && qs - ci.y < ci.z))) op[32 * q] = xl_rotate<1>(y[q], pp0[32 * q]);
           }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
-  };
-  __syncthreads();  // (cinfo, twl)
-  quarter(0);
-  quarter(1);
-  quarter(2);
-  quarter(3);
+  }
 }
 
 // ------------------------------------------------------------------------------------------- launchers
@@ -368,7 +375,7 @@ hipError_t xlp_launch_fused(const XlpArgs &a, hipStream_t s, hipEvent_t done) {
   if (a.M != XLF_M || nk == 0u || nk > XLF_NK_MAX || a.Rh == nullptr || a.cscale == nullptr || a.fmt == XLF_CF32 ||
       a.A < 2u || a.V + a.A != XLF_M + 1u || a.ncg == 0u || a.nco_blocks != 0u)
     return hipErrorInvalidValue;
-  const uint32_t nst = a.fus_split ? (a.nseg + 7u) >> 3 : (a.nseg + 15u) >> 4;
+  const uint32_t nst = (a.nseg + XLF_SEGS - 1u) / XLF_SEGS;
   const dim3 grid(8u * a.ncg * ((nst + 3u) & ~3u));
   void (*kern)(const XlpArgs) = nk == 1u ? xlp_fused_kernel<1> : nk == 2u ? xlp_fused_kernel<2> : nk == 3u ? xlp_fused_kernel<3> : xlp_fused_kernel<4>;
   if (done) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, s, nullptr, done, 0, a);

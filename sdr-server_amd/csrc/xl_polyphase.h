@@ -68,7 +68,6 @@ struct XlpArgs {
                        // 2 = mix + inverse as ONE launch with the mixed spectra on chip (xl_fused.hip: no Y image, X and Rh in that launch's operand forms)
   uint32_t nkb;        // mix_kind 1: k-blocks of 8 branches = ceil(D / 8), <= XLP_NKB_MAX; mix_kind 2: k-blocks of 16 branches, <= 4
   uint32_t mix_pp;     // mix_kind 1: passes per workgroup (0 = default)
-  uint32_t fus_split;  // mix_kind 2 (xl_fused.hip): 1 = the fused launch's tiles cover 8 segments instead of 16 (short calls)
   unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]

@@ -1250,7 +1250,7 @@ def _engine_outputs(eng, ids):
 
 
 @pytest.mark.parametrize("variant", ["native", "optimized", "optimized-register-inverse", "optimized-quad-register-inverse",
-                                     "optimized-swizzled-inverse", "optimized-fma-mix", "optimized-fused", "optimized-fused-split"])
+                                     "optimized-swizzled-inverse", "optimized-fma-mix", "optimized-fused"])
 def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
     server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
@@ -1264,18 +1264,14 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     if variant.endswith("-fma-mix"):
         monkeypatch.setenv("XL_EXP_MIX", "0")
         variant = "optimized"
-    split = None
-    if "-fused" in variant:
+    if variant.endswith("-fused"):
         monkeypatch.setenv("XL_EXP_MIX", "2")
-        split = 1 if variant.endswith("-split") else 0
         variant = "optimized"
     t48 = lpf(FS, 24000, 9600)
     G, nb = 8, 262144
     fcs = [-984000 + 1920 * c for c in range(1024)]
     eng = xl.BatchEngine(FS, "cu8", nb, group_blocks=G)
     ids = [eng.add_client(42, t48, fc) for fc in fcs]
-    if split is not None:
-        eng.set_option("fused_split", split)
     x = siggen.xs_u8(8100, 2 * G * nb)
     for k in range(2):
         eng.process_host_group(x[k * G * nb:(k + 1) * G * nb], G, variant)
