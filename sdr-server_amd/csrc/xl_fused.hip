@@ -336,15 +336,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           y[1] = XlpFftOps::add_j(t1, t3);
           y[2] = t0 - t2;
           y[3] = XlpFftOps::sub_j(t1, t3);
-          // shared point of y[q]: seg V + k + 32 q; the column's output index is that - shift, staged phase index that - base
+          // shared point of y[q]: seg V + k + 32 q; the column's output index is that - shift, staged phase index that - base.
+          // (32-bit index arithmetic on purpose: where a shared point lies below the column's first output the differences wrap,
+          // and wrap back for the points that are outputs -- as offsets of a 64-bit pointer they would not)
           const uint32_t q0 = seg * a.V + k;
           const bool inner = q0 >= ci.y + k && q0 - k + a.V <= ci.y + ci.z;  // every point of the segment is an output of the column
-          v2f *__restrict__ op = out + ci.x + (q0 - ci.y);                    // (wraps below the row only where nothing is stored)
-          const v2f *__restrict__ pp0 = &phl[cl][0] + (q0 - ci.y - ci.w);
+          const uint32_t o0 = ci.x + (q0 - ci.y), p0 = cl * XLF_PH_ROW + (q0 - ci.y - ci.w);
+          const v2f *__restrict__ phf = &phl[0][0];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const uint32_t n = k + 32u * (uint32_t)q, qs = q0 + 32u * (uint32_t)q;
-            if (n < a.V && (inner || (qs >= ci.y && qs - ci.y < ci.z))) op[32 * q] = xl_rotate<1>(y[q], pp0[32 * q]);
+            if (n < a.V && (inner || (qs >= ci.y && qs - ci.y < ci.z))) out[o0 + 32u * (uint32_t)q] = xl_rotate<1>(y[q], phf[p0 + 32u * (uint32_t)q]);
           }
         }
       }
