@@ -106,6 +106,14 @@ def reduce_max_seconds(dist, torch, dt, device):
     return float(t.item())
 
 
+def gather_seconds(dist, torch, dt, device, world):
+    """every rank's time of one timed repeat (rank order), next to the max the contract asks for"""
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[dist.get_rank()] = dt
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [round(float(v), 6) for v in t.tolist()]
+
+
 NSRC_GROUPS = 4  # distinct 8-block super-blocks the synthetic stream cycles through
 
 
@@ -273,6 +281,15 @@ class CHost:
                               device=torch.cuda.current_device())
         self.eng = self.m.engine(rank)
         self.k = 0
+        self.comm_count = self.m.comm_count()
+        if world > 1 and self.comm_count != world:  # (a communicator of another size would be another job's)
+            raise RuntimeError(f"RCCL communicator counts {self.comm_count} ranks, the job has {world}")
+        if world > 1:
+            self.m.feed_timing(True)
+
+    def feed_timing(self):
+        """(feeds measured, broadcast ms, hidden ms) since the last read -- HIP events on the communication stream."""
+        return self.m.feed_timing_read()
 
     def add_client(self, c, taps):
         return self.m.add_client(c, D, taps, client_center_freq(c))
@@ -299,10 +316,15 @@ def make_host(ctx, group):
     create the C host (e.g. an RCCL set-up problem) EVERY rank stops with an error: a multi-GPU run that silently measured
     the Python feeder instead would be mistaken for the C host's number."""
     torch, dist, world = ctx["torch"], ctx["dist"], ctx["world"]
-    if not ctx["cuda"] or ctx["feed"] == "torch":
-        return TorchHost(ctx, group)
     host, err = None, None
-    if world > 1 or os.environ.get("XL_BENCH_CHOST_THREAD"):
+    if not ctx["cuda"] or ctx["feed"] == "torch":
+        try:
+            if os.environ.get("XL_BENCH_FAIL_RANK") == str(ctx["rank"]):  # (tests/test_bench_launch.py: one rank cannot create its engine)
+                raise RuntimeError("simulated engine create failure (XL_BENCH_FAIL_RANK)")
+            host = TorchHost(ctx, group)
+        except Exception as e:  # noqa: BLE001 -- reported below, after every rank has heard of it
+            err = e
+    elif world > 1 or os.environ.get("XL_BENCH_CHOST_THREAD"):
         # (RCCL set-up is the one step of this path no single-GPU box can exercise: give it a deadline instead of trusting it)
         import threading
 
@@ -328,16 +350,16 @@ def make_host(ctx, group):
         except Exception as e:  # noqa: BLE001 -- reported below
             err = e
     ok = 1 if host is not None else 0
-    if world > 1:
-        t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+    if world > 1:  # every rank learns whether ALL of them have an engine: one failure stops the whole job, nobody waits in a collective
+        t = torch.tensor([ok], dtype=torch.int32, device="cuda" if ctx["cuda"] else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok = int(t.item())
     if ok:
         return host
     if host is not None:
         host.close()
-    raise SystemExit(f"bench.py: the C multi-GPU host (xlating_multi) could not be created on rank {ctx['rank']} ({err}); "
-                     "nothing was measured.  `--feed torch` runs the torch.distributed feeder instead (and says so in config.feed).")
+    raise SystemExit(f"bench.py: rank {ctx['rank']}: the engine host could not be created on every rank (here: {err if err else 'ok, another rank failed'}); "
+                     "nothing was measured.  (C host failures: `--feed torch` runs the torch.distributed feeder instead and says so in config.feed.)")
 
 
 def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROUP, options=None, staggered=False,
@@ -384,7 +406,9 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
     host.sync()
     eng.timing_stride(TIMING_STRIDE)
     eng.timing(True)
-    secs = []
+    if hasattr(host, "feed_timing") and world > 1:
+        host.feed_timing()  # (reset: the warm-up's feeds do not count)
+    secs, rank_secs = [], []
     for _ in range(repeats):
         if world > 1:
             dist.barrier()
@@ -398,8 +422,17 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
         host.sync()
         dt = time.perf_counter() - t0
         if world > 1:
+            rank_secs.append(gather_seconds(dist, torch, dt, "cuda" if cuda else "cpu", world))
             dt = reduce_max_seconds(dist, torch, dt, "cuda" if cuda else "cpu")
         secs.append(dt)
+    feed = None
+    if hasattr(host, "feed_timing") and world > 1:
+        nfeed, bms, hms = host.feed_timing()
+        if nfeed > 0:
+            feed = {"feeds_measured": nfeed, "broadcast_us": round(bms / nfeed * 1e3, 2), "hidden_us": round(hms / nfeed * 1e3, 2),
+                    "feed_overlap_frac": round(hms / bms, 4) if bms > 0 else None,
+                    "how": "HIP events on the communication stream around every ncclBroadcast (this rank); hidden = the part of a "
+                           "broadcast that elapsed while the previous feed's launches were still running on the compute stream"}
     nt, fir_ms, nco_ms = eng.timing_read(reset=True)
     eng.timing(False)
     dt = sorted(secs)[len(secs) // 2]
@@ -420,7 +453,9 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
         host.sync()
         n3, ms3 = eng.timing_polyphase(reset=True)
         eng.timing(False)
-        if n3 > 0:
+        if n3 > 0 and "mix=fused" in plan:
+            kernels_ms = {"xlp_forward_h_kernel": round(ms3[0] / n3, 4), "xlp_fused_kernel": round(ms3[1] / n3, 4)}
+        elif n3 > 0:
             mix_name = "xlp_mix_mfma_kernel" if "mix=mfma" in plan else "xlp_mix_kernel"
             kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), mix_name: round(ms3[1] / n3, 4),
                           "xlp_inverse_kernel": round(ms3[2] / n3, 4)}
@@ -430,7 +465,8 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
             "nco_ms_avg": nco_ms / max(nt, 1), "blocks_per_step": blocks_per_step,
             "timed_calls": nt, "clients_this_rank": len(mine), "total_clients": total_clients, "K_call": int(klen),
             "plan": plan, "polyphase": polyphase, "kernels_ms": kernels_ms, "group": group, "steps": steps,
-            "parity_spot": spot_res}
+            "parity_spot": spot_res, "rank_seconds": rank_secs, "feed_timing": feed,
+            "rccl_comm_count": getattr(host, "comm_count", None)}
 
 
 def parity_spot(ctx, eng, ids, mine, taps, mode, calls_done, call):
@@ -558,12 +594,20 @@ def variant_entry(m, note=None):
          "model_hbm_frac": round(g / HBM_PEAK_GBS, 4),
          "fp32_frac": None if m["polyphase"] else round(t / FP32_PEAK_TFLOPS, 4),
          "achieved_TFLOPs": None if m["polyphase"] else round(t, 2), "plan": m["plan"]}
+    if m.get("rank_seconds"):
+        e["per_rank_seconds"] = m["rank_seconds"]
+        e["feed_timing"] = m.get("feed_timing")
+        e["rccl_comm_count"] = m.get("rccl_comm_count")
     if note:
         e["note"] = note
     return e
 
 
-PMC_KERNEL_PREFIXES = ("xlp_forward", "xlp_mix", "xlp_inverse", "xl_fir_kernel", "xl_nco_chain", "xl_nco_table", "xl_update_history")
+# what FETCH_SIZE / WRITE_SIZE count (MI355X_MICROARCH.md, HBM section; profiles/r04_mall_calibration.txt)
+COUNTER_SCOPE = ("L2 <-> fabric requests (TCC_EA read / write requests x request size): Infinity-Cache (MALL) hits are included, so "
+                 "`traffic` is an UPPER bound of the HBM bytes and `frac` an upper bound of the HBM utilisation")
+
+PMC_KERNEL_PREFIXES = ("xlp_forward", "xlp_mix", "xlp_inverse", "xlp_fused", "xl_fir_kernel", "xl_nco_chain", "xl_nco_table", "xl_update_history")
 
 
 def measure_traffic(args):
@@ -731,17 +775,18 @@ def main():
     variants = {}
     native = None
     VB = 320  # blocks per step of the variants (their number is context, not the headline)
-    if not args.no_variants and cuda:
+    if not args.no_variants and (cuda or world > 1):
         vs = max(2, args.steps // 4)
         other_mode = "native" if args.mode == "optimized" else "optimized"
-        mn = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, other_mode, spot=not args.no_spot, poly3=False, blocks_per_step=VB)
-        native = variant_entry(mn, "the reference's default arithmetic (cpu_optimization NATIVE_CF32, src/config.c:252-264): bit-exact "
-                                   "scalar tap order, 4 packed unfused ops per complex MAC, direct FIR kernel")
-        native["parity_spot"] = mn["parity_spot"]
+        if cuda:
+            mn = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, other_mode, spot=not args.no_spot, poly3=False, blocks_per_step=VB)
+            native = variant_entry(mn, "the reference's default arithmetic (cpu_optimization NATIVE_CF32, src/config.c:252-264): bit-exact "
+                                       "scalar tap order, 4 packed unfused ops per complex MAC, direct FIR kernel")
+            native["parity_spot"] = mn["parity_spot"]
         if world > 1:  # the other way to use N GPUs, next to the strong-scaling headline (or vice versa)
             other = "weak" if args.scaling == "strong" else "strong"
             mw = run_workload(ctx, args.clients * world if other == "weak" else args.clients, args.lpf_cutoff_rate, vs, 1, args.mode,
-                              poly3=False, blocks_per_step=VB)
+                              poly3=False, blocks_per_step=VB if cuda else 64)
             variants[f"{other} scaling ({args.clients} clients {'per GPU' if other == 'weak' else 'in total'})"] = variant_entry(mw)
         else:
             other_rate = 1 if args.lpf_cutoff_rate != 1 else 5
@@ -756,10 +801,28 @@ def main():
                 variants[f"one GPU's share at 8 GPUs ({total_clients // 8} clients): aggregate = 8 x this value minus the feed"] = variant_entry(m8)
             for big in (2048, 4096):  # where the launches, not the NCO recurrence, bound the engine
                 if total_clients == 1024:
-                    mb = run_workload(ctx, big, args.lpf_cutoff_rate, 2, 1, args.mode, blocks_per_step=VB)
+                    # (2048: EVERY client against the oracle population after the timed region, like the headline)
+                    mb = run_workload(ctx, big, args.lpf_cutoff_rate, 2, 1, args.mode, blocks_per_step=VB, spot=(big == 2048 and not args.no_spot))
                     e = variant_entry(mb)
                     e["kernels_ms_per_call"] = mb["kernels_ms"]
+                    e["parity_spot"] = mb["parity_spot"]
                     variants[f"{big} clients on this GPU (kernel-bound regime)"] = e
+            if m["polyphase"] and "mix=mfma" in m["plan"]:
+                # the same path with every product formed in float32 (xlp_mix_kernel: packed FP32 FMAs instead of two-half operands
+                # on the matrix cores): the all-float32 number of this workload, every client against the oracle
+                mf = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, options={"mix_kernel": 0},
+                                  spot=not args.no_spot, blocks_per_step=VB)
+                e = variant_entry(mf, "float32 operands, float32 FMAs, float32 accumulation in all three launches")
+                e["kernels_ms_per_call"] = mf["kernels_ms"]
+                e["parity_spot"] = mf["parity_spot"]
+                variants["polyphase, packed-FMA mix (all-float32 products)"] = e
+                # mix + inverse as ONE launch with the mixed spectra on chip (xl_fused.hip, option mix_kernel = 2): round 4's
+                # experiment, kept selectable; not the default (profiles/r04_fused_designB_counters.txt)
+                for big in (total_clients, 4096):
+                    mu = run_workload(ctx, big, args.lpf_cutoff_rate, 2, 1, args.mode, options={"mix_kernel": 2}, blocks_per_step=VB)
+                    e = variant_entry(mu, "mix + inverse fused, mixed spectra in registers: no Y round trip, but operand re-reads and low occupancy")
+                    e["kernels_ms_per_call"] = mu["kernels_ms"]
+                    variants[f"fused mix + inverse launch, {big} clients (option mix_kernel=2; not the default)"] = e
             if m["polyphase"]:  # the same workload through the direct FIR kernels: the FP32-bound design
                 md = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, options={"polyphase": 0}, poly3=False, blocks_per_step=VB)
                 variants[f"process_{args.mode}_cu8_cf32 through the direct FIR kernel ({md['ntaps']} taps)"] = variant_entry(
@@ -825,6 +888,7 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+        "counter_scope": COUNTER_SCOPE,
         "frac_is": ("HBM bytes of one call's launches by the PMC counters / the HIP-event duration of those launches / peak" if traffic else
                     "NO counter value available: bytes the path moves by design (design_traffic) / launch duration / peak"),
         "kernel_ms": round(m["call_ms_avg"], 4),
@@ -876,13 +940,21 @@ def main():
                 pk[kname]["frac_mfma_f16"] = round(mfma_flops / (ms_k * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
         chain = next((v for k, v in per_kernel_bytes.items() if k.startswith("xl_nco_chain")), None)
         if chain is not None:
-            pk["xl_nco_chain_kernel"] = {"ms": next((v for k, v in trace_ms.items() if k.startswith("xl_nco_chain") and v), None), "hbm_bytes": chain, "binding": "a dependent float32 recurrence on a side stream (reserved CUs), "
+            chain_ms = next((v for k, v in trace_ms.items() if k.startswith("xl_nco_chain") and v), None)
+            pk["xl_nco_chain_kernel"] = {"ms": chain_ms, "ms_source": "rocprofv3 --kernel-trace pass over `bench.py --replay-calls` (profiler attached, "
+                                         "NOT the timed region: under the profiler a chain launch runs 2-4 % longer than in the timed run, so "
+                                         "ms x launches per step may exceed ms_per_step; ms_per_call_timed_region below is the timed region's own bound)",
+                                         "ms_per_call_profiled": round(chain_ms / 4.0, 4) if chain_ms else None,
+                                         "ms_per_call_timed_region_upper_bound": round(period_ms, 4),
+                                         "hbm_bytes": chain, "binding": "a dependent float32 recurrence on a side stream (reserved CUs), "
                                          "concurrent with the three launches; bounds the engine below ~1500 clients",
-                                         "note": "bytes per CALL, ms per LAUNCH (one launch tabulates the phase tables of four calls)"}
+                                         "note": "bytes per CALL, ms per LAUNCH (one launch tabulates the phase tables of four calls); in the timed region a "
+                                                 "call cannot be shorter than a quarter of a chain launch, so that launch is at most 4 x call_period_ms"}
         roofline["kernel"] = ("xlp_forward_kernel + " + ("xlp_mix_mfma_kernel" if "mix=mfma" in m["plan"] else "xlp_mix_kernel") + " + xlp_inverse_kernel: the three launches of one call on the polyphase "
                               "overlap-save path (the next call's NCO phase recurrence runs beside them on a side stream)")
         roofline["per_kernel"] = pk
-        roofline["per_kernel_note"] = ("ms: the kernel's own duration from a rocprofv3 --kernel-trace pass of this run (ms_hip_events: event pairs around "
+        roofline["per_kernel_note"] = ("ms: the kernel's own duration from a rocprofv3 --kernel-trace pass of this run over `bench.py --replay-calls` -- a "
+                                       "separate, profiled pass, not the timed region (ms_hip_events: event pairs around "
                                        "each launch, 16 extra calls after the timed region -- they include the event records and forbid the overlap "
                                        "of one launch's tail with the next one's head, so their sum exceeds kernel_ms)")
         roofline["design_traffic"] = dict(tm, note="bytes the path moves through HBM per call by design (xl_polyphase.h); compare with 'traffic'")
@@ -896,6 +968,26 @@ def main():
         roofline["fp32"] = {"achieved": round(ach_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(ach_tf / FP32_PEAK_TFLOPS, 4), "flop_per_unit": round(fpu, 2)}
 
+    # the numbers of this workload whose every product is a float32 product, next to the headline (whose mix launch multiplies two-half
+    # operands): bit-exact native, optimized through the direct FMA kernel, optimized polyphase with the packed-FMA mix
+    def pick(prefix):
+        k = next((k for k in variants if k.startswith(prefix)), None)
+        return None if k is None else {kk: variants[k].get(kk) for kk in ("value", "us_per_block", "parity_spot") if variants[k].get(kk) is not None}
+    all_f32 = {"native (bit-exact, direct kernel: the server default NATIVE_CF32)": None if native is None else
+               {"value": native["value"], "us_per_block": native["us_per_block"], "parity_spot": native.get("parity_spot")},
+               "optimized, direct FMA kernel": pick(f"process_{args.mode}_cu8_cf32 through the direct FIR kernel"),
+               "optimized, polyphase with the packed-FMA mix": pick("polyphase, packed-FMA mix")}
+    # N > 1: both ways to use the GPUs, fully populated (the headline is one of them)
+    multi_gpu = None
+    if world > 1:
+        head = {"value": round(value, 1), "ms_per_step": round(m["seconds"] / args.steps * 1e3, 4), "clients_total": total_clients,
+                "clients_per_gpu": nloc, "per_rank_seconds": m["rank_seconds"], "feed_timing": m["feed_timing"],
+                "rccl_comm_count": m["rccl_comm_count"], "scaling": args.scaling}
+        other = "weak" if args.scaling == "strong" else "strong"
+        ko = next((k for k in variants if k.startswith(other + " scaling")), None)
+        multi_gpu = {args.scaling: head, other: (dict(variants[ko], scaling=other) if ko else None),
+                     "note": "strong = BASELINE configs[3] read literally (1024 clients in total); weak = 1024 clients per GPU; per_rank_seconds: "
+                             "every rank's wall time of each timed repeat (the value uses the max); feed_timing: rank 0's broadcasts"}
     rep_ms = [round(sec / args.steps * 1e3, 4) for sec in m["repeat_seconds"]]
     out = {
         "metric": "input IQ Msamples/s processed (all clients), 2.016 Msps->48 kHz xlating FIR",
@@ -908,11 +1000,12 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": ("f32 (mix products: 2xf16 split, f32 accumulate)" if (m["polyphase"] and "mix=mfma" in m["plan"]) else "f32"),
         "dtype_note": ("float32 in, float32 out, float32 accumulation everywhere; on the polyphase path the per-client sums (mix launch) "
                        "multiply float32 operands carried as two half-precision terms each (products exact in float32, 2^-22 per product "
                        "dropped: as accurate as the float32 FMA chain, tests/test_mix_split_model.py) -- not a reduced-precision run: "
-                       "parity_spot holds every client to the 1e-5 bar against the float32 reference") if (m["polyphase"] and "mix=mfma" in m["plan"]) else "float32 throughout",
+                       "parity_spot holds every client to the 1e-5 bar against the float32 reference.  The all-float32 and bit-exact "
+                       "numbers of the same workload are in `all_f32`") if (m["polyphase"] and "mix=mfma" in m["plan"]) else "float32 throughout",
         "data": "synthetic" if cuda else "cpu-plumbing-test",
         "repeats": {"n": len(rep_ms), "ms_per_step": rep_ms, "min": min(rep_ms), "median": sorted(rep_ms)[len(rep_ms) // 2], "max": max(rep_ms),
                     "value_is": "the median repeat; each repeat = exactly `steps` steps between barrier + synchronize, max over ranks",
@@ -934,6 +1027,8 @@ def main():
         "parity_spot": m["parity_spot"],
         "plan": m["plan"],
         "native": native,
+        "all_f32": all_f32,
+        "multi_gpu": multi_gpu,
         "variants": variants,
         "expected_scaling": {"strong": EXPECTED_STRONG, "weak": EXPECTED_WEAK,
                              "note": "what DESIGN.md section 7 predicts for --gpus 1/2/4/8, to judge a measured curve against"},

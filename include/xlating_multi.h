@@ -82,6 +82,15 @@ int xlating_multi_feed_done(xlating_multi *multi);
 int xlating_multi_feed_query(xlating_multi *multi);
 int xlating_multi_feed_wait_on_stream(xlating_multi *multi, void *hip_stream);
 
+/* Feed timing (off by default; only with a communicator): every broadcast is bracketed by two HIP events on the
+ * communication stream of the first local GPU.  _read returns the number of feeds measured and their totals: the broadcasts'
+ * duration and the part of it that elapsed while the PREVIOUS feed's filtering was still running on the compute stream
+ * (hidden / bcast = the fraction of the exchange step hidden behind the independent per-GPU work).  0 / n, -EINVAL. */
+int xlating_multi_feed_timing(xlating_multi *multi, int enable);
+int xlating_multi_feed_timing_read(xlating_multi *multi, double *bcast_ms_total, double *hidden_ms_total, int reset);
+/* Ranks of the RCCL communicator this host broadcasts over (ncclCommCount): `world` when it exists, 0 without one. */
+int xlating_multi_comm_count(const xlating_multi *multi);
+
 /* Wait until everything fed so far has been filtered on the local GPUs. */
 int xlating_multi_sync(xlating_multi *multi);
 

@@ -59,6 +59,7 @@ EXPORTED_SYMBOLS = (
 MULTI_SYMBOLS = ["xlating_multi_unique_id", "xlating_multi_create_rank", "xlating_multi_create_local", "xlating_multi_world",
                  "xlating_multi_local", "xlating_multi_add_client", "xlating_multi_engine", "xlating_multi_feed",
                  "xlating_multi_feed_done", "xlating_multi_feed_query", "xlating_multi_feed_wait_on_stream",
+                 "xlating_multi_feed_timing", "xlating_multi_feed_timing_read", "xlating_multi_comm_count",
                  "xlating_multi_sync", "xlating_multi_destroy"]
 
 _lib = None
@@ -104,6 +105,12 @@ def multi_lib():
         getattr(M, name).restype = C.c_int
     M.xlating_multi_feed_wait_on_stream.argtypes = [C.c_void_p, C.c_void_p]
     M.xlating_multi_feed_wait_on_stream.restype = C.c_int
+    M.xlating_multi_feed_timing.argtypes = [C.c_void_p, C.c_int]
+    M.xlating_multi_feed_timing.restype = C.c_int
+    M.xlating_multi_feed_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    M.xlating_multi_feed_timing_read.restype = C.c_int
+    M.xlating_multi_comm_count.argtypes = [C.c_void_p]
+    M.xlating_multi_comm_count.restype = C.c_int
     M.xlating_multi_destroy.argtypes = [C.c_void_p]
     M.xlating_multi_destroy.restype = None
     _mlib = M
@@ -553,6 +560,27 @@ class MultiHost:
         code = multi_lib().xlating_multi_feed_wait_on_stream(self.h, C.c_void_p(stream) if stream else None)
         if code != 0:
             raise XlatingError("xlating_multi_feed_wait_on_stream", code)
+
+    def feed_timing(self, enable=True):
+        """Bracket every broadcast with HIP events on the communication stream (xlating_multi_feed_timing)."""
+        code = multi_lib().xlating_multi_feed_timing(self.h, 1 if enable else 0)
+        if code != 0:
+            raise XlatingError("xlating_multi_feed_timing", code)
+
+    def feed_timing_read(self, reset=True):
+        """-> (feeds measured, broadcast ms in total, of which hidden behind the previous feed's filtering)."""
+        b, hd = C.c_double(0.0), C.c_double(0.0)
+        n = multi_lib().xlating_multi_feed_timing_read(self.h, C.byref(b), C.byref(hd), 1 if reset else 0)
+        if n < 0:
+            raise XlatingError("xlating_multi_feed_timing_read", n)
+        return n, b.value, hd.value
+
+    def comm_count(self):
+        """Ranks of the RCCL communicator the host broadcasts over (0: none)."""
+        n = multi_lib().xlating_multi_comm_count(self.h)
+        if n < 0:
+            raise XlatingError("xlating_multi_comm_count", n)
+        return n
 
     def sync(self):
         code = multi_lib().xlating_multi_sync(self.h)

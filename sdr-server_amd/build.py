@@ -6,8 +6,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path():
-    # XL_LIBRARY_PATH: test infrastructure only (tools/sanitize.sh points the host-code tests at an instrumented build)
-    return os.environ.get("XL_LIBRARY_PATH") or os.path.join(HERE, "lib", "libxlating_hip.so")
+    # XL_LIBRARY_PATH: test infrastructure only (tools/sanitize.sh points the host-code tests at an instrumented build,
+    # tools/experiments/build_variant.sh at a variant of one kernel file) -- honoured only next to XL_TESTING=1, so that a stray
+    # environment variable cannot redirect a production process to another shared object
+    if os.environ.get("XL_TESTING") == "1" and os.environ.get("XL_LIBRARY_PATH"):
+        return os.environ["XL_LIBRARY_PATH"]
+    return os.path.join(HERE, "lib", "libxlating_hip.so")
 
 
 def build_library(verbose=False):

@@ -935,6 +935,12 @@ static float xl_poly_col_scale(const Client &c, uint32_t D, uint32_t T) {
 
 // Brings the device images of a polyphase class in line with its member list: columns, branch spectra of the NEW columns.
 static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vector<uint32_t> &new_cols, bool fresh, uint32_t cap_samples) {
+  // the images a growing class moves into: owned by nobody until they are handed to `pc` below -- a failure in between gives
+  // them back (fail:)
+  float2 *nR = nullptr, *nY = nullptr;
+  void *nRh = nullptr;
+  float *ncs = nullptr;
+  XlpCol *ncols = nullptr;
   // ---- capacity: column groups (R, Y, cols) and segments (Y, X)
   const uint32_t need_cg = ((uint32_t)pc.col_client.size() + XLP_COLS - 1) / XLP_COLS;
   const uint32_t nseg_cap = (cap_samples / pc.D + 2 + pc.V - 1) / pc.V + 1;
@@ -942,10 +948,6 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
   if (fresh || need_cg > pc.ncg_cap || nseg_cap != pc.nseg_cap) {
     // grow by an eighth (at least one group) so that the next joins find room; the old spectra move over on the device
     const uint32_t cap = fresh ? need_cg : std::max(need_cg, pc.ncg_cap + std::max(1u, pc.ncg_cap / 8u));
-    float2 *nR = nullptr, *nY = nullptr;
-    void *nRh = nullptr;
-    float *ncs = nullptr;
-    XlpCol *ncols = nullptr;
     if (pc.mix_kind != 0u) {
       // operand-form image [cg][m][quarter][term][k-block][lane][8 halves] (fused launch: [16-column group][m][k-block][term][lane]):
       // a group's image is contiguous here too
@@ -974,6 +976,7 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     xl_plan_release(b, pc.d_Y);
     xl_plan_release(b, pc.d_cols);
     pc.d_R = nR, pc.d_Rh = nRh, pc.d_cscale = ncs, pc.d_Y = nY, pc.d_cols = ncols;
+    nR = nY = nullptr, nRh = nullptr, ncs = nullptr, ncols = nullptr;
     pc.ncg_cap = cap;
     if (fresh || nseg_cap != pc.nseg_cap || pc.d_X == nullptr) {
       xl_plan_release(b, pc.d_X);
@@ -1053,7 +1056,10 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     }
   }
   return 0;
-fail:
+fail : {
+  void *unowned[] = {nR, nRh, ncs, nY, ncols};
+  for (void *q : unowned) xl_plan_release(b, q);
+}
   return xl_errno_of_last_hip_error();
 }
 
@@ -1286,7 +1292,13 @@ static int xl_batch_plan(xlating_batch *b) {
   std::vector<float> image_rest;  // tap image of the optimized-mode launch set
   if (!b->poly.empty()) {
     int rc = xl_build_launches(b, b->launches_rest, b->classes_rest, big_h, &image_rest, nullptr);
-    if (rc != 0) return rc;
+    if (rc != 0) {
+      // (b->poly already holds the updated classes whose new columns have no branch spectra yet: a plan that stops here must not
+      // be reused -- drop it like every other failure does)
+      xl_batch_free_plan(b, true);
+      b->dirty = true;
+      return rc;
+    }
   }
   lap("tiles + tap images (host)");
 
@@ -2142,6 +2154,13 @@ extern "C" int xlating_batch_output_host(xlating_batch *b, int id, const float *
       output == nullptr || output_len == nullptr || b->last_q15)
     return -EINVAL;
   const Client &c = b->clients[id];
+  // (a client that joined since the latest call has a row -- assigned at add_client -- but no outputs, and its row may lie
+  // beyond what the fetched image holds: the images grow with the next plan)
+  if (c.last_K == 0 || (size_t)c.out_off + c.last_K > b->h_out_alloc) {
+    *output = nullptr;
+    *output_len = 0;
+    return c.last_K == 0 ? 0 : -EINVAL;
+  }
   *output = b->h_out ? reinterpret_cast<const float *>(b->h_out + c.out_off) : nullptr;
   *output_len = c.last_K;
   return 0;
@@ -2153,6 +2172,11 @@ extern "C" int xlating_batch_output_device(xlating_batch *b, int id, const void 
                                                                // is only rebuilt by the next process call)
     return -EINVAL;
   const Client &c = b->clients[id];
+  if (c.last_K == 0 || (size_t)c.out_off + c.last_K > b->out_alloc) {  // (joined since the latest call: a row, but nothing in it yet)
+    *d_output = nullptr;
+    *output_len = 0;
+    return c.last_K == 0 ? 0 : -EINVAL;
+  }
   *d_output = b->d_out[b->ocur] + c.out_off;
   *output_len = c.last_K;
   return 0;

@@ -6,7 +6,10 @@
 // receive buffers and per buffer an event pair: `ready` (recorded on the communication stream behind the broadcast; the
 // compute stream waits for it before the engine's launches) and `free` (recorded behind the launches that read the buffer; the
 // communication stream waits for it before the broadcast two feeds later overwrites the buffer).  Consecutive feeds
-// alternate the buffers, so the broadcast of super-block k+1 runs while super-block k is filtered.
+// alternate the buffers, so the broadcast of super-block k+1 runs while super-block k is filtered.  The `free` events live in a
+// ring of four (feed k: slot k & 3) and carry timestamps, and with feed timing on (xlating_multi_feed_timing) every broadcast is
+// bracketed by two more events on the communication stream: feed k harvests feed k-2's broadcast duration and how much of it ran
+// while feed k-3's filtering was still going on -- the measured "is the broadcast hidden" number of a multi-GPU run.
 // The driver of GPU 0 also owns `src_done`: recorded behind the root's broadcast (or, without a communicator, behind the
 // launches that read d_src in place) -- what xlating_multi_feed_done / _feed_query / _feed_wait_on_stream observe.
 //
@@ -32,8 +35,11 @@ struct Gpu {
   ncclComm_t comm = nullptr;
   hipStream_t comm_stream = nullptr;
   void *recv[2] = {nullptr, nullptr};
-  hipEvent_t ready[2] = {nullptr, nullptr}, free_[2] = {nullptr, nullptr};
-  bool free_valid[2] = {false, false};
+  hipEvent_t ready[2] = {nullptr, nullptr};
+  hipEvent_t free_[4] = {nullptr, nullptr, nullptr, nullptr};  // feed k: slot k & 3 (behind the launches that read buffer k & 1)
+  bool free_valid[4] = {false, false, false, false};
+  hipEvent_t tb0[4] = {nullptr, nullptr, nullptr, nullptr}, tb1[4] = {nullptr, nullptr, nullptr, nullptr};  // around feed k's broadcast
+  bool tb_valid[4] = {false, false, false, false};
   hipEvent_t src_done = nullptr;  // GPU 0's driver only: the latest feed no longer reads d_src
   bool src_valid = false;
 };
@@ -46,6 +52,9 @@ struct xlating_multi_t {
   size_t recv_bytes = 0;
   uint32_t bps = 2;
   uint64_t feeds = 0;
+  bool timing = false;  // bracket the broadcasts (first local GPU)
+  double bcast_ms = 0.0, hidden_ms = 0.0;
+  int timed = 0;
 };
 
 #define XL_NCCL(expr)                                                                          \
@@ -75,7 +84,11 @@ static int xl_multi_open_gpu(xlating_multi *m, Gpu &g, uint32_t fs, int fmt, uin
   for (int i = 0; i < 2; ++i) {
     if (m->bcast) XL_TRY(hipMalloc(&g.recv[i], m->recv_bytes));
     XL_TRY(hipEventCreateWithFlags(&g.ready[i], hipEventDisableTiming));
-    XL_TRY(hipEventCreateWithFlags(&g.free_[i], hipEventDisableTiming));
+  }
+  for (int i = 0; i < 4; ++i) {
+    XL_TRY(hipEventCreate(&g.free_[i]));
+    XL_TRY(hipEventCreate(&g.tb0[i]));
+    XL_TRY(hipEventCreate(&g.tb1[i]));
   }
   return 0;
 fail:
@@ -194,6 +207,7 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
   Gpu *root = xl_multi_find(m, 0);
   if (root != nullptr && d_src == nullptr && bytes > 0) return -EINVAL;  // the driver of GPU 0 holds the source
   const int i = (int)(m->feeds & 1);
+  const int k4 = (int)(m->feeds & 3), k2 = (int)((m->feeds + 2) & 3), k3 = (int)((m->feeds + 1) & 3);  // this feed, feed - 2, feed - 3
   if (!m->bcast) {  // one GPU, no communicator: the engine reads d_src in place; the source is free behind its launches
     Gpu &g = m->gpus[0];
     int rc = xlating_batch_process_device_group_ev(g.engine, d_src, input_len, nblocks, mode, XL_STREAM_ENGINE, nullptr,
@@ -206,7 +220,28 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
   // ---- the path's only exchange step: GPU 0's raw blocks -> every GPU, on the communication streams
   for (Gpu &g : m->gpus) {
     XL_TRY(hipSetDevice(g.device));
-    if (g.free_valid[i]) XL_TRY(hipStreamWaitEvent(g.comm_stream, g.free_[i], 0));
+    if (g.free_valid[k2]) XL_TRY(hipStreamWaitEvent(g.comm_stream, g.free_[k2], 0));  // (the feed that read this buffer last)
+  }
+  if (m->timing && m->feeds >= 3) {
+    // feed - 2's broadcast [tb0, tb1] against the end of feed - 3's filtering (free_[k3], not re-recorded before the next feed):
+    // harvested only when all three timestamps are there (no host wait on the data path)
+    Gpu &g = m->gpus[0];
+    XL_TRY(hipSetDevice(g.device));
+    if (g.tb_valid[k2] && g.free_valid[k3] && hipEventQuery(g.tb1[k2]) == hipSuccess && hipEventQuery(g.free_[k3]) == hipSuccess) {
+      float b = 0.0f, h = 0.0f;
+      if (hipEventElapsedTime(&b, g.tb0[k2], g.tb1[k2]) == hipSuccess && hipEventElapsedTime(&h, g.tb0[k2], g.free_[k3]) == hipSuccess) {
+        m->bcast_ms += b;
+        m->hidden_ms += h <= 0.0f ? 0.0 : (h >= b ? b : h);
+        m->timed++;
+      }
+    }
+    (void)hipGetLastError();  // (hipErrorNotReady of a query is not an error)
+    g.tb_valid[k2] = false;
+  }
+  if (m->timing) {
+    Gpu &g = m->gpus[0];
+    XL_TRY(hipSetDevice(g.device));
+    XL_TRY(hipEventRecord(g.tb0[k4], g.comm_stream));
   }
   if (m->gpus.size() > 1) XL_NCCL(ncclGroupStart());
   for (Gpu &g : m->gpus) {
@@ -214,6 +249,12 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
     XL_NCCL(ncclBroadcast(g.index == 0 ? d_src : g.recv[i], g.recv[i], bytes, ncclUint8, 0, g.comm, g.comm_stream));
   }
   if (m->gpus.size() > 1) XL_NCCL(ncclGroupEnd());
+  if (m->timing) {
+    Gpu &g = m->gpus[0];
+    XL_TRY(hipSetDevice(g.device));
+    XL_TRY(hipEventRecord(g.tb1[k4], g.comm_stream));
+    g.tb_valid[k4] = true;
+  }
   if (root != nullptr) {  // the broadcast is the only reader of d_src
     XL_TRY(hipSetDevice(root->device));
     XL_TRY(hipEventRecord(root->src_done, root->comm_stream));
@@ -225,9 +266,9 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
     XL_TRY(hipEventRecord(g.ready[i], g.comm_stream));
     // on the engine's own compute stream (CU-masked for these calls): wait for the broadcast, filter, mark the buffer free
     int rc = xlating_batch_process_device_group_ev(g.engine, g.recv[i], input_len, nblocks, mode, XL_STREAM_ENGINE, g.ready[i],
-                                                   g.free_[i]);
+                                                   g.free_[k4]);
     if (rc != 0) return rc;
-    g.free_valid[i] = true;
+    g.free_valid[k4] = true;
   }
   m->feeds++;
   return 0;
@@ -266,6 +307,34 @@ extern "C" int xlating_multi_feed_wait_on_stream(xlating_multi *m, void *hip_str
   return hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), root->src_done, 0) == hipSuccess ? 0 : -EIO;
 }
 
+extern "C" int xlating_multi_feed_timing(xlating_multi *m, int enable) {
+  if (m == nullptr) return -EINVAL;
+  m->timing = enable != 0 && m->bcast;
+  return 0;
+}
+
+extern "C" int xlating_multi_feed_timing_read(xlating_multi *m, double *bcast_ms_total, double *hidden_ms_total, int reset) {
+  if (m == nullptr) return -EINVAL;
+  if (bcast_ms_total) *bcast_ms_total = m->bcast_ms;
+  if (hidden_ms_total) *hidden_ms_total = m->hidden_ms;
+  const int n = m->timed;
+  if (reset) {
+    m->bcast_ms = m->hidden_ms = 0.0;
+    m->timed = 0;
+  }
+  return n;
+}
+
+extern "C" int xlating_multi_comm_count(const xlating_multi *m) {
+  if (m == nullptr) return -EINVAL;
+  for (const Gpu &g : m->gpus)
+    if (g.comm != nullptr) {
+      int n = 0;
+      return ncclCommCount(g.comm, &n) == ncclSuccess ? n : -EIO;
+    }
+  return 0;
+}
+
 extern "C" int xlating_multi_sync(xlating_multi *m) {
   if (m == nullptr) return -EINVAL;
   for (Gpu &g : m->gpus) {
@@ -286,7 +355,11 @@ extern "C" void xlating_multi_destroy(xlating_multi *m) {
     for (int i = 0; i < 2; ++i) {
       if (g.recv[i]) (void)hipFree(g.recv[i]);
       if (g.ready[i]) (void)hipEventDestroy(g.ready[i]);
+    }
+    for (int i = 0; i < 4; ++i) {
       if (g.free_[i]) (void)hipEventDestroy(g.free_[i]);
+      if (g.tb0[i]) (void)hipEventDestroy(g.tb0[i]);
+      if (g.tb1[i]) (void)hipEventDestroy(g.tb1[i]);
     }
     if (g.src_done) (void)hipEventDestroy(g.src_done);
     if (g.comm_stream) (void)hipStreamDestroy(g.comm_stream);

@@ -1117,6 +1117,42 @@ def test_multi_feed_done_one_source_buffer_refilled_every_feed(loopback):
     m.close()
 
 
+def test_multi_feed_timing_and_comm_count_loopback():
+    """xlating_multi_feed_timing / _feed_timing_read / _comm_count (round 4: what bench.py prints for a multi-GPU run) on the
+    one-rank loop-back communicator: the communicator counts 1 rank, every feed but the last two is harvested, the broadcasts
+    take a plausible time and the hidden part never exceeds them; timing changes no result."""
+    import torch
+
+    t48 = lpf(FS, 24000, 9600)
+    n, G = 262144, 4
+    m = xl.MultiHost(FS, "cu8", n, group_blocks=G, rank=0, world=1, uid=xl.MultiHost.unique_id())
+    assert m.comm_count() == 1
+    eng = m.engine(0)
+    oracles = {}
+    for c in range(160):
+        cid = m.add_client(c, 42, t48, -900000 + 11000 * c)
+        if c % 40 == 0:
+            oracles[cid] = Oracle(42, t48, -900000 + 11000 * c, FS, n)
+    m.feed_timing(True)
+    srcs = [torch.from_numpy(siggen.xs_u8(5500 + k, G * n)).cuda() for k in range(3)]
+    feeds = 12
+    for k in range(feeds):
+        m.feed(srcs[k % 3].data_ptr(), n, G, "optimized")
+    m.sync()
+    cnt, bcast_ms, hidden_ms = m.feed_timing_read()
+    assert feeds - 5 <= cnt <= feeds - 2, cnt  # (feed k harvests feed k - 2; a timestamp not there yet is skipped, never waited for)
+    assert 0.0 < bcast_ms / cnt < 5.0 and 0.0 <= hidden_ms <= bcast_ms * (1 + 1e-6), (cnt, bcast_ms, hidden_ms)
+    eng.fetch()
+    for cid, o in oracles.items():
+        for k in range(feeds):
+            want = np.concatenate([o.process("cu8", bl) for bl in np.split(srcs[k % 3].cpu().numpy(), G)])
+        assert rel_err(eng.output(cid), want) <= REL_TOL, cid
+    no_comm = xl.MultiHost(FS, "cu8", n, group_blocks=G, rank=0, world=1)
+    assert no_comm.comm_count() == 0
+    no_comm.close()
+    m.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The Q15 (cs16 output) family on the batched boundary (XL_MODE_Q15): exact integers.
 @pytest.mark.parametrize("fmt", ["cu8", "cs8", "cs16"])

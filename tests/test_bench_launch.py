@@ -11,13 +11,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, env_extra=None, timeout=300):
+def _run(extra, env_extra=None, timeout=300, variants=False):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing-test", "--steps", "2", "--warmup", "1",
-                        "--no-variants", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+                        "--no-cpu-baseline"] + ([] if variants else ["--no-variants"]) + extra, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
@@ -51,3 +51,28 @@ def test_world_size_mismatch_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing-test", "--gpus", "2"], capture_output=True,
                        text=True, timeout=120, env=env, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_two_ranks_line_carries_strong_and_weak_fully_populated():
+    """N > 1: ONE line with both ways to use the GPUs -- the headline's scaling mode and the other one -- each with its value, step
+    time and every rank's wall time of every timed repeat (the value uses the max over ranks)."""
+    j = _run(["--gpus", "2", "--clients", "64"], variants=True)
+    mg = j["multi_gpu"]
+    assert set(mg) >= {"strong", "weak"} and mg["weak"]["value"] == j["value"] and mg["weak"]["clients_total"] == 128
+    assert mg["strong"]["value"] > 0 and mg["strong"]["ms_per_step"] > 0
+    for mode in ("strong", "weak"):
+        prs = mg[mode]["per_rank_seconds"]
+        assert len(prs) >= 1 and all(len(r) == 2 and min(r) > 0 for r in prs), prs
+
+
+def test_a_rank_without_engine_stops_every_rank_within_the_deadline():
+    """One rank cannot create its engine: every rank learns it (an all-reduce right after the create) and exits with an error;
+    nobody is left waiting in a barrier or a broadcast."""
+    env = dict(os.environ, XL_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing-test", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-variants", "--no-cpu-baseline"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert "could not be created on every rank" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # no measurement line

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/experiments/build_variant.sh NAME "EXTRA HIPCC FLAGS" [SOURCE] -- a variant of libxlating_hip.so with one kernel file (default
 # xl_polyphase.hip; e.g. xl_fused.hip) compiled with extra flags, into sdr-server_amd/build/variants/libNAME.so (travels with gpurun;
-# select with XL_LIBRARY_PATH): several hypotheses per GPU call
+# select with XL_TESTING=1 XL_LIBRARY_PATH=...): several hypotheses per GPU call
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 C=$ROOT/sdr-server_amd/csrc; B=$ROOT/sdr-server_amd/build; V=$B/variants; mkdir -p $V

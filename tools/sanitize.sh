@@ -34,12 +34,12 @@ build() {  # $1 = tag, $2 = sanitizer flags
 run() {  # $1 = tag, $2 = runtime library, $3 = log, $4 = test files, $5... = env
   local tag=$1 rt=$2 log=$3 tests=$4; shift 4
   rm -f $B/report_$tag.*
-  ( cd $ROOT && timeout 600 env "$@" LD_PRELOAD=$rt XL_LIBRARY_PATH=$B/libxlating_host_$tag.so python -m pytest $tests -q -x -p no:cacheprovider -k "$KEXPR" ) > $log.tmp 2>&1
+  ( cd $ROOT && timeout 600 env "$@" LD_PRELOAD=$rt XL_TESTING=1 XL_LIBRARY_PATH=$B/libxlating_host_$tag.so python -m pytest $tests -q -x -p no:cacheprovider -k "$KEXPR" ) > $log.tmp 2>&1
   local rc=$?
   cat $B/report_$tag.* >> $log.tmp 2>/dev/null  # (log_path: pytest captures the tests' stderr)
   local TESTS=$tests
   { echo "# tools/sanitize.sh: $tag build of lpf.c xl_taps.c xl_wire.c xl_sinks.cpp (+ xl_grid.h shim), $(gcc --version | head -1)";
-    echo "# command: LD_PRELOAD=$(basename $rt) XL_LIBRARY_PATH=libxlating_host_$tag.so pytest $TESTS -k \"$KEXPR\"";
+    echo "# command: LD_PRELOAD=$(basename $rt) XL_TESTING=1 XL_LIBRARY_PATH=libxlating_host_$tag.so pytest $TESTS -k \"$KEXPR\"";
     echo "# exit code $rc; sanitizer reports below (none = clean)"; grep -E "ERROR: (Address|Thread|Leak)Sanitizer|runtime error:|WARNING: ThreadSanitizer|SUMMARY:" $log.tmp | sort | uniq -c | head -50;
     echo "# pytest tail:"; tail -4 $log.tmp; } > $log
   rm -f $log.tmp
