@@ -72,7 +72,7 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                           on the matrix cores -- see "mix_kernel" --, 128 elsewhere; a given value holds for every class)
  *   "riders" 0/1, "riders_min_workgroups" n, "tile_height" 0/8/9/10/12, "nco_slices" (a << 16 | b): launch shaping
  *   "nco_side_stream"       -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light, and one-block
- *                           polyphase calls of up to 2048 clients), 0 never, 1
+ *                           polyphase calls of up to 2048 clients -- of any size with "mix_kernel" 2), 0 never, 1
  *                           always: the NCO phase recurrence of the following calls runs as a kernel of its own on a side
  *                           stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE)
  *   "nco_calls_per_launch"  1..4 (default 4): calls of the same shape one such kernel tabulates ahead
@@ -82,7 +82,14 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *   "mix_kernel"            polyphase classes: the mix launch (spectra x branch spectra, summed over the branches) on the matrix
  *                           cores (1, default: every float32 operand as two halves, three v_mfma_f32_32x32x16_f16 per 8
  *                           branches, FP32 accumulation; classes of an integer input format with decimation <= 64) or as
- *                           packed FP32 FMAs (0; always for cf32 input and decimation > 64).  Same 1e-5 bar either way
+ *                           packed FP32 FMAs (0; always for cf32 input and decimation > 64), or mix + inverse as ONE launch
+ *                           with the mixed spectra kept in registers (2: xl_fused.hip; integer input, decimation <= 64, up to
+ *                           64 taps per branch; slower than the three launches on an MI355X -- DESIGN.md 3.5 -- and kept as
+ *                           an option).  Same 1e-5 bar in every case
+ *   "pipeline_calls"        1 (default) / 0: an engine created for ONE block per call (xlating_batch_create) that is driven
+ *                           through XL_STREAM_ENGINE alternates its optimized polyphase calls between two compute streams it
+ *                           owns; only the calls' forward launches are ordered against each other, so that call k + 1 starts
+ *                           beside call k's inverse launch (same results; xlating_batch_sync waits for both streams)
  *   "mix_passes_per_workgroup"  matrix-core mix: passes of 14 segments one workgroup runs with its operands in registers
  *                           (0 = default 16; a launch parameter, no re-plan)
  * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call. */

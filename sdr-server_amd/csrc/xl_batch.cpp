@@ -127,6 +127,9 @@ struct PolyClass {
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]; mix_kind 2: operand form (xlf_xh_slot)
   float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]; mix_kind 2: none
   XlpCol *d_cols = nullptr;  // per column: output row, grid offset, NCO increment
+  // engines of one block per call (the reference's call granularity): a second set of the per-call images, so that consecutive
+  // calls may overlap (xl_batch_run: pipelined one-block calls); null otherwise
+  float2 *d_X2 = nullptr, *d_Y2 = nullptr;
 };
 
 }  // namespace
@@ -152,6 +155,16 @@ struct xlating_batch_t {
   // mask of `reserve_r` CUs per XCD (mask bit b = XCD b % 8, CU b / 8 of it; tools/ubench_cumask.hip) and the engine's
   // own compute stream for side-stream calls, cs_masked, with the complement.  Callers that pass XL_STREAM_ENGINE get it.
   hipStream_t cs_masked = nullptr;
+  // Pipelined one-block calls (option "pipeline_calls", default on): an engine created for one block per call alternates its
+  // polyphase calls between cs_masked and cs_masked2 (same CU mask).  A one-block call is three short, latency-bound launches
+  // (small grids, a tail round, launch gaps); call k+1's forward and mix launches run beside call k's inverse launch.  Only the
+  // forward launches are ordered against each other (raw history, ev_fwd); the per-call images X and Y exist twice.
+  hipStream_t cs_masked2 = nullptr;
+  hipEvent_t ev_fwd[2] = {nullptr, nullptr};  // behind the forward launch of the latest pipelined call on cs_masked / cs_masked2
+  hipEvent_t dep_ev2 = nullptr;
+  bool last_piped = false;            // the latest call was pipelined: BOTH compute streams may hold work
+  hipStream_t piped_other = nullptr;  // ... the stream of the call before it
+  int pipeline_calls = 1;
   hipStream_t last_nco = nullptr;    // the side stream of the latest chain launch
   unsigned long long *d_chain_stats = nullptr;  // tuning (XL_EXP_CHAIN_STATS): per chain workgroup cycles / ticks of the latest launch
   hipStream_t nco_masked = nullptr;  // the side stream that goes with cs_masked; nco_stream (unmasked) serves callers' own streams
@@ -292,7 +305,9 @@ static void xl_batch_sync_all(xlating_batch *b) {
   if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
   if (b->nco_stream) (void)hipStreamSynchronize(b->nco_stream);
   if (b->cs_masked) (void)hipStreamSynchronize(b->cs_masked);
+  if (b->cs_masked2) (void)hipStreamSynchronize(b->cs_masked2);
   if (b->nco_masked) (void)hipStreamSynchronize(b->nco_masked);
+  b->last_piped = false;
 }
 
 // A plan buffer of at least `bytes`: the smallest spare one that fits (and is not more than twice too big), else a fresh
@@ -331,9 +346,9 @@ static void xl_plan_trim(xlating_batch *b) {
 }
 
 static void xl_poly_release(xlating_batch *b, PolyClass &pc) {
-  void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_cols, pc.d_Rh, pc.d_cscale};
+  void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_cols, pc.d_Rh, pc.d_cscale, pc.d_X2, pc.d_Y2};
   for (void *q : dev) xl_plan_release(b, q);
-  pc.d_R = pc.d_X = pc.d_Y = nullptr;
+  pc.d_R = pc.d_X = pc.d_Y = pc.d_X2 = pc.d_Y2 = nullptr;
   pc.d_cols = nullptr;
   pc.d_Rh = nullptr;
   pc.d_cscale = nullptr;
@@ -394,12 +409,16 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   for (hipEvent_t e : b->ev_poly) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
   if (b->dep_ev) (void)hipEventDestroy(b->dep_ev);
+  if (b->dep_ev2) (void)hipEventDestroy(b->dep_ev2);
+  for (hipEvent_t e : b->ev_fwd)
+    if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_chain)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_done)
     if (e) (void)hipEventDestroy(e);
   if (b->nco_stream) (void)hipStreamDestroy(b->nco_stream);
   if (b->cs_masked) (void)hipStreamDestroy(b->cs_masked);
+  if (b->cs_masked2) (void)hipStreamDestroy(b->cs_masked2);
   if (b->nco_masked) (void)hipStreamDestroy(b->nco_masked);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
@@ -420,6 +439,9 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
   } else if (n == "mix_kernel") {
     if (value < 0 || value > 2) return -EINVAL;
     b->mix_kernel = (uint32_t)value;
+  } else if (n == "pipeline_calls") {
+    if (value < 0 || value > 1) return -EINVAL;
+    b->pipeline_calls = (int)value;
   } else if (n == "mix_passes_per_workgroup") {
     if (value < 0 || value > 64) return -EINVAL;
     b->mix_pp = (uint32_t)value;
@@ -478,6 +500,8 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
     XL_TRY(hipSetDevice(dev));
     XL_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     XL_TRY(hipEventCreateWithFlags(&b->dep_ev, hipEventDisableTiming));
+    XL_TRY(hipEventCreateWithFlags(&b->dep_ev2, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) XL_TRY(hipEventCreateWithFlags(&b->ev_fwd[i], hipEventDisableTiming));
     XL_TRY(hipStreamCreateWithFlags(&b->nco_stream, hipStreamNonBlocking));
     for (int i = 0; i < XL_NTAB; ++i) {
       XL_TRY(hipEventCreateWithFlags(&b->ev_chain[i], hipEventDisableTiming));
@@ -977,6 +1001,10 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     xl_plan_release(b, pc.d_cols);
     pc.d_R = nR, pc.d_Rh = nRh, pc.d_cscale = ncs, pc.d_Y = nY, pc.d_cols = ncols;
     nR = nY = nullptr, nRh = nullptr, ncs = nullptr, ncols = nullptr;
+    xl_plan_release(b, pc.d_Y2);
+    pc.d_Y2 = nullptr;
+    if (b->gcap == 1 && pc.mix_kind != 2u)  // (one block per call: the second mixed-spectra image of the pipelined calls)
+      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_Y2, (size_t)cap * nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
     pc.ncg_cap = cap;
     if (fresh || nseg_cap != pc.nseg_cap || pc.d_X == nullptr) {
       xl_plan_release(b, pc.d_X);
@@ -986,6 +1014,12 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
                                               : (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2);
       XL_TRY(xl_plan_alloc(b, (void **)&pc.d_X, xbytes));
       XL_TRY(hipMemsetAsync(pc.d_X, 0, xbytes, b->own_stream));
+      xl_plan_release(b, pc.d_X2);
+      pc.d_X2 = nullptr;
+      if (b->gcap == 1 && pc.mix_kind != 2u) {
+        XL_TRY(xl_plan_alloc(b, (void **)&pc.d_X2, xbytes));
+        XL_TRY(hipMemsetAsync(pc.d_X2, 0, xbytes, b->own_stream));
+      }
     }
     pc.nseg_cap = nseg_cap;
   }
@@ -1178,7 +1212,7 @@ static int xl_batch_plan(xlating_batch *b) {
       if (reuse) {
         pc = std::move(*old);
         old->keep = true;
-        old->d_R = old->d_X = old->d_Y = nullptr;
+        old->d_R = old->d_X = old->d_Y = old->d_X2 = old->d_Y2 = nullptr;
         old->d_cols = nullptr;
         old->d_Rh = nullptr;
         old->d_cscale = nullptr;
@@ -1321,9 +1355,11 @@ static int xl_batch_plan(xlating_batch *b) {
     // a client count hovering around a multiple of 512 does not recreate the streams at every join and leave)
     if (want > b->reserve_r || want + 2u <= b->reserve_r || (want == 0u && b->reserve_r != 0u)) {
       if (b->cs_masked) (void)hipStreamDestroy(b->cs_masked);
+      if (b->cs_masked2) (void)hipStreamDestroy(b->cs_masked2);
       if (b->nco_masked) (void)hipStreamDestroy(b->nco_masked);
-      b->cs_masked = b->nco_masked = nullptr;
+      b->cs_masked = b->cs_masked2 = b->nco_masked = nullptr;
       b->last_nco = nullptr;
+      b->last_piped = false;
       b->reserve_r = 0;
       b->last_stream = b->own_stream;  // (everything was synchronised at the top of the plan)
       for (int i = 0; i < XL_NTAB; ++i) b->ev_done_valid[i] = false;
@@ -1338,11 +1374,16 @@ static int xl_batch_plan(xlating_batch *b) {
         if (hipExtStreamCreateWithCUMask(&b->nco_masked, 8, chain_mask) == hipSuccess &&
             hipExtStreamCreateWithCUMask(&b->cs_masked, 8, main_mask) == hipSuccess) {
           b->reserve_r = want;
+          // (one block per call: the second compute stream of the pipelined calls; doing without it only costs the overlap)
+          if (b->gcap == 1 && hipExtStreamCreateWithCUMask(&b->cs_masked2, 8, main_mask) != hipSuccess) {
+            b->cs_masked2 = nullptr;
+            (void)hipGetLastError();
+          }
         } else {
           XL_LOG_ERR("CU-masked streams are not available (%s): the NCO chain kernel shares the chip", hipGetErrorString(hipGetLastError()));
           if (b->cs_masked) (void)hipStreamDestroy(b->cs_masked);
           if (b->nco_masked) (void)hipStreamDestroy(b->nco_masked);
-          b->cs_masked = b->nco_masked = nullptr;
+          b->cs_masked = b->cs_masked2 = b->nco_masked = nullptr;
         }
       }
     }
@@ -1522,12 +1563,36 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
   for (const PolyClass &pc : b->poly) all_fused = all_fused && pc.mix_kind == 2u;
   const bool one_block_side = G == 1 && use_poly && (all_fused || b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX);
   const bool side_call = mode != XL_MODE_Q15 && (b->nco_side > 0 || (b->nco_side < 0 && (G >= 2 || one_block_side) && (use_poly || (light && b->cs_masked && s == XL_STREAM_ENGINE_P))));  // (a caller's own, unmasked stream would keep filling the chain's CUs)
-  if (s == XL_STREAM_ENGINE_P) s = (side_call && b->cs_masked) ? b->cs_masked : b->own_stream;
+  // Pipelined one-block calls (engines created for one block per call, on the engine's own streams, every client on the
+  // polyphase launches): consecutive calls alternate between two compute streams and only their FORWARD launches are ordered
+  // (raw history); X and Y exist twice (PolyClass::d_X2, d_Y2), outputs and phase tables are per call anyway.  Call k + 1's
+  // forward and mix launches then run beside call k's inverse launch: each is a short, latency-bound grid of its own.
+  bool pipe = b->pipeline_calls != 0 && s == XL_STREAM_ENGINE_P && G == 1 && b->gcap == 1 && side_call && b->cs_masked != nullptr &&
+              b->cs_masked2 != nullptr && use_poly && mode == XL_MODE_OPTIMIZED;
+  for (int lq = 0; lq < XL_NLAUNCH && pipe; ++lq) pipe = b->launches_rest[lq].groups.empty();  // (no direct launch in the call)
+  for (const PolyClass &pc : b->poly) pipe = pipe && pc.d_X2 != nullptr && pc.d_Y2 != nullptr;
+  const int pidx = (int)(b->ncalls & 1);
+  if (s == XL_STREAM_ENGINE_P) s = pipe ? (pidx ? b->cs_masked2 : b->cs_masked) : ((side_call && b->cs_masked) ? b->cs_masked : b->own_stream);
   // Calls depend on each other through the engine's device state (history, phases, tables): a call on another
-  // stream than the previous one is ordered behind it.
-  if (s != b->last_stream) {
-    XL_TRY(hipEventRecord(b->dep_ev, b->last_stream));
-    XL_TRY(hipStreamWaitEvent(s, b->dep_ev, 0));
+  // stream than the previous one is ordered behind it -- behind BOTH compute streams when the previous calls were pipelined.
+  {
+    const hipStream_t prev = b->last_stream;
+    const bool prev_piped = b->last_piped;
+    if (pipe && prev_piped && s != prev) {
+      XL_TRY(hipStreamWaitEvent(s, b->ev_fwd[pidx ^ 1], 0));  // (the previous call's forward launch: the only order needed)
+      b->piped_other = prev;
+    } else {
+      if (s != prev) {
+        XL_TRY(hipEventRecord(b->dep_ev, prev));
+        XL_TRY(hipStreamWaitEvent(s, b->dep_ev, 0));
+      }
+      if (prev_piped && b->piped_other != nullptr && b->piped_other != s) {
+        XL_TRY(hipEventRecord(b->dep_ev2, b->piped_other));
+        XL_TRY(hipStreamWaitEvent(s, b->dep_ev2, 0));
+      }
+      b->piped_other = nullptr;
+    }
+    b->last_piped = pipe;
   }
   b->last_stream = s;
   b->fetched = false;
@@ -1821,9 +1886,9 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           pa.Rh = pc.d_Rh;
           pa.cscale = pc.d_cscale;
           pa.W = b->d_W;
-          pa.X = pc.d_X;
+          pa.X = (pipe && pidx) ? pc.d_X2 : pc.d_X;
           pa.R = pc.d_R;
-          pa.Y = pc.d_Y;
+          pa.Y = (pipe && pidx) ? pc.d_Y2 : pc.d_Y;
           pa.cols = pc.d_cols;
           pa.phtab = b->d_phtab[tab];
           pa.out = b->d_out[p];
@@ -1877,6 +1942,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
             continue;
           }
           XL_TRY(xlp_launch_forward(pa, s));
+          if (pipe && &pc == &b->poly.back()) XL_TRY(hipEventRecord(b->ev_fwd[pidx], s));  // (what the next call's forward launches wait for)
           if (pe[1]) XL_TRY(hipEventRecord(pe[1], s));
           pa.roll_blocks = 0;
           if (carry && pc.mix_kind == 0u) {
@@ -2112,6 +2178,7 @@ extern "C" size_t xlating_batch_output_len_block(const xlating_batch *b, int id,
 extern "C" int xlating_batch_sync(xlating_batch *b) {
   if (b == nullptr) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  if (b->last_piped && b->piped_other && hipStreamSynchronize(b->piped_other) != hipSuccess) return -EIO;  // (the call before the latest)
   return hipStreamSynchronize(b->last_stream) == hipSuccess ? 0 : -EIO;
 }
 

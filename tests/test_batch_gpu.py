@@ -541,6 +541,35 @@ def test_matrix_core_mix_role_phases_bit_exact(monkeypatch):
         e.close()
 
 
+def test_role_phases_soak_4096_clients_2000_one_block_calls(monkeypatch):
+    """VERDICT r3 item 3's soak: 4096 clients, 2000 one-block calls with the recurrence INSIDE the launches (nco_side_stream = 0) --
+    the packed-FMA mix engine (role in all three launches) against the matrix-core mix engine (role in the forward and inverse
+    launches only: no launch that issues matrix instructions hosts it any more); all 4096 committed phases compared bit for bit
+    every 100 calls (a corrupted phase never heals: the recurrence carries it on)."""
+    t48 = lpf(FS, 24000, 9600)
+    engs = []
+    for mix in (0, 1):
+        monkeypatch.setenv("XL_EXP_MIX", str(mix))
+        e = xl.BatchEngine(FS, "cu8", 262144)
+        e.set_option("nco_side_stream", 0)
+        ids = [e.add_client(42, t48, -984000 + 480 * c) for c in range(4096)]
+        engs.append((e, ids))
+    assert "mix=fma" in engs[0][0].describe() and "mix=mfma" in engs[1][0].describe()
+    blocks = [siggen.xs_u8(7300 + k, 262144) for k in range(4)]
+    for k in range(2000):
+        for e, _ in engs:
+            e.process_host(blocks[k % 4], "optimized")
+        if k % 100 == 99:
+            ph = []
+            for e, ids in engs:
+                e.sync()
+                ph.append(np.array([e.phase(i) for i in ids], dtype=np.float32))
+            bad = np.flatnonzero((ph[0].view(np.uint32) != ph[1].view(np.uint32)).any(axis=1))
+            assert len(bad) == 0, (k, bad[:32])
+    for e, _ in engs:
+        e.close()
+
+
 def test_polyphase_class_next_to_direct_classes():
     """The size rule at work inside one engine: 200 x 48 kHz clients (505 taps) take the polyphase path, 9 x 96 kHz
     clients (253 taps, too few for it) stay on the direct kernel, whose launch then carries the NCO role for ALL
@@ -1324,6 +1353,50 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
         else:
             worst = max(worst, rel_err(got[c], want[c]))
     assert worst <= REL_TOL, worst
+    eng.close()
+
+
+@pytest.mark.parametrize("pipeline", [1, 0])
+def test_one_block_calls_pipelined_on_the_engine_streams(pipeline):
+    """The reference's call granularity on the engine's own streams (XL_STREAM_ENGINE, what include/xlating_multi.h feeds):
+    1024 clients, one 262144-byte block per call, 40 calls enqueued back to back without a host wait.  With "pipeline_calls"
+    (default) consecutive calls alternate between two compute streams and only their forward launches are ordered; the
+    outputs of the calls that are looked at -- sampled clients after calls 9, 10 and 39, a native call and a host-path
+    call in between (both must wait for BOTH streams) -- match the oracle, and the committed phases are the oracle's bit for bit."""
+    import torch
+
+    t48 = lpf(FS, 24000, 9600)
+    nb = 262144
+    eng = xl.BatchEngine(FS, "cu8", nb)
+    eng.set_option("pipeline_calls", pipeline)
+    fcs = [-984000 + 1920 * c for c in range(1024)]
+    ids = [eng.add_client(42, t48, fc) for fc in fcs]
+    sample = [0, 1, 63, 64, 500, 777, 1022, 1023]
+    oracles = {ids[c]: Oracle(42, t48, fcs[c], FS, nb) for c in sample}
+    blocks = [siggen.xs_u8(8600 + k, nb) for k in range(6)]
+    dev = [torch.from_numpy(x).cuda() for x in blocks]
+    look = {9, 10, 20, 39}
+    for k in range(40):
+        x = blocks[k % 6]
+        if k == 20:    # a native call in the middle of the pipelined run: ordered behind both compute streams
+            eng.process_device_group(dev[k % 6].data_ptr(), nb, 1, "native", "engine")
+        elif k == 30:  # ... and a host-path call (the engine's plain stream)
+            eng.process_host(x, "optimized")
+        else:
+            eng.process_device_group(dev[k % 6].data_ptr(), nb, 1, "optimized", "engine")
+        want = {cid: o.process("cu8", x) for cid, o in oracles.items()}
+        if k in look:
+            eng.fetch()  # (xlating_batch_sync inside: both streams)
+            for cid in oracles:
+                got = eng.output(cid)
+                if k == 20:
+                    assert bits_equal(got, want[cid]), (k, cid)
+                else:
+                    assert rel_err(got, want[cid]) <= REL_TOL, (k, cid, rel_err(got, want[cid]))
+    for cid, o in oracles.items():
+        pr, pi = eng.phase(cid)
+        assert (np.float32(pr), np.float32(pi)) == tuple(np.float32(v) for v in o.phase), cid
+    assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
     eng.close()
 
 
