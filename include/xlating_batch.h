@@ -86,10 +86,12 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                           with the mixed spectra kept in registers (2: xl_fused.hip; integer input, decimation <= 64, up to
  *                           64 taps per branch; slower than the three launches on an MI355X -- DESIGN.md 3.5 -- and kept as
  *                           an option).  Same 1e-5 bar in every case
- *   "pipeline_calls"        1 (default) / 0: an engine created for ONE block per call (xlating_batch_create) that is driven
+ *   "pipeline_calls"        0 (default) / 1: an engine created for ONE block per call (xlating_batch_create) that is driven
  *                           through XL_STREAM_ENGINE alternates its optimized polyphase calls between two compute streams it
- *                           owns; only the calls' forward launches are ordered against each other, so that call k + 1 starts
- *                           beside call k's inverse launch (same results; xlating_batch_sync waits for both streams)
+ *                           owns; only the calls' forward launches are ordered against each other, so that call k + 1 may
+ *                           start beside call k's inverse launch (same results; xlating_batch_sync waits for both streams).
+ *                           Off by default: a dependency between two HIP streams costs more than the overlap gains
+ *                           (profiles/r04_one_block_pipelining.txt)
  *   "mix_passes_per_workgroup"  matrix-core mix: passes of 14 segments one workgroup runs with its operands in registers
  *                           (0 = default 16; a launch parameter, no re-plan)
  * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call. */

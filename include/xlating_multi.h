@@ -83,9 +83,10 @@ int xlating_multi_feed_query(xlating_multi *multi);
 int xlating_multi_feed_wait_on_stream(xlating_multi *multi, void *hip_stream);
 
 /* Feed timing (off by default; only with a communicator): every broadcast is bracketed by two HIP events on the
- * communication stream of the first local GPU.  _read returns the number of feeds measured and their totals: the broadcasts'
- * duration and the part of it that elapsed while the PREVIOUS feed's filtering was still running on the compute stream
- * (hidden / bcast = the fraction of the exchange step hidden behind the independent per-GPU work).  0 / n, -EINVAL. */
+ * communication stream of the first local GPU.  _read -- call it after xlating_multi_sync: it touches nothing on the data path --
+ * looks at the latest feeds (at most 14: the events live in a ring) and returns how many it measured and their totals: the
+ * broadcasts' duration and the part of it that elapsed while the PREVIOUS feed's filtering was still running on the compute
+ * stream (hidden / bcast = the fraction of the exchange step hidden behind the independent per-GPU work).  0 / n, -EINVAL. */
 int xlating_multi_feed_timing(xlating_multi *multi, int enable);
 int xlating_multi_feed_timing_read(xlating_multi *multi, double *bcast_ms_total, double *hidden_ms_total, int reset);
 /* Ranks of the RCCL communicator this host broadcasts over (ncclCommCount): `world` when it exists, 0 without one. */

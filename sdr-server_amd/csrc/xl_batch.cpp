@@ -155,7 +155,7 @@ struct xlating_batch_t {
   // mask of `reserve_r` CUs per XCD (mask bit b = XCD b % 8, CU b / 8 of it; tools/ubench_cumask.hip) and the engine's
   // own compute stream for side-stream calls, cs_masked, with the complement.  Callers that pass XL_STREAM_ENGINE get it.
   hipStream_t cs_masked = nullptr;
-  // Pipelined one-block calls (option "pipeline_calls", default on): an engine created for one block per call alternates its
+  // Pipelined one-block calls (option "pipeline_calls", default OFF: correct, but slower on this runtime): an engine created for one block per call alternates its
   // polyphase calls between cs_masked and cs_masked2 (same CU mask).  A one-block call is three short, latency-bound launches
   // (small grids, a tail round, launch gaps); call k+1's forward and mix launches run beside call k's inverse launch.  Only the
   // forward launches are ordered against each other (raw history, ev_fwd); the per-call images X and Y exist twice.
@@ -164,7 +164,7 @@ struct xlating_batch_t {
   hipEvent_t dep_ev2 = nullptr;
   bool last_piped = false;            // the latest call was pipelined: BOTH compute streams may hold work
   hipStream_t piped_other = nullptr;  // ... the stream of the call before it
-  int pipeline_calls = 1;
+  int pipeline_calls = 0;  // (measured slower: cross-stream event waits cost this runtime tens of us -- profiles/r04_one_block_pipelining.txt)
   hipStream_t last_nco = nullptr;    // the side stream of the latest chain launch
   unsigned long long *d_chain_stats = nullptr;  // tuning (XL_EXP_CHAIN_STATS): per chain workgroup cycles / ticks of the latest launch
   hipStream_t nco_masked = nullptr;  // the side stream that goes with cs_masked; nco_stream (unmasked) serves callers' own streams

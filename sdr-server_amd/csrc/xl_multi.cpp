@@ -7,9 +7,10 @@
 // compute stream waits for it before the engine's launches) and `free` (recorded behind the launches that read the buffer; the
 // communication stream waits for it before the broadcast two feeds later overwrites the buffer).  Consecutive feeds
 // alternate the buffers, so the broadcast of super-block k+1 runs while super-block k is filtered.  The `free` events live in a
-// ring of four (feed k: slot k & 3) and carry timestamps, and with feed timing on (xlating_multi_feed_timing) every broadcast is
-// bracketed by two more events on the communication stream: feed k harvests feed k-2's broadcast duration and how much of it ran
-// while feed k-3's filtering was still going on -- the measured "is the broadcast hidden" number of a multi-GPU run.
+// ring of XL_MRING (feed k: slot k mod XL_MRING) and carry timestamps, and with feed timing on (xlating_multi_feed_timing) every
+// broadcast is bracketed by two more events on the communication stream; xlating_multi_feed_timing_read -- called after a sync, never
+// on the data path -- reads the latest feeds' broadcast durations and how much of each ran while the PREVIOUS feed's filtering was
+// still going on: the measured "is the broadcast hidden" number of a multi-GPU run.
 // The driver of GPU 0 also owns `src_done`: recorded behind the root's broadcast (or, without a communicator, behind the
 // launches that read d_src in place) -- what xlating_multi_feed_done / _feed_query / _feed_wait_on_stream observe.
 //
@@ -27,6 +28,8 @@
 #include "../../include/xlating_multi.h"
 #include "xl_common.h"
 
+#define XL_MRING 16  // feeds whose events are kept (timing samples per read: XL_MRING - 2)
+
 namespace {
 struct Gpu {
   int index = 0;   // position in the job (0 .. world-1)
@@ -36,10 +39,10 @@ struct Gpu {
   hipStream_t comm_stream = nullptr;
   void *recv[2] = {nullptr, nullptr};
   hipEvent_t ready[2] = {nullptr, nullptr};
-  hipEvent_t free_[4] = {nullptr, nullptr, nullptr, nullptr};  // feed k: slot k & 3 (behind the launches that read buffer k & 1)
-  bool free_valid[4] = {false, false, false, false};
-  hipEvent_t tb0[4] = {nullptr, nullptr, nullptr, nullptr}, tb1[4] = {nullptr, nullptr, nullptr, nullptr};  // around feed k's broadcast
-  bool tb_valid[4] = {false, false, false, false};
+  hipEvent_t free_[XL_MRING] = {};  // feed k: slot k mod XL_MRING (behind the launches that read buffer k & 1)
+  bool free_valid[XL_MRING] = {};
+  hipEvent_t tb0[XL_MRING] = {}, tb1[XL_MRING] = {};  // around feed k's broadcast
+  bool tb_valid[XL_MRING] = {};
   hipEvent_t src_done = nullptr;  // GPU 0's driver only: the latest feed no longer reads d_src
   bool src_valid = false;
 };
@@ -85,7 +88,7 @@ static int xl_multi_open_gpu(xlating_multi *m, Gpu &g, uint32_t fs, int fmt, uin
     if (m->bcast) XL_TRY(hipMalloc(&g.recv[i], m->recv_bytes));
     XL_TRY(hipEventCreateWithFlags(&g.ready[i], hipEventDisableTiming));
   }
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < XL_MRING; ++i) {
     XL_TRY(hipEventCreate(&g.free_[i]));
     XL_TRY(hipEventCreate(&g.tb0[i]));
     XL_TRY(hipEventCreate(&g.tb1[i]));
@@ -207,7 +210,7 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
   Gpu *root = xl_multi_find(m, 0);
   if (root != nullptr && d_src == nullptr && bytes > 0) return -EINVAL;  // the driver of GPU 0 holds the source
   const int i = (int)(m->feeds & 1);
-  const int k4 = (int)(m->feeds & 3), k2 = (int)((m->feeds + 2) & 3), k3 = (int)((m->feeds + 1) & 3);  // this feed, feed - 2, feed - 3
+  const int k4 = (int)(m->feeds % XL_MRING), k2 = (int)((m->feeds + XL_MRING - 2) % XL_MRING);  // this feed's slot, feed - 2's
   if (!m->bcast) {  // one GPU, no communicator: the engine reads d_src in place; the source is free behind its launches
     Gpu &g = m->gpus[0];
     int rc = xlating_batch_process_device_group_ev(g.engine, d_src, input_len, nblocks, mode, XL_STREAM_ENGINE, nullptr,
@@ -222,25 +225,10 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
     XL_TRY(hipSetDevice(g.device));
     if (g.free_valid[k2]) XL_TRY(hipStreamWaitEvent(g.comm_stream, g.free_[k2], 0));  // (the feed that read this buffer last)
   }
-  if (m->timing && m->feeds >= 3) {
-    // feed - 2's broadcast [tb0, tb1] against the end of feed - 3's filtering (free_[k3], not re-recorded before the next feed):
-    // harvested only when all three timestamps are there (no host wait on the data path)
-    Gpu &g = m->gpus[0];
-    XL_TRY(hipSetDevice(g.device));
-    if (g.tb_valid[k2] && g.free_valid[k3] && hipEventQuery(g.tb1[k2]) == hipSuccess && hipEventQuery(g.free_[k3]) == hipSuccess) {
-      float b = 0.0f, h = 0.0f;
-      if (hipEventElapsedTime(&b, g.tb0[k2], g.tb1[k2]) == hipSuccess && hipEventElapsedTime(&h, g.tb0[k2], g.free_[k3]) == hipSuccess) {
-        m->bcast_ms += b;
-        m->hidden_ms += h <= 0.0f ? 0.0 : (h >= b ? b : h);
-        m->timed++;
-      }
-    }
-    (void)hipGetLastError();  // (hipErrorNotReady of a query is not an error)
-    g.tb_valid[k2] = false;
-  }
   if (m->timing) {
     Gpu &g = m->gpus[0];
     XL_TRY(hipSetDevice(g.device));
+    g.tb_valid[k4] = false;
     XL_TRY(hipEventRecord(g.tb0[k4], g.comm_stream));
   }
   if (m->gpus.size() > 1) XL_NCCL(ncclGroupStart());
@@ -313,8 +301,27 @@ extern "C" int xlating_multi_feed_timing(xlating_multi *m, int enable) {
   return 0;
 }
 
+// The latest feeds whose three timestamps are complete (call it after xlating_multi_sync): feed j's broadcast [tb0, tb1] against the
+// end of feed j - 1's filtering (free_ of j - 1).  At most XL_MRING - 2 samples: older events have been re-recorded.
 extern "C" int xlating_multi_feed_timing_read(xlating_multi *m, double *bcast_ms_total, double *hidden_ms_total, int reset) {
   if (m == nullptr) return -EINVAL;
+  if (!m->gpus.empty() && m->timing && hipSetDevice(m->gpus[0].device) == hipSuccess) {
+    Gpu &g = m->gpus[0];
+    const uint64_t lo = m->feeds > (uint64_t)(XL_MRING - 2) ? m->feeds - (XL_MRING - 2) : 1;
+    for (uint64_t j = lo; j < m->feeds; ++j) {
+      const int sj = (int)(j % XL_MRING), sp = (int)((j - 1) % XL_MRING);
+      if (!g.tb_valid[sj] || !g.free_valid[sp]) continue;
+      if (hipEventQuery(g.tb1[sj]) != hipSuccess || hipEventQuery(g.free_[sp]) != hipSuccess) continue;
+      float bms = 0.0f, hms = 0.0f;
+      if (hipEventElapsedTime(&bms, g.tb0[sj], g.tb1[sj]) == hipSuccess && hipEventElapsedTime(&hms, g.tb0[sj], g.free_[sp]) == hipSuccess) {
+        m->bcast_ms += bms;
+        m->hidden_ms += hms <= 0.0f ? 0.0 : (hms >= bms ? bms : hms);
+        m->timed++;
+      }
+      g.tb_valid[sj] = false;  // (counted once)
+    }
+    (void)hipGetLastError();  // (hipErrorNotReady of a query is not an error)
+  }
   if (bcast_ms_total) *bcast_ms_total = m->bcast_ms;
   if (hidden_ms_total) *hidden_ms_total = m->hidden_ms;
   const int n = m->timed;
@@ -356,7 +363,7 @@ extern "C" void xlating_multi_destroy(xlating_multi *m) {
       if (g.recv[i]) (void)hipFree(g.recv[i]);
       if (g.ready[i]) (void)hipEventDestroy(g.ready[i]);
     }
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < XL_MRING; ++i) {
       if (g.free_[i]) (void)hipEventDestroy(g.free_[i]);
       if (g.tb0[i]) (void)hipEventDestroy(g.tb0[i]);
       if (g.tb1[i]) (void)hipEventDestroy(g.tb1[i]);
