@@ -216,6 +216,9 @@ struct xlating_batch_t {
   uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = the mix launch on the matrix cores where the class allows it (integer input
                               // format, D <= 64), 0 = packed FP32 FMAs everywhere, 2 = mix + inverse as ONE launch with the mixed spectra
                               // on chip (xl_fused.hip) where the class allows it (integer input, D <= 64, <= 32 taps per branch)
+  uint32_t y_format = 1;      // option "y_format": 1 (default) = the mixed spectra Y as 48-bit values (xl_y6.h: shared exponent, two 21-bit
+                              // mantissas) where the class's mix launch runs on the matrix cores and the inverse launch stages its
+                              // transform in LDS ("inverse_kernel" 0 / 3 / 4); 0 = float32 pairs everywhere
   uint32_t mix_pp = 0;        // option "mix_passes_per_workgroup" (matrix-core mix): 0 = the launcher's default
   uint32_t mix_skip_at = 0;   // position of the mix launch's skipped workgroups; 0 = 1024
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
@@ -439,6 +442,10 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
   } else if (n == "mix_kernel") {
     if (value < 0 || value > 2) return -EINVAL;
     b->mix_kernel = (uint32_t)value;
+  } else if (n == "y_format") {
+    if (value < 0 || value > 1) return -EINVAL;
+    b->y_format = (uint32_t)value;
+    return 0;  // (a launch parameter: Y is rewritten by every call)
   } else if (n == "pipeline_calls") {
     if (value < 0 || value > 1) return -EINVAL;
     b->pipeline_calls = (int)value;
@@ -525,6 +532,7 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
   if (getenv("XL_EXP_POLY_MIN")) (void)xlating_batch_set_option(b, "polyphase_min_clients", atol(getenv("XL_EXP_POLY_MIN")));
   if (getenv("XL_EXP_INV")) (void)xlating_batch_set_option(b, "inverse_kernel", atol(getenv("XL_EXP_INV")));
   if (getenv("XL_EXP_MIX")) (void)xlating_batch_set_option(b, "mix_kernel", atol(getenv("XL_EXP_MIX")));
+  if (getenv("XL_EXP_Y6")) (void)xlating_batch_set_option(b, "y_format", atol(getenv("XL_EXP_Y6")));
   if (getenv("XL_EXP_MIX_PP")) (void)xlating_batch_set_option(b, "mix_passes_per_workgroup", atol(getenv("XL_EXP_MIX_PP")));
   if (getenv("XL_EXP_CHAIN_STATS")) (void)hipMalloc((void **)&b->d_chain_stats, 4096 * 4 * sizeof(unsigned long long));
   if (getenv("XL_EXP_NCO_SIDE")) (void)xlating_batch_set_option(b, "nco_side_stream", atol(getenv("XL_EXP_NCO_SIDE")));
@@ -1883,6 +1891,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           pa.mix_kind = pc.mix_kind;
           pa.nkb = pc.nkb;
           pa.mix_pp = b->mix_pp;
+          pa.y6 = (b->y_format == 1u && pc.mix_kind == 1u && !(pc.M == 128u && (b->inv_reg == 1u || b->inv_reg == 2u))) ? 1u : 0u;
           pa.Rh = pc.d_Rh;
           pa.cscale = pc.d_cscale;
           pa.W = b->d_W;
@@ -2103,6 +2112,7 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
          std::to_string(pc.members.size()) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
     if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
     d += pc.mix_kind == 2u ? " mix=fused" : (pc.mix_kind == 1u ? " mix=mfma" : " mix=fma");
+    if (b->y_format == 1u && pc.mix_kind == 1u && !(pc.M == 128u && (b->inv_reg == 1u || b->inv_reg == 2u))) d += " Y=48bit";
   }
   if (!b->poly.empty()) {
     d += " | optimized-mode direct:";

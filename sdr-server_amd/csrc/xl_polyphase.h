@@ -68,6 +68,7 @@ struct XlpArgs {
                        // 2 = mix + inverse as ONE launch with the mixed spectra on chip (xl_fused.hip: no Y image, X and Rh in that launch's operand forms)
   uint32_t nkb;        // mix_kind 1: k-blocks of 8 branches = ceil(D / 8), <= XLP_NKB_MAX; mix_kind 2: k-blocks of 16 branches, <= 4
   uint32_t mix_pp;     // mix_kind 1: passes per workgroup (0 = default)
+  uint32_t y6;         // mix_kind 1 + LDS-transform inverse kernels: Y holds 48-bit values (xl_y6.h) instead of float32 pairs
   unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
@@ -76,6 +77,7 @@ struct XlpArgs {
                        //   [cg][M][32-column quarter][term 2][k-block nkb][lane 64][8 halves] (see xlp_mix_mfma_kernel)
   const float *cscale; // mix_kind 1: per column, what the sums are multiplied by = 1 / (column scale * XLP_H_XSCALE)
   float2 *Y;           // mixed spectra    [cg][nseg_cap][sub][M][CW], CW = 32 (M = 128) / 16 (M = 256) columns: one inverse tile contiguous
+                       //   (y6: the same tiles, 6 bytes per value in two planes: xl_y6.h)
   const XlpCol *cols;  // per column
   const float2 *phtab;
   float2 *out;

@@ -18,6 +18,7 @@
 
 #include "xl_poly_dev.h"
 #include "xl_mix_layout.h"
+#include "xl_y6.h"
 
 #include <hip/hip_ext.h>
 
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
 // was never found, so the combination was designed out (round 4): the recurrence rides in the forward and inverse launches or
 // runs on the side stream (xl_batch.cpp), xlp_launch_mix refuses a role for this kernel, and
 // tests/test_batch_gpu.py::test_matrix_core_mix_role_phases_bit_exact keeps comparing all phases of two engines bit for bit.
-template <int NKB>
+template <int NKB, bool Y6>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void xlp_mix_mfma_kernel(const XlpArgs a) {
   // A operands of one pass: [term][k-block][lane][8 halves]; two buffers (one barrier per pass: a buffer is rewritten two
   // barriers after it was read)
@@ -377,11 +378,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (pass + 2u < p1) request(pass + 2u);
     // this lane's rows: registers g, g + 1 (g even) = (re, im) of the pass's segment xlm_result_row(g, h) / 2
     const uint32_t s0 = pass * XLP_SEG;
+    if constexpr (Y6) {
+      // 48 bits per value (xl_y6.h): the UNSCALED sums with a shared exponent; the reader applies the column's factor.  Plane A:
+      // 32 lanes x 4 bytes = one 128-byte run per (segment, bin); plane B: 64 bytes.
+      char *__restrict__ Yb = reinterpret_cast<char *>(a.Y);
 #pragma unroll
-    for (int g2 = 0; g2 < 16; g2 += 2) {
-      const uint32_t sl = xlm_result_row((uint32_t)g2, h) >> 1;
-      const v2f y = {(hi[g2] + lo[g2]) * cs, (hi[g2 + 1] + lo[g2 + 1]) * cs};
-      if (sl < XLP_SEG && s0 + sl < a.nseg) __builtin_nontemporal_store(y, &Yc[(size_t)(s0 + sl) * ystride]);
+      for (int g2 = 0; g2 < 16; g2 += 2) {
+        const uint32_t sl = xlm_result_row((uint32_t)g2, h) >> 1;
+        uint32_t w0, w1;
+        xly6_encode(hi[g2] + lo[g2], hi[g2 + 1] + lo[g2 + 1], &w0, &w1);
+        if (sl < XLP_SEG && s0 + sl < a.nseg) {
+          char *__restrict__ t = Yb + xly6_tile(cg, a.nseg_cap, s0 + sl, NSUB, col / CW, M, CW);
+          __builtin_nontemporal_store(w0, reinterpret_cast<uint32_t *>(t + xly6_a(m, CW, col % CW)));
+          __builtin_nontemporal_store((uint16_t)w1, reinterpret_cast<uint16_t *>(t + xly6_b(M, m, CW, col % CW)));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g2 = 0; g2 < 16; g2 += 2) {
+        const uint32_t sl = xlm_result_row((uint32_t)g2, h) >> 1;
+        const v2f y = {(hi[g2] + lo[g2]) * cs, (hi[g2 + 1] + lo[g2 + 1]) * cs};
+        if (sl < XLP_SEG && s0 + sl < a.nseg) __builtin_nontemporal_store(y, &Yc[(size_t)(s0 + sl) * ystride]);
+      }
     }
     __syncthreads();  // the other buffer is staged; everybody is done with this one
   }
@@ -422,11 +440,34 @@ XL_DEV void xlp_inverse_body(const XlpArgs &a) {
     // 16 bytes = 2 columns of bin mrow + MR i -- every load instruction of the workgroup covers 4 KB back to back.
     constexpr uint32_t PARTS = CW / 2, MR = 256 / PARTS;
     const uint32_t part = threadIdx.x % PARTS, mrow = threadIdx.x / PARTS;
-    const v4f *__restrict__ src = reinterpret_cast<const v4f *>(
-        a.Y + ((((size_t)cg * a.nseg_cap + s) * NSUB + sub) * M) * CW) + part;
     v4f v[8];
+    if (a.y6) {
+      // 48-bit values (xl_y6.h): per bin 8 bytes of plane A + 4 of plane B for this thread's two columns; the columns' power-of-two
+      // factors (cscale: what undoes the mix's operand scales) go into the decoding's exponent
+      const char *__restrict__ t = reinterpret_cast<const char *>(a.Y) + xly6_tile(cg, a.nseg_cap, s, NSUB, sub, M, CW);
+      const uint32_t cbase = cg * XLP_COLS + sub * CW + 2u * part;
+      const int k0 = (int)((xly6_bits(a.cscale[cbase]) >> 23) & 0xFFu) - 127, k1 = (int)((xly6_bits(a.cscale[cbase + 1u]) >> 23) & 0xFFu) - 127;
+      uint2 wa[8];
+      uint32_t wb[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(mrow + MR * i) * PARTS];
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t m = mrow + MR * i;
+        wa[i] = *reinterpret_cast<const uint2 *>(t + xly6_a(m, CW, 2u * part));
+        wb[i] = *reinterpret_cast<const uint32_t *>(t + xly6_b(M, m, CW, 2u * part));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float r0, i0, r1, i1;
+        xly6_decode(wa[i].x, wb[i] & 0xFFFFu, k0, &r0, &i0);
+        xly6_decode(wa[i].y, wb[i] >> 16, k1, &r1, &i1);
+        v[i] = (v4f){r0, i0, r1, i1};
+      }
+    } else {
+      const v4f *__restrict__ src = reinterpret_cast<const v4f *>(
+          a.Y + ((((size_t)cg * a.nseg_cap + s) * NSUB + sub) * M) * CW) + part;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(mrow + MR * i) * PARTS];
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t m = mrow + MR * i;
@@ -943,7 +984,8 @@ static XlpArgs xlp_checked_skip(const XlpArgs &a, uint32_t work_blocks) {
 
 template <int NKB>
 static void xlp_launch_mix_mfma_n(const XlpArgs &a, const dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(xlp_mix_mfma_kernel<NKB>, grid, dim3(256), 0, s, a);
+  if (a.y6) hipLaunchKernelGGL((xlp_mix_mfma_kernel<NKB, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((xlp_mix_mfma_kernel<NKB, false>), grid, dim3(256), 0, s, a);
 }
 
 hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
@@ -974,6 +1016,7 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
     }
     return hipGetLastError();
   }
+  if (a0.y6) return hipErrorInvalidValue;  // (the 48-bit form of Y is the matrix-core mix's: its sums are bounded by construction)
   const uint32_t work = a0.M * a0.ncg * passes;
   XlpArgs a = xlp_checked_skip(a0, work);
   a.mix_passes = passes;
@@ -990,6 +1033,7 @@ hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done)
   // = (segment, column group): four tiles), 2 = registers, lane quad per column (workgroup = two tiles)
   // 3 = staged in LDS like 0, dense rows with an XOR swizzle instead of the pad; 4 = the same built for five workgroups per CU
   const uint32_t kind = a0.M == 128u ? a0.inv_reg : 0u;
+  if (a0.y6 && (kind == 1u || kind == 2u || a0.cscale == nullptr)) return hipErrorInvalidValue;  // (the register-transform kernels read float32 pairs)
   const uint32_t work = a0.nseg * a0.ncg * (kind == 1u ? 1u : (kind == 2u ? 2u : (a0.M == 256u ? 8u : 4u)));
   const XlpArgs a = xlp_checked_skip(a0, work);
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
