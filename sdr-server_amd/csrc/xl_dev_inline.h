@@ -145,6 +145,21 @@ XL_DEV v2f xl_nco_next_any(const v2f p, const v2f inc, const uint32_t flags) {
   return (flags & XL_POS_FMA_STEP) ? xl_nco_next_fma(p, inc) : xl_nco_next(p, inc);
 }
 
+// The step for the NCO ROLE (xl_nco_client_chain: a wave that runs the recurrence for thousands of steps INSIDE a launch, next to
+// whatever else is resident on its SIMD): the same IEEE operations as SIX SCALAR instructions.  Round 4 pinned the corruption
+// round 3 could not explain: a role wave stepping with the packed instructions above got the phases of its lanes
+// 48..63 wrong -- about once per 10^7 steps -- whenever waves issuing MATRIX instructions were resident on the chip at the same
+// time, its own launch's or ANOTHER engine's (two engines in one process: each alone bit-exact over 1500 calls, together the
+// packed role of one corrupt within 100; tools/experiments/dbg_soak.py).  Work waves next to matrix-core launches compute the same
+// bits (dbg_soak2.py), the short phase walks of the consumers too, the side-stream chain kernel owns its SIMDs outright; with
+// the scalar step the role is immune (1500 calls x 4096 clients beside a matrix-core engine: bit-exact) at ~1.4 x the cycles per
+// step -- which only launches long enough to hide it carry anyway.
+XL_DEV v2f xl_nco_role_step(const v2f p, const v2f inc, const uint32_t flags) {
+  if (flags & XL_POS_FMA_STEP) return (v2f){__builtin_fmaf(p.x, inc.x, -(p.y * inc.y)), __builtin_fmaf(p.x, inc.y, p.y * inc.x)};
+  const float a = p.x * inc.x, b = p.y * inc.y, c = p.x * inc.y, d = p.y * inc.x;
+  return (v2f){a - b, d + c};
+}
+
 // xlating.c:73 `phase /= hypotf(re, im)`: glibc's hypotf evaluates sqrt(x*x + y*y) in double and narrows; restated with
 // IEEE double operations (equal to libm on 2e8 inputs, tests/test_oracle.py) and correctly rounded float divisions.
 XL_DEV v2f xl_nco_renorm(const v2f p) {
@@ -179,25 +194,25 @@ XL_DEV void xl_nco_client_chain(const XlNcoClient k, const XlBnd bnd, const uint
     const uint32_t me = nb < ke ? nb : ke;
     for (; m < me && (m & (2u * XL_PH_STRIDE - 1u)) != 0u; ++m) {  // head: up to the next pair boundary
       if (tab != nullptr && (m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
-      p = xl_nco_next_any(p, inc, bnd.flags);
+      p = xl_nco_role_step(p, inc, bnd.flags);
     }
     // 2 * XL_PH_STRIDE steps and ONE store (two entries) per trip (plain step; FMA-step calls take the loops around it)
     for (; !(bnd.flags & XL_POS_FMA_STEP) && m + 2u * XL_PH_STRIDE <= me; m += 2u * XL_PH_STRIDE) {
       const v2f q0 = p;
       for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) p = xl_nco_next(p, inc);
+        for (int j = 0; j < 16; ++j) p = xl_nco_role_step(p, inc, 0u);
       }
       const v2f q1 = p;
       for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) p = xl_nco_next(p, inc);
+        for (int j = 0; j < 16; ++j) p = xl_nco_role_step(p, inc, 0u);
       }
       if (tab != nullptr) o4[m >> (XL_PH_SHIFT + 1u)] = (v4f){q0.x, q0.y, q1.x, q1.y};
     }
     for (; m < me; ++m) {
       if (tab != nullptr && (m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
-      p = xl_nco_next_any(p, inc, bnd.flags);
+      p = xl_nco_role_step(p, inc, bnd.flags);
     }
     if (me == nb) p = xl_nco_renorm(p);  // a block of the call ends here
   }
