@@ -155,9 +155,29 @@ XL_DEV v2f xl_nco_next_any(const v2f p, const v2f inc, const uint32_t flags) {
 // the scalar step the role is immune (1500 calls x 4096 clients beside a matrix-core engine: bit-exact) at ~1.4 x the cycles per
 // step -- which only launches long enough to hide it carry anyway.
 XL_DEV v2f xl_nco_role_step(const v2f p, const v2f inc, const uint32_t flags) {
-  if (flags & XL_POS_FMA_STEP) return (v2f){__builtin_fmaf(p.x, inc.x, -(p.y * inc.y)), __builtin_fmaf(p.x, inc.y, p.y * inc.x)};
-  const float a = p.x * inc.x, b = p.y * inc.y, c = p.x * inc.y, d = p.y * inc.x;
-  return (v2f){a - b, d + c};
+  // (inline assembly on purpose: written in C the vectoriser turns the four products and two sums back into v_pk_mul_f32 /
+  // v_pk_add_f32; plain VALU dependencies are interlocked by the hardware, no wait states are needed in here)
+  float a, b, c, d;
+  if (flags & XL_POS_FMA_STEP) {  // re = fma(pr, ir, -(pi ii)), im = fma(pr, ii, pi ir)
+    asm volatile(
+        "v_mul_f32 %0, %3, %5\n\t"
+        "v_mul_f32 %1, %3, %4\n\t"
+        "v_fma_f32 %0, %2, %4, -%0\n\t"
+        "v_fma_f32 %1, %2, %5, %1"
+        : "=&v"(a), "=&v"(b)
+        : "v"(p.x), "v"(p.y), "v"(inc.x), "v"(inc.y));
+    return (v2f){a, b};
+  }
+  asm volatile(
+      "v_mul_f32 %0, %4, %6\n\t"
+      "v_mul_f32 %1, %5, %7\n\t"
+      "v_mul_f32 %2, %4, %7\n\t"
+      "v_mul_f32 %3, %5, %6\n\t"
+      "v_sub_f32 %0, %0, %1\n\t"
+      "v_add_f32 %1, %3, %2"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+      : "v"(p.x), "v"(p.y), "v"(inc.x), "v"(inc.y));
+  return (v2f){a, b};
 }
 
 // xlating.c:73 `phase /= hypotf(re, im)`: glibc's hypotf evaluates sqrt(x*x + y*y) in double and narrows; restated with
