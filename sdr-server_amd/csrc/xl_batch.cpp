@@ -224,7 +224,10 @@ struct xlating_batch_t {
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
   uint32_t poly_exp = 0;     // XL_TUNING builds: tuning switches of the mix kernel
   uint32_t poly_slice1 = 8000, poly_slice2 = 50000;  // NCO slice boundaries in 1/65536 of the call (forward | mix | inverse)
-  uint32_t poly_slice1_m = 6000, poly_slice2_m = 35000;  // ... of classes whose mix launch runs on the matrix cores (a shorter launch)
+  uint32_t poly_slice1_m = 6000, poly_slice2_m = 35000;  // (round 3: ... of classes whose mix launch ran the role too; kept for the option's sake)
+  uint32_t poly_slice_fi = 20000;  // classes whose mix launch runs on the matrix cores: TWO slices, forward | inverse (the inverse launch is
+                                   // the longer one: 31 % | 69 % keeps both slices inside their launches at 4096 clients with the
+                                   // scalar role step)
   std::vector<XlNcoClient> nco;
   size_t out_total = 0;
   uint64_t ncalls = 0;  // calls processed
@@ -475,6 +478,7 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     b->poly_slice2 = (uint32_t)(value & 0xFFFF);
     if (b->poly_slice1 > b->poly_slice2) return -EINVAL;
     b->poly_slice1_m = b->poly_slice1, b->poly_slice2_m = b->poly_slice2;
+    b->poly_slice_fi = b->poly_slice2;
   } else {
     return -ENOENT;
   }
@@ -1907,7 +1911,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           // Packed-FMA mix: three slices (forward | mix | inverse); matrix-core mix: two (forward | inverse); fused: the
           // forward launch carries all of it (such calls take the side stream whenever there is one).
           const bool carry = fuse && !nco_fused;
-          const uint32_t sl1 = pc.mix_kind == 2u ? 65536u : (pc.mix_kind == 1u ? std::min(b->poly_slice2_m, 60000u) : b->poly_slice1);
+          const uint32_t sl1 = pc.mix_kind == 2u ? 65536u : (pc.mix_kind == 1u ? std::min(b->poly_slice_fi, 60000u) : b->poly_slice1);
           const uint32_t sl2 = pc.mix_kind == 0u ? b->poly_slice2 : sl1;
           if (carry) {
             pa.nco_clients = b->d_nco;

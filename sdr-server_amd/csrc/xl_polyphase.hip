@@ -285,6 +285,13 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
 // was never found, so the combination was designed out (round 4): the recurrence rides in the forward and inverse launches or
 // runs on the side stream (xl_batch.cpp), xlp_launch_mix refuses a role for this kernel, and
 // tests/test_batch_gpu.py::test_matrix_core_mix_role_phases_bit_exact keeps comparing all phases of two engines bit for bit.
+// lane ^ 1's value (DPP quad_perm [1,0,3,2]; inline assembly: see xlp_dpp_pair below for why, and for the s_nop)
+XL_DEV uint32_t xlp_dpp_pair_u32(const uint32_t v) {
+  uint32_t r;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+  return r;
+}
+
 template <int NKB, bool Y6>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void xlp_mix_mfma_kernel(const XlpArgs a) {
   // A operands of one pass: [term][k-block][lane][8 halves]; two buffers (one barrier per pass: a buffer is rewritten two
@@ -379,18 +386,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // this lane's rows: registers g, g + 1 (g even) = (re, im) of the pass's segment xlm_result_row(g, h) / 2
     const uint32_t s0 = pass * XLP_SEG;
     if constexpr (Y6) {
-      // 48 bits per value (xl_y6.h): the UNSCALED sums with a shared exponent; the reader applies the column's factor.  Plane A:
-      // 32 lanes x 4 bytes = one 128-byte run per (segment, bin); plane B: 64 bytes.
+      // 48 bits per value (xl_y6.h): the UNSCALED sums with a shared exponent; the reader applies the column's factor.  An even
+      // lane fetches its odd neighbour's value (DPP) and stores the pair: 12 bytes, 16 lanes x 12 = 192 contiguous bytes per
+      // (segment, bin).
       char *__restrict__ Yb = reinterpret_cast<char *>(a.Y);
 #pragma unroll
       for (int g2 = 0; g2 < 16; g2 += 2) {
         const uint32_t sl = xlm_result_row((uint32_t)g2, h) >> 1;
         uint32_t w0, w1;
         xly6_encode(hi[g2] + lo[g2], hi[g2 + 1] + lo[g2 + 1], &w0, &w1);
-        if (sl < XLP_SEG && s0 + sl < a.nseg) {
-          char *__restrict__ t = Yb + xly6_tile(cg, a.nseg_cap, s0 + sl, NSUB, col / CW, M, CW);
-          __builtin_nontemporal_store(w0, reinterpret_cast<uint32_t *>(t + xly6_a(m, CW, col % CW)));
-          __builtin_nontemporal_store((uint16_t)w1, reinterpret_cast<uint16_t *>(t + xly6_b(M, m, CW, col % CW)));
+        const uint32_t n0 = xlp_dpp_pair_u32(w0), n1 = xlp_dpp_pair_u32(w1);  // (lane ^ 1's)
+        if (sl < XLP_SEG && s0 + sl < a.nseg && (c & 1u) == 0u) {
+          char *__restrict__ t = Yb + xly6_tile(cg, a.nseg_cap, s0 + sl, NSUB, col / CW, M, CW) + xly6_pair(m, CW, (col % CW) >> 1);
+          typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+          __builtin_nontemporal_store((v3u){w0, n0, w1 | (n1 << 16)}, reinterpret_cast<v3u *>(t));
         }
       }
     } else {
@@ -442,24 +451,20 @@ XL_DEV void xlp_inverse_body(const XlpArgs &a) {
     const uint32_t part = threadIdx.x % PARTS, mrow = threadIdx.x / PARTS;
     v4f v[8];
     if (a.y6) {
-      // 48-bit values (xl_y6.h): per bin 8 bytes of plane A + 4 of plane B for this thread's two columns; the columns' power-of-two
-      // factors (cscale: what undoes the mix's operand scales) go into the decoding's exponent
+      // 48-bit values (xl_y6.h): per bin the 12 bytes of this thread's column pair; the columns' power-of-two factors (cscale: what
+      // undoes the mix's operand scales) go into the decoding's exponent
       const char *__restrict__ t = reinterpret_cast<const char *>(a.Y) + xly6_tile(cg, a.nseg_cap, s, NSUB, sub, M, CW);
       const uint32_t cbase = cg * XLP_COLS + sub * CW + 2u * part;
       const int k0 = (int)((xly6_bits(a.cscale[cbase]) >> 23) & 0xFFu) - 127, k1 = (int)((xly6_bits(a.cscale[cbase + 1u]) >> 23) & 0xFFu) - 127;
-      uint2 wa[8];
-      uint32_t wb[8];
+      typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+      v3u wp[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint32_t m = mrow + MR * i;
-        wa[i] = *reinterpret_cast<const uint2 *>(t + xly6_a(m, CW, 2u * part));
-        wb[i] = *reinterpret_cast<const uint32_t *>(t + xly6_b(M, m, CW, 2u * part));
-      }
+      for (int i = 0; i < 8; ++i) wp[i] = *reinterpret_cast<const v3u *>(t + xly6_pair(mrow + MR * i, CW, part));
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float r0, i0, r1, i1;
-        xly6_decode(wa[i].x, wb[i] & 0xFFFFu, k0, &r0, &i0);
-        xly6_decode(wa[i].y, wb[i] >> 16, k1, &r1, &i1);
+        xly6_decode(wp[i].x, wp[i].z & 0xFFFFu, k0, &r0, &i0);
+        xly6_decode(wp[i].y, wp[i].z >> 16, k1, &r1, &i1);
         v[i] = (v4f){r0, i0, r1, i1};
       }
     } else {
