@@ -86,10 +86,11 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                           with the mixed spectra kept in registers (2: xl_fused.hip; integer input, decimation <= 64, up to
  *                           64 taps per branch; slower than the three launches on an MI355X -- DESIGN.md 3.5 -- and kept as
  *                           an option).  Same 1e-5 bar in every case
- *   "y_format"              1 (default) / 0: the mixed spectra between the mix and the inverse launch as 48-bit values (one shared
- *                           6-bit exponent + two 21-bit mantissas per complex value: a quarter less of the path's largest stream)
- *                           where the mix runs on the matrix cores and the inverse transform is staged in LDS; 0: float32 pairs.
- *                           Adds <= 7e-7 of max|y| (tests/test_y6_model.py) to the ~1.6e-6 of the path; same 1e-5 bar
+ *   "y_format"              0 (default) / 1: the mixed spectra between the mix and the inverse launch as float32 pairs, or as
+ *                           48-bit values (one shared 6-bit exponent + two 21-bit mantissas per complex value: a quarter less of
+ *                           the path's largest stream) where the mix runs on the matrix cores and the inverse transform is staged in
+ *                           LDS.  1 adds <= 7e-7 of max|y| (tests/test_y6_model.py; same 1e-5 bar) and moves 16 % fewer bytes per
+ *                           call, but measured 10 % slower on an MI355X (profiles/r04_y48.txt): an option, not the default
  *   "pipeline_calls"        0 (default) / 1: an engine created for ONE block per call (xlating_batch_create) that is driven
  *                           through XL_STREAM_ENGINE alternates its optimized polyphase calls between two compute streams it
  *                           owns; only the calls' forward launches are ordered against each other, so that call k + 1 may

@@ -216,9 +216,11 @@ struct xlating_batch_t {
   uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = the mix launch on the matrix cores where the class allows it (integer input
                               // format, D <= 64), 0 = packed FP32 FMAs everywhere, 2 = mix + inverse as ONE launch with the mixed spectra
                               // on chip (xl_fused.hip) where the class allows it (integer input, D <= 64, <= 32 taps per branch)
-  uint32_t y_format = 1;      // option "y_format": 1 (default) = the mixed spectra Y as 48-bit values (xl_y6.h: shared exponent, two 21-bit
-                              // mantissas) where the class's mix launch runs on the matrix cores and the inverse launch stages its
-                              // transform in LDS ("inverse_kernel" 0 / 3 / 4); 0 = float32 pairs everywhere
+  uint32_t y_format = 0;      // option "y_format": 1 = the mixed spectra Y as 48-bit values (xl_y6.h: shared exponent, two 21-bit mantissas)
+                              // where the class's mix launch runs on the matrix cores and the inverse launch stages its transform in
+                              // LDS ("inverse_kernel" 0 / 3 / 4); 0 (default) = float32 pairs.  Measured (profiles/r04_y48.txt): 16 %
+                              // fewer bytes per call, 10 % MORE time at 2048 - 4096 clients -- the encoding costs the mix launch more
+                              // vector instructions than the bytes buy
   uint32_t mix_pp = 0;        // option "mix_passes_per_workgroup" (matrix-core mix): 0 = the launcher's default
   uint32_t mix_skip_at = 0;   // position of the mix launch's skipped workgroups; 0 = 1024
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs

@@ -9,8 +9,8 @@
 // (|X * 128| < 2^15.6, |R * column scale| < 2^13: xl_polyphase.h), so |sum| < 84 * 2^28.6 < 2^35 whatever the taps' gain, and the
 // column's power-of-two factor that undoes the scales (cscale) is applied by the reader as an exponent offset -- exactly.
 // Layout of a (segment, 32- or 16-column) tile: [bin][column PAIR][12 bytes] = the two columns' low words (mantissa of re, low
-// 11 bits of the mantissa of im) and one word with their two high half-words (high 10 bits of the mantissa of im, off): 6 M CW
-// bytes, contiguous.  A pair is what one thread of the inverse launch's tile fill handles -- one 12-byte load where the float32 form
+// 11 bits of the mantissa of im) and one word with their two high half-words (high 10 bits of the mantissa of im, off): 6 CW
+// bytes per bin in a pitch of 8 CW.  A pair is what one thread of the inverse launch's tile fill handles -- one 12-byte load where the float32 form
 // took one of 16 -- and what an even lane of the mix launch stores after fetching its odd neighbour's value through DPP: one
 // 12-byte store per two values, 192 contiguous bytes per (segment, bin).  (A first layout with a plane of low words and a plane of
 // half-words moved the same bytes with twice the store instructions, half of them 2-byte stores: 16 % fewer bytes, 10 % MORE
@@ -58,9 +58,11 @@ XLY_FN void xly6_decode(uint32_t lo, uint32_t hi16, int kexp, float *re, float *
 }
 
 // byte offsets inside the Y image: tile (cg, segment, sub) and, inside it, the 12 bytes of (bin m, column pair cw / 2)
+// (a bin's row of CW / 2 pairs = 6 CW bytes sits in a pitch of 8 CW bytes -- 192 of 256, 96 of 128 -- so that no 128-byte line is
+// shared by two bins: their rows are written by different workgroups of the mix launch, on different XCDs)
 XLY_FN size_t xly6_tile(uint32_t cg, uint32_t nseg_cap, uint32_t seg, uint32_t nsub, uint32_t sub, uint32_t M, uint32_t CW) {
-  return ((((size_t)cg * nseg_cap + seg) * nsub + sub) * M) * CW * 6u;
+  return ((((size_t)cg * nseg_cap + seg) * nsub + sub) * M) * CW * 8u;
 }
-XLY_FN uint32_t xly6_pair(uint32_t m, uint32_t CW, uint32_t pair) { return (m * (CW / 2u) + pair) * 12u; }
+XLY_FN uint32_t xly6_pair(uint32_t m, uint32_t CW, uint32_t pair) { return m * CW * 8u + pair * 12u; }
 
 #endif  // XL_Y6_H_

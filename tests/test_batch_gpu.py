@@ -293,17 +293,17 @@ def test_1000_clients_split_group_riders():
 # that the oracle can check every client.
 # The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
 # the forced-path tests run with both.
-@pytest.fixture(params=[(128, 0, 1, 1), (128, 1, 1, 1), (128, 2, 1, 1), (128, 3, 1, 1), (256, 0, 1, 1), (128, 3, 0, 1), (256, 0, 0, 1), (128, 3, 2, 1),
-                        (128, 3, 1, 0), (256, 0, 1, 0)],
+@pytest.fixture(params=[(128, 0, 1, 0), (128, 1, 1, 0), (128, 2, 1, 0), (128, 3, 1, 0), (256, 0, 1, 0), (128, 3, 0, 0), (256, 0, 0, 0), (128, 3, 2, 0),
+                        (128, 3, 1, 1), (256, 0, 1, 1)],
                 ids=["M128", "M128-register-inverse", "M128-quad-register-inverse", "M128-swizzled-inverse", "M256",
-                     "M128-fma-mix", "M256-fma-mix", "M128-fused", "M128-swizzled-inverse-float32-Y", "M256-float32-Y"])
+                     "M128-fma-mix", "M256-fma-mix", "M128-fused", "M128-swizzled-inverse-48bit-Y", "M256-48bit-Y"])
 def poly_m(request, monkeypatch):
     """Transform length of the forced polyphase plan; at M = 128 also with the inverse launch's transform in registers
     (option "inverse_kernel" = 1: xlp_inverse_reg_kernel, a lane pair per column; 2: xlp_inverse_quad_kernel, a lane quad);
     the mix launch on the matrix cores (option "mix_kernel" = 1, the default where the class allows it: integer input, D <= 64)
     or as packed FP32 FMAs (0), or mix + inverse as ONE launch with the mixed spectra on chip (2: xl_fused.hip); the mixed spectra
-    between the matrix-core mix and an LDS-staged inverse launch as 48-bit values (option "y_format" = 1, the default: xl_y6.h) or as
-    float32 pairs (0)."""
+    between the matrix-core mix and an LDS-staged inverse launch as float32 pairs (option "y_format" = 0, the default) or as
+    48-bit values (1: xl_y6.h)."""
     m, inv, mix, y6 = request.param
     monkeypatch.setenv("XL_EXP_POLY_M", str(m))
     monkeypatch.setenv("XL_EXP_INV", str(inv))
@@ -1319,7 +1319,7 @@ def _engine_outputs(eng, ids):
 
 
 @pytest.mark.parametrize("variant", ["native", "optimized", "optimized-register-inverse", "optimized-quad-register-inverse",
-                                     "optimized-swizzled-inverse", "optimized-fma-mix", "optimized-fused", "optimized-float32-Y"])
+                                     "optimized-swizzled-inverse", "optimized-fma-mix", "optimized-fused", "optimized-48bit-Y"])
 def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
     server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
@@ -1336,8 +1336,8 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     if variant.endswith("-fused"):
         monkeypatch.setenv("XL_EXP_MIX", "2")
         variant = "optimized"
-    if variant.endswith("-float32-Y"):
-        monkeypatch.setenv("XL_EXP_Y6", "0")
+    if variant.endswith("-48bit-Y"):
+        monkeypatch.setenv("XL_EXP_Y6", "1")
         variant = "optimized"
     t48 = lpf(FS, 24000, 9600)
     G, nb = 8, 262144
@@ -1351,7 +1351,7 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     if variant == "optimized":
         assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
         assert {"0": "mix=fma", "2": "mix=fused"}.get(os.environ.get("XL_EXP_MIX"), "mix=mfma") in eng.describe(), eng.describe()
-        y48 = os.environ.get("XL_EXP_MIX") in (None, "1") and os.environ.get("XL_EXP_Y6") != "0" and os.environ.get("XL_EXP_INV") not in ("1", "2")
+        y48 = os.environ.get("XL_EXP_MIX") in (None, "1") and os.environ.get("XL_EXP_Y6") == "1" and os.environ.get("XL_EXP_INV") not in ("1", "2")
         assert ("Y=48bit" in eng.describe()) == y48, eng.describe()
     want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
     worst = 0.0
