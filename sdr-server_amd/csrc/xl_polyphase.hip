@@ -407,7 +407,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int g2 = 0; g2 < 16; g2 += 2) {
         const uint32_t sl = xlm_result_row((uint32_t)g2, h) >> 1;
         const v2f y = {(hi[g2] + lo[g2]) * cs, (hi[g2 + 1] + lo[g2 + 1]) * cs};
+#ifdef XLP_Y_TEMPORAL  // (tools/mall_calibration.sh: the same stores with the default cache policy)
+        if (sl < XLP_SEG && s0 + sl < a.nseg) Yc[(size_t)(s0 + sl) * ystride] = y;
+#else
         if (sl < XLP_SEG && s0 + sl < a.nseg) __builtin_nontemporal_store(y, &Yc[(size_t)(s0 + sl) * ystride]);
+#endif
       }
     }
     __syncthreads();  // the other buffer is staged; everybody is done with this one
