@@ -166,6 +166,12 @@ int xlating_batch_client_phase(xlating_batch *batch, int client_id, float *re, f
 
 /* Block until all enqueued work of the engine has finished. */
 int xlating_batch_sync(xlating_batch *batch);
+/* Without blocking: 1 if everything enqueued by the process calls so far has completed, 0 if not yet; -EINVAL, -EIO.
+ * xlating_batch_record_event: record `hip_event` (a hipEvent_t of the engine's device) behind the latest call's launches, on the
+ * stream(s) they were enqueued on -- what a caller needs to make another stream wait for the latest call without a per-call
+ * event (a launch that carries a completion event delays the next launch by ~8 us: a fifth of a one-block call).  0, -EINVAL, -EIO. */
+int xlating_batch_query(xlating_batch *batch);
+int xlating_batch_record_event(xlating_batch *batch, void *hip_event);
 
 /* Kernel timing with HIP events recorded on the launch stream around the FIR kernel of every block
  * (for bench.py's roofline figures).  enable: 0/1.  _read returns the number of timed launches since

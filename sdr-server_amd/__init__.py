@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = (
        "xlating_batch_process_device_group", "xlating_batch_process_device_group_ev", "xlating_batch_output_len_block", "xlating_batch_add_client", "xlating_batch_remove_client", "xlating_batch_num_clients",
        "xlating_batch_process_host", "xlating_batch_process_device", "xlating_batch_output_len", "xlating_batch_fetch",
        "xlating_batch_output_host", "xlating_batch_output_host_cs16", "xlating_batch_output_device", "xlating_batch_client_phase", "xlating_batch_sync",
-       "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_timing_polyphase", "xlating_batch_timing_stride", "xlating_batch_describe", "xlating_batch_destroy",
+       "xlating_batch_query", "xlating_batch_record_event", "xlating_batch_timing", "xlating_batch_timing_read", "xlating_batch_timing_polyphase", "xlating_batch_timing_stride", "xlating_batch_describe", "xlating_batch_destroy",
        "xlating_hip_device_info"]
     + ["xlating_sinks_create", "xlating_sinks_attach_fd", "xlating_sinks_attach_file", "xlating_sinks_write",
        "xlating_sinks_submit", "xlating_sinks_failed", "xlating_sinks_flush", "xlating_sinks_detach", "xlating_sinks_stats",

@@ -172,6 +172,15 @@ struct xlating_batch_t {
   hipEvent_t ev_chain[XL_NTAB] = {}, ev_done[XL_NTAB] = {};  // per phase table
   bool ev_done_valid[XL_NTAB] = {};
   hipStream_t ev_done_stream[XL_NTAB] = {};  // where ev_done[t] was recorded
+  // Round 4: a launch that carries a completion event keeps the queue ~8 us from starting the next launch (a fifth of a one-block
+  // call), and in the steady side-stream pattern only ONE call in `chain_calls` needs its event: a chain launch made at call k
+  // overwrites the tables last read by calls k-7 .. k-4, and call k-4 is the previous chain-launching call.  So side-stream calls
+  // record ev_done only when they launch a chain; tab_call[] / done_call let a chain launch check that the latest recorded event
+  // post-dates every reader of its tables (calls run in order: an event behind call j covers all calls <= j), and fall back to an
+  // event recorded on the spot when it does not (irregular patterns only).
+  uint64_t tab_call[XL_NTAB] = {};  // ncalls + 1 of the latest call that read table t (0: never)
+  uint64_t done_call = 0;           // ncalls + 1 of the latest call that recorded an ev_done (0: none)
+  int done_tab = 0;                 // ... and which one
   bool spec_on_side = false;  // the look-ahead table was produced on nco_stream (ev_chain must be waited for)
   double macs_all = 0.0, macs_rest = 0.0;  // complex MACs per sample of a block: all clients' direct launches / those outside `poly`
   int nco_side = -1;          // option "nco_side_stream": 1 always, 0 never (NCO role inside the launches), -1: calls of >= 2 blocks
@@ -1376,7 +1385,8 @@ static int xl_batch_plan(xlating_batch *b) {
       b->last_piped = false;
       b->reserve_r = 0;
       b->last_stream = b->own_stream;  // (everything was synchronised at the top of the plan)
-      for (int i = 0; i < XL_NTAB; ++i) b->ev_done_valid[i] = false;
+      for (int i = 0; i < XL_NTAB; ++i) b->ev_done_valid[i] = false, b->tab_call[i] = 0;
+      b->done_call = 0;
       if (want > 0u) {
         uint32_t chain_mask[8], main_mask[8];
         for (uint32_t wd = 0; wd < 8; ++wd) {
@@ -1750,14 +1760,27 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
       }
       // the tables' last readers (XL_NTAB - 1 - i calls back): one wait for the latest of them covers the earlier ones that
       // were recorded on the same stream (every wait is a queue packet of its own, ~4 us in front of the chain launch)
-      hipStream_t covered = nullptr;
-      bool any = false;
-      for (int i = (int)cc.n - 1; i >= 0; --i) {
-        const int t = tt[i];
-        if (!b->ev_done_valid[t] || (any && b->ev_done_stream[t] == covered)) continue;
-        XL_TRY(hipStreamWaitEvent(ns, b->ev_done[t], 0));
-        if (!any) covered = b->ev_done_stream[t];
-        any = true;
+      if (b->pipeline_calls) {  // (pipelined calls finish out of order across the two compute streams: every call records, every stream counts)
+        hipStream_t covered = nullptr;
+        bool any = false;
+        for (int i = (int)cc.n - 1; i >= 0; --i) {
+          const int t = tt[i];
+          if (!b->ev_done_valid[t] || (any && b->ev_done_stream[t] == covered)) continue;
+          XL_TRY(hipStreamWaitEvent(ns, b->ev_done[t], 0));
+          if (!any) covered = b->ev_done_stream[t];
+          any = true;
+        }
+      } else {
+        uint64_t need = 0;  // the latest call that read one of these tables
+        for (int i = 0; i < (int)cc.n; ++i) need = std::max(need, b->tab_call[tt[i]]);
+        if (need != 0) {
+          if (b->done_call >= need) {
+            XL_TRY(hipStreamWaitEvent(ns, b->ev_done[b->done_tab], 0));
+          } else if (!tab_from_s) {  // (tab_from_s: the side stream was just ordered behind everything on `s`)
+            XL_TRY(hipEventRecord(b->dep_ev, s));  // all earlier calls' launches precede this point of `s`
+            XL_TRY(hipStreamWaitEvent(ns, b->dep_ev, 0));
+          }
+        }
       }
       XL_TRY(xl_launch_nco_chain(b->d_nco, (uint32_t)b->nco.size(), b->d_phase[pcur], cc, xl_grid_next(pos),
                                  b->d_chain_stats, ns, b->ev_chain[xl_nx(tab)]));
@@ -1780,6 +1803,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     }
     bool rolled = false;
     bool done_attached = false;  // ev_done[tab] rides on the call's last launch
+    // does this call record ev_done[tab]?  Side-stream calls: only the ones that launch a chain (see tab_call); pipelined and
+    // non-side calls after a side stream was used: always, as before
+    const bool want_done = (side || b->last_nco != nullptr) && (!side || launched_n > 0 || b->pipeline_calls != 0);
+    bool record_attached = false;  // the caller's record_ev rides on the last launch instead (no ev_done wanted there)
     Launch *const Ls = use_poly ? b->launches_rest : b->launches;
     if (maxK > 0) {
       if (f0) XL_TRY(hipEventRecord(f0, s));
@@ -1950,8 +1977,9 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
               chain_wait = false;
               b->waited_valid = true, b->waited_ev = chain_ev, b->waited_stream = s;
             }
-            XL_TRY(xlp_launch_fused(pa, s, last_launch ? b->ev_done[tab] : nullptr));
-            done_attached = last_launch;
+            XL_TRY(xlp_launch_fused(pa, s, last_launch ? (want_done ? b->ev_done[tab] : record_ev) : nullptr));
+            done_attached = last_launch && want_done;
+            record_attached = last_launch && !want_done && record_ev != nullptr;
             if (pe[2]) XL_TRY(hipEventRecord(pe[2], s));
             if (pe[3]) XL_TRY(hipEventRecord(pe[3], s));
             continue;
@@ -2023,8 +2051,9 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
                                 && !trace_inv
 #endif
                 ;
-            XL_TRY(xlp_launch_inverse(pa, s, attach ? b->ev_done[tab] : nullptr));
-            done_attached = attach;
+            XL_TRY(xlp_launch_inverse(pa, s, attach ? (want_done ? b->ev_done[tab] : record_ev) : nullptr));
+            done_attached = attach && want_done;
+            record_attached = attach && !want_done && record_ev != nullptr;
           }
 #ifdef XL_TUNING
           if (trace_inv) {
@@ -2043,15 +2072,18 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     // -- and a LATER side-stream chain launch may find this slot in its ring even when this call ran no side stream
     // (alternating modes, alternating caller streams, nco_calls_per_launch < 4): once a side stream has been used the
     // event is recorded for every call.  Engines that never use the side stream never pay for it.
-    if (side || b->last_nco != nullptr) {
+    if (side || b->last_nco != nullptr) b->tab_call[tab] = b->ncalls + 1;
+    if (want_done) {
       if (!done_attached) XL_TRY(hipEventRecord(b->ev_done[tab], s));
       b->ev_done_valid[tab] = true;
       b->ev_done_stream[tab] = s;
+      b->done_call = b->ncalls + 1;
+      b->done_tab = tab;
     } else {
       b->ev_done_valid[tab] = false;
     }
 
-    if (record_ev) XL_TRY(hipEventRecord(record_ev, s));
+    if (record_ev && !record_attached) XL_TRY(hipEventRecord(record_ev, s));
     // ---- everything is enqueued: commit the host-side state of the call
     b->poisoned = false;
     for (Client &c : b->clients) {
@@ -2196,6 +2228,32 @@ extern "C" int xlating_batch_sync(xlating_batch *b) {
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
   if (b->last_piped && b->piped_other && hipStreamSynchronize(b->piped_other) != hipSuccess) return -EIO;  // (the call before the latest)
   return hipStreamSynchronize(b->last_stream) == hipSuccess ? 0 : -EIO;
+}
+
+extern "C" int xlating_batch_query(xlating_batch *b) {
+  if (b == nullptr) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  hipStream_t ss[2] = {b->last_stream, (b->last_piped && b->piped_other) ? b->piped_other : nullptr};
+  for (hipStream_t st : ss) {
+    if (st == nullptr) continue;
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipErrorNotReady) {
+      (void)hipGetLastError();  // (not an error: clear the sticky code)
+      return 0;
+    }
+    if (e != hipSuccess) return -EIO;
+  }
+  return 1;
+}
+
+extern "C" int xlating_batch_record_event(xlating_batch *b, void *hip_event) {
+  if (b == nullptr || hip_event == nullptr) return -EINVAL;
+  if (hipSetDevice(b->device) != hipSuccess) return -EIO;
+  hipEvent_t ev = reinterpret_cast<hipEvent_t>(hip_event);
+  if (b->last_piped && b->piped_other) {  // (two compute streams hold work: the event goes behind both)
+    if (hipEventRecord(b->dep_ev2, b->piped_other) != hipSuccess || hipStreamWaitEvent(b->last_stream, b->dep_ev2, 0) != hipSuccess) return -EIO;
+  }
+  return hipEventRecord(ev, b->last_stream) == hipSuccess ? 0 : -EIO;
 }
 
 extern "C" int xlating_batch_fetch(xlating_batch *b) {

@@ -212,9 +212,10 @@ extern "C" int xlating_multi_feed(xlating_multi *m, const void *d_src, size_t in
   const int i = (int)(m->feeds & 1);
   const int k4 = (int)(m->feeds % XL_MRING), k2 = (int)((m->feeds + XL_MRING - 2) % XL_MRING);  // this feed's slot, feed - 2's
   if (!m->bcast) {  // one GPU, no communicator: the engine reads d_src in place; the source is free behind its launches
+    // (no per-feed event: a launch that carries one delays the next launch by ~8 us, a fifth of a one-block feed; the three
+    // "is the source free" calls below ask the engine's stream instead, or record src_done when somebody wants to wait on it)
     Gpu &g = m->gpus[0];
-    int rc = xlating_batch_process_device_group_ev(g.engine, d_src, input_len, nblocks, mode, XL_STREAM_ENGINE, nullptr,
-                                                   g.src_done);
+    int rc = xlating_batch_process_device_group_ev(g.engine, d_src, input_len, nblocks, mode, XL_STREAM_ENGINE, nullptr, nullptr);
     if (rc != 0) return rc;
     g.src_valid = true;
     m->feeds++;
@@ -270,6 +271,7 @@ extern "C" int xlating_multi_feed_done(xlating_multi *m) {
   Gpu *root = xl_multi_find(m, 0);
   if (root == nullptr || !root->src_valid) return 0;
   if (hipSetDevice(root->device) != hipSuccess) return -EIO;
+  if (!m->bcast) return xlating_batch_sync(root->engine) == 0 ? 0 : -EIO;  // (in place: the readers are the engine's launches)
   return hipEventSynchronize(root->src_done) == hipSuccess ? 0 : -EIO;
 }
 
@@ -278,6 +280,10 @@ extern "C" int xlating_multi_feed_query(xlating_multi *m) {
   Gpu *root = xl_multi_find(m, 0);
   if (root == nullptr || !root->src_valid) return 1;
   if (hipSetDevice(root->device) != hipSuccess) return -EIO;
+  if (!m->bcast) {
+    const int q = xlating_batch_query(root->engine);
+    return q < 0 ? -EIO : q;
+  }
   const hipError_t e = hipEventQuery(root->src_done);
   if (e == hipSuccess) return 1;
   if (e == hipErrorNotReady) {
@@ -292,6 +298,7 @@ extern "C" int xlating_multi_feed_wait_on_stream(xlating_multi *m, void *hip_str
   Gpu *root = xl_multi_find(m, 0);
   if (root == nullptr || !root->src_valid) return 0;
   if (hipSetDevice(root->device) != hipSuccess) return -EIO;
+  if (!m->bcast && xlating_batch_record_event(root->engine, root->src_done) != 0) return -EIO;  // (behind the latest feed's launches, now)
   return hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), root->src_done, 0) == hipSuccess ? 0 : -EIO;
 }
 
