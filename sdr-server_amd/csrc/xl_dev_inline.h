@@ -188,11 +188,14 @@ XL_DEV v2f xl_nco_renorm(const v2f p) {
   return (v2f){p.x / mag, p.y / mag};
 }
 
+// PACKED: the three packed instructions per step -- ONLY for a wave that owns its SIMD (xl_nco_table_kernel claims all 512 registers,
+// like the side-stream chain kernel); false: the six scalar instructions of xl_nco_role_step (every role inside a launch).
 // The work of one lane = one client: advance the recurrence over the outputs [kb, ke) of a call of bnd.K outputs in
 // bnd.G blocks, tabulating every XL_PH_STRIDE-th phase (entry (out_off + m) / XL_PH_STRIDE = phase of output m, m on
 // the call's output index) and renormalising at every block end inside the range (xlating.c:73; the table entry of a
 // block's first output is the renormalised phase).  The running phase comes from state_src[slot] and goes to
 // state_dst[slot]: a slice that ends the call (ke == bnd.K) leaves the committed post-call phase there.
+template <bool PACKED>
 XL_DEV void xl_nco_client_chain(const XlNcoClient k, const XlBnd bnd, const uint32_t kb, const uint32_t ke,
                                 const float2 *state_src, float2 *state_dst, float2 *__restrict__ tab,
                                 unsigned long long *stamp = nullptr) {
@@ -214,25 +217,25 @@ XL_DEV void xl_nco_client_chain(const XlNcoClient k, const XlBnd bnd, const uint
     const uint32_t me = nb < ke ? nb : ke;
     for (; m < me && (m & (2u * XL_PH_STRIDE - 1u)) != 0u; ++m) {  // head: up to the next pair boundary
       if (tab != nullptr && (m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
-      p = xl_nco_role_step(p, inc, bnd.flags);
+      p = PACKED ? xl_nco_next_any(p, inc, bnd.flags) : xl_nco_role_step(p, inc, bnd.flags);
     }
     // 2 * XL_PH_STRIDE steps and ONE store (two entries) per trip (plain step; FMA-step calls take the loops around it)
     for (; !(bnd.flags & XL_POS_FMA_STEP) && m + 2u * XL_PH_STRIDE <= me; m += 2u * XL_PH_STRIDE) {
       const v2f q0 = p;
       for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) p = xl_nco_role_step(p, inc, 0u);
+        for (int j = 0; j < 16; ++j) p = PACKED ? xl_nco_next(p, inc) : xl_nco_role_step(p, inc, 0u);
       }
       const v2f q1 = p;
       for (uint32_t i = 0; i < XL_PH_STRIDE; i += 16u) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) p = xl_nco_role_step(p, inc, 0u);
+        for (int j = 0; j < 16; ++j) p = PACKED ? xl_nco_next(p, inc) : xl_nco_role_step(p, inc, 0u);
       }
       if (tab != nullptr) o4[m >> (XL_PH_SHIFT + 1u)] = (v4f){q0.x, q0.y, q1.x, q1.y};
     }
     for (; m < me; ++m) {
       if (tab != nullptr && (m & (XL_PH_STRIDE - 1u)) == 0u) o[m >> XL_PH_SHIFT] = p;
-      p = xl_nco_role_step(p, inc, bnd.flags);
+      p = PACKED ? xl_nco_next_any(p, inc, bnd.flags) : xl_nco_role_step(p, inc, bnd.flags);
     }
     if (me == nb) p = xl_nco_renorm(p);  // a block of the call ends here
   }

@@ -216,7 +216,7 @@ XL_DEV void xlp_nco_role(const XlpArgs &a) {
   const uint32_t kb = a.nco_k0 == 0u ? 0u : (uint32_t)(((uint64_t)K * a.nco_k0) >> 16) & ~(2u * XL_PH_STRIDE - 1u);
   const uint32_t ke = a.nco_k1 >= 65536u ? K : (uint32_t)(((uint64_t)K * a.nco_k1) >> 16) & ~(2u * XL_PH_STRIDE - 1u);
   unsigned long long st[2] = {0ull, 0ull};
-  xl_nco_client_chain(k, bnd, kb, ke, a.nco_state_src, a.nco_state_dst, a.nco_tab, a.trace ? st : nullptr);
+  xl_nco_client_chain<false>(k, bnd, kb, ke, a.nco_state_src, a.nco_state_dst, a.nco_tab, a.trace ? st : nullptr);
   if (a.trace && threadIdx.x == 0) {
     unsigned long long *t = a.trace + 8 + 8 * blockIdx.x;
     t[0] = t0;
