@@ -75,6 +75,10 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                           polyphase calls of up to 2048 clients -- of any size with "mix_kernel" 2), 0 never, 1
  *                           always: the NCO phase recurrence of the following calls runs as a kernel of its own on a side
  *                           stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE)
+ *   "expected_clients"      0 (default) .. 8192: the CUs of that side kernel are reserved for this many clients from the
+ *                           first plan on (64 clients per CU), not for the clients joined so far -- the reservation then never
+ *                           grows while clients join up to that number (growing it re-creates two streams: ~25 ms, once per
+ *                           512 clients); until then the launches run on correspondingly fewer CUs
  *   "nco_calls_per_launch"  1..4 (default 4): calls of the same shape one such kernel tabulates ahead
  *   "inverse_kernel"        128-point polyphase classes: the inverse launch's transform -- staged in LDS on padded rows (0),
  *                           on dense XOR-swizzled rows (3, default; 4: built for five workgroups per CU), or in the registers

@@ -169,6 +169,7 @@ struct xlating_batch_t {
   unsigned long long *d_chain_stats = nullptr;  // tuning (XL_EXP_CHAIN_STATS): per chain workgroup cycles / ticks of the latest launch
   hipStream_t nco_masked = nullptr;  // the side stream that goes with cs_masked; nco_stream (unmasked) serves callers' own streams
   uint32_t reserve_r = 0;
+  uint32_t expected_clients = 0;  // option "expected_clients": the CUs are reserved for this many clients from the first plan on
   hipEvent_t ev_chain[XL_NTAB] = {}, ev_done[XL_NTAB] = {};  // per phase table
   bool ev_done_valid[XL_NTAB] = {};
   hipStream_t ev_done_stream[XL_NTAB] = {};  // where ev_done[t] was recorded
@@ -460,6 +461,9 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     if (value < 0 || value > 1) return -EINVAL;
     b->y_format = (uint32_t)value;
     return 0;  // (a launch parameter: Y is rewritten by every call)
+  } else if (n == "expected_clients") {
+    if (value < 0 || value > 8192) return -EINVAL;
+    b->expected_clients = (uint32_t)value;
   } else if (n == "pipeline_calls") {
     if (value < 0 || value > 1) return -EINVAL;
     b->pipeline_calls = (int)value;
@@ -1371,8 +1375,11 @@ static int xl_batch_plan(xlating_batch *b) {
     bool plan_fused = !b->poly.empty();
     for (const PolyClass &pc : b->poly) plan_fused = plan_fused && pc.mix_kind == 2u;
     const bool one_block_side = !b->poly.empty() && (plan_fused || b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX);
-    uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? (nwg + 7u) / 8u : 0u;
-    if (want > 16u) want = 0u;  // (more than half the chip for the chain: such engines are bound by the filtering anyway)
+    // (a server that knows how many clients it admits says so -- option "expected_clients" --, and the reservation is made for
+    // that many at once: the 25 ms of a stream re-creation then never fall on a call between two joins)
+    const uint32_t nwg_res = std::max(nwg, (b->expected_clients + 63u) / 64u);
+    uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? (nwg_res + 7u) / 8u : 0u;
+    if (want > 16u) want = (nwg + 7u) / 8u > 16u ? 0u : 16u;  // (more than half the chip for the chain: such engines are bound by the filtering anyway)
     if (getenv("XL_EXP_NOMASK")) want = 0u;
     // (creating a masked stream pair takes ~25 ms: grow at once, shrink only when two CUs per XCD too many are held, so that
     // a client count hovering around a multiple of 512 does not recreate the streams at every join and leave)
@@ -2162,6 +2169,7 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
       }
     if (!any) d += " none";
   }
+  if (b->reserve_r) d += " | side kernel: " + std::to_string(8u * b->reserve_r) + " CUs reserved";
   if (pending) d += " | re-plan pending (client set or options changed: the next process call plans again)";
   const size_t len = std::min(d.size(), n - 1);
   memcpy(buf, d.data(), len);

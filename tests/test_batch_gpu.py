@@ -1491,6 +1491,39 @@ def test_config5_cf32_10msps_all_clients(nclients):
         eng.close()
 
 
+def test_expected_clients_reserves_the_side_kernels_cus_once():
+    """Option "expected_clients": the CUs of the side-stream recurrence kernel are reserved for the announced population at the
+    first plan, so joins up to it never re-create the CU-masked streams (25 ms each time the count crosses a multiple of 512
+    otherwise).  Same results either way (oracle, clients on both sides of the crossing)."""
+    t48 = lpf(FS, 24000, 9600)
+    nb = 131072
+    reserved = {}
+    for expect in (0, 1024):
+        eng = xl.BatchEngine(FS, "cu8", nb, group_blocks=2)
+        if expect:
+            eng.set_option("expected_clients", expect)
+        fcs = [-984000 + 1920 * c for c in range(700)]
+        cids = [eng.add_client(42, t48, fc) for fc in fcs[:500]]
+        watch = {cids[i]: Oracle(42, t48, fcs[i], FS, nb) for i in (0, 257, 499)}
+        x0, x1 = siggen.xs_u8(4100, 2 * nb), siggen.xs_u8(4101, 2 * nb)
+        _check_group(eng, watch, "cu8", x0, 2, "optimized")
+        d0 = eng.describe()
+        cids += [eng.add_client(42, t48, fc) for fc in fcs[500:]]  # 500 -> 700 clients: past 512
+        watch[cids[650]] = Oracle(42, t48, fcs[650], FS, nb)
+        _check_group(eng, watch, "cu8", x1, 2, "optimized")
+        d1 = eng.describe()
+        reserved[expect] = (d0.split("side kernel: ")[1].split()[0], d1.split("side kernel: ")[1].split()[0])
+        for o in watch.values():
+            o.close()
+        eng.close()
+    assert reserved[0] == ("8", "16"), reserved     # by the clients joined so far: one CU per XCD per 512 clients
+    assert reserved[1024] == ("16", "16"), reserved  # announced: reserved once
+    eng = xl.BatchEngine(FS, "cu8", nb)
+    with pytest.raises(Exception):
+        eng.set_option("expected_clients", -1)
+    eng.close()
+
+
 def test_churn_one_join_and_one_leave_per_block():
     """Incremental re-planning under churn: 1024 x 48 kHz clients, and for 200 blocks one client joins AND one leaves before
     every block (dsp_worker_start / dsp_worker_destroy while the stream runs, src/dsp_worker.c:90-108, 172-197).  A joiner

@@ -5,7 +5,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 C=$ROOT/sdr-server_amd/csrc; B=$ROOT/sdr-server_amd/build; V=$B/variants; mkdir -p $V
-SRC=${3:-xl_polyphase.hip}; STEM=${SRC%.hip}
+SRC=${3:-xl_polyphase.hip}; STEM=${SRC%.*}   # (.hip or .cpp: e.g. xl_batch.cpp with -DXL_TUNING for the launch traces)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wno-unused-function -fhip-fp32-correctly-rounded-divide-sqrt"
 hipcc $FLAGS $2 -c $C/$SRC -o $V/$1_$STEM.o
 OBJS=""

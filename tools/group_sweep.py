@@ -15,7 +15,7 @@ import torch  # noqa: E402
 import siggen  # noqa: E402
 import sdr_server_amd as xl  # noqa: E402
 
-FS, D, BLOCK = 2016000, 42, 262144
+BLOCK = 262144
 
 
 def main():
@@ -25,18 +25,25 @@ def main():
     ap.add_argument("--modes", default="optimized")
     ap.add_argument("--m", default="0")
     ap.add_argument("--rate", type=int, default=5)
+    ap.add_argument("--decimations", default="42", help="client decimations to time (input rate = 48 kHz x decimation), e.g. 42,50,64")
     ap.add_argument("--blocks", type=int, default=320, help="blocks in the timed region")
     ap.add_argument("--poly3", action="store_true", help="also time the three polyphase launches separately")
     ap.add_argument("--slices", default="")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable), e.g. mix_kernel=2")
     ap.add_argument("--engine-stream", type=int, default=1, help="1: XL_STREAM_ENGINE (the engine's own, CU-masked compute stream); 0: torch's stream")
     args = ap.parse_args()
-    code, taps = xl.create_low_pass_filter(1.0, FS, 24000, 48000 // args.rate)
     gmax = max(int(g) for g in args.groups.split(","))
     data = torch.from_numpy(siggen.xs_u8(99, gmax * BLOCK)).cuda()
     st = torch.cuda.current_stream()
     sarg = "engine" if args.engine_stream else st.cuda_stream
     print(f"{'mode':10s} {'M':>4s} {'clients':>7s} {'G':>2s} {'us/block':>9s} {'kern us/blk':>11s} {'Msps':>10s}   plan / launches us per block")
+    for dec in [int(v) for v in args.decimations.split(",")]:
+        sweep(args, dec, data, sarg)
+
+
+def sweep(args, D, data, sarg):
+    FS = 48000 * D
+    code, taps = xl.create_low_pass_filter(1.0, FS, 24000, 48000 // args.rate)
     for mode in args.modes.split(","):
         for m in [int(v) for v in args.m.split(",")]:
             for n in [int(c) for c in args.clients.split(",")]:
