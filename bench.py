@@ -457,8 +457,8 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
             kernels_ms = {"xlp_forward_h_kernel": round(ms3[0] / n3, 4), "xlp_fused_kernel": round(ms3[1] / n3, 4)}
         elif n3 > 0:
             mix_name = "xlp_mix_mfma_kernel" if "mix=mfma" in plan else "xlp_mix_kernel"
-            kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), mix_name: round(ms3[1] / n3, 4),
-                          "xlp_inverse_kernel": round(ms3[2] / n3, 4)}
+            inv_name = "xlp_inverse8_kernel" if "inv=lanes8" in plan else "xlp_inverse_kernel"
+            kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), mix_name: round(ms3[1] / n3, 4), inv_name: round(ms3[2] / n3, 4)}
     feed_name = host.name
     host.close()
     return {"feed": feed_name, "ntaps": int(taps.size), "seconds": dt, "repeat_seconds": secs, "call_ms_avg": fir_ms / max(nt, 1),
@@ -916,6 +916,7 @@ def main():
         flops = {"xlp_forward_kernel": 5.0 * M * lg * D * nseg, "xlp_mix_kernel": 8.0 * nloc * nseg * M * D,
                  "xlp_mix_mfma_kernel": 8.0 * nloc * nseg * M * D,
                  "xlp_inverse_kernel": nloc * nseg * (5.0 * M * lg + 8.0 * (M - A + 1))}
+        flops["xlp_inverse8_kernel"] = flops["xlp_inverse_kernel"]
         # matrix-core mix: half-precision flops the launch EXECUTES = 3 products x (32 rows x 32 columns x 16 k x 2) per k-block of
         # 8 branches, per (bin, 32 columns, pass of 14 segments in 32 rows)
         mfma_flops = 3.0 * 32 * 32 * 16 * 2 * -(-D // 8) * M * -(-nloc // 32) * -(-nseg // 14)
@@ -924,6 +925,8 @@ def main():
                    "xlp_mix_mfma_kernel": "hbm (writes the mixed spectra once, reads the operand-form branch spectra once); the products run on the "
                                           "matrix cores as two-term half-precision splits (3 v_mfma_f32_32x32x16_f16 per 8 branches)",
                    "xlp_inverse_kernel": "hbm (reads the mixed spectra, writes the outputs)"}
+        binding["xlp_inverse8_kernel"] = ("hbm access pattern: with transform and phases compiled out the launch is no faster (profiles/r04_inverse8.txt); "
+                                          "reads 4.7 TB/s, the output pieces of 928 bytes per (segment, client) 3.0-4.3 TB/s, and the two do not overlap")
         pk = {}
         trace_ms = {k: v.get("ms_per_dispatch_kernel_trace") for k, v in (pmc["per_kernel"] if pmc else {}).items()}
         for kname, ms_ev in (m["kernels_ms"] or {}).items():
@@ -950,7 +953,7 @@ def main():
                                          "concurrent with the three launches; bounds the engine below ~1500 clients",
                                          "note": "bytes per CALL, ms per LAUNCH (one launch tabulates the phase tables of four calls); in the timed region a "
                                                  "call cannot be shorter than a quarter of a chain launch, so that launch is at most 4 x call_period_ms"}
-        roofline["kernel"] = ("xlp_forward_kernel + " + ("xlp_mix_mfma_kernel" if "mix=mfma" in m["plan"] else "xlp_mix_kernel") + " + xlp_inverse_kernel: the three launches of one call on the polyphase "
+        roofline["kernel"] = ("xlp_forward_kernel + " + ("xlp_mix_mfma_kernel" if "mix=mfma" in m["plan"] else "xlp_mix_kernel") + " + " + next((k for k in (m["kernels_ms"] or {}) if k.startswith("xlp_inverse")), "xlp_inverse_kernel") + ": the three launches of one call on the polyphase "
                               "overlap-save path (the next call's NCO phase recurrence runs beside them on a side stream)")
         roofline["per_kernel"] = pk
         roofline["per_kernel_note"] = ("ms: the kernel's own duration from a rocprofv3 --kernel-trace pass of this run over `bench.py --replay-calls` -- a "

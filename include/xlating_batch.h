@@ -80,9 +80,11 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                           grows while clients join up to that number (growing it re-creates two streams: ~25 ms, once per
  *                           512 clients); until then the launches run on correspondingly fewer CUs
  *   "nco_calls_per_launch"  1..4 (default 4): calls of the same shape one such kernel tabulates ahead
- *   "inverse_kernel"        128-point polyphase classes: the inverse launch's transform -- staged in LDS on padded rows (0),
- *                           on dense XOR-swizzled rows (3, default; 4: built for five workgroups per CU), or in the registers
- *                           of a lane pair (1) / lane quad (2) per client column with one LDS pass for the stores
+ *   "inverse_kernel"        128-point polyphase classes: the inverse launch's transform -- in the registers of EIGHT lanes per
+ *                           client column as 16 x 8 points with one exchange through LDS (5, default: xl_inv8.hip), staged in
+ *                           LDS on padded rows (0) or on dense XOR-swizzled rows (3, round 3's default, still what 48-bit Y takes;
+ *                           4: built for five workgroups per CU), or in the registers of a lane pair (1) / lane quad (2) per
+ *                           client column with one LDS pass for the stores
  *   "mix_kernel"            polyphase classes: the mix launch (spectra x branch spectra, summed over the branches) on the matrix
  *                           cores (1, default: every float32 operand as two halves, three v_mfma_f32_32x32x16_f16 per 8
  *                           branches, FP32 accumulation; classes of an integer input format with decimation <= 64) or as

@@ -219,7 +219,7 @@ struct xlating_batch_t {
   bool poly_min_set = false;        // "polyphase_min_clients" was given: it holds for every class (else 32 where the mix runs on the matrix cores)
   uint32_t poly_min_clients = 128;  // measured at 505 taps, D = 42: x1.10 at 128 clients, x0.96 at 64 (profiles/r01_polyphase_vs_direct.txt)
   uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
-  uint32_t inv_reg = 3;       // option "inverse_kernel", M = 128 classes: 0 = LDS transform on padded rows (round 2), 3 = on dense rows with an XOR
+  uint32_t inv_reg = 5;       // option "inverse_kernel", M = 128 classes: 0 = LDS transform on padded rows (round 2), 3 = on dense rows with an XOR
                               // swizzle (default: LDS bank-conflict cycles 0.44 -> 0.24 of the LDS cycles, -1 % time in two A/B sessions),
                               // 4 = the same at five workgroups per CU (no gain), 1 / 2 = transform in registers of a lane pair / quad
                               // (fewer instructions and LDS cycles, 25-30 % slower: profiles/r03_inverse_reg_vs_lds.txt)
@@ -452,7 +452,7 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     if (value != 0 && value != 128 && value != 256) return -EINVAL;
     b->poly_m = (uint32_t)value;
   } else if (n == "inverse_kernel") {
-    if (value < 0 || value > 4) return -EINVAL;
+    if (value < 0 || value > 5) return -EINVAL;
     b->inv_reg = (uint32_t)value;
   } else if (n == "mix_kernel") {
     if (value < 0 || value > 2) return -EINVAL;
@@ -1932,6 +1932,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           pa.nkb = pc.nkb;
           pa.mix_pp = b->mix_pp;
           pa.y6 = (b->y_format == 1u && pc.mix_kind == 1u && !(pc.M == 128u && (b->inv_reg == 1u || b->inv_reg == 2u))) ? 1u : 0u;
+          if (b->inv_reg == 5u && (pc.M != 128u || pa.y6)) pa.inv_reg = 3u;  // (the 8-lane kernel reads float32 pairs of 128-point segments)
           pa.Rh = pc.d_Rh;
           pa.cscale = pc.d_cscale;
           pa.W = b->d_W;
@@ -2157,7 +2158,9 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
          std::to_string(pc.members.size()) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
     if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
     d += pc.mix_kind == 2u ? " mix=fused" : (pc.mix_kind == 1u ? " mix=mfma" : " mix=fma");
-    if (b->y_format == 1u && pc.mix_kind == 1u && !(pc.M == 128u && (b->inv_reg == 1u || b->inv_reg == 2u))) d += " Y=48bit";
+    const bool y48 = b->y_format == 1u && pc.mix_kind == 1u && !(pc.M == 128u && (b->inv_reg == 1u || b->inv_reg == 2u));
+    if (y48) d += " Y=48bit";
+    if (pc.M == 128u && pc.mix_kind != 2u && b->inv_reg == 5u && !y48) d += " inv=lanes8";
   }
   if (!b->poly.empty()) {
     d += " | optimized-mode direct:";

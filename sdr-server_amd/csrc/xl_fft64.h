@@ -187,5 +187,38 @@ XL_FFT_FN void xl_fft128_combine_quad(V (&u)[32], const float sA, const float sB
   if constexpr (K + 1 < 32) xl_fft128_combine_quad<V, Ex, K + 1>(u, sA, sB, ex);
 }
 
+// =====================================================================================================================
+// Small in-register inverse transforms for the 16 x 8 split of xl_inv8_layout.h (one lane, all indices compile-time).
+//   xl_fft16_inverse: x[t] = sum_{k<16} v[k] e^{+2 pi j k t / 16}: radix-4 (span 4, twiddles W_16^{i q} = W_128^{8 i q}),
+//                     radix-4 (span 1); output t in slot 4 (t & 3) + (t >> 2)
+//   xl_fft8_inverse:  x[g] = sum_{k<8} v[k] e^{+2 pi j k g / 8}:   radix-4 (span 2, twiddles W_8^{i q} = W_128^{16 i q}),
+//                     radix-2 on the slot pairs; output g = q + 4 r in slot 2 q + r
+template <class V, class Ops, int NN, int L, int G, int I>
+struct XlFftNStage {
+  XL_FFT_FN void run(V (&u)[NN]) {
+    constexpr int base = G * 4 * L + I;
+    xl_fft_bfly4<V, Ops, base, base + L, base + 2 * L, base + 3 * L, (L > 1 ? I * (32 / L) : 0), NN>(u);
+    if constexpr (I + 1 < L) XlFftNStage<V, Ops, NN, L, G, I + 1>::run(u);
+    else if constexpr ((G + 1) * 4 * L < NN) XlFftNStage<V, Ops, NN, L, G + 1, 0>::run(u);
+  }
+};
+template <class V, class Ops>
+XL_FFT_FN void xl_fft16_inverse(V (&u)[16]) {
+  XlFftNStage<V, Ops, 16, 4, 0, 0>::run(u);
+  XlFftNStage<V, Ops, 16, 1, 0, 0>::run(u);
+}
+template <class V, class Ops>
+XL_FFT_FN void xl_fft8_inverse(V (&u)[8]) {
+  XlFftNStage<V, Ops, 8, 2, 0, 0>::run(u);
+#if defined(__clang__)
+#pragma unroll
+#endif
+  for (int q = 0; q < 4; ++q) {
+    const V a = u[2 * q], b = u[2 * q + 1];
+    u[2 * q] = a + b;
+    u[2 * q + 1] = a - b;
+  }
+}
+
 #endif  // XL_FFT64_H_
 

@@ -63,7 +63,8 @@ struct XlpArgs {
   uint32_t nseg_cap;   // segment capacity of the Y image
   uint32_t ncg;        // column groups of XLP_COLS client columns
   uint32_t exp;        // tuning switches (XL_TUNING builds only; 0 otherwise)
-  uint32_t inv_reg;    // M = 128: the inverse launch's transform: 0 = staged in LDS, 1 = registers of a lane pair, 2 = of a lane quad
+  uint32_t inv_reg;    // M = 128: the inverse launch's transform: 0 = staged in LDS, 1 = registers of a lane pair, 2 = of a lane quad,
+                       // 3 / 4 = staged in LDS on swizzled rows, 5 = registers of eight lanes per column (xl_inv8.hip)
   uint32_t mix_kind;   // the mix launch: 0 = packed FP32 FMAs (xlp_mix_kernel), 1 = matrix cores on two-term half splits (xlp_mix_mfma_kernel),
                        // 2 = mix + inverse as ONE launch with the mixed spectra on chip (xl_fused.hip: no Y image, X and Rh in that launch's operand forms)
   uint32_t nkb;        // mix_kind 1: k-blocks of 8 branches = ceil(D / 8), <= XLP_NKB_MAX; mix_kind 2: k-blocks of 16 branches, <= 4
@@ -119,5 +120,7 @@ hipError_t xlp_launch_fused(const XlpArgs &a, hipStream_t s, hipEvent_t done);
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);
+// (xl_inv8.hip: the kernel behind inv_reg 5; called by xlp_launch_inverse with the checked arguments and the launch's grid)
+void xlp_inverse8_launch(const XlpArgs &a, const dim3 grid, hipStream_t s, hipEvent_t done);
 
 #endif  // XL_POLYPHASE_H_

@@ -1041,11 +1041,17 @@ hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done)
   // M = 128: 0 = transform staged in LDS (workgroup = one 32-column tile), 1 = registers, lane pair per column (workgroup
   // = (segment, column group): four tiles), 2 = registers, lane quad per column (workgroup = two tiles)
   // 3 = staged in LDS like 0, dense rows with an XOR swizzle instead of the pad; 4 = the same built for five workgroups per CU
+  // 5 = eight lanes per column, transforms of 16 and 8 points in registers (xl_inv8.hip)
   const uint32_t kind = a0.M == 128u ? a0.inv_reg : 0u;
+  if (kind == 5u && a0.y6) return hipErrorInvalidValue;
   if (a0.y6 && (kind == 1u || kind == 2u || a0.cscale == nullptr)) return hipErrorInvalidValue;  // (the register-transform kernels read float32 pairs)
   const uint32_t work = a0.nseg * a0.ncg * (kind == 1u ? 1u : (kind == 2u ? 2u : (a0.M == 256u ? 8u : 4u)));
   const XlpArgs a = xlp_checked_skip(a0, work);
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
+  if (kind == 5u) {
+    xlp_inverse8_launch(a, grid, s, done);
+    return hipGetLastError();
+  }
   void (*kern)(const XlpArgs) = kind == 1u   ? xlp_inverse_reg_kernel
                                 : kind == 2u ? xlp_inverse_quad_kernel
                                 : kind == 3u ? xlp_inverse_kernel<128, XlpPosSwz>

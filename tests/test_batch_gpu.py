@@ -294,12 +294,15 @@ def test_1000_clients_split_group_riders():
 # The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
 # the forced-path tests run with both.
 @pytest.fixture(params=[(128, 0, 1, 0), (128, 1, 1, 0), (128, 2, 1, 0), (128, 3, 1, 0), (256, 0, 1, 0), (128, 3, 0, 0), (256, 0, 0, 0), (128, 3, 2, 0),
-                        (128, 3, 1, 1), (256, 0, 1, 1)],
+                        (128, 3, 1, 1), (256, 0, 1, 1), (128, 5, 1, 0), (128, 5, 0, 0), (128, 5, 1, 1)],
                 ids=["M128", "M128-register-inverse", "M128-quad-register-inverse", "M128-swizzled-inverse", "M256",
-                     "M128-fma-mix", "M256-fma-mix", "M128-fused", "M128-swizzled-inverse-48bit-Y", "M256-48bit-Y"])
+                     "M128-fma-mix", "M256-fma-mix", "M128-fused", "M128-swizzled-inverse-48bit-Y", "M256-48bit-Y",
+                     "M128-8-lane-inverse", "M128-8-lane-inverse-fma-mix", "M128-8-lane-inverse-asked-with-48bit-Y"])
 def poly_m(request, monkeypatch):
     """Transform length of the forced polyphase plan; at M = 128 also with the inverse launch's transform in registers
-    (option "inverse_kernel" = 1: xlp_inverse_reg_kernel, a lane pair per column; 2: xlp_inverse_quad_kernel, a lane quad);
+    (option "inverse_kernel" = 1: xlp_inverse_reg_kernel, a lane pair per column; 2: xlp_inverse_quad_kernel, a lane quad; 5:
+    xlp_inverse8_kernel, eight lanes per column with 16- and 8-point transforms in registers -- with 48-bit Y the engine falls back
+    to the swizzled LDS transform);
     the mix launch on the matrix cores (option "mix_kernel" = 1, the default where the class allows it: integer input, D <= 64)
     or as packed FP32 FMAs (0), or mix + inverse as ONE launch with the mixed spectra on chip (2: xl_fused.hip); the mixed spectra
     between the matrix-core mix and an LDS-staged inverse launch as float32 pairs (option "y_format" = 0, the default) or as
