@@ -70,7 +70,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // of the segment, from the one table entry requested here (the table holds every XL_PH_STRIDE-th phase).
   static_assert(XL_PH_STRIDE == 16u, "one table entry per lane: 8 entries per column and segment");
   const uint32_t c8 = xli8_col(j), u = xli8_u(j);
+#ifdef XLI8_EXP_NOMETA  // experiment: no column record, no phase-table entry (synthetic rows of 199936 bytes)
+  XlpCol ce;
+  ce.out_off = (cg * XLP_COLS + sub * CW + 8u * w + c8) * 24992u, ce.delta = 0u, ce.incr = make_float2(1.0f, 0.0f);
+#else
   const XlpCol ce = a.cols[cg * XLP_COLS + sub * CW + 8u * w + c8];
+#endif
   const uint32_t N = a.pos.S * a.pos.G;
   const uint32_t Ka = N / a.D, Nr = N - Ka * a.D;  // a column with j0 < Nr owns Ka + 1 outputs, else Ka
   XlBnd ebnd;
@@ -81,7 +86,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const uint32_t ibeg = q0 < esh ? 1u : 0u;  // (shared point 0 of a column with shift 1 is nobody's output)
   const uint32_t m0 = q0 + ibeg - esh;       // the column's output index of the first phase to expand
   const bool eok = ce.out_off != 0xFFFFFFFFu && u * XL_PH_STRIDE < a.V && m0 < ebnd.K;
+#ifdef XLI8_EXP_NOMETA
+  const v2f pe = {1.0f, eok ? 0.0f : 1.0f};
+#else
   const v2f pe = reinterpret_cast<const v2f *>(a.phtab)[eok ? (ce.out_off >> XL_PH_SHIFT) + (m0 >> XL_PH_SHIFT) : 0u];
+#endif
   __syncthreads();  // (the table; the tile loads are still travelling)
   unsigned char *const reg = region[w];
 #ifdef XLI8_EXP_COPY  // experiment (wrong results): the launch's memory traffic alone -- tile loads, output stores in the same pattern, no transform, no phases

@@ -8,6 +8,7 @@
 //   pieces<...>   workgroup = (segment, 32 columns) like the launch; per column a piece of PIECE bytes at row + seg * PIECE + shift;
 //                 LPC lanes x BPL bytes per store instruction and column (8 x 8 = the 8-lane kernel, 32 x 8 = the LDS kernel, 8 x 16,
 //                 16 x 16); SEGS consecutive segments per workgroup; non-temporal or plain
+// argv: [rows = 4096] [dynamic LDS bytes per workgroup = 0] [row pitch in bytes = 200704]: 35840 gives the pieces kernels the real launch's 4 workgroups per CU
 // Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_store_pattern.hip -o sdr-server_amd/build/ubench_store_pattern
 #include <hip/hip_runtime.h>
 
@@ -68,8 +69,9 @@ __global__ __launch_bounds__(256) void fill_pieces(char *out, const uint32_t nco
 
 int main(int argc, char **argv) {
   const uint32_t ncols = argc > 1 ? (uint32_t)atoi(argv[1]) : 4096u;
+  const size_t lds = argc > 2 ? (size_t)atoi(argv[2]) : 0u;  // dynamic LDS per workgroup: caps the workgroups per CU like the real launch's 35 840 bytes do
   const uint32_t nseg = 216u;  // 8 blocks of 27 segments
-  const size_t row_bytes = 200704;  // >= 216 * 928 + 8, a multiple of 256
+  const size_t row_bytes = argc > 3 ? (size_t)atol(argv[3]) : 200704;  // >= 216 * 928 + 8, a multiple of 256 (the engine's rows at 8 blocks per call: 199936)
   const size_t total = (size_t)ncols * row_bytes;
   char *out;
   CK(hipMalloc(&out, total + 4096));
@@ -92,12 +94,13 @@ int main(int argc, char **argv) {
     printf("%-78s %8.1f us  %6.2f TB/s\n", name, ms * 1e3 / reps, (double)bytes * reps / (ms * 1e-3) / 1e12);
   };
   const size_t n16 = (size_t)ncols * nseg * 928 / 16;
-  printf("rows %u, %u segments per row (8 blocks), footprint %.0f MB\n", ncols, nseg, (double)ncols * nseg * 928 / 1e6);
+  printf("rows %u, %u segments per row (8 blocks), footprint %.0f MB, %zu bytes of LDS per workgroup (%s)\n", ncols, nseg, (double)ncols * nseg * 928 / 1e6, lds,
+         lds ? "workgroups per CU capped by it" : "occupancy not capped");
   time("linear: 32 KB contiguous per workgroup, 16 B per lane", n16 * 16, [&] { hipLaunchKernelGGL(fill_linear, dim3((unsigned)((n16 + 2047) / 2048)), dim3(256), 0, st, reinterpret_cast<v4f *>(out), n16); });
   const dim3 g1(ncols / 32 * nseg), g4(ncols / 32 * ((nseg + 3) / 4));
   const size_t pb = (size_t)ncols * nseg * 928, pa = (size_t)ncols * nseg * 896;
 #define RUNP(desc, LPC, BPL, SEGS, NT, grid, piece, shift, bytes) \
-  time(desc, bytes, [&] { hipLaunchKernelGGL((fill_pieces<LPC, BPL, SEGS, NT>), grid, dim3(256), 0, st, out, ncols, nseg, row_bytes, piece, shift); })
+  time(desc, bytes, [&] { hipLaunchKernelGGL((fill_pieces<LPC, BPL, SEGS, NT>), grid, dim3(256), lds, st, out, ncols, nseg, row_bytes, piece, shift); })
   RUNP("pieces 928 B (+8 B on odd columns),  8 lanes x  8 B (the 8-lane kernel)", 8, 8, 1, false, g1, 928u, 8u, pb);
   RUNP("pieces 928 B (+8 B on odd columns), 32 lanes x  8 B (the LDS-transform kernel)", 32, 8, 1, false, g1, 928u, 8u, pb);
   RUNP("pieces 928 B (+8 B on odd columns),  8 lanes x 16 B", 8, 16, 1, false, g1, 928u, 8u, pb);
