@@ -72,6 +72,10 @@ int main(int argc, char **argv) {
   const size_t lds = argc > 2 ? (size_t)atoi(argv[2]) : 0u;  // dynamic LDS per workgroup: caps the workgroups per CU like the real launch's 35 840 bytes do
   const uint32_t nseg = 216u;  // 8 blocks of 27 segments
   const size_t row_bytes = argc > 3 ? (size_t)atol(argv[3]) : 200704;  // >= 216 * 928 + 8, a multiple of 256 (the engine's rows at 8 blocks per call: 199936)
+  if (row_bytes < (size_t)nseg * 928 + 8 || ncols % 32u != 0u) {
+    fprintf(stderr, "row pitch must hold %u pieces of 928 bytes + 8 (>= %zu), rows a multiple of 32\n", nseg, (size_t)nseg * 928 + 8);
+    return 2;
+  }
   const size_t total = (size_t)ncols * row_bytes;
   char *out;
   CK(hipMalloc(&out, total + 4096));
