@@ -219,10 +219,11 @@ struct xlating_batch_t {
   bool poly_min_set = false;        // "polyphase_min_clients" was given: it holds for every class (else 32 where the mix runs on the matrix cores)
   uint32_t poly_min_clients = 128;  // measured at 505 taps, D = 42: x1.10 at 128 clients, x0.96 at 64 (profiles/r01_polyphase_vs_direct.txt)
   uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
-  uint32_t inv_reg = 5;       // option "inverse_kernel", M = 128 classes: 0 = LDS transform on padded rows (round 2), 3 = on dense rows with an XOR
-                              // swizzle (default: LDS bank-conflict cycles 0.44 -> 0.24 of the LDS cycles, -1 % time in two A/B sessions),
-                              // 4 = the same at five workgroups per CU (no gain), 1 / 2 = transform in registers of a lane pair / quad
-                              // (fewer instructions and LDS cycles, 25-30 % slower: profiles/r03_inverse_reg_vs_lds.txt)
+  uint32_t inv_reg = 5;       // option "inverse_kernel", M = 128 classes: 5 = eight lanes per column, 16- and 8-point transforms in registers
+                              // (default since round 4: xl_inv8.hip; -2 to -7 % where the launches bind, profiles/r04_inverse8.txt); 0 = LDS
+                              // transform on padded rows (round 2), 3 = on dense rows with an XOR swizzle (round 3's default; what 48-bit Y
+                              // takes), 4 = the same at five workgroups per CU (no gain), 1 / 2 = transform in registers of a lane pair /
+                              // quad (fewer instructions and LDS cycles, 25-30 % slower: profiles/r03_inverse_reg_vs_lds.txt)
   uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = the mix launch on the matrix cores where the class allows it (integer input
                               // format, D <= 64), 0 = packed FP32 FMAs everywhere, 2 = mix + inverse as ONE launch with the mixed spectra
                               // on chip (xl_fused.hip) where the class allows it (integer input, D <= 64, <= 32 taps per branch)
