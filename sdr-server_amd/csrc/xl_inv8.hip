@@ -9,7 +9,8 @@
 //   * two of the three exchanges through LDS are gone (a lane's 16-point and 8-point transforms run in registers with
 //     compile-time twiddles), and the one that is left, like the phase staging and the twiddle table, uses addresses of the form
 //     "one register per lane + an immediate": the 4 x 4 x 4 x 2 kernel spends 40 % of its vector instructions on LDS addresses
-//     (XOR swizzles per access), this one a handful;
+//     (XOR swizzles per access), this one a handful (counters per 1024-client call: 21.1 M vector / 1.53 M LDS instructions against
+//     31.1 M / 4.42 M, no bank-conflict cycles);
 //   * a lane serves ONE client column in the epilogue (one XlpCol record, one set of output bounds) instead of four.
 // A wave owns 8 columns of the tile and a private 8.5 KB LDS region; the four waves of a workgroup meet once, behind the
 // twiddle table's fill (while their tile loads are in flight).
