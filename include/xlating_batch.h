@@ -85,6 +85,10 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                           LDS on padded rows (0) or on dense XOR-swizzled rows (3, round 3's default, still what 48-bit Y takes;
  *                           4: built for five workgroups per CU), or in the registers of a lane pair (1) / lane quad (2) per
  *                           client column with one LDS pass for the stores
+ *   "inverse_persistent"    0 (default) .. 8: the 8-lane inverse launch as that many workgroups per CU that walk the tiles, the next
+ *                           tile requested while the current one is transformed and stored (branch-free epilogue: points that are
+ *                           nobody's output go to a dump address).  Same results; measured 8-16 % slower than one workgroup per
+ *                           tile on an MI355X (profiles/r04_inverse8.txt): an option, not the default (a launch parameter, no re-plan)
  *   "mix_kernel"            polyphase classes: the mix launch (spectra x branch spectra, summed over the branches) on the matrix
  *                           cores (1, default: every float32 operand as two halves, three v_mfma_f32_32x32x16_f16 per 8
  *                           branches, FP32 accumulation; classes of an integer input format with decimation <= 64) or as

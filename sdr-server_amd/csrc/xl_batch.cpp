@@ -219,6 +219,8 @@ struct xlating_batch_t {
   bool poly_min_set = false;        // "polyphase_min_clients" was given: it holds for every class (else 32 where the mix runs on the matrix cores)
   uint32_t poly_min_clients = 128;  // measured at 505 taps, D = 42: x1.10 at 128 clients, x0.96 at 64 (profiles/r01_polyphase_vs_direct.txt)
   uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
+  uint32_t inv_persist = 0;   // option "inverse_persistent": work workgroups per CU of the persistent form of the 8-lane inverse launch (0 = off)
+  int num_cus = 256;
   uint32_t inv_reg = 5;       // option "inverse_kernel", M = 128 classes: 5 = eight lanes per column, 16- and 8-point transforms in registers
                               // (default since round 4: xl_inv8.hip; -2 to -7 % where the launches bind, profiles/r04_inverse8.txt); 0 = LDS
                               // transform on padded rows (round 2), 3 = on dense rows with an XOR swizzle (round 3's default; what 48-bit Y
@@ -455,6 +457,10 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
   } else if (n == "inverse_kernel") {
     if (value < 0 || value > 5) return -EINVAL;
     b->inv_reg = (uint32_t)value;
+  } else if (n == "inverse_persistent") {
+    if (value < 0 || value > 8) return -EINVAL;
+    b->inv_persist = (uint32_t)value;
+    return 0;  // (a launch parameter: no re-plan)
   } else if (n == "mix_kernel") {
     if (value < 0 || value > 2) return -EINVAL;
     b->mix_kernel = (uint32_t)value;
@@ -526,6 +532,7 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
     const size_t bbytes = (size_t)b->max_samples * b->gcap * b->bps + 16;
     XL_TRY(hipSetDevice(dev));
     XL_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+    if (hipDeviceGetAttribute(&b->num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || b->num_cus <= 0) b->num_cus = 256;
     XL_TRY(hipEventCreateWithFlags(&b->dep_ev, hipEventDisableTiming));
     XL_TRY(hipEventCreateWithFlags(&b->dep_ev2, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) XL_TRY(hipEventCreateWithFlags(&b->ev_fwd[i], hipEventDisableTiming));
@@ -551,6 +558,7 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
   if (getenv("XL_EXP_POLY_M")) (void)xlating_batch_set_option(b, "polyphase_m", atol(getenv("XL_EXP_POLY_M")));
   if (getenv("XL_EXP_POLY_MIN")) (void)xlating_batch_set_option(b, "polyphase_min_clients", atol(getenv("XL_EXP_POLY_MIN")));
   if (getenv("XL_EXP_INV")) (void)xlating_batch_set_option(b, "inverse_kernel", atol(getenv("XL_EXP_INV")));
+  if (getenv("XL_EXP_INV_PERSIST")) (void)xlating_batch_set_option(b, "inverse_persistent", atol(getenv("XL_EXP_INV_PERSIST")));
   if (getenv("XL_EXP_MIX")) (void)xlating_batch_set_option(b, "mix_kernel", atol(getenv("XL_EXP_MIX")));
   if (getenv("XL_EXP_Y6")) (void)xlating_batch_set_option(b, "y_format", atol(getenv("XL_EXP_Y6")));
   if (getenv("XL_EXP_MIX_PP")) (void)xlating_batch_set_option(b, "mix_passes_per_workgroup", atol(getenv("XL_EXP_MIX_PP")));
@@ -1929,6 +1937,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           pa.ncg = pc.ncg;
           pa.exp = b->poly_exp;
           pa.inv_reg = b->inv_reg;
+          pa.inv_wgs = b->inv_persist * (uint32_t)std::max(1, b->num_cus - (s == b->cs_masked || s == b->cs_masked2 ? 8 * (int)b->reserve_r : 0));
           pa.mix_kind = pc.mix_kind;
           pa.nkb = pc.nkb;
           pa.mix_pp = b->mix_pp;

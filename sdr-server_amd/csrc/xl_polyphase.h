@@ -69,6 +69,8 @@ struct XlpArgs {
                        // 2 = mix + inverse as ONE launch with the mixed spectra on chip (xl_fused.hip: no Y image, X and Rh in that launch's operand forms)
   uint32_t nkb;        // mix_kind 1: k-blocks of 8 branches = ceil(D / 8), <= XLP_NKB_MAX; mix_kind 2: k-blocks of 16 branches, <= 4
   uint32_t mix_pp;     // mix_kind 1: passes per workgroup (0 = default)
+  uint32_t inv_wgs;    // inv_reg 5: work workgroups of the PERSISTENT form of that launch (each walks tiles bid, bid + inv_wgs, ..; option
+                       // "inverse_persistent"); 0 = one workgroup per tile
   uint32_t y6;         // mix_kind 1 + LDS-transform inverse kernels: Y holds 48-bit values (xl_y6.h) instead of float32 pairs
   unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256

@@ -1045,8 +1045,11 @@ hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done)
   const uint32_t kind = a0.M == 128u ? a0.inv_reg : 0u;
   if (kind == 5u && a0.y6) return hipErrorInvalidValue;
   if (a0.y6 && (kind == 1u || kind == 2u || a0.cscale == nullptr)) return hipErrorInvalidValue;  // (the register-transform kernels read float32 pairs)
-  const uint32_t work = a0.nseg * a0.ncg * (kind == 1u ? 1u : (kind == 2u ? 2u : (a0.M == 256u ? 8u : 4u)));
-  const XlpArgs a = xlp_checked_skip(a0, work);
+  uint32_t work = a0.nseg * a0.ncg * (kind == 1u ? 1u : (kind == 2u ? 2u : (a0.M == 256u ? 8u : 4u)));
+  XlpArgs a1 = a0;
+  if (kind != 5u || a1.inv_wgs >= work) a1.inv_wgs = 0u;  // (persistent form: the 8-lane kernel only, and only with more tiles than workgroups)
+  if (a1.inv_wgs) work = a1.inv_wgs;
+  const XlpArgs a = xlp_checked_skip(a1, work);
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
   if (kind == 5u) {
     xlp_inverse8_launch(a, grid, s, done);

@@ -1412,7 +1412,7 @@ def test_one_block_calls_pipelined_on_the_engine_streams(pipeline):
     eng.close()
 
 
-@pytest.mark.parametrize("mix", [1, 2], ids=["mfma-mix", "fused"])
+@pytest.mark.parametrize("mix", [1, 2, 3], ids=["mfma-mix", "fused", "mfma-mix-persistent-inverse"])
 @pytest.mark.parametrize("variant", ["native", "optimized"])
 def test_group_2048_clients_all(variant, mix, monkeypatch):
     """The shape the >= 50 % claim of DESIGN 6 rests on (the launches, not the recurrence, bound the call): 2048 x 48 kHz
@@ -1420,9 +1420,13 @@ def test_group_2048_clients_all(variant, mix, monkeypatch):
     native bit for bit, optimized <= 1e-5 per client (fixture semantics: test/test_xlating.c:24-61, test/utils.c:176-196)."""
     from pyoracle import population
 
-    if variant == "native" and mix == 2:
-        pytest.skip("native calls do not depend on the mix kernel")
+    if variant == "native" and mix >= 2:
+        pytest.skip("native calls do not depend on the mix or the inverse kernel")
+    persist = mix == 3  # option "inverse_persistent": the 8-lane inverse launch as 4 workgroups per CU walking the 13 824 tiles
+    mix = 1 if persist else mix
     monkeypatch.setenv("XL_EXP_MIX", str(mix))
+    if persist:
+        monkeypatch.setenv("XL_EXP_INV_PERSIST", "4")
     t48 = lpf(FS, 24000, 9600)
     G, nb, n = 8, 262144, 2048
     fcs = [-984000 + 960 * c for c in range(n)]
