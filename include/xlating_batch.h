@@ -89,13 +89,15 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                           tile requested while the current one is transformed and stored (branch-free epilogue: points that are
  *                           nobody's output go to a dump address).  Same results; measured 8-16 % slower than one workgroup per
  *                           tile on an MI355X (profiles/r04_inverse8.txt): an option, not the default (a launch parameter, no re-plan)
- *   "mix_kernel"            polyphase classes: the mix launch (spectra x branch spectra, summed over the branches) on the matrix
- *                           cores (1, default: every float32 operand as two halves, three v_mfma_f32_32x32x16_f16 per 8
- *                           branches, FP32 accumulation; classes of an integer input format with decimation <= 64) or as
- *                           packed FP32 FMAs (0; always for cf32 input and decimation > 64), or mix + inverse as ONE launch
- *                           with the mixed spectra kept in registers (2: xl_fused.hip; integer input, decimation <= 64, up to
- *                           64 taps per branch; slower than the three launches on an MI355X -- DESIGN.md 3.5 -- and kept as
- *                           an option).  Same 1e-5 bar in every case
+ *   "mix_kernel"            polyphase classes: the mix launch (spectra x branch spectra, summed over the branches).  1 (default): on
+ *                           the matrix cores -- classes of an integer input format with decimation <= 64 carry every float32
+ *                           operand as two halves (three v_mfma_f32_32x32x16_f16 per 8 branches, FP32 accumulation), every other
+ *                           class (cf32 input, decimation > 64) multiplies float32 operands (v_mfma_f32_32x32x2_f32: exactly the
+ *                           float32 FMA chain, nothing split or scaled); 3: float32 operands on the matrix cores for EVERY class --
+ *                           the all-float32 arithmetic of the path; 0: packed FP32 FMAs on the vector ALUs for every class (the
+ *                           same chain, slower); 2: mix + inverse as ONE launch with the mixed spectra kept in registers
+ *                           (xl_fused.hip; integer input, decimation <= 64, up to 64 taps per branch; slower than the three
+ *                           launches on an MI355X -- DESIGN.md 3.5 -- and kept as an option).  Same 1e-5 bar in every case
  *   "y_format"              0 (default) / 1: the mixed spectra between the mix and the inverse launch as float32 pairs, or as
  *                           48-bit values (one shared 6-bit exponent + two 21-bit mantissas per complex value: a quarter less of
  *                           the path's largest stream) where the mix runs on the matrix cores and the inverse transform is staged in

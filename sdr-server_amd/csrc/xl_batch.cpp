@@ -43,6 +43,7 @@
 #include "xl_common.h"
 #include "xl_device.h"
 #include "xl_fused_layout.h"
+#include "xl_mixf_layout.h"
 #include "xl_polyphase.h"
 #include "xl_taps.h"
 
@@ -226,9 +227,11 @@ struct xlating_batch_t {
                               // transform on padded rows (round 2), 3 = on dense rows with an XOR swizzle (round 3's default; what 48-bit Y
                               // takes), 4 = the same at five workgroups per CU (no gain), 1 / 2 = transform in registers of a lane pair /
                               // quad (fewer instructions and LDS cycles, 25-30 % slower: profiles/r03_inverse_reg_vs_lds.txt)
-  uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = the mix launch on the matrix cores where the class allows it (integer input
-                              // format, D <= 64), 0 = packed FP32 FMAs everywhere, 2 = mix + inverse as ONE launch with the mixed spectra
-                              // on chip (xl_fused.hip) where the class allows it (integer input, D <= 64, <= 32 taps per branch)
+  uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = the mix launch on the matrix cores: two-half float16 operands where the class
+                              // allows them (integer input format, D <= 64), float32 operands everywhere else (cf32 input, D > 64);
+                              // 3 = float32 operands on the matrix cores for every class (the all-float32 arithmetic of the path);
+                              // 0 = packed FP32 FMAs everywhere, 2 = mix + inverse as ONE launch with the mixed spectra
+                              // on chip (xl_fused.hip) where the class allows it (integer input, D <= 64, <= 64 taps per branch)
   uint32_t y_format = 0;      // option "y_format": 1 = the mixed spectra Y as 48-bit values (xl_y6.h: shared exponent, two 21-bit mantissas)
                               // where the class's mix launch runs on the matrix cores and the inverse launch stages its transform in
                               // LDS ("inverse_kernel" 0 / 3 / 4); 0 (default) = float32 pairs.  Measured (profiles/r04_y48.txt): 16 %
@@ -462,7 +465,7 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     b->inv_persist = (uint32_t)value;
     return 0;  // (a launch parameter: no re-plan)
   } else if (n == "mix_kernel") {
-    if (value < 0 || value > 2) return -EINVAL;
+    if (value < 0 || value > 3) return -EINVAL;
     b->mix_kernel = (uint32_t)value;
   } else if (n == "y_format") {
     if (value < 0 || value > 1) return -EINVAL;
@@ -974,8 +977,11 @@ static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t D, uint32_t A, s
 // and needs them bounded -- integer input formats -- and at most XLP_NKB_MAX k-blocks of 8 branches.
 // The fused launch (2) keeps a tile's mixed spectra in registers, 128 bins per segment: filters of up to 64 taps per branch
 // (the same bound the three-launch path puts on 128-point segments).
+// The float32 matrix instruction (3) has no such conditions: it is what cf32 streams and D > 64 take, and every class on request.
 static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D, uint32_t A) {
-  if (b->mix_kernel == 0u || b->fmt == XL_FMT_CF32 || D > 8u * XLP_NKB_MAX) return 0u;
+  if (b->mix_kernel == 0u) return 0u;
+  const bool halves_ok = b->fmt != XL_FMT_CF32 && D <= 8u * XLP_NKB_MAX;
+  if (b->mix_kernel == 3u || !halves_ok) return 3u;
   if (b->mix_kernel == 2u && A <= XLF_M / 2u && (b->poly_m == 0u || b->poly_m == XLF_M)) return 2u;
   return 1u;
 }
@@ -1011,7 +1017,9 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     if (pc.mix_kind != 0u) {
       // operand-form image [cg][m][quarter][term][k-block][lane][8 halves] (fused launch: [16-column group][m][k-block][term][lane]):
       // a group's image is contiguous here too
-      const size_t per_cg = pc.mix_kind == 2u ? (XLP_COLS / XLF_COLS) * xlf_rh_bytes_per_cg16(pc.nkb) : xlp_rh_bytes_per_group(pc.M, pc.nkb);
+      const size_t per_cg = pc.mix_kind == 2u   ? (XLP_COLS / XLF_COLS) * xlf_rh_bytes_per_cg16(pc.nkb)
+                            : pc.mix_kind == 3u ? xlmf_rf_bytes_per_group(pc.M, pc.nkb)
+                                                : xlp_rh_bytes_per_group(pc.M, pc.nkb);
       XL_TRY(xl_plan_alloc(b, &nRh, (size_t)cap * per_cg));
       const size_t old_bytes = fresh ? 0 : (size_t)pc.ncg_cap * per_cg;
       if (old_bytes) XL_TRY(hipMemcpyAsync(nRh, pc.d_Rh, old_bytes, hipMemcpyDeviceToDevice, b->own_stream));
@@ -1079,10 +1087,12 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     if (pc.mix_kind != 0u) {  // what the matrix-core mix multiplies a column's sums by: 1 / (its scale * the spectra's)
       std::vector<float> cs((size_t)pc.ncg_cap * XLP_COLS, 1.0f);
       pc.col_scale.resize(pc.col_client.size(), 1.0f);
-      for (uint32_t j : new_cols) pc.col_scale[j] = xl_poly_col_scale(b->clients[pc.col_client[j]], pc.D, pc.T);
-      for (size_t j = 0; j < pc.col_client.size(); ++j) {
-        if (pc.col_client[j] < 0) continue;
-        cs[j] = 1.0f / (pc.col_scale[j] * XLP_H_XSCALE);
+      if (pc.mix_kind != 3u) {  // (float32 operands are neither scaled nor split: the table stays at 1 and nobody reads it)
+        for (uint32_t j : new_cols) pc.col_scale[j] = xl_poly_col_scale(b->clients[pc.col_client[j]], pc.D, pc.T);
+        for (size_t j = 0; j < pc.col_client.size(); ++j) {
+          if (pc.col_client[j] < 0) continue;
+          cs[j] = 1.0f / (pc.col_scale[j] * XLP_H_XSCALE);
+        }
       }
       XL_TRY(hipMemcpy(pc.d_cscale, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -1116,6 +1126,8 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
           : pc.mix_kind == 1u
               ? xlp_launch_tables_h(d_rt, d_meta, d_meta + nn, reinterpret_cast<const float *>(d_meta + 2 * nn), (uint32_t)nn, pc.T,
                                     pc.D, pc.A, pc.M, pc.nkb, pc.d_Rh, b->own_stream)
+          : pc.mix_kind == 3u
+              ? xlp_launch_tables_f(d_rt, d_meta, d_meta + nn, (uint32_t)nn, pc.T, pc.D, pc.A, pc.M, pc.nkb, pc.d_Rh, b->own_stream)
               : xlp_launch_tables(d_rt, d_meta, d_meta + nn, (uint32_t)nn, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.d_R, b->own_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->own_stream);
     xl_plan_release(b, d_rt);  // (scratch: spare again at once)
@@ -1958,7 +1970,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           // Packed-FMA mix: three slices (forward | mix | inverse); matrix-core mix: two (forward | inverse); fused: the
           // forward launch carries all of it (such calls take the side stream whenever there is one).
           const bool carry = fuse && !nco_fused;
-          const uint32_t sl1 = pc.mix_kind == 2u ? 65536u : (pc.mix_kind == 1u ? std::min(b->poly_slice_fi, 60000u) : b->poly_slice1);
+          const uint32_t sl1 = pc.mix_kind == 2u ? 65536u : (pc.mix_kind != 0u ? std::min(b->poly_slice_fi, 60000u) : b->poly_slice1);
           const uint32_t sl2 = pc.mix_kind == 0u ? b->poly_slice2 : sl1;
           if (carry) {
             pa.nco_clients = b->d_nco;
@@ -2167,7 +2179,7 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
     d += " cls" + std::to_string(k) + " D" + std::to_string(pc.D) + " T" + std::to_string(pc.T) + " cols" +
          std::to_string(pc.members.size()) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
     if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
-    d += pc.mix_kind == 2u ? " mix=fused" : (pc.mix_kind == 1u ? " mix=mfma" : " mix=fma");
+    d += pc.mix_kind == 2u ? " mix=fused" : (pc.mix_kind == 1u ? " mix=mfma" : (pc.mix_kind == 3u ? " mix=mf32" : " mix=fma"));
     const bool y48 = b->y_format == 1u && pc.mix_kind == 1u && !(pc.M == 128u && (b->inv_reg == 1u || b->inv_reg == 2u));
     if (y48) d += " Y=48bit";
     if (pc.M == 128u && pc.mix_kind != 2u && b->inv_reg == 5u && !y48) d += " inv=lanes8";

@@ -1,0 +1,252 @@
+// xl_mixf32.hip -- the mix launch of the polyphase path on the matrix cores with FLOAT32 operands (PolyClass::mix_kind 3).
+//
+// Same sums as xlp_mix_kernel / xlp_mix_mfma_kernel (xl_polyphase.hip): Y[c][s][m] = sum_b X[s][b][m] R[c][b][m], the per-client
+// multiply-accumulate of xlating.c:66-71 evaluated per spectrum bin of the D polyphase branches (xl_polyphase.h) -- here as one
+// real matrix product per bin on v_mfma_f32_32x32x2_f32: float32 in, float32 accumulate, bit for bit a chain of fmaf in branch
+// order (the very chain xlp_mix_kernel issues as packed FMAs; nothing is split or scaled, so cf32 streams -- whose spectra have
+// no bound -- and any branch count take it).  rows = (segment of the pass, re / im), columns = 32 clients, one instruction =
+// one branch (k = 0: the "re" factor, k = 1: the "im" factor): xl_mixf_layout.h.
+//
+// Why it beats the packed-FMA kernel although the two have the same peak (64 flop per cycle and SIMD): the matrix pipe takes one
+// instruction per 4096 flop and reads two registers for it; the vector pipe needed 16 packed FMAs, each reading three 64-bit
+// operands, and everything else the wave does (addresses, waits, stores) competed with them for the same issue slots.
+//
+// Workgroup = 4 waves = (bin m, column group of 128 clients, a run of passes); wave w = the group's columns 32 w .. 32 w + 31.
+//   B operands: the wave's branch spectra of bin m in operand form (Rf: xlmf_rf_slot), ONE float per lane and branch, read once per
+//               workgroup as 1 KB runs and kept in registers for all its passes (D <= 112; xlp_mix_f32_stream_kernel beyond).
+//   A operands: NO staging.  The forward launch's image row X[pass][b][m][0..15] (16 segments x (re, im) = 128 bytes) IS the k = 0
+//               operand in row order, and the k = 1 operand is the same line with the floats of each pair swapped and the second
+//               negated: lane (h, r) loads float r ^ h of the row and flips its sign when h & r & 1 -- one 4-byte load per lane and
+//               branch straight into the operand register (two 128-byte requests of one cache line per instruction; the four
+//               waves of a workgroup read the same lines, three of them from the CU's L1).  A branch's operand of the NEXT pass
+//               is requested right behind the instruction that consumed this pass's: D loads in flight per wave, no LDS, no
+//               barrier -- waves never wait for each other.
+// This launch never hosts the NCO role (no launch that issues matrix instructions does: DESIGN 3.6).
+#include "xl_poly_dev.h"
+
+#include "xl_mixf_layout.h"
+
+#include <hip/hip_ext.h>
+
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+
+// where workgroup `bid` works: bin, column group, passes [p0, p1) -- the pass runs of one (bin, column group) sit 8 positions
+// apart in the grid: same XCD, dispatched together, so that the group's operands come from HBM once (as in xlp_mix_mfma_kernel)
+struct XlmfJob {
+  uint32_t m, cg, p0, p1;
+};
+XL_DEV XlmfJob xlmf_job(const XlpArgs &a, const uint32_t bid) {
+  const uint32_t pp = a.mix_pp, runs = (a.mix_passes + pp - 1u) / pp;
+  const uint32_t grp = bid / (8u * runs), rr = bid - grp * 8u * runs;
+  const uint32_t run = rr >> 3, pair = grp * 8u + (rr & 7u);
+  XlmfJob j;
+  j.m = pair & (a.M - 1u), j.cg = pair / a.M;
+  j.p0 = run * pp;
+  j.p1 = j.p0 + pp < a.mix_passes ? j.p0 + pp : a.mix_passes;
+  return j;
+}
+
+// the wave's results of one pass -> Y image [cg][segment][sub][bin][CW columns] (the inverse workgroups' tiles): registers g, g + 1
+// (g even) = (re, im) of the pass's segment xlmf_result_row(g, h) / 2, column c
+XL_DEV void xlmf_store_pass(const XlpArgs &a, const v16f32 &acc, v2f *__restrict__ Yc, const size_t ystride, const uint32_t pass,
+                            const uint32_t h) {
+  const uint32_t s0 = pass * XLP_SEG;
+#pragma unroll
+  for (int g2 = 0; g2 < 16; g2 += 2) {
+    const uint32_t sl = xlmf_result_row((uint32_t)g2, h) >> 1;
+    // (written once, read once by the next launch: streamed past the L2 lines that hold the operands)
+    if (sl < XLP_SEG && s0 + sl < a.nseg) __builtin_nontemporal_store((v2f){acc[g2], acc[g2 + 1]}, &Yc[(size_t)(s0 + sl) * ystride]);
+  }
+}
+
+XL_DEV float xlmf_flip(const float v, const uint32_t sgn) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) ^ sgn); }
+
+template <int NB8>
+__global__ __launch_bounds__(256) void xlp_mix_f32_kernel(const XlpArgs a) {
+  constexpr int NJ = 8 * NB8;
+  const XlmfJob job = xlmf_job(a, blockIdx.x);
+  if (job.p0 >= job.p1) return;
+  const uint32_t tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+  const uint32_t M = a.M, m = job.m, cg = job.cg;
+  // ---- B operands of this wave: 2 NB8 runs of 1 KB
+  float bq[NJ];
+  {
+    const v4f32 *__restrict__ Rp = reinterpret_cast<const v4f32 *>(a.Rh);
+#pragma unroll
+    for (int jb = 0; jb < NB8; ++jb)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const v4f32 v = Rp[xlmf_rf_slot(cg, M, m, w, (uint32_t)NB8, (uint32_t)jb, (uint32_t)q, lane)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[8 * jb + 4 * q + e] = v[e];
+      }
+  }
+  // ---- A operands: image row (pass, branch j, bin m) = 128 bytes at X + ((pass Dpad + j) M + m) 128; this lane's float of it
+  const uint32_t h = lane >> 5, c = lane & 31u;
+  const uint32_t sgn = xlmf_a_negate(lane) << 31;
+  const uint32_t loff = xlmf_a_float(lane) * 4u;
+  const char *__restrict__ xb = reinterpret_cast<const char *>(a.X) + (size_t)m * (XLP_XS * sizeof(float2));
+  const size_t xrow = (size_t)M * (XLP_XS * sizeof(float2));  // bytes from one branch's row of a bin to the next one's
+  const uint32_t D = a.D;
+  auto xload = [&](const uint32_t pass, const int j) __attribute__((always_inline)) {
+    return *reinterpret_cast<const float *>(xb + ((size_t)pass * a.Dpad + (uint32_t)j) * xrow + loff);
+  };
+  float av[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) av[j] = (j < NJ - 8 || (uint32_t)j < D) ? xload(job.p0, j) : 0.0f;  // (only the last k-block may be short)
+  // (the B operands are waited for HERE, once, with the first pass's A operands still in flight behind them: left to itself the
+  // compiler puts those waits into the pass loop -- `vmcnt(12)` ahead of every pass's first products, which also drains all but
+  // twelve of the operand loads the previous pass has just issued)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(bq[j]));
+  // ---- Y: this lane's column of segment s
+  const uint32_t CW = M == 256u ? 16u : 32u, NSUB = XLP_COLS / CW;
+  const uint32_t col = w * 32u + c;
+  v2f *__restrict__ Yc = reinterpret_cast<v2f *>(a.Y) + ((((size_t)cg * a.nseg_cap) * NSUB + col / CW) * M + m) * CW + col % CW;
+  const size_t ystride = (size_t)NSUB * M * CW;  // v2f per segment
+  for (uint32_t pass = job.p0; pass < job.p1; ++pass) {
+    const uint32_t nxt = pass + 1u < job.p1 ? pass + 1u : pass;  // (the last pass requests its own rows again: no branch around the loads)
+    v16f32 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (j < NJ - 8 || (uint32_t)j < D) {  // (wave-uniform)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xlmf_flip(av[j], sgn), bq[j], acc, 0, 0, 0);
+        av[j] = xload(nxt, j);
+        // (nothing crosses: left alone, the scheduler gathers the sign flips of ALL branches -- and with them the waits for all
+        // their loads -- in front of the first matrix instruction of the pass)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    xlmf_store_pass(a, acc, Yc, ystride, pass, h);
+  }
+}
+
+// Any branch count (D > 112: huge decimations, few segments per call): the B operands do not fit a wave's registers for all its
+// passes, so every pass streams them again, one k-block of 8 branches ahead of the products (they come from L2 after the first
+// pass of a workgroup).
+__global__ __launch_bounds__(256) void xlp_mix_f32_stream_kernel(const XlpArgs a) {
+  const XlmfJob job = xlmf_job(a, blockIdx.x);
+  if (job.p0 >= job.p1) return;
+  const uint32_t tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+  const uint32_t M = a.M, m = job.m, cg = job.cg, nb8 = a.nkb, D = a.D;
+  const v4f32 *__restrict__ Rp = reinterpret_cast<const v4f32 *>(a.Rh) + xlmf_rf_slot(cg, M, m, w, nb8, 0u, 0u, lane);
+  const uint32_t h = lane >> 5, c = lane & 31u;
+  const uint32_t sgn = xlmf_a_negate(lane) << 31;
+  const uint32_t loff = xlmf_a_float(lane) * 4u;
+  const char *__restrict__ xb = reinterpret_cast<const char *>(a.X) + (size_t)m * (XLP_XS * sizeof(float2));
+  const size_t xrow = (size_t)M * (XLP_XS * sizeof(float2));
+  const uint32_t CW = M == 256u ? 16u : 32u, NSUB = XLP_COLS / CW;
+  const uint32_t col = w * 32u + c;
+  v2f *__restrict__ Yc = reinterpret_cast<v2f *>(a.Y) + ((((size_t)cg * a.nseg_cap) * NSUB + col / CW) * M + m) * CW + col % CW;
+  const size_t ystride = (size_t)NSUB * M * CW;
+  struct Block {
+    v4f32 b0, b1;
+    float x[8];
+  };
+  auto fetch = [&](const uint32_t pass, const uint32_t jb) __attribute__((always_inline)) {
+    Block k;
+    k.b0 = Rp[(size_t)jb * 128u];  // (xlmf_rf_slot: a k-block = two slots of 64 lanes)
+    k.b1 = Rp[(size_t)jb * 128u + 64u];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t j = 8u * jb + (uint32_t)e;
+      // (rows D .. Dpad - 1 of the image are zeros, beyond Dpad there is nothing to read)
+      k.x[e] = j < D ? *reinterpret_cast<const float *>(xb + ((size_t)pass * a.Dpad + j) * xrow + loff) : 0.0f;
+    }
+    return k;
+  };
+  for (uint32_t pass = job.p0; pass < job.p1; ++pass) {
+    v16f32 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    Block cur = fetch(pass, 0u);
+    for (uint32_t jb = 0; jb < nb8; ++jb) {
+      const Block nxt = fetch(pass, jb + 1u < nb8 ? jb + 1u : jb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float bv = e < 4 ? cur.b0[e & 3] : cur.b1[e & 3];
+        if (8u * jb + (uint32_t)e < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xlmf_flip(cur.x[e], sgn), bv, acc, 0, 0, 0);
+      }
+      cur = nxt;
+    }
+    xlmf_store_pass(a, acc, Yc, ystride, pass, h);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- branch spectra, operand form
+// The values xlp_tables_kernel computes (double arithmetic, rounded once), laid out as this kernel's B operands: (R.re, -R.im) of
+// branch b of column cl = 32 w + c -> element b & 3 of the slots of lanes (0, c) and (1, c) of k-block b >> 3, half (b >> 2) & 1.
+// Grid: 8 nb8 branches (those >= D: zeros), thread j of block (m, b) handles list entry j.
+__global__ __launch_bounds__(XLP_COLS) void xlp_tables_f_kernel(const float2 *__restrict__ rt, const uint32_t *__restrict__ delta,
+                                                                const uint32_t *__restrict__ colidx, uint32_t nlist, uint32_t T,
+                                                                uint32_t D, uint32_t A, uint32_t M, uint32_t nb8,
+                                                                float *__restrict__ Rf) {
+  __shared__ double wc[256], ws[256];
+  for (uint32_t n = threadIdx.x; n < M; n += blockDim.x) sincospi(2.0 * (double)n / (double)M, &ws[n], &wc[n]);
+  __syncthreads();
+  const uint32_t m = blockIdx.x % M;
+  const uint32_t b = blockIdx.x / M;
+  const uint32_t j = blockIdx.y * XLP_COLS + threadIdx.x;
+  if (j >= nlist) return;
+  const uint32_t col = colidx[j];
+  double sr, si;
+  xlp_branch_spectrum(rt, nlist, j, delta[j], T, D, A, M, m, b, wc, ws, sr, si);
+  const uint32_t cg = col / XLP_COLS, cl = col % XLP_COLS;
+  const uint32_t w = cl >> 5, c = cl & 31u;
+  Rf[xlmf_rf_slot(cg, M, m, w, nb8, xlmf_b_block(b), xlmf_b_half(b), c) * 4u + xlmf_b_elem(b)] = (float)sr;
+  Rf[xlmf_rf_slot(cg, M, m, w, nb8, xlmf_b_block(b), xlmf_b_half(b), 32u + c) * 4u + xlmf_b_elem(b)] = -(float)si;
+}
+
+hipError_t xlp_launch_tables_f(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, uint32_t nlist, uint32_t T, uint32_t D,
+                               uint32_t A, uint32_t M, uint32_t nb8, void *Rf, hipStream_t s) {
+  if ((M != 128u && M != 256u) || nlist == 0u || nb8 == 0u || D > 8u * nb8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(xlp_tables_f_kernel, dim3(M * 8u * nb8, (nlist + XLP_COLS - 1u) / XLP_COLS), dim3(XLP_COLS), 0, s, rt, delta, colidx,
+                     nlist, T, D, A, M, nb8, reinterpret_cast<float *>(Rf));
+  return hipGetLastError();
+}
+
+// Passes per workgroup when the caller names none: the launch is bound by the matrix pipe, so what matters is that every SIMD gets
+// the same number of (wave, pass) jobs -- runs of 16 passes (operands fetched once) while that still makes >= 4096 workgroups
+// (four rounds of the chip), shorter runs (the operands then come from L2 again) for smaller classes.
+static uint32_t xlmf_default_pp(const XlpArgs &a, uint32_t passes) {
+  uint32_t pp = 16u;
+  while (pp > 2u && (size_t)a.M * a.ncg * ((passes + pp - 1u) / pp) < 4096u) pp >>= 1;
+  return pp;
+}
+
+template <int NB8>
+static void xlmf_launch_n(const XlpArgs &a, const dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL(xlp_mix_f32_kernel<NB8>, grid, dim3(256), 0, s, a);
+}
+
+// (called by xlp_launch_mix for mix_kind 3, with a.mix_passes set)
+hipError_t xlp_launch_mix_f32(const XlpArgs &a0, hipStream_t s) {
+  if (a0.nkb == 0u || a0.D > 8u * a0.nkb || a0.Rh == nullptr || a0.nco_blocks != 0u)  // (no NCO role next to matrix instructions)
+    return hipErrorInvalidValue;
+  XlpArgs a = a0;
+  a.nco_skip = 0u;
+  a.nco_skip_at = 0xFFFFFFFFu;
+  if (a.mix_pp == 0u) a.mix_pp = xlmf_default_pp(a, a.mix_passes);
+  const uint32_t runs = (a.mix_passes + a.mix_pp - 1u) / a.mix_pp;
+  const dim3 grid(a.M * a.ncg * runs);
+  switch (a.nkb) {
+    case 1: xlmf_launch_n<1>(a, grid, s); break;
+    case 2: xlmf_launch_n<2>(a, grid, s); break;
+    case 3: xlmf_launch_n<3>(a, grid, s); break;
+    case 4: xlmf_launch_n<4>(a, grid, s); break;
+    case 5: xlmf_launch_n<5>(a, grid, s); break;
+    case 6: xlmf_launch_n<6>(a, grid, s); break;
+    case 7: xlmf_launch_n<7>(a, grid, s); break;
+    case 8: xlmf_launch_n<8>(a, grid, s); break;
+    case 9: xlmf_launch_n<9>(a, grid, s); break;
+    case 10: xlmf_launch_n<10>(a, grid, s); break;
+    case 11: xlmf_launch_n<11>(a, grid, s); break;
+    case 12: xlmf_launch_n<12>(a, grid, s); break;
+    case 13: xlmf_launch_n<13>(a, grid, s); break;
+    case 14: xlmf_launch_n<14>(a, grid, s); break;
+    default: hipLaunchKernelGGL(xlp_mix_f32_stream_kernel, grid, dim3(256), 0, s, a); break;
+  }
+  return hipGetLastError();
+}

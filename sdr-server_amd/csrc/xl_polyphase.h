@@ -66,8 +66,9 @@ struct XlpArgs {
   uint32_t inv_reg;    // M = 128: the inverse launch's transform: 0 = staged in LDS, 1 = registers of a lane pair, 2 = of a lane quad,
                        // 3 / 4 = staged in LDS on swizzled rows, 5 = registers of eight lanes per column (xl_inv8.hip)
   uint32_t mix_kind;   // the mix launch: 0 = packed FP32 FMAs (xlp_mix_kernel), 1 = matrix cores on two-term half splits (xlp_mix_mfma_kernel),
-                       // 2 = mix + inverse as ONE launch with the mixed spectra on chip (xl_fused.hip: no Y image, X and Rh in that launch's operand forms)
-  uint32_t nkb;        // mix_kind 1: k-blocks of 8 branches = ceil(D / 8), <= XLP_NKB_MAX; mix_kind 2: k-blocks of 16 branches, <= 4
+                       // 2 = mix + inverse as ONE launch with the mixed spectra on chip (xl_fused.hip: no Y image, X and Rh in that launch's operand forms),
+                       // 3 = matrix cores with float32 operands (xl_mixf32.hip: xlp_mix_f32_kernel; any input format, any branch count)
+  uint32_t nkb;        // mix_kind 1, 3: k-blocks of 8 branches = ceil(D / 8) (kind 1: <= XLP_NKB_MAX); mix_kind 2: k-blocks of 16 branches, <= 4
   uint32_t mix_pp;     // mix_kind 1: passes per workgroup (0 = default)
   uint32_t inv_wgs;    // inv_reg 5: work workgroups of the PERSISTENT form of that launch (each walks tiles bid, bid + inv_wgs, ..; option
                        // "inverse_persistent"); 0 = one workgroup per tile
@@ -78,6 +79,8 @@ struct XlpArgs {
   const float2 *R;     // branch spectra   [cg][M][Dpad][XLP_COLS] (+ XLP_BSTEP rows of tail padding)
   const void *Rh;      // mix_kind 1: the same, scaled per column and split in two halves, in MFMA operand order
                        //   [cg][M][32-column quarter][term 2][k-block nkb][lane 64][8 halves] (see xlp_mix_mfma_kernel)
+                       // mix_kind 3: the same values as float32 (R.re, -R.im) in v_mfma_f32_32x32x2_f32's B-operand order
+                       //   [cg][M][32-column quarter][k-block nkb][half 2][lane 64][4 branches] (xl_mixf_layout.h)
   const float *cscale; // mix_kind 1: per column, what the sums are multiplied by = 1 / (column scale * XLP_H_XSCALE)
   float2 *Y;           // mixed spectra    [cg][nseg_cap][sub][M][CW], CW = 32 (M = 128) / 16 (M = 256) columns: one inverse tile contiguous
                        //   (y6: the same tiles, 6 bytes per value in two planes: xl_y6.h)
@@ -119,6 +122,10 @@ hipError_t xlp_launch_tables_h16(const float2 *rt, const uint32_t *delta, const 
                                  uint32_t nlist, uint32_t T, uint32_t D, uint32_t A, uint32_t nk, void *Rh, hipStream_t s);
 hipError_t xlp_launch_forward_h(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_fused(const XlpArgs &a, hipStream_t s, hipEvent_t done);
+// mix_kind 3 (xl_mixf32.hip): the branch spectra as float32 B operands, and the mix launch itself (called by xlp_launch_mix)
+hipError_t xlp_launch_tables_f(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, uint32_t nlist, uint32_t T, uint32_t D,
+                               uint32_t A, uint32_t M, uint32_t nb8, void *Rf, hipStream_t s);
+hipError_t xlp_launch_mix_f32(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);

@@ -1026,6 +1026,11 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
     return hipGetLastError();
   }
   if (a0.y6) return hipErrorInvalidValue;  // (the 48-bit form of Y is the matrix-core mix's: its sums are bounded by construction)
+  if (a0.mix_kind == 3u) {  // matrix cores, float32 operands (xl_mixf32.hip)
+    XlpArgs a = a0;
+    a.mix_passes = passes;
+    return xlp_launch_mix_f32(a, s);
+  }
   const uint32_t work = a0.M * a0.ncg * passes;
   XlpArgs a = xlp_checked_skip(a0, work);
   a.mix_passes = passes;

@@ -294,16 +294,18 @@ def test_1000_clients_split_group_riders():
 # The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
 # the forced-path tests run with both.
 @pytest.fixture(params=[(128, 0, 1, 0), (128, 1, 1, 0), (128, 2, 1, 0), (128, 3, 1, 0), (256, 0, 1, 0), (128, 3, 0, 0), (256, 0, 0, 0), (128, 3, 2, 0),
-                        (128, 3, 1, 1), (256, 0, 1, 1), (128, 5, 1, 0), (128, 5, 0, 0), (128, 5, 1, 1)],
+                        (128, 3, 1, 1), (256, 0, 1, 1), (128, 5, 1, 0), (128, 5, 0, 0), (128, 5, 1, 1), (128, 5, 3, 0), (256, 0, 3, 0)],
                 ids=["M128", "M128-register-inverse", "M128-quad-register-inverse", "M128-swizzled-inverse", "M256",
                      "M128-fma-mix", "M256-fma-mix", "M128-fused", "M128-swizzled-inverse-48bit-Y", "M256-48bit-Y",
-                     "M128-8-lane-inverse", "M128-8-lane-inverse-fma-mix", "M128-8-lane-inverse-asked-with-48bit-Y"])
+                     "M128-8-lane-inverse", "M128-8-lane-inverse-fma-mix", "M128-8-lane-inverse-asked-with-48bit-Y",
+                     "M128-8-lane-inverse-f32-matrix-mix", "M256-f32-matrix-mix"])
 def poly_m(request, monkeypatch):
     """Transform length of the forced polyphase plan; at M = 128 also with the inverse launch's transform in registers
     (option "inverse_kernel" = 1: xlp_inverse_reg_kernel, a lane pair per column; 2: xlp_inverse_quad_kernel, a lane quad; 5:
     xlp_inverse8_kernel, eight lanes per column with 16- and 8-point transforms in registers -- with 48-bit Y the engine falls back
     to the swizzled LDS transform);
-    the mix launch on the matrix cores (option "mix_kernel" = 1, the default where the class allows it: integer input, D <= 64)
+    the mix launch on the matrix cores (option "mix_kernel" = 1, the default: two-half float16 operands where the class allows them --
+    integer input, D <= 64 --, float32 operands elsewhere; 3: float32 operands for every class)
     or as packed FP32 FMAs (0), or mix + inverse as ONE launch with the mixed spectra on chip (2: xl_fused.hip); the mixed spectra
     between the matrix-core mix and an LDS-staged inverse launch as float32 pairs (option "y_format" = 0, the default) or as
     48-bit values (1: xl_y6.h)."""
@@ -460,14 +462,16 @@ def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, mix, monke
     eng.close()
 
 
-@pytest.mark.parametrize("mix", [1, 2], ids=["mfma", "fused"])
+@pytest.mark.parametrize("mix", [1, 2, 3], ids=["mfma", "fused", "f32-mfma"])
 @pytest.mark.parametrize("D,fs", [(12, 576000), (33, 1584000), (50, 2400000), (64, 3072000)])
 def test_polyphase_matrix_core_mix_other_branch_counts(D, fs, mix, monkeypatch):
     """The matrix-core mix is built per number of k-blocks of 8 branches (1..8): the server default is 6 (D = 42), the
     fixture shapes cover 1 (D = 5) and 3 (D = 21); here 2, 5, 7 and 8 (the last two keep a few operand registers in
     scratch) -- 48 kHz clients off other sample rates, 12 taps per branch, both transform lengths by the size rule's
     forcing, every client vs the oracle.  The fused launch (mix = 2) is built per number of k-blocks of SIXTEEN branches (1..4;
-    128-point segments only): 1, 3, 4 and 4 here, 1 (D = 5), 2 (D = 21) and 3 (D = 42) in the fixture shapes."""
+    128-point segments only): 1, 3, 4 and 4 here, 1 (D = 5), 2 (D = 21) and 3 (D = 42) in the fixture shapes.  The float32 matrix-core
+    mix (mix = 3, xl_mixf32.hip) is built per number of k-blocks of 8 branches whose operands stay in registers (1..14; D = 100 and
+    D = 400 -- the streaming kernel -- run in test_polyphase_forced_other_shapes)."""
     monkeypatch.setenv("XL_EXP_MIX", str(mix))
     taps = lpf(fs, 24000, fs // 210)
     assert len(taps) >= 9 * D // 2
@@ -479,7 +483,7 @@ def test_polyphase_matrix_core_mix_other_branch_counts(D, fs, mix, monkeypatch):
         for c in range(37):
             fc = int(-0.4 * fs + c * 0.021 * fs)
             oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, fs, 2 * n)
-        assert ("mix=fused" if mix == 2 else "mix=mfma") in eng.describe() and " M%d " % m in eng.describe(), eng.describe()
+        assert {2: "mix=fused", 3: "mix=mf32"}.get(mix, "mix=mfma") in eng.describe() and " M%d " % m in eng.describe(), eng.describe()
         for k in range(3):
             check_clients(eng, oracles, "cu8", siggen.xs_u8(5300 + k, 2 * n if k != 1 else 2 * n - 1234), "optimized")
         eng.close()
@@ -489,8 +493,9 @@ def test_polyphase_matrix_core_mix_other_branch_counts(D, fs, mix, monkeypatch):
 
 def test_size_rule_of_matrix_core_classes():
     """The engine's own plan (no forcing): classes whose mix launch runs on the matrix cores take the polyphase path from 32
-    clients and 2 taps per branch on (101 taps at D = 42: 3 per branch), cf32 streams keep round 1's rule (128 clients, 4.5
-    taps per branch), a given "polyphase_min_clients" holds for every class -- and the 101-tap class matches the oracle."""
+    clients and 2 taps per branch on (101 taps at D = 42: 3 per branch) -- cf32 streams too, since their mix launch multiplies
+    float32 operands on the matrix cores (round 5; before: 128 clients, 4.5 taps per branch) --, a given "polyphase_min_clients"
+    holds for every class -- and the 101-tap class and the cf32 class match the oracle."""
     t101 = lpf(FS, 24000, 48000)
     assert len(t101) == 101
     eng = xl.BatchEngine(FS, "cu8", 262144, group_blocks=2)
@@ -512,10 +517,12 @@ def test_size_rule_of_matrix_core_classes():
     eng.close()
     eng = xl.BatchEngine(FS, "cf32", 8 * 65536)
     taps = lpf(FS, 24000, 9600)
+    oracles = {}
     for c in range(40):
-        eng.add_client(42, taps, -800000 + 41000 * c)
-    eng.process_host((siggen.xs_s16(5420, 2 * 65536).astype(np.float32) / np.float32(32768)).astype(np.float32), "optimized")
-    assert "polyphase: none" in eng.describe(), eng.describe()
+        oracles[eng.add_client(42, taps, -800000 + 41000 * c)] = Oracle(42, taps, -800000 + 41000 * c, FS, 262144)
+    for k in range(2):
+        check_clients(eng, oracles, "cf32", (siggen.xs_s16(5420 + k, 2 * 65536).astype(np.float32) / np.float32(32768)).astype(np.float32), "optimized")
+    assert "polyphase: cls0 D42 T505 cols40 " in eng.describe() and "mix=mf32" in eng.describe(), eng.describe()
     eng.close()
 
 
@@ -909,11 +916,12 @@ def test_group_of_blocks_equals_successive_calls_direct(variant):
 
 
 @pytest.mark.parametrize("m,inv,mix", [(128, 0, 1), (128, 1, 1), (128, 2, 1), (128, 3, 1), (128, 4, 1), (256, 0, 1),
-                                       (128, 3, 0), (256, 0, 0), (128, 3, 2)])
+                                       (128, 3, 0), (256, 0, 0), (128, 3, 2), (128, 5, 3), (256, 0, 3)])
 def test_group_of_blocks_polyphase(m, inv, mix, monkeypatch):
     """Forced polyphase path, G = 4 server-default blocks per call (108 segments at M = 128): every client vs the
     oracle's four successive calls; a native group in between (shared history and phases); ragged group.  mix = 1: the mix
-    launch on the matrix cores (8 passes of 14 segments = two runs of 4 per workgroup), 0: packed FP32 FMAs."""
+    launch on the matrix cores (8 passes of 14 segments = two runs of 4 per workgroup), 0: packed FP32 FMAs, 3: the matrix cores
+    with float32 operands (runs of 2 passes per workgroup at this size)."""
     monkeypatch.setenv("XL_EXP_INV", str(inv))
     monkeypatch.setenv("XL_EXP_MIX", str(mix))
     t48 = lpf(FS, 24000, 9600)
@@ -1322,7 +1330,8 @@ def _engine_outputs(eng, ids):
 
 
 @pytest.mark.parametrize("variant", ["native", "optimized", "optimized-register-inverse", "optimized-quad-register-inverse",
-                                     "optimized-swizzled-inverse", "optimized-fma-mix", "optimized-fused", "optimized-48bit-Y"])
+                                     "optimized-swizzled-inverse", "optimized-fma-mix", "optimized-fused", "optimized-48bit-Y",
+                                     "optimized-f32-mfma"])
 def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
     server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
@@ -1339,6 +1348,9 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     if variant.endswith("-fused"):
         monkeypatch.setenv("XL_EXP_MIX", "2")
         variant = "optimized"
+    if variant.endswith("-f32-mfma"):  # float32 operands on the matrix cores: the all-float32 arithmetic of the path
+        monkeypatch.setenv("XL_EXP_MIX", "3")
+        variant = "optimized"
     if variant.endswith("-48bit-Y"):
         monkeypatch.setenv("XL_EXP_Y6", "1")
         variant = "optimized"
@@ -1353,7 +1365,7 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     got = _engine_outputs(eng, ids)
     if variant == "optimized":
         assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
-        assert {"0": "mix=fma", "2": "mix=fused"}.get(os.environ.get("XL_EXP_MIX"), "mix=mfma") in eng.describe(), eng.describe()
+        assert {"0": "mix=fma", "2": "mix=fused", "3": "mix=mf32"}.get(os.environ.get("XL_EXP_MIX"), "mix=mfma") in eng.describe(), eng.describe()
         y48 = os.environ.get("XL_EXP_MIX") in (None, "1") and os.environ.get("XL_EXP_Y6") == "1" and os.environ.get("XL_EXP_INV") not in ("1", "2")
         assert ("Y=48bit" in eng.describe()) == y48, eng.describe()
     want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
@@ -1412,7 +1424,7 @@ def test_one_block_calls_pipelined_on_the_engine_streams(pipeline):
     eng.close()
 
 
-@pytest.mark.parametrize("mix", [1, 2, 3], ids=["mfma-mix", "fused", "mfma-mix-persistent-inverse"])
+@pytest.mark.parametrize("mix", [1, 2, 3, 4], ids=["mfma-mix", "fused", "mfma-mix-persistent-inverse", "f32-mfma-mix"])
 @pytest.mark.parametrize("variant", ["native", "optimized"])
 def test_group_2048_clients_all(variant, mix, monkeypatch):
     """The shape the >= 50 % claim of DESIGN 6 rests on (the launches, not the recurrence, bound the call): 2048 x 48 kHz
@@ -1423,7 +1435,7 @@ def test_group_2048_clients_all(variant, mix, monkeypatch):
     if variant == "native" and mix >= 2:
         pytest.skip("native calls do not depend on the mix or the inverse kernel")
     persist = mix == 3  # option "inverse_persistent": the 8-lane inverse launch as 4 workgroups per CU walking the 13 824 tiles
-    mix = 1 if persist else mix
+    mix = 1 if persist else (3 if mix == 4 else mix)  # (4: option "mix_kernel" = 3, float32 operands on the matrix cores)
     monkeypatch.setenv("XL_EXP_MIX", str(mix))
     if persist:
         monkeypatch.setenv("XL_EXP_INV_PERSIST", "4")
@@ -1437,7 +1449,7 @@ def test_group_2048_clients_all(variant, mix, monkeypatch):
         eng.process_host_group(x[k * G * nb:(k + 1) * G * nb], G, variant)
     got = _engine_outputs(eng, ids)
     if variant == "optimized":
-        assert "polyphase: cls0 D42 T505 cols2048" in eng.describe() and ("mix=fused" if mix == 2 else "mix=mfma") in eng.describe(), eng.describe()
+        assert "polyphase: cls0 D42 T505 cols2048" in eng.describe() and {2: "mix=fused", 3: "mix=mf32"}.get(mix, "mix=mfma") in eng.describe(), eng.describe()
     want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
     worst = 0.0
     for c in range(n):
@@ -1470,12 +1482,13 @@ def test_group_4096_clients_sampled(mix, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("nclients", [64, 256])
+@pytest.mark.parametrize("nclients", [64, 256, 1024])
 def test_config5_cf32_10msps_all_clients(nclients):
     """BASELINE config 5 at the client counts SURVEY 8(d) lists (N = 64, 256; N = 1 runs in
     test_config5_cf32_10msps_257_taps's family): cf32 input at 10 Msps, D = 100, 257 explicit taps, S = 131072; every
-    client of two consecutive blocks vs the oracle population, native bit-exact and optimized <= 1e-5 (at 256 clients the
-    optimized call takes the polyphase path)."""
+    client of two consecutive blocks vs the oracle population, native bit-exact and optimized <= 1e-5 (the optimized calls take
+    the polyphase path with the mix on the matrix cores, float32 operands: 13 k-blocks of 8 branches; 1024 clients = the
+    count bench.py's config-5 variant is quoted on)."""
     from pyoracle import population
 
     taps = siggen.hamming_sinc(257, 0.004)
@@ -1488,6 +1501,8 @@ def test_config5_cf32_10msps_all_clients(nclients):
         ids = [eng.add_client(100, taps, fc) for fc in fcs]
         for k in range(2):
             eng.process_host(x[k * 2 * nsamp:(k + 1) * 2 * nsamp], variant)
+        if variant == "optimized":
+            assert "polyphase: cls0 D100 T257 cols%d " % nclients in eng.describe() and "mix=mf32" in eng.describe(), eng.describe()
         got = _engine_outputs(eng, ids)
         for c in range(nclients):
             assert len(got[c]) == len(want[c]), c

@@ -30,25 +30,32 @@ def main():
     ap.add_argument("--poly3", action="store_true", help="also time the three polyphase launches separately")
     ap.add_argument("--slices", default="")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable), e.g. mix_kernel=2")
+    ap.add_argument("--shape", default="server", choices=["server", "config5"], help="config5: BASELINE configs[4] -- cf32 input at 10 Msps, D = 100, 257 explicit taps")
     ap.add_argument("--engine-stream", type=int, default=1, help="1: XL_STREAM_ENGINE (the engine's own, CU-masked compute stream); 0: torch's stream")
     args = ap.parse_args()
     gmax = max(int(g) for g in args.groups.split(","))
-    data = torch.from_numpy(siggen.xs_u8(99, gmax * BLOCK)).cuda()
+    if args.shape == "config5":
+        data = torch.from_numpy((siggen.xs_s16(99, gmax * BLOCK).astype(np.float32) / np.float32(32768)).astype(np.float32)).cuda()
+    else:
+        data = torch.from_numpy(siggen.xs_u8(99, gmax * BLOCK)).cuda()
     st = torch.cuda.current_stream()
     sarg = "engine" if args.engine_stream else st.cuda_stream
     print(f"{'mode':10s} {'M':>4s} {'clients':>7s} {'G':>2s} {'us/block':>9s} {'kern us/blk':>11s} {'Msps':>10s}   plan / launches us per block")
-    for dec in [int(v) for v in args.decimations.split(",")]:
+    for dec in ([100] if args.shape == "config5" else [int(v) for v in args.decimations.split(",")]):
         sweep(args, dec, data, sarg)
 
 
 def sweep(args, D, data, sarg):
     FS = 48000 * D
     code, taps = xl.create_low_pass_filter(1.0, FS, 24000, 48000 // args.rate)
+    fmt = "cu8"
+    if args.shape == "config5":
+        FS, fmt, taps = 10000000, "cf32", siggen.hamming_sinc(257, 0.004)
     for mode in args.modes.split(","):
         for m in [int(v) for v in args.m.split(",")]:
             for n in [int(c) for c in args.clients.split(",")]:
                 for G in [int(g) for g in args.groups.split(",")]:
-                    eng = xl.BatchEngine(FS, "cu8", BLOCK, group_blocks=G)
+                    eng = xl.BatchEngine(FS, fmt, BLOCK, group_blocks=G)
                     if m:
                         eng.set_option("polyphase_m", m)
                     if args.slices:
@@ -58,7 +65,10 @@ def sweep(args, D, data, sarg):
                         name, val = kv.split("=")
                         eng.set_option(name, int(val))
                     for c in range(n):
-                        eng.add_client(D, taps, -984000 + 1920 * (c % 1024) + 240 * (c // 1024))
+                        if args.shape == "config5":
+                            eng.add_client(D, taps, -4000000 + (8000000 // n) * c)
+                        else:
+                            eng.add_client(D, taps, -984000 + 1920 * (c % 1024) + 240 * (c // 1024))
                     calls = max(4, args.blocks // G)
                     for k in range(4):
                         eng.process_device_group(data.data_ptr(), BLOCK, G, mode, sarg)
