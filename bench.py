@@ -44,6 +44,7 @@ Prints ONE JSON line (rank 0): value = input IQ Msamples/s summed over all clien
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -68,6 +69,9 @@ FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA 
 MFMA_F16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16 / F16 MFMA peak
 TIMING_STRIDE = 5               # HIP events bracket every 5th call of the timed region (an event pair costs ~6 us of stream time; odd, so that both calls of a chain launch's pair are sampled)
 PMC_REPLAY_CALLS = 12           # calls of the counter passes (rocprofv3 serialises the dispatches; the first 3 per kernel are dropped)
+# BASELINE configs[4] as SURVEY D4 / 8(d) define it: Airspy-style cf32 input at 10 Msps, D = 100 (-> 100 kHz: 96 kHz is no integer
+# decimation of 10 MHz and the server would reject it), 257 explicit Hamming-sinc taps, 131072 complex samples per block
+C5_FS, C5_D, C5_TAPS, C5_CUTOFF = 10000000, 100, 257, 0.004
 
 
 def shard_clients(total_clients, world_size, rank):
@@ -469,6 +473,167 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
             "rccl_comm_count": getattr(host, "comm_count", None)}
 
 
+def config5_center_freq(c, n):
+    return -4000000 + (8000000 // n) * c
+
+
+def run_config5(ctx, nclients, steps, spot=True, blocks_per_step=320, replay_calls=0, options=None):
+    """BASELINE configs[4] on this GPU: `nclients` clients x 100 kHz off one 10 Msps cf32 stream (D = 100, 257 taps), GROUP blocks of
+    131072 samples per call on the engine's own stream, inputs resident in HBM.  Before the timed region EVERY client of one whole
+    call is compared with the oracle population (after a first call that loads every filter's history and phase)."""
+    import siggen
+
+    xl, torch = ctx["xl"], ctx["torch"]
+    taps = siggen.hamming_sinc(C5_TAPS, C5_CUTOFF)
+    nel = 2 * S  # float32 elements per block
+    x = np.concatenate([(siggen.xs_s16(300 + k, GROUP * nel).astype(np.float32) / np.float32(32768)) for k in range(2)]).astype(np.float32)
+    dev = [torch.from_numpy(x[k * GROUP * nel:(k + 1) * GROUP * nel]).cuda() for k in range(2)]
+    eng = xl.BatchEngine(C5_FS, "cf32", nel, device=torch.cuda.current_device(), group_blocks=GROUP)
+    for k, v in (options or {}).items():
+        eng.set_option(k, v)
+    fcs = [config5_center_freq(c, nclients) for c in range(nclients)]
+    ids = [eng.add_client(C5_D, taps, fc) for fc in fcs]
+    ncall = [0]
+
+    def call():
+        eng.process_device_group(dev[ncall[0] % 2].data_ptr(), nel, GROUP, "optimized", "engine")
+        ncall[0] += 1
+
+    if replay_calls:
+        for _ in range(4 + replay_calls):
+            call()
+        eng.sync()
+        eng.close()
+        return None
+    spot_res = None
+    call()
+    call()
+    if spot:
+        odir = os.path.join(ROOT, "oracle")  # the checker (test infrastructure): never on the timed path
+        if odir not in sys.path:
+            sys.path.insert(0, odir)
+        from pyoracle import population
+
+        t0 = time.perf_counter()
+        eng.fetch()
+        want = population(C5_D, taps, fcs, C5_FS, nel, "cf32", x, GROUP, nwarm=GROUP)
+        worst, bad = 0.0, 0
+        for c, w in zip(ids, want):
+            got = eng.output(c)
+            e = float(np.abs(got.astype(np.complex128) - w).max() / np.abs(w).max()) if got.shape == w.shape else float("inf")
+            worst, bad = max(worst, e), bad + (0 if e <= 1e-5 else 1)
+        spot_res = {"clients": nclients, "clients_failing": bad, "outputs_compared_per_client": int(len(want[0])), "max_rel": worst,
+                    "tolerance": 1e-5, "ok": bool(worst <= 1e-5), "seconds": round(time.perf_counter() - t0, 2),
+                    "how": "every client of the second call vs oracle/population.c on the host cores (the first call loads history and phase)"}
+    calls_per_step = blocks_per_step // GROUP
+    for _ in range(calls_per_step):
+        call()
+    eng.sync()
+    eng.timing_stride(TIMING_STRIDE)
+    eng.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps * calls_per_step):
+        call()
+    eng.sync()
+    dt = time.perf_counter() - t0
+    nt, fir_ms, _ = eng.timing_read(reset=True)
+    eng.timing(False)
+    plan = eng.describe()
+    klen = eng.output_len(ids[0])
+    kernels_ms = None
+    if "polyphase: none" not in plan:
+        eng.timing_stride(1)
+        eng.timing(2)
+        for _ in range(16):
+            call()
+        eng.sync()
+        n3, ms3 = eng.timing_polyphase(reset=True)
+        eng.timing(False)
+        if n3 > 0:
+            mix_name = {"mix=mfma": "xlp_mix_mfma_kernel", "mix=mf32": "xlp_mix_f32_kernel"}.get(next((t for t in ("mix=mfma", "mix=mf32") if t in plan), ""), "xlp_mix_kernel")
+            inv_name = "xlp_inverse8_kernel" if "inv=lanes8" in plan else "xlp_inverse_kernel"
+            kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), mix_name: round(ms3[1] / n3, 4), inv_name: round(ms3[2] / n3, 4)}
+    eng.close()
+    blocks = steps * blocks_per_step
+    return {"value": nclients * S * blocks / dt / 1e6, "us_per_block": dt / blocks * 1e6, "call_ms_avg": fir_ms / max(nt, 1), "K_call": int(klen),
+            "plan": plan, "kernels_ms": kernels_ms, "parity_spot": spot_res, "clients": nclients, "steps": steps, "blocks_per_step": blocks_per_step}
+
+
+def config5_entry(m5, pmc5):
+    """variants[...] entry of BASELINE configs[4] with its own roofline block."""
+    n, K = m5["clients"], m5["K_call"]
+    units = n * S * GROUP
+    call_s = m5["call_ms_avg"] * 1e-3
+    fpu = 8.0 * C5_TAPS / C5_D + 6.0 / C5_D
+    shared = units * (8.0 / n + 8.0 / C5_D)
+    e = {"value": round(m5["value"], 1), "us_per_block": round(m5["us_per_block"], 3), "launches_ms_per_call": round(m5["call_ms_avg"], 4),
+         "blocks_per_call": GROUP, "plan": m5["plan"], "parity_spot": m5["parity_spot"], "kernels_ms_per_call": m5["kernels_ms"],
+         "workload": f"{n} clients x 100 kHz off one 10 Msps cf32 stream, {2 * S * 4}-byte blocks of {S} complex samples, D={C5_D}, {C5_TAPS} explicit "
+                     "Hamming-sinc taps, process_optimized_cf32_cf32 semantics (the cf32-input extension: SURVEY D4; the reference's Airspy "
+                     "path feeds the same arithmetic through process_optimized_cs16_cf32, src/xlating.c:374-382)",
+         "note": "BASELINE configs[4] ('HBM-roofline run'): 96 kHz is not an integer decimation of 10 Msps (the server rejects it, "
+                 "src/tcp_server.c:101-105) -> 100 kHz; 257 taps (computeNtaps never returns an even count)"}
+    rl = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": round(m5["call_ms_avg"], 4), "units_per_launch": units,
+          "algorithmic": {"per_client_read_bytes_per_unit": round(8.0 + 8.0 / C5_D, 4), "shared_read_bytes_per_unit": round(8.0 / n + 8.0 / C5_D, 5),
+                          "shared_read_bytes_per_call": int(shared), "flop_per_unit_direct_form": round(fpu, 2)}}
+    if call_s > 0:
+        rl["frac_algorithmic_shared"] = round(shared / call_s / 1e9 / HBM_PEAK_GBS, 4)
+        rl["frac_fp32_direct_form"] = round(units * fpu / call_s / 1e12 / FP32_PEAK_TFLOPS, 4)
+    if pmc5 and call_s > 0:
+        gbs = pmc5["bytes_per_call"] / call_s / 1e9
+        rl.update({"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc5["bytes_per_call"], "traffic_source": "measured in this run",
+                   "counter_scope": COUNTER_SCOPE, "traffic_over_shared_read_minimum": round(pmc5["bytes_per_call"] / shared, 2),
+                   "frac_is": "HBM bytes of one call's launches by the PMC counters (measured in this run) / the HIP-event duration of those "
+                              "launches in this variant's timed region / peak"})
+        pk = {}
+        mm = re.search(r" V(\d+) M(\d+)", m5["plan"])
+        V, M = (int(mm.group(1)), int(mm.group(2))) if mm else (126, 128)
+        nseg = -(-(K + 2) // V)
+        for kname, ms_ev in (m5["kernels_ms"] or {}).items():
+            kpre = kname[:-len("_kernel")]
+            pkk = next((v for k, v in pmc5["per_kernel"].items() if k.startswith(kpre) and ("mfma" in k) == ("mfma" in kname)), None)
+            ms_k = (pkk or {}).get("ms_per_dispatch_kernel_trace") or ms_ev
+            pk[kname] = {"ms": ms_k, "ms_hip_events": ms_ev, "hbm_bytes": (pkk or {}).get("hbm_bytes_per_call"),
+                         "frac_hbm": round(pkk["hbm_bytes_per_call"] / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pkk and ms_k else None}
+            if kname.startswith("xlp_mix") and ms_k:
+                # flops the launch EXECUTES on the matrix cores: one v_mfma_f32_32x32x2_f32 (4096 flop) per (branch, bin, 32 columns, pass)
+                passes = -(-nseg // 14)
+                pk[kname]["frac_matrix_f32"] = round(4096.0 * C5_D * M * -(-n // 32) * passes / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
+                pk[kname]["frac_fp32_useful"] = round(8.0 * n * nseg * M * C5_D / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
+        rl["per_kernel"] = pk
+    else:
+        rl["traffic"] = None
+    e["roofline"] = rl
+    return e
+
+
+def run_host_delivered(ctx, nclients, ntaps_rate, calls=12):
+    """What the reference's dsp_worker does with every block (src/dsp_worker.c:57-77: process, then write the output): host blocks
+    in (xlating_batch_process_host_group: pinned staging + H2D), every client's outputs back on the host (xlating_batch_fetch: D2H of
+    the whole output image) before the next call -- synchronous, PCIe-inclusive, never `value`."""
+    xl = ctx["xl"]
+    code, taps = ctx["lpf"](1.0, FS, RATE // 2, RATE // ntaps_rate)
+    eng = xl.BatchEngine(FS, "cu8", BLOCK_BYTES, device=ctx["torch"].cuda.current_device(), group_blocks=GROUP)
+    for c in range(nclients):
+        eng.add_client(D, taps, client_center_freq(c))
+    xs = [make_group(g) for g in range(2)]
+    for k in range(2):
+        eng.process_host_group(xs[k % 2], GROUP, "optimized")
+        eng.fetch()
+    t0 = time.perf_counter()
+    for k in range(calls):
+        eng.process_host_group(xs[k % 2], GROUP, "optimized")
+        eng.fetch()
+    dt = time.perf_counter() - t0
+    out_bytes = sum(eng.output_len(c) for c in range(nclients)) * 8
+    eng.close()
+    return {"value": round(nclients * S * GROUP * calls / dt / 1e6, 1), "us_per_block": round(dt / (calls * GROUP) * 1e6, 2), "blocks_per_call": GROUP,
+            "host_bytes_in_per_call": GROUP * BLOCK_BYTES, "host_bytes_out_per_call": int(out_bytes),
+            "pcie_GBs_out": round(out_bytes * calls / dt / 1e9, 2),
+            "note": "process_host_group + fetch per call, synchronous: every client's outputs of every block delivered to host memory "
+                    "(src/dsp_worker.c:74-77 writes them out).  PCIe-inclusive; the headline keeps outputs in HBM"}
+
+
 def parity_spot(ctx, eng, ids, mine, taps, mode, calls_done, call):
     """EVERY client of the engine the timed region just ran, vs a population of oracle filters on the host cores
     (oracle/population.c, one reference-model filter per client over pthreads).  The oracles' stream state (phase
@@ -610,12 +775,42 @@ COUNTER_SCOPE = ("L2 <-> fabric requests (TCC_EA read / write requests x request
 PMC_KERNEL_PREFIXES = ("xlp_forward", "xlp_mix", "xlp_inverse", "xlp_fused", "xl_fir_kernel", "xl_nco_chain", "xl_nco_table", "xl_update_history")
 
 
-def measure_traffic(args):
-    """HBM bytes per call of THIS workload on THIS box: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: the guide's
-    HBM section asks for separate passes) over `bench.py --replay-calls N`, run as subprocesses after the timed region.
-    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of wide coalesced reads ->
-    bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB.  Returns (result dict | None, note)."""
+def _pmc_rows(path, value_of):
+    """rows of a rocprofv3 csv in dispatch order: (kernel name without template arguments, value_of(row))"""
     import csv
+
+    rows = []
+    for i, row in enumerate(csv.DictReader(open(path))):
+        k = row["Kernel_Name"].split("(")[0]
+        k = k[5:] if k.startswith("void ") else k
+        k = k.split("<")[0]
+        if not k.startswith(PMC_KERNEL_PREFIXES):
+            continue
+        order = int(row.get("Dispatch_Id") or row.get("Start_Timestamp") or i)
+        rows.append((order, k, value_of(row)))
+    rows.sort(key=lambda r: r[0])
+    return rows
+
+
+def _split_workloads(rows, n):
+    """The replay process runs its workloads one after the other, each on a fresh engine -- whose FIRST call (and no other of a
+    replay) tabulates its own phases with a stand-alone xl_nco_table_kernel launch: that launch marks where a workload begins."""
+    segs = []
+    for _, k, v in rows:
+        if k.startswith("xl_nco_table"):
+            segs.append({})
+        if segs:
+            segs[-1].setdefault(k, []).append(v)
+    return segs if len(segs) == n else None
+
+
+def measure_traffic(args, workloads):
+    """HBM bytes per call of `workloads` (a list of "server:<clients>" / "config5:<clients>") on THIS box: two rocprofv3 --pmc passes
+    (FETCH_SIZE, WRITE_SIZE: the guide's HBM section asks for separate passes) over `bench.py --replay-calls N --replay-set ...`
+    (ONE process per pass replays all the workloads back to back), run as subprocesses after the timed region, and a third pass
+    without counters for the kernels' own durations.
+    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of wide coalesced reads ->
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB.  Returns ({workload: result dict} | None, note)."""
     import glob
     import shutil
     import tempfile
@@ -625,66 +820,68 @@ def measure_traffic(args):
         return None, "rocprofv3 not found"
     out = tempfile.mkdtemp(prefix="xl_bench_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    tail = [sys.executable, os.path.abspath(__file__), "--replay-calls", str(PMC_REPLAY_CALLS), "--clients", str(args.clients),
+    tail = [sys.executable, os.path.abspath(__file__), "--replay-calls", str(PMC_REPLAY_CALLS), "--replay-set", ",".join(workloads),
             "--mode", args.mode, "--lpf-cutoff-rate", str(args.lpf_cutoff_rate)]
-    vals = {}  # kernel -> counter -> [per dispatch]
+    tmo = float(os.environ.get("XL_BENCH_PMC_TIMEOUT", "240"))
+    segs = {}  # counter -> per workload {kernel: [per dispatch]}
     t0 = time.perf_counter()
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, counter)
             r = subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + tail,
-                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=float(os.environ.get("XL_BENCH_PMC_TIMEOUT", "240")))
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=tmo)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
-            for row in csv.DictReader(open(files[0])):
-                k = row["Kernel_Name"].split("(")[0]
-                k = k[5:] if k.startswith("void ") else k
-                if k.startswith(PMC_KERNEL_PREFIXES) and row["Counter_Name"] == counter:
-                    vals.setdefault(k, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+            rows = _pmc_rows(files[0], lambda row, c=counter: float(row["Counter_Value"]) if row["Counter_Name"] == c else None)
+            segs[counter] = _split_workloads([x for x in rows if x[2] is not None], len(workloads))
+            if segs[counter] is None:
+                return None, f"the {counter} pass does not show {len(workloads)} workloads"
         # third pass, no counters: the kernels' own durations as the profiler sees them in the production arrangement (the chain
         # kernel running beside the three launches on its side stream) -- what `rocprofv3 --kernel-trace --stats` prints
-        durs = {}
+        durs = None
         d = os.path.join(out, "trace")
         r = subprocess.run([rocprof, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + tail,
-                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=float(os.environ.get("XL_BENCH_PMC_TIMEOUT", "240")))
+                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=tmo)
         files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
         if r.returncode == 0 and files:
-            for row in csv.DictReader(open(files[0])):
-                k = row["Kernel_Name"].split("(")[0]
-                k = k[5:] if k.startswith("void ") else k
-                if k.startswith(PMC_KERNEL_PREFIXES):
-                    durs.setdefault(k, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
+            durs = _split_workloads(_pmc_rows(files[0], lambda row: (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6), len(workloads))
     except subprocess.TimeoutExpired:
         return None, "rocprofv3 --pmc pass timed out"
     finally:
         shutil.rmtree(out, ignore_errors=True)
-    main_k = next((k for k in vals if k.startswith("xlp_inverse")), None) or next((k for k in vals if k.startswith("xl_fir_kernel")), None)
-    if main_k is None:
-        return None, "no engine kernel in the counter output"
-    per, total = {}, 0.0
-    ncalls = max(len(vals[main_k].get("FETCH_SIZE", [])), 1)
-    for k, d in vals.items():
-        f, w = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
-        n = max(len(f), len(w), 1)
-        drop = 3 if n > 6 else 0  # (the first calls: stand-alone NCO tabulation, cold caches)
-        fm = sum(f[drop:]) / max(len(f[drop:]), 1)
-        wm = sum(w[drop:]) / max(len(w[drop:]), 1)
-        per_dispatch = (2.0 * fm + wm) * 1024.0
-        per_call = per_dispatch * n / ncalls  # (a chain launch covers several calls; every other kernel is once per call)
-        per[k] = {"hbm_bytes_per_dispatch": int(per_dispatch), "dispatches_per_call": round(n / ncalls, 3), "hbm_bytes_per_call": int(per_call),
-                  "FETCH_SIZE_KiB": round(fm, 1), "WRITE_SIZE_KiB": round(wm, 1)}
-        dk = durs.get(k, [])
-        dk = dk[3:] if len(dk) > 6 else dk
-        if dk:
-            per[k]["ms_per_dispatch_kernel_trace"] = round(sum(dk) / len(dk), 4)
-        total += per_call
-    return {"bytes_per_call": int(total), "per_kernel": per, "calls_profiled": ncalls, "seconds": round(time.perf_counter() - t0, 1),
-            "correction": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM): "
-                          "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
-            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --replay-calls %d (two passes) + one "
-                       "rocprofv3 --kernel-trace pass without counters for the kernels' durations" % PMC_REPLAY_CALLS}, \
-        "measured in this run"
+    results = {}
+    for wi, wl in enumerate(workloads):
+        fs, ws = segs["FETCH_SIZE"][wi], segs["WRITE_SIZE"][wi]
+        main_k = next((k for k in fs if k.startswith("xlp_inverse")), None) or next((k for k in fs if k.startswith("xl_fir_kernel")), None)
+        if main_k is None:
+            return None, f"no engine kernel in the counter output of {wl}"
+        per, total = {}, 0.0
+        ncalls = max(len(fs[main_k]), 1)
+        for k in sorted(set(fs) | set(ws)):
+            f, w = fs.get(k, []), ws.get(k, [])
+            n = max(len(f), len(w), 1)
+            drop = 3 if n > 6 else 0  # (the first calls: cold caches)
+            fm = sum(f[drop:]) / max(len(f[drop:]), 1)
+            wm = sum(w[drop:]) / max(len(w[drop:]), 1)
+            per_dispatch = (2.0 * fm + wm) * 1024.0
+            per_call = per_dispatch * n / ncalls  # (a chain launch covers several calls; every other kernel is once per call)
+            per[k] = {"hbm_bytes_per_dispatch": int(per_dispatch), "dispatches_per_call": round(n / ncalls, 3), "hbm_bytes_per_call": int(per_call),
+                      "FETCH_SIZE_KiB": round(fm, 1), "WRITE_SIZE_KiB": round(wm, 1)}
+            dk = (durs[wi] if durs else {}).get(k, [])
+            dk = dk[3:] if len(dk) > 6 else dk
+            if dk:
+                per[k]["ms_per_dispatch_kernel_trace"] = round(sum(dk) / len(dk), 4)
+            if not k.startswith("xl_nco_table"):  # (the stand-alone tabulation of a fresh engine's first call: not part of a steady call)
+                total += per_call
+        per.pop(next((k for k in per if k.startswith("xl_nco_table")), None), None)
+        results[wl] = {"bytes_per_call": int(total), "per_kernel": per, "calls_profiled": ncalls, "seconds": round(time.perf_counter() - t0, 1),
+                       "correction": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM): "
+                                     "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
+                       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --replay-calls %d --replay-set %s (two passes; "
+                                  "one process per pass replays all the listed workloads) + one rocprofv3 --kernel-trace pass without counters for the "
+                                  "kernels' durations" % (PMC_REPLAY_CALLS, ",".join(workloads))}
+    return results, "measured in this run"
 
 
 # the curve this workload is EXPECTED to follow (per-GPU step times measured on one GPU; the 2 MB

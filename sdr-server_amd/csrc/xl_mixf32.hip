@@ -14,13 +14,14 @@
 // Workgroup = 4 waves = (bin m, column group of 128 clients, a run of passes); wave w = the group's columns 32 w .. 32 w + 31.
 //   B operands: the wave's branch spectra of bin m in operand form (Rf: xlmf_rf_slot), ONE float per lane and branch, read once per
 //               workgroup as 1 KB runs and kept in registers for all its passes (D <= 112; xlp_mix_f32_stream_kernel beyond).
-//   A operands: NO staging.  The forward launch's image row X[pass][b][m][0..15] (16 segments x (re, im) = 128 bytes) IS the k = 0
-//               operand in row order, and the k = 1 operand is the same line with the floats of each pair swapped and the second
-//               negated: lane (h, r) loads float r ^ h of the row and flips its sign when h & r & 1 -- one 4-byte load per lane and
-//               branch straight into the operand register (two 128-byte requests of one cache line per instruction; the four
-//               waves of a workgroup read the same lines, three of them from the CU's L1).  A branch's operand of the NEXT pass
-//               is requested right behind the instruction that consumed this pass's: D loads in flight per wave, no LDS, no
-//               barrier -- waves never wait for each other.
+//   A operands: the forward launch's image row X[pass][b][m][0..15] (16 segments x (re, im) = 128 bytes) IS the k = 0 operand in
+//               row order, and the k = 1 operand is the same line with the floats of each pair swapped and the second negated: lane
+//               (h, r) takes float r ^ h of the row and flips its sign when h & r & 1.  So the rows are staged into LDS AS THEY ARE
+//               (16 bytes per thread, a wave instruction = 8 whole rows, one pass ahead: the software pipeline of
+//               xlp_mix_mfma_kernel) and a matrix instruction's operand is one conflict-free ds_read_b32 (64 lanes, 32 distinct
+//               floats of one row) -- no conversion, no transposition.  (Round 5's first build loaded the operand straight from
+//               the image, one 4-byte load per lane and branch and no LDS: parity-equal, but 42 single-line requests per wave and
+//               pass ran the launch at 58 % of the matrix pipe's rate -- profiles/r05_mix_f32.txt; kept as -DXLMF_DIRECT.)
 // This launch never hosts the NCO role (no launch that issues matrix instructions does: DESIGN 3.6).
 #include "xl_poly_dev.h"
 
@@ -63,6 +64,93 @@ XL_DEV float xlmf_flip(const float v, const uint32_t sgn) { return __builtin_bit
 
 template <int NB8>
 __global__ __launch_bounds__(256) void xlp_mix_f32_kernel(const XlpArgs a) {
+  constexpr int NJ = 8 * NB8;
+  constexpr int ROUNDS = (NJ + 31) / 32;  // staging: 256 threads x 16 bytes = 32 image rows per round
+  // the bin's image rows of two passes, as they lie in the image: [branch][16 segments x (re, im)]
+  __shared__ __attribute__((aligned(16))) float xs[2][NJ][32];
+  const XlmfJob job = xlmf_job(a, blockIdx.x);
+  if (job.p0 >= job.p1) return;
+  const uint32_t tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+  const uint32_t M = a.M, m = job.m, cg = job.cg;
+  // ---- B operands of this wave: 2 NB8 runs of 1 KB
+  float bq[NJ];
+  {
+    const v4f32 *__restrict__ Rp = reinterpret_cast<const v4f32 *>(a.Rh);
+#pragma unroll
+    for (int jb = 0; jb < NB8; ++jb)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const v4f32 v = Rp[xlmf_rf_slot(cg, M, m, w, (uint32_t)NB8, (uint32_t)jb, (uint32_t)q, lane)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[8 * jb + 4 * q + e] = v[e];
+      }
+  }
+  // ---- staging role of this thread: 16 bytes (part) of the image rows jr, jr + 32, .. of the bin: row (pass, branch j, bin m) = 128
+  // bytes at X + ((pass Dpad + j) M + m) 128 -- a wave instruction covers 8 whole rows
+  const uint32_t D = a.D;
+  const uint32_t jr = tid >> 3, part = tid & 7u;
+  const char *__restrict__ xb = reinterpret_cast<const char *>(a.X) + (size_t)m * (XLP_XS * sizeof(float2)) + part * 16u;
+  const size_t xrow = (size_t)M * (XLP_XS * sizeof(float2));  // bytes from one branch's row of a bin to the next one's
+  v4f32 g[ROUNDS];
+  auto request = [&](const uint32_t pass) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < ROUNDS; ++q) {
+      const uint32_t j = jr + 32u * (uint32_t)q;
+      // (rows D .. Dpad - 1 of the image are zeros; beyond Dpad there is nothing to read)
+#ifdef XLMF_EXP_NOLOAD
+      g[q] = (v4f32){0.25f, -0.5f, 0.125f, 1.0f};
+#else
+      g[q] = j < D ? *reinterpret_cast<const v4f32 *>(xb + ((size_t)pass * a.Dpad + j) * xrow) : (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+#endif
+    }
+  };
+  auto stage = [&](const uint32_t buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < ROUNDS; ++q) {
+      const uint32_t j = jr + 32u * (uint32_t)q;
+      if (j < (uint32_t)NJ) *reinterpret_cast<v4f32 *>(&xs[buf][j][4u * part]) = g[q];
+    }
+  };
+  // ---- A operand of lane (h, r): float r ^ h of a row, negated when h & r & 1 (xl_mixf_layout.h)
+  const uint32_t h = lane >> 5, c = lane & 31u;
+  const uint32_t sgn = xlmf_a_negate(lane) << 31;
+  const uint32_t af = xlmf_a_float(lane);
+  // ---- Y: this lane's column of segment s
+  const uint32_t CW = M == 256u ? 16u : 32u, NSUB = XLP_COLS / CW;
+  const uint32_t col = w * 32u + c;
+  v2f *__restrict__ Yc = reinterpret_cast<v2f *>(a.Y) + ((((size_t)cg * a.nseg_cap) * NSUB + col / CW) * M + m) * CW + col % CW;
+  const size_t ystride = (size_t)NSUB * M * CW;  // v2f per segment
+  // Software pipeline (as xlp_mix_mfma_kernel): the rows of pass p + 1 go into the other buffer AFTER pass p's products and BEFORE
+  // its stores, so that the wait for them finds no store younger than pass p - 1's.
+  request(job.p0);
+  stage(0u);
+  if (job.p0 + 1u < job.p1) request(job.p0 + 1u);
+  // (the B operands are waited for HERE, once -- they were requested first, the second pass's rows stay in flight behind them: left to
+  // itself the compiler puts those waits into the pass loop, `vmcnt(5)` ahead of every pass's first products, which also waits for the
+  // rows the previous pass has just requested)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(bq[j]));
+  __syncthreads();
+  for (uint32_t pass = job.p0; pass < job.p1; ++pass) {
+    const uint32_t buf = (pass - job.p0) & 1u;
+    v16f32 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (j < NJ - 8 || (uint32_t)j < D)  // (wave-uniform; only the last k-block may be short)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xlmf_flip(xs[buf][j][af], sgn), bq[j], acc, 0, 0, 0);
+    }
+    if (pass + 1u < job.p1) stage(buf ^ 1u);
+    if (pass + 2u < job.p1) request(pass + 2u);
+    xlmf_store_pass(a, acc, Yc, ystride, pass, h);
+    __syncthreads();  // the other buffer is staged; everybody is done with this one
+  }
+}
+
+#ifdef XLMF_DIRECT  // (A/B builds only: every lane loads its A operands straight from the image, one 4-byte load per branch)
+template <int NB8>
+__global__ __launch_bounds__(256) void xlp_mix_f32_direct_kernel(const XlpArgs a) {
   constexpr int NJ = 8 * NB8;
   const XlmfJob job = xlmf_job(a, blockIdx.x);
   if (job.p0 >= job.p1) return;
@@ -122,6 +210,8 @@ __global__ __launch_bounds__(256) void xlp_mix_f32_kernel(const XlpArgs a) {
     xlmf_store_pass(a, acc, Yc, ystride, pass, h);
   }
 }
+
+#endif
 
 // Any branch count (D > 112: huge decimations, few segments per call): the B operands do not fit a wave's registers for all its
 // passes, so every pass streams them again, one k-block of 8 branches ahead of the products (they come from L2 after the first
@@ -218,7 +308,11 @@ static uint32_t xlmf_default_pp(const XlpArgs &a, uint32_t passes) {
 
 template <int NB8>
 static void xlmf_launch_n(const XlpArgs &a, const dim3 grid, hipStream_t s) {
+#ifdef XLMF_DIRECT
+  hipLaunchKernelGGL(xlp_mix_f32_direct_kernel<NB8>, grid, dim3(256), 0, s, a);
+#else
   hipLaunchKernelGGL(xlp_mix_f32_kernel<NB8>, grid, dim3(256), 0, s, a);
+#endif
 }
 
 // (called by xlp_launch_mix for mix_kind 3, with a.mix_passes set)

@@ -27,7 +27,9 @@
 #include "xl_device.h"
 
 #define XLP_M_MAX 256u  // transform length M (branch samples per segment): 256 or 128, chosen per class
+#ifndef XLP_SEG
 #define XLP_SEG 14u    // segments accumulated per lane in one pass of the mix kernel
+#endif
 #define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: XLP_SEG padded to 128 bytes
 #define XLP_COLS 128u  // client columns per column group (= one mix workgroup: a wave with two columns per lane)
 #define XLP_NKB_MAX 8u // matrix-core mix: at most 8 k-blocks of 8 branches (D <= 64)

@@ -109,6 +109,7 @@ XL_DEV void xlp_cmac_s(v2f &acc, const v2f r, const v2f x) {
       : "+v"(acc)
       : "v"(r), "s"(x));
 }
+#if XLP_SEG == 14u
 // one row of the shared-spectrum image: XLP_SEG = 14 complex values = 28 dwords, fetched by scalar loads
 typedef float v8f __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -248,6 +249,8 @@ __global__ __launch_bounds__(64) void xlp_mix_kernel(const XlpArgs a) {
       __builtin_nontemporal_store((v4f){acc0[i].x, acc0[i].y, acc1[i].x, acc1[i].y}, &Yp[(size_t)i * ystride]);
   xlp_trace_work(a, t_begin);
 }
+
+#endif  // XLP_SEG == 14
 
 // ------------------------------------------------------------------------------------------- mix on the matrix cores
 // The same sums as xlp_mix_kernel, Y[c][s][m] = sum_b X[s][b][m] R[c][b][m], as one real matrix product per bin m:
@@ -1035,9 +1038,14 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
   XlpArgs a = xlp_checked_skip(a0, work);
   a.mix_passes = passes;
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
+#if XLP_SEG == 14u
   if (a.Dpad == 7u * XLP_BSTEP) hipLaunchKernelGGL(xlp_mix_kernel<7>, grid, dim3(64), 0, s, a);
   else hipLaunchKernelGGL(xlp_mix_kernel<0>, grid, dim3(64), 0, s, a);
   return hipGetLastError();
+#else
+  (void)grid;
+  return hipErrorInvalidValue;
+#endif
 }
 
 // `done` (optional): recorded with the launch's own completion signal -- one queue packet instead of launch + event record
