@@ -457,10 +457,8 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
         host.sync()
         n3, ms3 = eng.timing_polyphase(reset=True)
         eng.timing(False)
-        if n3 > 0 and "mix=fused" in plan:
-            kernels_ms = {"xlp_forward_h_kernel": round(ms3[0] / n3, 4), "xlp_fused_kernel": round(ms3[1] / n3, 4)}
-        elif n3 > 0:
-            mix_name = "xlp_mix_mfma_kernel" if "mix=mfma" in plan else "xlp_mix_kernel"
+        if n3 > 0:
+            mix_name = "xlp_mix_mfma_kernel" if "mix=mfma" in plan else "xlp_mix_f32_kernel"
             inv_name = "xlp_inverse8_kernel" if "inv=lanes8" in plan else "xlp_inverse_kernel"
             kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), mix_name: round(ms3[1] / n3, 4), inv_name: round(ms3[2] / n3, 4)}
     feed_name = host.name
@@ -550,7 +548,7 @@ def run_config5(ctx, nclients, steps, spot=True, blocks_per_step=320, replay_cal
         n3, ms3 = eng.timing_polyphase(reset=True)
         eng.timing(False)
         if n3 > 0:
-            mix_name = {"mix=mfma": "xlp_mix_mfma_kernel", "mix=mf32": "xlp_mix_f32_kernel"}.get(next((t for t in ("mix=mfma", "mix=mf32") if t in plan), ""), "xlp_mix_kernel")
+            mix_name = "xlp_mix_mfma_kernel" if "mix=mfma" in plan else "xlp_mix_f32_kernel"
             inv_name = "xlp_inverse8_kernel" if "inv=lanes8" in plan else "xlp_inverse_kernel"
             kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), mix_name: round(ms3[1] / n3, 4), inv_name: round(ms3[2] / n3, 4)}
     eng.close()
@@ -597,7 +595,7 @@ def config5_entry(m5, pmc5):
                          "frac_hbm": round(pkk["hbm_bytes_per_call"] / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pkk and ms_k else None}
             if kname.startswith("xlp_mix") and ms_k:
                 # flops the launch EXECUTES on the matrix cores: one v_mfma_f32_32x32x2_f32 (4096 flop) per (branch, bin, 32 columns, pass)
-                passes = -(-nseg // 14)
+                passes = -(-nseg // 16)
                 pk[kname]["frac_matrix_f32"] = round(4096.0 * C5_D * M * -(-n // 32) * passes / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
                 pk[kname]["frac_fp32_useful"] = round(8.0 * n * nseg * M * C5_D / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
         rl["per_kernel"] = pk
@@ -728,8 +726,8 @@ def polyphase_traffic_model(nclients, K_call, ntaps, group, M=128, mfma=True):
     A = -(-ntaps // D)
     V = M - A + 1
     nseg = -(-(K_call + 2) // V)
-    # (packed-FMA mix: float2 per branch padded to a multiple of 6; matrix-core mix: two halves per component, 8 branches per k-block)
-    dpad = -(-D // 8) * 8 if mfma else -(-D // 6) * 6
+    # (operand-form images: 8 bytes per (branch, bin) -- two halves per component, or two float32 factors --, 8 branches per k-block)
+    dpad = -(-D // 8) * 8
     per_client = 8 * dpad * M + 2 * 8 * M * nseg + 8 * K_call + 2 * 8 * (K_call // 16)
     return {"transform_length_M": M, "blocks_per_call": group, "bytes_per_call": int(nclients * per_client),
             "bytes_per_block": int(nclients * per_client / group), "bytes_per_client_per_block": int(per_client / group),
@@ -912,6 +910,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--feed", default="c", choices=["c", "torch"], help="c: include/xlating_multi.h (C host, RCCL); torch: torch.distributed feeder")
     ap.add_argument("--replay-calls", type=int, default=0, help=argparse.SUPPRESS)  # the counter passes profile this: no timing, N calls
+    ap.add_argument("--replay-set", default="", help=argparse.SUPPRESS)  # ... of each of these workloads, back to back ("server:1024,config5:1024")
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_launch.py only
     args = ap.parse_args()
 
@@ -961,8 +960,13 @@ def main():
            "feed": args.feed}
 
     total_clients = args.clients if args.scaling == "strong" else args.clients * world
-    if args.replay_calls:  # what the counter passes profile: this workload, no timing
-        run_workload(ctx, total_clients, args.lpf_cutoff_rate, 0, 0, args.mode, replay_calls=args.replay_calls)
+    if args.replay_calls:  # what the counter passes profile: these workloads back to back, no timing
+        for wl in (args.replay_set.split(",") if args.replay_set else [f"server:{total_clients}"]):
+            kind, n = wl.split(":")
+            if kind == "config5":
+                run_config5(ctx, int(n), 0, spot=False, replay_calls=args.replay_calls)
+            else:
+                run_workload(ctx, int(n), args.lpf_cutoff_rate, 0, 0, args.mode, replay_calls=args.replay_calls)
         return
     bps = BLOCKS_PER_STEP if cuda else 64
     m = run_workload(ctx, total_clients, args.lpf_cutoff_rate, args.steps, args.warmup, args.mode,
@@ -1005,21 +1009,36 @@ def main():
                     e["parity_spot"] = mb["parity_spot"]
                     variants[f"{big} clients on this GPU (kernel-bound regime)"] = e
             if m["polyphase"] and "mix=mfma" in m["plan"]:
-                # the same path with every product formed in float32 (xlp_mix_kernel: packed FP32 FMAs instead of two-half operands
-                # on the matrix cores): the all-float32 number of this workload, every client against the oracle
-                mf = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, options={"mix_kernel": 0},
+                # the same path with every product formed in float32 (option mix_kernel = 3: float32 operands on
+                # v_mfma_f32_32x32x2_f32 -- the float32 FMA chain of xlating.c:66-71 -- instead of two-half operands): the all-float32
+                # number of this workload, every client against the oracle
+                mf = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, options={"mix_kernel": 3},
                                   spot=not args.no_spot, blocks_per_step=VB)
-                e = variant_entry(mf, "float32 operands, float32 FMAs, float32 accumulation in all three launches")
+                e = variant_entry(mf, "float32 operands, float32 FMAs (matrix cores, v_mfma_f32_32x32x2_f32), float32 accumulation in all three launches")
                 e["kernels_ms_per_call"] = mf["kernels_ms"]
                 e["parity_spot"] = mf["parity_spot"]
-                variants["polyphase, packed-FMA mix (all-float32 products)"] = e
-                # mix + inverse as ONE launch with the mixed spectra on chip (xl_fused.hip, option mix_kernel = 2): round 4's
-                # experiment, kept selectable; not the default (profiles/r04_fused_designB_counters.txt)
-                for big in (total_clients, 4096):
-                    mu = run_workload(ctx, big, args.lpf_cutoff_rate, 2, 1, args.mode, options={"mix_kernel": 2}, blocks_per_step=VB)
-                    e = variant_entry(mu, "mix + inverse fused, mixed spectra in registers: no Y round trip, but operand re-reads and low occupancy")
-                    e["kernels_ms_per_call"] = mu["kernels_ms"]
-                    variants[f"fused mix + inverse launch, {big} clients (option mix_kernel=2; not the default)"] = e
+                variants["polyphase, float32 matrix-core mix (all-float32 products)"] = e
+            if m["polyphase"] and total_clients == 1024:
+                # the inverse launch's two kernels in THIS process on THIS box, alternating (box-to-box differences
+                # are larger than the difference between them): option inverse_kernel = 5 (eight lanes per column; the default) / 3 (LDS
+                # transform on swizzled rows)
+                ab = {}
+                for big in (2048, 4096):
+                    rows = []
+                    for rnd in range(2):
+                        for inv in (5, 3):
+                            mi = run_workload(ctx, big, args.lpf_cutoff_rate, 2, 1, args.mode, options={"inverse_kernel": inv}, blocks_per_step=VB)
+                            inv_ms = next((v for k, v in (mi["kernels_ms"] or {}).items() if k.startswith("xlp_inverse")), None)
+                            rows.append({"inverse_kernel": inv, "us_per_block": round(mi["seconds"] / (mi["steps"] * mi["blocks_per_step"]) * 1e6, 3),
+                                         "inverse_launch_ms_per_call": inv_ms, "launches_ms_per_call": round(mi["call_ms_avg"], 4)})
+                    best = {inv: min(r["us_per_block"] for r in rows if r["inverse_kernel"] == inv) for inv in (5, 3)}
+                    ab[f"{big} clients"] = {"runs": rows, "best_us_per_block": best, "faster": 5 if best[5] <= best[3] else 3}
+                variants["inverse launch A/B in this process (inverse_kernel 5 = default, 3 = LDS transform)"] = ab
+                # BASELINE configs[4]: cf32 input at 10 Msps, D = 100, 257 taps (the 'HBM-roofline run'): 1024 clients, every client checked
+                m5 = run_config5(ctx, 1024, vs, spot=not args.no_spot, blocks_per_step=VB)
+                variants["config 5: cf32 10 Msps, D=100, 257 taps, 1024 clients"] = m5  # (finished below, once the counters are in)
+                # what the reference's dsp_worker does with every block: outputs delivered to host memory
+                variants["host-delivered outputs (process_host + fetch per call)"] = run_host_delivered(ctx, total_clients, args.lpf_cutoff_rate)
             if m["polyphase"]:  # the same workload through the direct FIR kernels: the FP32-bound design
                 md = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, options={"polyphase": 0}, poly3=False, blocks_per_step=VB)
                 variants[f"process_{args.mode}_cu8_cf32 through the direct FIR kernel ({md['ntaps']} taps)"] = variant_entry(
@@ -1032,35 +1051,39 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- HBM traffic of one call: counters measured now, on this box; else the committed digest, and the line says so
+    # ---- HBM traffic of one call: counters measured now, on this box; else the committed digest, and the line says so.  One rocprofv3
+    # process per counter replays the headline workload, the 2048-client variant (the regime where the launches, not the NCO recurrence,
+    # bound the call: north_star's single-GPU target reads ">= 1000 clients at >= 50 % of the rocprof-reported HBM rate") and config 5
     pmc, traffic, traffic_source, per_kernel_bytes = None, None, None, {}
+    k5 = next((k for k in variants if k.startswith("config 5")), None)
+    kb = next((k for k in variants if k.startswith("2048 clients")), None)
+    pmc_all = None
     if cuda and world == 1 and not args.no_pmc:
-        pmc, note = measure_traffic(args)
-        if pmc:
+        wls = [f"server:{total_clients}"] + ([f"server:2048"] if kb and args.clients == 1024 else []) + (["config5:1024"] if k5 else [])
+        pmc_all, note = measure_traffic(args, wls)
+        if pmc_all:
+            pmc = pmc_all[wls[0]]
             traffic, traffic_source = pmc["bytes_per_call"], note
             per_kernel_bytes = {k: v["hbm_bytes_per_call"] for k, v in pmc["per_kernel"].items()}
         else:
             traffic_source = f"in-run counter passes failed ({note}); "
-    # the same measurement for the 2048-client variant: the regime where the launches, not the NCO recurrence, bound the call --
-    # north_star's single-GPU target reads ">= 1000 clients at >= 50 % of the rocprof-reported HBM rate"
-    if pmc and args.clients == 1024 and world == 1:
-        import copy
-        kb = next((k for k in variants if k.startswith("2048 clients")), None)
-        if kb is not None and variants[kb].get("launches_ms_per_call"):
-            a2 = copy.copy(args)
-            a2.clients = 2048
-            pmc2, note2 = measure_traffic(a2)
-            if pmc2:
-                ms2 = variants[kb]["launches_ms_per_call"]
-                gbs2 = pmc2["bytes_per_call"] / (ms2 * 1e-3) / 1e9
-                variants[kb]["roofline"] = {"bound": "hbm", "achieved": round(gbs2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": round(gbs2 / HBM_PEAK_GBS, 4), "traffic": pmc2["bytes_per_call"],
-                                            "traffic_source": note2, "kernel_ms": ms2,
-                                            "frac_is": "HBM bytes of one call's launches by the PMC counters (measured in this run, 2048 clients) / "
-                                                       "the HIP-event duration of those launches in this variant's timed region / peak",
-                                            "per_kernel_bytes": {k: v["hbm_bytes_per_call"] for k, v in pmc2["per_kernel"].items()}}
-            else:
-                variants[kb]["roofline"] = {"traffic": None, "traffic_source": f"counter passes failed ({note2})"}
+    if kb is not None and variants[kb].get("launches_ms_per_call") and args.clients == 1024 and world == 1 and cuda and not args.no_pmc:
+        pmc2 = (pmc_all or {}).get("server:2048")
+        if pmc2:
+            ms2 = variants[kb]["launches_ms_per_call"]
+            gbs2 = pmc2["bytes_per_call"] / (ms2 * 1e-3) / 1e9
+            shared2 = 2048 * S * GROUP * (2.0 / 2048 + 8.0 / D)
+            variants[kb]["roofline"] = {"bound": "hbm", "achieved": round(gbs2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(gbs2 / HBM_PEAK_GBS, 4), "traffic": pmc2["bytes_per_call"],
+                                        "frac_algorithmic_shared": round(shared2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "traffic_source": "measured in this run", "kernel_ms": ms2,
+                                        "frac_is": "HBM bytes of one call's launches by the PMC counters (measured in this run, 2048 clients) / "
+                                                   "the HIP-event duration of those launches in this variant's timed region / peak",
+                                        "per_kernel_bytes": {k: v["hbm_bytes_per_call"] for k, v in pmc2["per_kernel"].items()}}
+        else:
+            variants[kb]["roofline"] = {"traffic": None, "traffic_source": "counter passes failed"}
+    if k5 is not None:
+        variants[k5] = config5_entry(variants[k5], (pmc_all or {}).get("config5:1024"))
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if traffic is None and os.path.exists(pmc_path) and world == 1 and args.clients == 1024:
         try:
@@ -1084,7 +1107,11 @@ def main():
     ach = phys_bytes / call_s / 1e9 if phys_bytes and call_s > 0 else 0.0
     roofline = {
         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+        "frac": round(ach / HBM_PEAK_GBS, 4),
+        # the USEFUL fraction: SURVEY 8(d)'s shared-read algorithmic bytes (2/N B in + 8/D B out per (client, sample): the block read
+        # once per GPU, every output written once) over the same launch time -- what `frac` would be if the path moved nothing else
+        "frac_algorithmic_shared": round(nloc * S * m["group"] * (2.0 / max(nloc, 1) + 8.0 / D) / call_s / 1e9 / HBM_PEAK_GBS, 4) if call_s > 0 else None,
+        "traffic": traffic, "traffic_source": traffic_source,
         "counter_scope": COUNTER_SCOPE,
         "frac_is": ("HBM bytes of one call's launches by the PMC counters / the HIP-event duration of those launches / peak" if traffic else
                     "NO counter value available: bytes the path moves by design (design_traffic) / launch duration / peak"),
@@ -1110,15 +1137,15 @@ def main():
         M = tm["transform_length_M"]
         nseg = -(-(m["K_call"] + 2) // (M - A + 1))
         lg = 7 if M == 128 else 8
-        flops = {"xlp_forward_kernel": 5.0 * M * lg * D * nseg, "xlp_mix_kernel": 8.0 * nloc * nseg * M * D,
+        flops = {"xlp_forward_kernel": 5.0 * M * lg * D * nseg, "xlp_mix_f32_kernel": 8.0 * nloc * nseg * M * D,
                  "xlp_mix_mfma_kernel": 8.0 * nloc * nseg * M * D,
                  "xlp_inverse_kernel": nloc * nseg * (5.0 * M * lg + 8.0 * (M - A + 1))}
         flops["xlp_inverse8_kernel"] = flops["xlp_inverse_kernel"]
         # matrix-core mix: half-precision flops the launch EXECUTES = 3 products x (32 rows x 32 columns x 16 k x 2) per k-block of
-        # 8 branches, per (bin, 32 columns, pass of 14 segments in 32 rows)
-        mfma_flops = 3.0 * 32 * 32 * 16 * 2 * -(-D // 8) * M * -(-nloc // 32) * -(-nseg // 14)
+        # 8 branches, per (bin, 32 columns, pass of 16 segments = 32 rows)
+        mfma_flops = 3.0 * 32 * 32 * 16 * 2 * -(-D // 8) * M * -(-nloc // 32) * -(-nseg // 16)
         binding = {"xlp_forward_kernel": "latency (a few % of the call; shared by all clients)",
-                   "xlp_mix_kernel": "fp32 vector issue: 2 packed FMAs per complex MAC, D per (client, bin, segment)",
+                   "xlp_mix_f32_kernel": "fp32 matrix pipe (v_mfma_f32_32x32x2_f32, one per (branch, bin, 32 columns, pass): the FP32 rate of the chip)",
                    "xlp_mix_mfma_kernel": "hbm (writes the mixed spectra once, reads the operand-form branch spectra once); the products run on the "
                                           "matrix cores as two-term half-precision splits (3 v_mfma_f32_32x32x16_f16 per 8 branches)",
                    "xlp_inverse_kernel": "hbm (reads the mixed spectra, writes the outputs)"}
@@ -1150,7 +1177,7 @@ def main():
                                          "concurrent with the three launches; bounds the engine below ~1500 clients",
                                          "note": "bytes per CALL, ms per LAUNCH (one launch tabulates the phase tables of four calls); in the timed region a "
                                                  "call cannot be shorter than a quarter of a chain launch, so that launch is at most 4 x call_period_ms"}
-        roofline["kernel"] = ("xlp_forward_kernel + " + ("xlp_mix_mfma_kernel" if "mix=mfma" in m["plan"] else "xlp_mix_kernel") + " + " + next((k for k in (m["kernels_ms"] or {}) if k.startswith("xlp_inverse")), "xlp_inverse_kernel") + ": the three launches of one call on the polyphase "
+        roofline["kernel"] = ("xlp_forward_kernel + " + ("xlp_mix_mfma_kernel" if "mix=mfma" in m["plan"] else "xlp_mix_f32_kernel") + " + " + next((k for k in (m["kernels_ms"] or {}) if k.startswith("xlp_inverse")), "xlp_inverse_kernel") + ": the three launches of one call on the polyphase "
                               "overlap-save path (the next call's NCO phase recurrence runs beside them on a side stream)")
         roofline["per_kernel"] = pk
         roofline["per_kernel_note"] = ("ms: the kernel's own duration from a rocprofv3 --kernel-trace pass of this run over `bench.py --replay-calls` -- a "
@@ -1169,14 +1196,14 @@ def main():
                             "frac": round(ach_tf / FP32_PEAK_TFLOPS, 4), "flop_per_unit": round(fpu, 2)}
 
     # the numbers of this workload whose every product is a float32 product, next to the headline (whose mix launch multiplies two-half
-    # operands): bit-exact native, optimized through the direct FMA kernel, optimized polyphase with the packed-FMA mix
+    # operands): bit-exact native, optimized through the direct FMA kernel, optimized polyphase with float32 operands in the mix launch
     def pick(prefix):
         k = next((k for k in variants if k.startswith(prefix)), None)
         return None if k is None else {kk: variants[k].get(kk) for kk in ("value", "us_per_block", "parity_spot") if variants[k].get(kk) is not None}
     all_f32 = {"native (bit-exact, direct kernel: the server default NATIVE_CF32)": None if native is None else
                {"value": native["value"], "us_per_block": native["us_per_block"], "parity_spot": native.get("parity_spot")},
                "optimized, direct FMA kernel": pick(f"process_{args.mode}_cu8_cf32 through the direct FIR kernel"),
-               "optimized, polyphase with the packed-FMA mix": pick("polyphase, packed-FMA mix")}
+               "optimized, polyphase with the float32 matrix-core mix": pick("polyphase, float32 matrix-core mix")}
     # N > 1: both ways to use the GPUs, fully populated (the headline is one of them)
     multi_gpu = None
     if world > 1:

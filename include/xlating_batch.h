@@ -64,54 +64,31 @@ int xlating_batch_create(uint32_t sampling_freq, int input_format, uint32_t max_
 int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint32_t max_input_buffer_length,
                                  unsigned max_group_blocks, int device, xlating_batch **batch);
 
-/* Plan options (result-neutral: every setting passes the same parity tests).  name / value:
- *   "polyphase"             -1 by the size rule (default), 0 never, 1 whenever the shape allows: which classes take the
- *                           polyphase overlap-save path in XL_MODE_OPTIMIZED
- *   "polyphase_m"           0 by the size rule, 128, 256: its transform length
- *   "polyphase_min_clients" smallest class that takes it under the size rule (default: 32 where the class's mix launch runs
- *                           on the matrix cores -- see "mix_kernel" --, 128 elsewhere; a given value holds for every class)
- *   "riders" 0/1, "riders_min_workgroups" n, "tile_height" 0/8/9/10/12, "nco_slices" (a << 16 | b): launch shaping
- *   "nco_side_stream"       -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light, and one-block
- *                           polyphase calls of up to 2048 clients -- of any size with "mix_kernel" 2), 0 never, 1
- *                           always: the NCO phase recurrence of the following calls runs as a kernel of its own on a side
- *                           stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE)
- *   "expected_clients"      0 (default) .. 8192: the CUs of that side kernel are reserved for this many clients from the
- *                           first plan on (64 clients per CU), not for the clients joined so far -- the reservation then never
- *                           grows while clients join up to that number (growing it re-creates two streams: ~25 ms, once per
- *                           512 clients); until then the launches run on correspondingly fewer CUs
- *   "nco_calls_per_launch"  1..4 (default 4): calls of the same shape one such kernel tabulates ahead
- *   "inverse_kernel"        128-point polyphase classes: the inverse launch's transform -- in the registers of EIGHT lanes per
- *                           client column as 16 x 8 points with one exchange through LDS (5, default: xl_inv8.hip), staged in
- *                           LDS on padded rows (0) or on dense XOR-swizzled rows (3, round 3's default, still what 48-bit Y takes;
- *                           4: built for five workgroups per CU), or in the registers of a lane pair (1) / lane quad (2) per
- *                           client column with one LDS pass for the stores
- *   "inverse_persistent"    0 (default) .. 8: the 8-lane inverse launch as that many workgroups per CU that walk the tiles, the next
- *                           tile requested while the current one is transformed and stored (branch-free epilogue: points that are
- *                           nobody's output go to a dump address).  Same results; measured 8-16 % slower than one workgroup per
- *                           tile on an MI355X (profiles/r04_inverse8.txt): an option, not the default (a launch parameter, no re-plan)
- *   "mix_kernel"            polyphase classes: the mix launch (spectra x branch spectra, summed over the branches).  1 (default): on
- *                           the matrix cores -- classes of an integer input format with decimation <= 64 carry every float32
- *                           operand as two halves (three v_mfma_f32_32x32x16_f16 per 8 branches, FP32 accumulation), every other
- *                           class (cf32 input, decimation > 64) multiplies float32 operands (v_mfma_f32_32x32x2_f32: exactly the
- *                           float32 FMA chain, nothing split or scaled); 3: float32 operands on the matrix cores for EVERY class --
- *                           the all-float32 arithmetic of the path; 0: packed FP32 FMAs on the vector ALUs for every class (the
- *                           same chain, slower); 2: mix + inverse as ONE launch with the mixed spectra kept in registers
- *                           (xl_fused.hip; integer input, decimation <= 64, up to 64 taps per branch; slower than the three
- *                           launches on an MI355X -- DESIGN.md 3.5 -- and kept as an option).  Same 1e-5 bar in every case
- *   "y_format"              0 (default) / 1: the mixed spectra between the mix and the inverse launch as float32 pairs, or as
- *                           48-bit values (one shared 6-bit exponent + two 21-bit mantissas per complex value: a quarter less of
- *                           the path's largest stream) where the mix runs on the matrix cores and the inverse transform is staged in
- *                           LDS.  1 adds <= 7e-7 of max|y| (tests/test_y6_model.py; same 1e-5 bar) and moves 16 % fewer bytes per
- *                           call, but measured 10 % slower on an MI355X (profiles/r04_y48.txt): an option, not the default
- *   "pipeline_calls"        0 (default) / 1: an engine created for ONE block per call (xlating_batch_create) that is driven
- *                           through XL_STREAM_ENGINE alternates its optimized polyphase calls between two compute streams it
- *                           owns; only the calls' forward launches are ordered against each other, so that call k + 1 may
- *                           start beside call k's inverse launch (same results; xlating_batch_sync waits for both streams).
- *                           Off by default: a dependency between two HIP streams costs more than the overlap gains
- *                           (profiles/r04_one_block_pipelining.txt)
- *   "mix_passes_per_workgroup"  matrix-core mix: passes of 14 segments one workgroup runs with its operands in registers
- *                           (0 = default 16; a launch parameter, no re-plan)
- * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call. */
+/* Plan options (result-neutral: every setting passes the same parity tests).  Six of them; name / value:
+ *   "polyphase"         -1 by the size rule (default: classes of >= 32 clients with >= 2 taps per polyphase branch), 0 never, 1
+ *                       whenever the shape allows: which classes take the polyphase overlap-save path in XL_MODE_OPTIMIZED
+ *   "polyphase_m"       0 by the size rule, 128, 256: its transform length
+ *   "mix_kernel"        polyphase classes: the mix launch (spectra x branch spectra, summed over the branches) runs on the matrix
+ *                       cores.  1 (default): classes of an integer input format with decimation <= 64 carry every float32 operand as
+ *                       two halves (three v_mfma_f32_32x32x16_f16 per 8 branches, FP32 accumulation; as accurate as the float32 FMA
+ *                       chain), every other class (cf32 input, decimation > 64) multiplies float32 operands (v_mfma_f32_32x32x2_f32:
+ *                       exactly the float32 FMA chain, nothing split or scaled); 3: float32 operands for EVERY class -- the
+ *                       all-float32 arithmetic of the path, ~40 % slower in the mix launch.  Same 1e-5 bar in both cases
+ *   "inverse_kernel"    128-point polyphase classes: the inverse launch's transform -- in the registers of EIGHT lanes per client
+ *                       column as 16 x 8 points with one exchange through LDS (5, default: xl_inv8.hip), or staged in LDS on dense
+ *                       XOR-swizzled rows (3: round 3's default; within 2 % on 8-block calls, 7 % behind on one-block calls)
+ *   "nco_side_stream"   -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light, and one-block polyphase
+ *                       calls of up to 2048 clients), 0 never, 1 always: the NCO phase recurrence of the following calls runs as a
+ *                       kernel of its own on a side stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE) instead of
+ *                       riding inside the call's launches
+ *   "expected_clients"  0 (default) .. 8192: the CUs of that side kernel are reserved for this many clients from the first plan on
+ *                       (64 clients per CU), not for the clients joined so far -- the reservation then never grows while clients
+ *                       join up to that number (growing it re-creates two streams: ~25 ms, once per 512 clients); until then the
+ *                       launches run on correspondingly fewer CUs
+ * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call.
+ * (Launch-shaping knobs of the tuning sessions -- tile heights, riders, slices, passes per workgroup, calls per chain launch, the
+ * size rule's client threshold -- are not options: they are read from XL_EXP_* environment variables when an engine is created,
+ * csrc/xl_batch.cpp; rounds 1-4's measured-and-lost kernel variants are gone from the library: tools/experiments/retired/.) */
 int xlating_batch_set_option(xlating_batch *batch, const char *name, long value);
 
 /* Add a client whose stream starts with the NEXT block (like dsp_worker_start, dsp_worker.c:90-108).

@@ -42,7 +42,6 @@
 #include "../../include/xlating_batch.h"
 #include "xl_common.h"
 #include "xl_device.h"
-#include "xl_fused_layout.h"
 #include "xl_mixf_layout.h"
 #include "xl_polyphase.h"
 #include "xl_taps.h"
@@ -116,21 +115,15 @@ struct PolyClass {
   std::map<int, uint32_t> col_of;     // client id -> column
   uint32_t ncg_cap = 0;               // column groups the R / Y / cols buffers hold
   bool keep = false;                  // (planning scratch: the class was taken over by the new plan)
-  float2 *d_R = nullptr;     // branch spectra [ncg][M][Dpad][128] (+ XLP_BSTEP rows of tail padding); mix_kind 0
-  // mix_kind 1 (the mix launch on the matrix cores, xlp_mix_mfma_kernel): the spectra scaled per column by a power of two and
-  // split in two halves, in the kernel's operand order, instead of d_R; per column the scale (host) and what undoes it (device)
-  // mix_kind 2 (mix + inverse as one launch, xl_fused.hip): the same in THAT launch's operand order (xl_fused_layout.h), the
-  // shared spectra d_X in its A-operand form, and no Y image at all
-  uint32_t mix_kind = 0, nkb = 0;
+  // The branch spectra live in the mix launch's B-operand order (d_Rh).  mix_kind 1 (xlp_mix_mfma_kernel): scaled per column by a power
+  // of two and split in two halves; per column the scale (host) and what undoes it (device).  mix_kind 3 (xlp_mix_f32_kernel): float32
+  uint32_t mix_kind = 1, nkb = 0;
   void *d_Rh = nullptr;
   std::vector<float> col_scale;
   float *d_cscale = nullptr;
-  float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]; mix_kind 2: operand form (xlf_xh_slot)
-  float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]; mix_kind 2: none
+  float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
+  float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
   XlpCol *d_cols = nullptr;  // per column: output row, grid offset, NCO increment
-  // engines of one block per call (the reference's call granularity): a second set of the per-call images, so that consecutive
-  // calls may overlap (xl_batch_run: pipelined one-block calls); null otherwise
-  float2 *d_X2 = nullptr, *d_Y2 = nullptr;
 };
 
 }  // namespace
@@ -156,16 +149,6 @@ struct xlating_batch_t {
   // mask of `reserve_r` CUs per XCD (mask bit b = XCD b % 8, CU b / 8 of it; tools/ubench_cumask.hip) and the engine's
   // own compute stream for side-stream calls, cs_masked, with the complement.  Callers that pass XL_STREAM_ENGINE get it.
   hipStream_t cs_masked = nullptr;
-  // Pipelined one-block calls (option "pipeline_calls", default OFF: correct, but slower on this runtime): an engine created for one block per call alternates its
-  // polyphase calls between cs_masked and cs_masked2 (same CU mask).  A one-block call is three short, latency-bound launches
-  // (small grids, a tail round, launch gaps); call k+1's forward and mix launches run beside call k's inverse launch.  Only the
-  // forward launches are ordered against each other (raw history, ev_fwd); the per-call images X and Y exist twice.
-  hipStream_t cs_masked2 = nullptr;
-  hipEvent_t ev_fwd[2] = {nullptr, nullptr};  // behind the forward launch of the latest pipelined call on cs_masked / cs_masked2
-  hipEvent_t dep_ev2 = nullptr;
-  bool last_piped = false;            // the latest call was pipelined: BOTH compute streams may hold work
-  hipStream_t piped_other = nullptr;  // ... the stream of the call before it
-  int pipeline_calls = 0;  // (measured slower: cross-stream event waits cost this runtime tens of us -- profiles/r04_one_block_pipelining.txt)
   hipStream_t last_nco = nullptr;    // the side stream of the latest chain launch
   unsigned long long *d_chain_stats = nullptr;  // tuning (XL_EXP_CHAIN_STATS): per chain workgroup cycles / ticks of the latest launch
   hipStream_t nco_masked = nullptr;  // the side stream that goes with cs_masked; nco_stream (unmasked) serves callers' own streams
@@ -218,34 +201,22 @@ struct xlating_batch_t {
   size_t phase_run_cap = 0;
   int poly_mode = -1;        // option "polyphase": 0 never, 1 whenever the shape allows, -1 (default) by the size rule
   bool poly_min_set = false;        // "polyphase_min_clients" was given: it holds for every class (else 32 where the mix runs on the matrix cores)
-  uint32_t poly_min_clients = 128;  // measured at 505 taps, D = 42: x1.10 at 128 clients, x0.96 at 64 (profiles/r01_polyphase_vs_direct.txt)
+  uint32_t poly_min_clients = 32;   // XL_EXP_POLY_MIN (tuning): smallest class that takes the polyphase path under the size rule
   uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
-  uint32_t inv_persist = 0;   // option "inverse_persistent": work workgroups per CU of the persistent form of the 8-lane inverse launch (0 = off)
   int num_cus = 256;
   uint32_t inv_reg = 5;       // option "inverse_kernel", M = 128 classes: 5 = eight lanes per column, 16- and 8-point transforms in registers
-                              // (default since round 4: xl_inv8.hip; -2 to -7 % where the launches bind, profiles/r04_inverse8.txt); 0 = LDS
-                              // transform on padded rows (round 2), 3 = on dense rows with an XOR swizzle (round 3's default; what 48-bit Y
-                              // takes), 4 = the same at five workgroups per CU (no gain), 1 / 2 = transform in registers of a lane pair /
-                              // quad (fewer instructions and LDS cycles, 25-30 % slower: profiles/r03_inverse_reg_vs_lds.txt)
-  uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = the mix launch on the matrix cores: two-half float16 operands where the class
-                              // allows them (integer input format, D <= 64), float32 operands everywhere else (cf32 input, D > 64);
-                              // 3 = float32 operands on the matrix cores for every class (the all-float32 arithmetic of the path);
-                              // 0 = packed FP32 FMAs everywhere, 2 = mix + inverse as ONE launch with the mixed spectra
-                              // on chip (xl_fused.hip) where the class allows it (integer input, D <= 64, <= 64 taps per branch)
-  uint32_t y_format = 0;      // option "y_format": 1 = the mixed spectra Y as 48-bit values (xl_y6.h: shared exponent, two 21-bit mantissas)
-                              // where the class's mix launch runs on the matrix cores and the inverse launch stages its transform in
-                              // LDS ("inverse_kernel" 0 / 3 / 4); 0 (default) = float32 pairs.  Measured (profiles/r04_y48.txt): 16 %
-                              // fewer bytes per call, 10 % MORE time at 2048 - 4096 clients -- the encoding costs the mix launch more
-                              // vector instructions than the bytes buy
-  uint32_t mix_pp = 0;        // option "mix_passes_per_workgroup" (matrix-core mix): 0 = the launcher's default
-  uint32_t mix_skip_at = 0;   // position of the mix launch's skipped workgroups; 0 = 1024
+                              // (xl_inv8.hip; default since round 4), 3 = staged in LDS on dense rows with an XOR swizzle (round 3's
+                              // default).  The two are within 2 % of each other on 8-block calls (profiles/r05_inverse_ab_same_box.txt;
+                              // bench.py runs both in its process), 5 is 7 % ahead on one-block calls (profiles/r04_inverse8.txt)
+  uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = two-half float16 operands on the matrix cores where the class allows them
+                              // (integer input format, D <= 64), float32 operands on the matrix cores everywhere else (cf32 input,
+                              // D > 64); 3 = float32 operands for every class (the all-float32 arithmetic of the path)
+  uint32_t mix_pp = 0;        // XL_EXP_MIX_PP (tuning): passes per workgroup of the mix launch; 0 = the launcher's default
   uint32_t inv_skip_at = 256;  // inverse launch (4-wave workgroups, dealt per CU): one workgroup slot kept empty on the chain CUs
   uint32_t poly_exp = 0;     // XL_TUNING builds: tuning switches of the mix kernel
-  uint32_t poly_slice1 = 8000, poly_slice2 = 50000;  // NCO slice boundaries in 1/65536 of the call (forward | mix | inverse)
-  uint32_t poly_slice1_m = 6000, poly_slice2_m = 35000;  // (round 3: ... of classes whose mix launch ran the role too; kept for the option's sake)
-  uint32_t poly_slice_fi = 20000;  // classes whose mix launch runs on the matrix cores: TWO slices, forward | inverse (the inverse launch is
-                                   // the longer one: 31 % | 69 % keeps both slices inside their launches at 4096 clients with the
-                                   // scalar role step)
+  uint32_t poly_slice_fi = 20000;  // NCO role inside the launches: TWO slices, forward | inverse, boundary in 1/65536 of the call (no launch
+                                   // that issues matrix instructions hosts the role; the inverse launch is the longer one: 31 % | 69 %
+                                   // keeps both slices inside their launches at 4096 clients with the scalar role step)
   std::vector<XlNcoClient> nco;
   size_t out_total = 0;
   uint64_t ncalls = 0;  // calls processed
@@ -329,9 +300,7 @@ static void xl_batch_sync_all(xlating_batch *b) {
   if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
   if (b->nco_stream) (void)hipStreamSynchronize(b->nco_stream);
   if (b->cs_masked) (void)hipStreamSynchronize(b->cs_masked);
-  if (b->cs_masked2) (void)hipStreamSynchronize(b->cs_masked2);
   if (b->nco_masked) (void)hipStreamSynchronize(b->nco_masked);
-  b->last_piped = false;
 }
 
 // A plan buffer of at least `bytes`: the smallest spare one that fits (and is not more than twice too big), else a fresh
@@ -370,9 +339,9 @@ static void xl_plan_trim(xlating_batch *b) {
 }
 
 static void xl_poly_release(xlating_batch *b, PolyClass &pc) {
-  void *dev[] = {pc.d_R, pc.d_X, pc.d_Y, pc.d_cols, pc.d_Rh, pc.d_cscale, pc.d_X2, pc.d_Y2};
+  void *dev[] = {pc.d_X, pc.d_Y, pc.d_cols, pc.d_Rh, pc.d_cscale};
   for (void *q : dev) xl_plan_release(b, q);
-  pc.d_R = pc.d_X = pc.d_Y = pc.d_X2 = pc.d_Y2 = nullptr;
+  pc.d_X = pc.d_Y = nullptr;
   pc.d_cols = nullptr;
   pc.d_Rh = nullptr;
   pc.d_cscale = nullptr;
@@ -433,19 +402,45 @@ extern "C" void xlating_batch_destroy(xlating_batch *b) {
   for (hipEvent_t e : b->ev_poly) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
   if (b->dep_ev) (void)hipEventDestroy(b->dep_ev);
-  if (b->dep_ev2) (void)hipEventDestroy(b->dep_ev2);
-  for (hipEvent_t e : b->ev_fwd)
-    if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_chain)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->ev_done)
     if (e) (void)hipEventDestroy(e);
   if (b->nco_stream) (void)hipStreamDestroy(b->nco_stream);
   if (b->cs_masked) (void)hipStreamDestroy(b->cs_masked);
-  if (b->cs_masked2) (void)hipStreamDestroy(b->cs_masked2);
   if (b->nco_masked) (void)hipStreamDestroy(b->nco_masked);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
+}
+
+// Tuning knobs that are not part of the documented option set: reachable through XL_EXP_* environment variables read at create
+// (tests and tools force a path this way; all of them are result-neutral within the parity bars)
+static int xl_batch_set_tuning(xlating_batch *b, const std::string &n, long value) {
+  if (n == "polyphase_min_clients") {
+    if (value < 1) return -EINVAL;
+    b->poly_min_clients = (uint32_t)value;
+    b->poly_min_set = true;
+  } else if (n == "mix_passes_per_workgroup") {
+    if (value < 0 || value > 64) return -EINVAL;
+    b->mix_pp = (uint32_t)value;
+  } else if (n == "riders") {
+    b->riders = value != 0;
+  } else if (n == "riders_min_workgroups") {
+    b->riders_min_wgs = (int)value;
+  } else if (n == "tile_height") {
+    if (value != 0 && value != 8 && value != 9 && value != 10 && value != 12) return -EINVAL;
+    b->exp_h = (int)value;
+  } else if (n == "nco_calls_per_launch") {
+    if (value < 1 || value > (long)XL_CHAIN_MAXCALLS) return -EINVAL;
+    b->chain_calls = (int)value;
+  } else if (n == "nco_slice") {  // forward | inverse boundary of the in-launch NCO role, in 1/65536 of a call
+    if (value < 0 || value > 65536) return -EINVAL;
+    b->poly_slice_fi = (uint32_t)value;
+  } else {
+    return -ENOENT;
+  }
+  b->dirty = true;
+  return 0;
 }
 
 extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long value) {
@@ -458,52 +453,17 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     if (value != 0 && value != 128 && value != 256) return -EINVAL;
     b->poly_m = (uint32_t)value;
   } else if (n == "inverse_kernel") {
-    if (value < 0 || value > 5) return -EINVAL;
+    if (value != 3 && value != 5) return -EINVAL;
     b->inv_reg = (uint32_t)value;
-  } else if (n == "inverse_persistent") {
-    if (value < 0 || value > 8) return -EINVAL;
-    b->inv_persist = (uint32_t)value;
-    return 0;  // (a launch parameter: no re-plan)
   } else if (n == "mix_kernel") {
-    if (value < 0 || value > 3) return -EINVAL;
+    if (value != 1 && value != 3) return -EINVAL;
     b->mix_kernel = (uint32_t)value;
-  } else if (n == "y_format") {
-    if (value < 0 || value > 1) return -EINVAL;
-    b->y_format = (uint32_t)value;
-    return 0;  // (a launch parameter: Y is rewritten by every call)
   } else if (n == "expected_clients") {
     if (value < 0 || value > 8192) return -EINVAL;
     b->expected_clients = (uint32_t)value;
-  } else if (n == "pipeline_calls") {
-    if (value < 0 || value > 1) return -EINVAL;
-    b->pipeline_calls = (int)value;
-  } else if (n == "mix_passes_per_workgroup") {
-    if (value < 0 || value > 64) return -EINVAL;
-    b->mix_pp = (uint32_t)value;
-    return 0;  // (a launch parameter: no re-plan)
-  } else if (n == "polyphase_min_clients") {
-    if (value < 1) return -EINVAL;
-    b->poly_min_clients = (uint32_t)value;
-    b->poly_min_set = true;
-  } else if (n == "riders") {
-    b->riders = value != 0;
-  } else if (n == "riders_min_workgroups") {
-    b->riders_min_wgs = (int)value;
-  } else if (n == "tile_height") {
-    if (value != 0 && value != 8 && value != 9 && value != 10 && value != 12) return -EINVAL;
-    b->exp_h = (int)value;
-  } else if (n == "nco_calls_per_launch") {
-    if (value < 1 || value > (long)XL_CHAIN_MAXCALLS) return -EINVAL;
-    b->chain_calls = (int)value;
   } else if (n == "nco_side_stream") {
     if (value < -1 || value > 1) return -EINVAL;
     b->nco_side = (int)value;
-  } else if (n == "nco_slices") {  // value = slice1 * 65536 + slice2, both in 1/65536 of a call
-    b->poly_slice1 = (uint32_t)((value >> 16) & 0xFFFF);
-    b->poly_slice2 = (uint32_t)(value & 0xFFFF);
-    if (b->poly_slice1 > b->poly_slice2) return -EINVAL;
-    b->poly_slice1_m = b->poly_slice1, b->poly_slice2_m = b->poly_slice2;
-    b->poly_slice_fi = b->poly_slice2;
   } else {
     return -ENOENT;
   }
@@ -537,8 +497,6 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
     XL_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     if (hipDeviceGetAttribute(&b->num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || b->num_cus <= 0) b->num_cus = 256;
     XL_TRY(hipEventCreateWithFlags(&b->dep_ev, hipEventDisableTiming));
-    XL_TRY(hipEventCreateWithFlags(&b->dep_ev2, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) XL_TRY(hipEventCreateWithFlags(&b->ev_fwd[i], hipEventDisableTiming));
     XL_TRY(hipStreamCreateWithFlags(&b->nco_stream, hipStreamNonBlocking));
     for (int i = 0; i < XL_NTAB; ++i) {
       XL_TRY(hipEventCreateWithFlags(&b->ev_chain[i], hipEventDisableTiming));
@@ -554,23 +512,24 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
   }
   // Result-neutral plan options may also come from the environment (tests and tools force a path this way); the
   // switches that trace launches or break results exist in -DXL_TUNING builds only (tools/experiments/).
-  if (getenv("XL_EXP_H")) (void)xlating_batch_set_option(b, "tile_height", atol(getenv("XL_EXP_H")));
-  if (getenv("XL_EXP_RIDERS")) (void)xlating_batch_set_option(b, "riders", atol(getenv("XL_EXP_RIDERS")));
-  if (getenv("XL_EXP_RIDERS_MIN")) (void)xlating_batch_set_option(b, "riders_min_workgroups", atol(getenv("XL_EXP_RIDERS_MIN")));
-  if (getenv("XL_EXP_POLY")) (void)xlating_batch_set_option(b, "polyphase", atol(getenv("XL_EXP_POLY")));
-  if (getenv("XL_EXP_POLY_M")) (void)xlating_batch_set_option(b, "polyphase_m", atol(getenv("XL_EXP_POLY_M")));
-  if (getenv("XL_EXP_POLY_MIN")) (void)xlating_batch_set_option(b, "polyphase_min_clients", atol(getenv("XL_EXP_POLY_MIN")));
-  if (getenv("XL_EXP_INV")) (void)xlating_batch_set_option(b, "inverse_kernel", atol(getenv("XL_EXP_INV")));
-  if (getenv("XL_EXP_INV_PERSIST")) (void)xlating_batch_set_option(b, "inverse_persistent", atol(getenv("XL_EXP_INV_PERSIST")));
-  if (getenv("XL_EXP_MIX")) (void)xlating_batch_set_option(b, "mix_kernel", atol(getenv("XL_EXP_MIX")));
-  if (getenv("XL_EXP_Y6")) (void)xlating_batch_set_option(b, "y_format", atol(getenv("XL_EXP_Y6")));
-  if (getenv("XL_EXP_MIX_PP")) (void)xlating_batch_set_option(b, "mix_passes_per_workgroup", atol(getenv("XL_EXP_MIX_PP")));
+  {
+    static const struct {
+      const char *env, *opt;
+      bool documented;
+    } knobs[] = {{"XL_EXP_POLY", "polyphase", true},          {"XL_EXP_POLY_M", "polyphase_m", true},
+                 {"XL_EXP_INV", "inverse_kernel", true},      {"XL_EXP_MIX", "mix_kernel", true},
+                 {"XL_EXP_NCO_SIDE", "nco_side_stream", true}, {"XL_EXP_EXPECTED", "expected_clients", true},
+                 {"XL_EXP_POLY_MIN", "polyphase_min_clients", false}, {"XL_EXP_MIX_PP", "mix_passes_per_workgroup", false},
+                 {"XL_EXP_H", "tile_height", false},          {"XL_EXP_RIDERS", "riders", false},
+                 {"XL_EXP_RIDERS_MIN", "riders_min_workgroups", false}, {"XL_EXP_CHAIN_CALLS", "nco_calls_per_launch", false},
+                 {"XL_EXP_NCO_SLICE", "nco_slice", false}};
+    for (const auto &k : knobs)
+      if (const char *v = getenv(k.env)) {
+        const int rc = k.documented ? xlating_batch_set_option(b, k.opt, atol(v)) : xl_batch_set_tuning(b, k.opt, atol(v));
+        if (rc != 0) XL_LOG_ERR("%s=%s is not a value of \"%s\" (ignored)", k.env, v, k.opt);
+      }
+  }
   if (getenv("XL_EXP_CHAIN_STATS")) (void)hipMalloc((void **)&b->d_chain_stats, 4096 * 4 * sizeof(unsigned long long));
-  if (getenv("XL_EXP_NCO_SIDE")) (void)xlating_batch_set_option(b, "nco_side_stream", atol(getenv("XL_EXP_NCO_SIDE")));
-  if (getenv("XL_EXP_CHAIN_CALLS")) (void)xlating_batch_set_option(b, "nco_calls_per_launch", atol(getenv("XL_EXP_CHAIN_CALLS")));
-  if (getenv("XL_EXP_POLY_SLICES")) (void)sscanf(getenv("XL_EXP_POLY_SLICES"), "%u,%u", &b->poly_slice1, &b->poly_slice2);
-  if (getenv("XL_EXP_POLY_SLICES_M")) (void)sscanf(getenv("XL_EXP_POLY_SLICES_M"), "%u,%u", &b->poly_slice1_m, &b->poly_slice2_m);
-  if (getenv("XL_EXP_MIXSKIP")) b->mix_skip_at = (uint32_t)atoi(getenv("XL_EXP_MIXSKIP"));
   if (getenv("XL_EXP_INVSKIP")) b->inv_skip_at = (uint32_t)atoi(getenv("XL_EXP_INVSKIP"));
   if (getenv("XL_EXP_NCOPRIO")) b->nco_prio = (uint32_t)atoi(getenv("XL_EXP_NCOPRIO")) & 3u;
   if (getenv("XL_EXP_FLATPRIO")) b->exp_flags |= 2u;
@@ -967,23 +926,16 @@ fail:
 // which is what bounds it with many clients and one block per call; M = 128 halves that for ~5-10 % more arithmetic
 // (valid outputs per segment M - A + 1) while the filter is short against the segment.  Measured at D = 42, 505 taps, one
 // block per call: x1.17 at 4096 clients, x1.08 at 2048, x1.015 at 1024, x0.99 at 512 and below.
-static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D, uint32_t A);
-static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t D, uint32_t A, size_t members) {
-  if (xl_poly_mix_kind(b, D, A) == 2u) return XLF_M;  // (the fused launch is written for 128-point segments)
+static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t A, size_t members) {
   return A > 64 ? 256u : (b->poly_m ? b->poly_m : (A <= 32 && members >= 768 ? 128u : 256u));
 }
 
-// Which mix launch a class of (D) takes (PolyClass::mix_kind): the matrix-core kernel carries the spectra as pairs of halves
-// and needs them bounded -- integer input formats -- and at most XLP_NKB_MAX k-blocks of 8 branches.
-// The fused launch (2) keeps a tile's mixed spectra in registers, 128 bins per segment: filters of up to 64 taps per branch
-// (the same bound the three-launch path puts on 128-point segments).
-// The float32 matrix instruction (3) has no such conditions: it is what cf32 streams and D > 64 take, and every class on request.
-static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D, uint32_t A) {
-  if (b->mix_kernel == 0u) return 0u;
+// Which mix launch a class of D branches takes (PolyClass::mix_kind): the two-half kernel (1) carries the spectra as pairs of halves
+// and needs them bounded -- integer input formats -- and at most XLP_NKB_MAX k-blocks of 8 branches; the float32 matrix instruction
+// (3) has no such conditions: it is what cf32 streams and D > 64 take, and every class on request.
+static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D) {
   const bool halves_ok = b->fmt != XL_FMT_CF32 && D <= 8u * XLP_NKB_MAX;
-  if (b->mix_kernel == 3u || !halves_ok) return 3u;
-  if (b->mix_kernel == 2u && A <= XLF_M / 2u && (b->poly_m == 0u || b->poly_m == XLF_M)) return 2u;
-  return 1u;
+  return (b->mix_kernel == 3u || !halves_ok) ? 3u : 1u;
 }
 
 // Power-of-two scale of a column's branch spectra for the matrix-core mix: every component of R_b[m] = sum_a r_b[a] e^{..} is at
@@ -1003,67 +955,42 @@ static float xl_poly_col_scale(const Client &c, uint32_t D, uint32_t T) {
 static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vector<uint32_t> &new_cols, bool fresh, uint32_t cap_samples) {
   // the images a growing class moves into: owned by nobody until they are handed to `pc` below -- a failure in between gives
   // them back (fail:)
-  float2 *nR = nullptr, *nY = nullptr;
+  float2 *nY = nullptr;
   void *nRh = nullptr;
   float *ncs = nullptr;
   XlpCol *ncols = nullptr;
-  // ---- capacity: column groups (R, Y, cols) and segments (Y, X)
+  // ---- capacity: column groups (Rh, Y, cols) and segments (Y, X)
   const uint32_t need_cg = ((uint32_t)pc.col_client.size() + XLP_COLS - 1) / XLP_COLS;
   const uint32_t nseg_cap = (cap_samples / pc.D + 2 + pc.V - 1) / pc.V + 1;
   const uint32_t passes = (nseg_cap + XLP_SEG - 1) / XLP_SEG;
   if (fresh || need_cg > pc.ncg_cap || nseg_cap != pc.nseg_cap) {
     // grow by an eighth (at least one group) so that the next joins find room; the old spectra move over on the device
     const uint32_t cap = fresh ? need_cg : std::max(need_cg, pc.ncg_cap + std::max(1u, pc.ncg_cap / 8u));
-    if (pc.mix_kind != 0u) {
-      // operand-form image [cg][m][quarter][term][k-block][lane][8 halves] (fused launch: [16-column group][m][k-block][term][lane]):
-      // a group's image is contiguous here too
-      const size_t per_cg = pc.mix_kind == 2u   ? (XLP_COLS / XLF_COLS) * xlf_rh_bytes_per_cg16(pc.nkb)
-                            : pc.mix_kind == 3u ? xlmf_rf_bytes_per_group(pc.M, pc.nkb)
-                                                : xlp_rh_bytes_per_group(pc.M, pc.nkb);
-      XL_TRY(xl_plan_alloc(b, &nRh, (size_t)cap * per_cg));
-      const size_t old_bytes = fresh ? 0 : (size_t)pc.ncg_cap * per_cg;
-      if (old_bytes) XL_TRY(hipMemcpyAsync(nRh, pc.d_Rh, old_bytes, hipMemcpyDeviceToDevice, b->own_stream));
-      XL_TRY(hipMemsetAsync((char *)nRh + old_bytes, 0, (size_t)cap * per_cg - old_bytes, b->own_stream));
-      XL_TRY(xl_plan_alloc(b, (void **)&ncs, (size_t)cap * XLP_COLS * sizeof(float)));
-    } else {
-      const size_t rrows = (size_t)cap * pc.Dpad + 1;  // (+1 x M rows: covers the XLP_BSTEP rows of tail padding)
-      XL_TRY(xl_plan_alloc(b, (void **)&nR, rrows * pc.M * XLP_COLS * sizeof(float2)));
-      // (R rows are [cg][m][b][col]: a group's image is contiguous -- the old groups are one copy, the new ones and the tail
-      // padding start as zeros: empty columns and padding branches are multiplied into sums that are never stored, but must
-      // be finite)
-      const size_t old_elems = fresh ? 0 : (size_t)pc.ncg_cap * pc.Dpad * pc.M * XLP_COLS;
-      if (old_elems) XL_TRY(hipMemcpyAsync(nR, pc.d_R, old_elems * sizeof(float2), hipMemcpyDeviceToDevice, b->own_stream));
-      XL_TRY(hipMemsetAsync(nR + old_elems, 0, (rrows * pc.M * XLP_COLS - old_elems) * sizeof(float2), b->own_stream));
-    }
-    if (pc.mix_kind != 2u) XL_TRY(xl_plan_alloc(b, (void **)&nY, (size_t)cap * nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
+    // operand-form image, a group's part contiguous: the old groups are one copy, the new ones start as zeros (empty columns are
+    // multiplied into sums that are never stored, but must be finite)
+    const size_t per_cg = pc.mix_kind == 3u ? xlmf_rf_bytes_per_group(pc.M, pc.nkb) : xlp_rh_bytes_per_group(pc.M, pc.nkb);
+    XL_TRY(xl_plan_alloc(b, &nRh, (size_t)cap * per_cg));
+    const size_t old_bytes = fresh ? 0 : (size_t)pc.ncg_cap * per_cg;
+    if (old_bytes) XL_TRY(hipMemcpyAsync(nRh, pc.d_Rh, old_bytes, hipMemcpyDeviceToDevice, b->own_stream));
+    XL_TRY(hipMemsetAsync((char *)nRh + old_bytes, 0, (size_t)cap * per_cg - old_bytes, b->own_stream));
+    XL_TRY(xl_plan_alloc(b, (void **)&ncs, (size_t)cap * XLP_COLS * sizeof(float)));
+    XL_TRY(xl_plan_alloc(b, (void **)&nY, (size_t)cap * nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
     XL_TRY(xl_plan_alloc(b, (void **)&ncols, (size_t)cap * XLP_COLS * sizeof(XlpCol)));
     XL_TRY(hipStreamSynchronize(b->own_stream));
-    xl_plan_release(b, pc.d_R);
     xl_plan_release(b, pc.d_Rh);
     xl_plan_release(b, pc.d_cscale);
     xl_plan_release(b, pc.d_Y);
     xl_plan_release(b, pc.d_cols);
-    pc.d_R = nR, pc.d_Rh = nRh, pc.d_cscale = ncs, pc.d_Y = nY, pc.d_cols = ncols;
-    nR = nY = nullptr, nRh = nullptr, ncs = nullptr, ncols = nullptr;
-    xl_plan_release(b, pc.d_Y2);
-    pc.d_Y2 = nullptr;
-    if (b->gcap == 1 && pc.mix_kind != 2u)  // (one block per call: the second mixed-spectra image of the pipelined calls)
-      XL_TRY(xl_plan_alloc(b, (void **)&pc.d_Y2, (size_t)cap * nseg_cap * pc.M * XLP_COLS * sizeof(float2)));
+    pc.d_Rh = nRh, pc.d_cscale = ncs, pc.d_Y = nY, pc.d_cols = ncols;
+    nY = nullptr, nRh = nullptr, ncs = nullptr, ncols = nullptr;
     pc.ncg_cap = cap;
     if (fresh || nseg_cap != pc.nseg_cap || pc.d_X == nullptr) {
       xl_plan_release(b, pc.d_X);
       pc.d_X = nullptr;
-      // (X: the padding branches and the unused segment slots of the last pass / group must be finite: cleared once)
-      const size_t xbytes = pc.mix_kind == 2u ? xlf_xh_slots((nseg_cap + XLF_SEGS - 1u) / XLF_SEGS, pc.nkb) * 16u
-                                              : (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2);
+      // (X: the padding branches and the unused segment slots of the last pass must be finite: cleared once)
+      const size_t xbytes = (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2);
       XL_TRY(xl_plan_alloc(b, (void **)&pc.d_X, xbytes));
       XL_TRY(hipMemsetAsync(pc.d_X, 0, xbytes, b->own_stream));
-      xl_plan_release(b, pc.d_X2);
-      pc.d_X2 = nullptr;
-      if (b->gcap == 1 && pc.mix_kind != 2u) {
-        XL_TRY(xl_plan_alloc(b, (void **)&pc.d_X2, xbytes));
-        XL_TRY(hipMemsetAsync(pc.d_X2, 0, xbytes, b->own_stream));
-      }
     }
     pc.nseg_cap = nseg_cap;
   }
@@ -1084,29 +1011,29 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
       cols[j].incr = make_float2(c.incr[0], c.incr[1]);
     }
     XL_TRY(hipMemcpy(pc.d_cols, cols.data(), cols.size() * sizeof(XlpCol), hipMemcpyHostToDevice));
-    if (pc.mix_kind != 0u) {  // what the matrix-core mix multiplies a column's sums by: 1 / (its scale * the spectra's)
-      std::vector<float> cs((size_t)pc.ncg_cap * XLP_COLS, 1.0f);
-      pc.col_scale.resize(pc.col_client.size(), 1.0f);
-      if (pc.mix_kind != 3u) {  // (float32 operands are neither scaled nor split: the table stays at 1 and nobody reads it)
-        for (uint32_t j : new_cols) pc.col_scale[j] = xl_poly_col_scale(b->clients[pc.col_client[j]], pc.D, pc.T);
-        for (size_t j = 0; j < pc.col_client.size(); ++j) {
-          if (pc.col_client[j] < 0) continue;
-          cs[j] = 1.0f / (pc.col_scale[j] * XLP_H_XSCALE);
-        }
+    // what the two-half mix multiplies a column's sums by: 1 / (its scale * the spectra's).  (float32 operands are neither scaled nor
+    // split: the table stays at 1 and nobody reads it)
+    std::vector<float> cs((size_t)pc.ncg_cap * XLP_COLS, 1.0f);
+    pc.col_scale.resize(pc.col_client.size(), 1.0f);
+    if (pc.mix_kind == 1u) {
+      for (uint32_t j : new_cols) pc.col_scale[j] = xl_poly_col_scale(b->clients[pc.col_client[j]], pc.D, pc.T);
+      for (size_t j = 0; j < pc.col_client.size(); ++j) {
+        if (pc.col_client[j] < 0) continue;
+        cs[j] = 1.0f / (pc.col_scale[j] * XLP_H_XSCALE);
       }
-      XL_TRY(hipMemcpy(pc.d_cscale, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    XL_TRY(hipMemcpy(pc.d_cscale, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   // ---- branch spectra of the new columns (device kernel, double arithmetic)
   if (!new_cols.empty()) {
     const size_t nn = new_cols.size();
     std::vector<float> rt(nn * pc.T * 2);  // [tap][new column]
-    std::vector<uint32_t> meta(3 * nn);    // [new column]: delay, then column index, then (matrix-core mix) the column scale's bits
+    std::vector<uint32_t> meta(3 * nn);    // [new column]: delay, then column index, then (two-half mix) the column scale's bits
     for (size_t j = 0; j < nn; ++j) {
       const Client &c = b->clients[pc.col_client[new_cols[j]]];
       meta[j] = pc.col_delta[new_cols[j]];
       meta[nn + j] = new_cols[j];
-      const float sc = pc.mix_kind != 0u ? pc.col_scale[new_cols[j]] : 1.0f;
+      const float sc = pc.col_scale[new_cols[j]];
       memcpy(&meta[2 * nn + j], &sc, sizeof(float));
       for (uint32_t i = 0; i < pc.T; ++i) {
         rt[((size_t)i * nn + j) * 2] = c.rt[2 * i];
@@ -1120,15 +1047,10 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
     if (e == hipSuccess) e = hipMemcpy(d_rt, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_meta, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
-      e = pc.mix_kind == 2u
-              ? xlp_launch_tables_h16(d_rt, d_meta, d_meta + nn, reinterpret_cast<const float *>(d_meta + 2 * nn), (uint32_t)nn, pc.T,
-                                      pc.D, pc.A, pc.nkb, pc.d_Rh, b->own_stream)
-          : pc.mix_kind == 1u
-              ? xlp_launch_tables_h(d_rt, d_meta, d_meta + nn, reinterpret_cast<const float *>(d_meta + 2 * nn), (uint32_t)nn, pc.T,
-                                    pc.D, pc.A, pc.M, pc.nkb, pc.d_Rh, b->own_stream)
-          : pc.mix_kind == 3u
+      e = pc.mix_kind == 3u
               ? xlp_launch_tables_f(d_rt, d_meta, d_meta + nn, (uint32_t)nn, pc.T, pc.D, pc.A, pc.M, pc.nkb, pc.d_Rh, b->own_stream)
-              : xlp_launch_tables(d_rt, d_meta, d_meta + nn, (uint32_t)nn, pc.T, pc.D, pc.Dpad, pc.A, pc.M, pc.d_R, b->own_stream);
+              : xlp_launch_tables_h(d_rt, d_meta, d_meta + nn, reinterpret_cast<const float *>(d_meta + 2 * nn), (uint32_t)nn, pc.T,
+                                    pc.D, pc.A, pc.M, pc.nkb, pc.d_Rh, b->own_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->own_stream);
     xl_plan_release(b, d_rt);  // (scratch: spare again at once)
     xl_plan_release(b, d_meta);
@@ -1139,7 +1061,7 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
   }
   return 0;
 fail : {
-  void *unowned[] = {nR, nRh, ncs, nY, ncols};
+  void *unowned[] = {nRh, ncs, nY, ncols};
   for (void *q : unowned) xl_plan_release(b, q);
 }
   return xl_errno_of_last_hip_error();
@@ -1231,7 +1153,7 @@ static int xl_batch_plan(xlating_batch *b) {
         ref = (old->rem_ref0 + advanced % D) % D;
         for (uint32_t r : distinct) dmax = std::max(dmax, (ref + D - r) % D);
         const uint32_t A = (T + dmax + D - 1) / D;
-        reuse = A == old->A && xl_poly_pick_m(b, D, A, m.size()) == old->M && xl_poly_mix_kind(b, D, A) == old->mix_kind;
+        reuse = A == old->A && xl_poly_pick_m(b, A, m.size()) == old->M && xl_poly_mix_kind(b, D) == old->mix_kind;
       }
       if (!reuse) {
         // the shared grid's reference: the member offset that keeps the largest delay of a member smallest
@@ -1244,15 +1166,14 @@ static int xl_batch_plan(xlating_batch *b) {
         ref = best_ref, dmax = best_dmax;
       }
       const uint32_t A = (T + dmax + D - 1) / D;
-      const uint32_t M = xl_poly_pick_m(b, D, A, m.size());
-      const bool fits = A >= 2 && A <= M / 2 && D <= 504;  // (the mix kernel stages D rows of 128 bytes in <= 64 KB of LDS)
-      // crossover, packed-FMA mix: ~4.5 taps per branch and 128 clients (x1.10 at 128, x0.96 at 64).  With the mix on the matrix
-      // cores the path costs the same whatever the filter length and little beside the recurrence in small classes (A/B at
-      // 8 blocks per call, direct kernel -> polyphase, us per block: 101 taps 37.3 -> 28.2 at 1024 clients, 124.8 -> 88.7 at
-      // 4096, 23.3 -> 22.9 at 128; 505 taps 24.8 -> 22.9 at 96 clients, 23.1 -> 22.7 at 32): 2 taps per branch, 32 clients
-      const bool mfma_class = xl_poly_mix_kind(b, D, A) != 0u;
-      const size_t min_clients = (mfma_class && !b->poly_min_set) ? 32u : b->poly_min_clients;
-      const bool pays = m.size() >= min_clients && (mfma_class ? T >= 2 * D : 2 * T >= 9 * D);
+      const uint32_t M = xl_poly_pick_m(b, A, m.size());
+      const bool fits = A >= 2 && A <= M / 2 && D <= 504;
+      // crossover: with the mix on the matrix cores the path costs the same whatever the filter length and little beside the
+      // recurrence in small classes (A/B at 8 blocks per call, direct kernel -> polyphase, us per block: 101 taps 37.3 -> 28.2 at
+      // 1024 clients, 124.8 -> 88.7 at 4096, 23.3 -> 22.9 at 128; 505 taps 24.8 -> 22.9 at 96 clients, 23.1 -> 22.7 at 32; cf32 10
+      // Msps, D = 100, 257 taps: 38.4 -> 23.4 at 1024 clients, 12.8 -> 11.8 at 256, 11.4 -> 11.3 at 64): 2 taps per branch, 32 clients
+      const size_t min_clients = b->poly_min_set ? b->poly_min_clients : 32u;
+      const bool pays = m.size() >= min_clients && T >= 2 * D;
       if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
       PolyClass pc;
       Pending pd;
@@ -1260,7 +1181,7 @@ static int xl_batch_plan(xlating_batch *b) {
       if (reuse) {
         pc = std::move(*old);
         old->keep = true;
-        old->d_R = old->d_X = old->d_Y = old->d_X2 = old->d_Y2 = nullptr;
+        old->d_X = old->d_Y = nullptr;
         old->d_cols = nullptr;
         old->d_Rh = nullptr;
         old->d_cscale = nullptr;
@@ -1288,8 +1209,8 @@ static int xl_batch_plan(xlating_batch *b) {
         pc.A = A;
         pc.M = M;
         pc.V = M - A + 1;
-        pc.mix_kind = xl_poly_mix_kind(b, D, A);
-        pc.nkb = pc.mix_kind == 2u ? xlf_nk(D) : (D + 7u) / 8u;
+        pc.mix_kind = xl_poly_mix_kind(b, D);
+        pc.nkb = (D + 7u) / 8u;
       }
       pc.keep = false;
       pc.rem_ref0 = ref;
@@ -1393,9 +1314,7 @@ static int xl_batch_plan(xlating_batch *b) {
     for (const DirectClass &cs : b->classes_rest) b->macs_rest += (double)cs.members.size() * cs.T / cs.D;
     const bool light = xl_direct_is_light(b->macs_all * b->max_samples) || (!b->poly.empty() && xl_direct_is_light(b->macs_rest * b->max_samples));
     // (one-block calls of a polyphase plan take the side stream too, up to XL_SIDE_ONE_BLOCK_MAX clients: see side_call)
-    bool plan_fused = !b->poly.empty();
-    for (const PolyClass &pc : b->poly) plan_fused = plan_fused && pc.mix_kind == 2u;
-    const bool one_block_side = !b->poly.empty() && (plan_fused || b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX);
+    const bool one_block_side = !b->poly.empty() && b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX;
     // (a server that knows how many clients it admits says so -- option "expected_clients" --, and the reservation is made for
     // that many at once: the 25 ms of a stream re-creation then never fall on a call between two joins)
     const uint32_t nwg_res = std::max(nwg, (b->expected_clients + 63u) / 64u);
@@ -1406,11 +1325,9 @@ static int xl_batch_plan(xlating_batch *b) {
     // a client count hovering around a multiple of 512 does not recreate the streams at every join and leave)
     if (want > b->reserve_r || want + 2u <= b->reserve_r || (want == 0u && b->reserve_r != 0u)) {
       if (b->cs_masked) (void)hipStreamDestroy(b->cs_masked);
-      if (b->cs_masked2) (void)hipStreamDestroy(b->cs_masked2);
       if (b->nco_masked) (void)hipStreamDestroy(b->nco_masked);
-      b->cs_masked = b->cs_masked2 = b->nco_masked = nullptr;
+      b->cs_masked = b->nco_masked = nullptr;
       b->last_nco = nullptr;
-      b->last_piped = false;
       b->reserve_r = 0;
       b->last_stream = b->own_stream;  // (everything was synchronised at the top of the plan)
       for (int i = 0; i < XL_NTAB; ++i) b->ev_done_valid[i] = false, b->tab_call[i] = 0;
@@ -1426,16 +1343,11 @@ static int xl_batch_plan(xlating_batch *b) {
         if (hipExtStreamCreateWithCUMask(&b->nco_masked, 8, chain_mask) == hipSuccess &&
             hipExtStreamCreateWithCUMask(&b->cs_masked, 8, main_mask) == hipSuccess) {
           b->reserve_r = want;
-          // (one block per call: the second compute stream of the pipelined calls; doing without it only costs the overlap)
-          if (b->gcap == 1 && hipExtStreamCreateWithCUMask(&b->cs_masked2, 8, main_mask) != hipSuccess) {
-            b->cs_masked2 = nullptr;
-            (void)hipGetLastError();
-          }
         } else {
           XL_LOG_ERR("CU-masked streams are not available (%s): the NCO chain kernel shares the chip", hipGetErrorString(hipGetLastError()));
           if (b->cs_masked) (void)hipStreamDestroy(b->cs_masked);
           if (b->nco_masked) (void)hipStreamDestroy(b->nco_masked);
-          b->cs_masked = b->cs_masked2 = b->nco_masked = nullptr;
+          b->cs_masked = b->nco_masked = nullptr;
         }
       }
     }
@@ -1611,40 +1523,15 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
   // the matrix cores, and a slice of the recurrence inside each made every one of them last as long as its slice (1024 clients:
   // 50.2 us per block; the chain kernel beside them, four calls per launch: 47.7; 128 clients: 40.4 -> 29.2; 4096: 129 -> 134,
   // hence the limit)
-  bool all_fused = use_poly;  // every polyphase class runs forward + fused: two short launches, neither a good host for the recurrence
-  for (const PolyClass &pc : b->poly) all_fused = all_fused && pc.mix_kind == 2u;
-  const bool one_block_side = G == 1 && use_poly && (all_fused || b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX);
+  const bool one_block_side = G == 1 && use_poly && b->nco.size() <= XL_SIDE_ONE_BLOCK_MAX;
   const bool side_call = mode != XL_MODE_Q15 && (b->nco_side > 0 || (b->nco_side < 0 && (G >= 2 || one_block_side) && (use_poly || (light && b->cs_masked && s == XL_STREAM_ENGINE_P))));  // (a caller's own, unmasked stream would keep filling the chain's CUs)
-  // Pipelined one-block calls (engines created for one block per call, on the engine's own streams, every client on the
-  // polyphase launches): consecutive calls alternate between two compute streams and only their FORWARD launches are ordered
-  // (raw history); X and Y exist twice (PolyClass::d_X2, d_Y2), outputs and phase tables are per call anyway.  Call k + 1's
-  // forward and mix launches then run beside call k's inverse launch: each is a short, latency-bound grid of its own.
-  bool pipe = b->pipeline_calls != 0 && s == XL_STREAM_ENGINE_P && G == 1 && b->gcap == 1 && side_call && b->cs_masked != nullptr &&
-              b->cs_masked2 != nullptr && use_poly && mode == XL_MODE_OPTIMIZED;
-  for (int lq = 0; lq < XL_NLAUNCH && pipe; ++lq) pipe = b->launches_rest[lq].groups.empty();  // (no direct launch in the call)
-  for (const PolyClass &pc : b->poly) pipe = pipe && pc.d_X2 != nullptr && pc.d_Y2 != nullptr;
-  const int pidx = (int)(b->ncalls & 1);
-  if (s == XL_STREAM_ENGINE_P) s = pipe ? (pidx ? b->cs_masked2 : b->cs_masked) : ((side_call && b->cs_masked) ? b->cs_masked : b->own_stream);
-  // Calls depend on each other through the engine's device state (history, phases, tables): a call on another
-  // stream than the previous one is ordered behind it -- behind BOTH compute streams when the previous calls were pipelined.
-  {
-    const hipStream_t prev = b->last_stream;
-    const bool prev_piped = b->last_piped;
-    if (pipe && prev_piped && s != prev) {
-      XL_TRY(hipStreamWaitEvent(s, b->ev_fwd[pidx ^ 1], 0));  // (the previous call's forward launch: the only order needed)
-      b->piped_other = prev;
-    } else {
-      if (s != prev) {
-        XL_TRY(hipEventRecord(b->dep_ev, prev));
-        XL_TRY(hipStreamWaitEvent(s, b->dep_ev, 0));
-      }
-      if (prev_piped && b->piped_other != nullptr && b->piped_other != s) {
-        XL_TRY(hipEventRecord(b->dep_ev2, b->piped_other));
-        XL_TRY(hipStreamWaitEvent(s, b->dep_ev2, 0));
-      }
-      b->piped_other = nullptr;
-    }
-    b->last_piped = pipe;
+  if (s == XL_STREAM_ENGINE_P) s = (side_call && b->cs_masked) ? b->cs_masked : b->own_stream;
+  // Calls depend on each other through the engine's device state (history, phases, tables): a call on another stream than the
+  // previous one is ordered behind it.  (Overlapping consecutive one-block calls through two compute streams -- round 4's
+  // "pipeline_calls" -- cost this runtime more in cross-stream events than it gained: profiles/r04_one_block_pipelining.txt.)
+  if (s != b->last_stream) {
+    XL_TRY(hipEventRecord(b->dep_ev, b->last_stream));
+    XL_TRY(hipStreamWaitEvent(s, b->dep_ev, 0));
   }
   b->last_stream = s;
   b->fetched = false;
@@ -1788,17 +1675,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
       }
       // the tables' last readers (XL_NTAB - 1 - i calls back): one wait for the latest of them covers the earlier ones that
       // were recorded on the same stream (every wait is a queue packet of its own, ~4 us in front of the chain launch)
-      if (b->pipeline_calls) {  // (pipelined calls finish out of order across the two compute streams: every call records, every stream counts)
-        hipStream_t covered = nullptr;
-        bool any = false;
-        for (int i = (int)cc.n - 1; i >= 0; --i) {
-          const int t = tt[i];
-          if (!b->ev_done_valid[t] || (any && b->ev_done_stream[t] == covered)) continue;
-          XL_TRY(hipStreamWaitEvent(ns, b->ev_done[t], 0));
-          if (!any) covered = b->ev_done_stream[t];
-          any = true;
-        }
-      } else {
+      {
         uint64_t need = 0;  // the latest call that read one of these tables
         for (int i = 0; i < (int)cc.n; ++i) need = std::max(need, b->tab_call[tt[i]]);
         if (need != 0) {
@@ -1831,9 +1708,9 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     }
     bool rolled = false;
     bool done_attached = false;  // ev_done[tab] rides on the call's last launch
-    // does this call record ev_done[tab]?  Side-stream calls: only the ones that launch a chain (see tab_call); pipelined and
-    // non-side calls after a side stream was used: always, as before
-    const bool want_done = (side || b->last_nco != nullptr) && (!side || launched_n > 0 || b->pipeline_calls != 0);
+    // does this call record ev_done[tab]?  Side-stream calls: only the ones that launch a chain (see tab_call); non-side calls
+    // after a side stream was used: always
+    const bool want_done = (side || b->last_nco != nullptr) && (!side || launched_n > 0);
     bool record_attached = false;  // the caller's record_ev rides on the last launch instead (no ev_done wanted there)
     Launch *const Ls = use_poly ? b->launches_rest : b->launches;
     if (maxK > 0) {
@@ -1949,29 +1826,22 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           pa.ncg = pc.ncg;
           pa.exp = b->poly_exp;
           pa.inv_reg = b->inv_reg;
-          pa.inv_wgs = b->inv_persist * (uint32_t)std::max(1, b->num_cus - (s == b->cs_masked || s == b->cs_masked2 ? 8 * (int)b->reserve_r : 0));
           pa.mix_kind = pc.mix_kind;
           pa.nkb = pc.nkb;
           pa.mix_pp = b->mix_pp;
-          pa.y6 = (b->y_format == 1u && pc.mix_kind == 1u && !(pc.M == 128u && (b->inv_reg == 1u || b->inv_reg == 2u))) ? 1u : 0u;
-          if (b->inv_reg == 5u && (pc.M != 128u || pa.y6)) pa.inv_reg = 3u;  // (the 8-lane kernel reads float32 pairs of 128-point segments)
           pa.Rh = pc.d_Rh;
           pa.cscale = pc.d_cscale;
           pa.W = b->d_W;
-          pa.X = (pipe && pidx) ? pc.d_X2 : pc.d_X;
-          pa.R = pc.d_R;
-          pa.Y = (pipe && pidx) ? pc.d_Y2 : pc.d_Y;
+          pa.X = pc.d_X;
+          pa.Y = pc.d_Y;
           pa.cols = pc.d_cols;
           pa.phtab = b->d_phtab[tab];
           pa.out = b->d_out[p];
           // the NEXT call's phase recurrence rides in these launches (a direct launch above carries all of it if there is
-          // one): forward and inverse, never a launch that issues matrix instructions -- the first matrix-core mix build
-          // corrupted the phases of role waves riding in it, cause unknown, so no product launch mixes the two.
-          // Packed-FMA mix: three slices (forward | mix | inverse); matrix-core mix: two (forward | inverse); fused: the
-          // forward launch carries all of it (such calls take the side stream whenever there is one).
+          // one): TWO slices, forward | inverse -- never the mix launch: no launch that issues matrix instructions hosts the role
+          // 
           const bool carry = fuse && !nco_fused;
-          const uint32_t sl1 = pc.mix_kind == 2u ? 65536u : (pc.mix_kind != 0u ? std::min(b->poly_slice_fi, 60000u) : b->poly_slice1);
-          const uint32_t sl2 = pc.mix_kind == 0u ? b->poly_slice2 : sl1;
+          const uint32_t sl1 = std::min(b->poly_slice_fi, 60000u);
           if (carry) {
             pa.nco_clients = b->d_nco;
             pa.nco_nclients = (uint32_t)b->nco.size();
@@ -1981,7 +1851,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
             pa.nco_k0 = 0;
             pa.nco_k1 = sl1;
             pa.nco_state_src = b->d_phase[pcur];
-            pa.nco_state_dst = sl1 >= 65536u ? b->d_phase[xl_nx(pcur)] : b->d_phase_run;
+            pa.nco_state_dst = b->d_phase_run;
           }
           hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
           if (b->timing == 2) {
@@ -1993,46 +1863,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           }
           // the call's last launch carries the "table has been read" event the side stream waits for
           const bool last_launch = side && rolled && &pc == &b->poly.back();
-          if (pc.mix_kind == 2u) {
-            // ---- two launches: spectra in operand form, then mix + inverse with the mixed spectra on chip
-            XL_TRY(xlp_launch_forward_h(pa, s));
-            if (pe[1]) XL_TRY(hipEventRecord(pe[1], s));
-            pa.roll_blocks = 0;
-            if (carry) nco_fused = true;
-            pa.nco_clients = nullptr;
-            pa.nco_nclients = pa.nco_blocks = 0;
-            pa.nco_tab = nullptr;
-            if (chain_wait) {  // (the forward launch does not read the table)
-              XL_TRY(hipStreamWaitEvent(s, b->ev_chain[chain_ev], 0));
-              chain_wait = false;
-              b->waited_valid = true, b->waited_ev = chain_ev, b->waited_stream = s;
-            }
-            XL_TRY(xlp_launch_fused(pa, s, last_launch ? (want_done ? b->ev_done[tab] : record_ev) : nullptr));
-            done_attached = last_launch && want_done;
-            record_attached = last_launch && !want_done && record_ev != nullptr;
-            if (pe[2]) XL_TRY(hipEventRecord(pe[2], s));
-            if (pe[3]) XL_TRY(hipEventRecord(pe[3], s));
-            continue;
-          }
           XL_TRY(xlp_launch_forward(pa, s));
-          if (pipe && &pc == &b->poly.back()) XL_TRY(hipEventRecord(b->ev_fwd[pidx], s));  // (what the next call's forward launches wait for)
           if (pe[1]) XL_TRY(hipEventRecord(pe[1], s));
           pa.roll_blocks = 0;
-          if (carry && pc.mix_kind == 0u) {
-            pa.nco_k0 = sl1;
-            pa.nco_k1 = sl2;
-            pa.nco_state_src = b->d_phase_run;
-            if (!(b->poly_exp & 16u)) {  // keep the second wave slot of the chain SIMDs empty (1024 SIMDs, round-robin deal)
-              pa.nco_skip_at = b->mix_skip_at ? b->mix_skip_at : 1024;
-              pa.nco_skip = pa.nco_blocks;
-            }
-#ifdef XL_TUNING
-            if (b->poly_exp & 4u) pa.nco_tab = nullptr;  // tuning: the mix launch's slice stores nothing (WRONG results)
-            if (b->poly_exp & 8u) pa.nco_blocks = 0;     // tuning: the mix launch carries no slice at all (WRONG results)
-#endif
-          } else {
-            pa.nco_blocks = 0;  // (matrix-core mix: no role in this launch)
-          }
+          pa.nco_blocks = 0;  // (no role in the mix launch)
 #ifdef XL_TUNING
           const bool trace_inv = b->poly_trace && getenv("XL_EXP_POLY_TRACE_INV");  // (the inverse launch instead)
           if (b->poly_trace && !trace_inv) {  // timeline of the mix launch (work waves' span + each NCO wave)
@@ -2053,7 +1887,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           if (carry) {
             pa.nco_tab = b->d_phtab[xl_nx(tab)];
             pa.nco_blocks = (pa.nco_nclients + XL_NCO_LANES - 1) / XL_NCO_LANES;
-            pa.nco_k0 = sl2;
+            pa.nco_k0 = sl1;
             pa.nco_k1 = 65536;
             pa.nco_state_src = b->d_phase_run;
             if (b->inv_skip_at > 0) {
@@ -2179,10 +2013,8 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
     d += " cls" + std::to_string(k) + " D" + std::to_string(pc.D) + " T" + std::to_string(pc.T) + " cols" +
          std::to_string(pc.members.size()) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
     if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
-    d += pc.mix_kind == 2u ? " mix=fused" : (pc.mix_kind == 1u ? " mix=mfma" : (pc.mix_kind == 3u ? " mix=mf32" : " mix=fma"));
-    const bool y48 = b->y_format == 1u && pc.mix_kind == 1u && !(pc.M == 128u && (b->inv_reg == 1u || b->inv_reg == 2u));
-    if (y48) d += " Y=48bit";
-    if (pc.M == 128u && pc.mix_kind != 2u && b->inv_reg == 5u && !y48) d += " inv=lanes8";
+    d += pc.mix_kind == 3u ? " mix=mf32" : " mix=mfma";
+    if (pc.M == 128u && b->inv_reg == 5u) d += " inv=lanes8";
   }
   if (!b->poly.empty()) {
     d += " | optimized-mode direct:";
@@ -2259,33 +2091,24 @@ extern "C" size_t xlating_batch_output_len_block(const xlating_batch *b, int id,
 extern "C" int xlating_batch_sync(xlating_batch *b) {
   if (b == nullptr) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
-  if (b->last_piped && b->piped_other && hipStreamSynchronize(b->piped_other) != hipSuccess) return -EIO;  // (the call before the latest)
   return hipStreamSynchronize(b->last_stream) == hipSuccess ? 0 : -EIO;
 }
 
 extern "C" int xlating_batch_query(xlating_batch *b) {
   if (b == nullptr) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
-  hipStream_t ss[2] = {b->last_stream, (b->last_piped && b->piped_other) ? b->piped_other : nullptr};
-  for (hipStream_t st : ss) {
-    if (st == nullptr) continue;
-    const hipError_t e = hipStreamQuery(st);
-    if (e == hipErrorNotReady) {
-      (void)hipGetLastError();  // (not an error: clear the sticky code)
-      return 0;
-    }
-    if (e != hipSuccess) return -EIO;
+  const hipError_t e = hipStreamQuery(b->last_stream);
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();  // (not an error: clear the sticky code)
+    return 0;
   }
-  return 1;
+  return e == hipSuccess ? 1 : -EIO;
 }
 
 extern "C" int xlating_batch_record_event(xlating_batch *b, void *hip_event) {
   if (b == nullptr || hip_event == nullptr) return -EINVAL;
   if (hipSetDevice(b->device) != hipSuccess) return -EIO;
   hipEvent_t ev = reinterpret_cast<hipEvent_t>(hip_event);
-  if (b->last_piped && b->piped_other) {  // (two compute streams hold work: the event goes behind both)
-    if (hipEventRecord(b->dep_ev2, b->piped_other) != hipSuccess || hipStreamWaitEvent(b->last_stream, b->dep_ev2, 0) != hipSuccess) return -EIO;
-  }
   return hipEventRecord(ev, b->last_stream) == hipSuccess ? 0 : -EIO;
 }
 

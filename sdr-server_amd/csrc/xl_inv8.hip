@@ -1,5 +1,5 @@
-// xl_inv8.hip -- the inverse launch of the polyphase path with EIGHT LANES PER CLIENT COLUMN (option "inverse_kernel" 5, the
-// default for 128-point classes).
+// xl_inv8.hip -- the inverse launch of the polyphase path with EIGHT LANES PER CLIENT COLUMN (the default for 128-point
+// classes; option "inverse_kernel" = 3 selects the LDS transform of xl_polyphase.hip instead).
 //
 // Same job as xlp_inverse_kernel (xl_polyphase.hip): per (segment, client column) the 128-point inverse transform of the mixed
 // spectra, the valid outputs scaled, rotated by the client's NCO phases and stored (xlating.c:70 `out = temp * phase`).  What is
@@ -167,153 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
-// ------------------------------------------------------------------------------------------- the same, PERSISTENT (option)
-// a.inv_wgs work workgroups walk the tiles (bid, bid + inv_wgs, ..); every wave runs on its own after the start (the four waves of a
-// workgroup share nothing but the twiddle table).  The next tile -- its column record, its 16 values per lane, then its phase-table
-// entry -- is requested while the current tile's exchange, second transforms, phases and stores run, and the stores of a tile are
-// never waited for: the epilogue is branch-free (a point that is nobody's output is stored to a dump address instead -- the wave's
-// own, already consumed element of the tile in Y), so that the compiler's wait counts stay exact, and one `s_waitcnt vmcnt(16)`
-// behind the sixteen stores says "the next tile has arrived, the stores may still fly" (the compiler would add what it needs on
-// top: the explicit wait only keeps it from falling back to vmcnt(0) at the loop's back edge).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void xlp_inverse8p_kernel(const XlpArgs a) {
-  constexpr uint32_t M = 128u, CW = 32u, NSUB = XLP_COLS / CW;
-  __shared__ __attribute__((aligned(16))) unsigned char region[4][XLI8_WAVE_BYTES];
-  __shared__ v2f twl[16][8];
-  if (blockIdx.x < a.nco_blocks) {
-    xlp_nco_role(a);
-    return;
-  }
-  if (blockIdx.x >= a.nco_skip_at && blockIdx.x < a.nco_skip_at + a.nco_skip) return;
-  const uint32_t bid = blockIdx.x - a.nco_blocks - (blockIdx.x >= a.nco_skip_at ? a.nco_skip : 0u);
-  const uint32_t ntiles = a.nseg * a.ncg * NSUB, stride = a.inv_wgs;
-  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = threadIdx.x & 63u;
-  const uint32_t c8 = xli8_col(j), u = xli8_u(j);
-  if (threadIdx.x < 128u) {
-    v2f tv = reinterpret_cast<const v2f *>(a.W)[(2u * (threadIdx.x & 7u) * (threadIdx.x >> 3)) & 255u];
-    tv.y = -tv.y;
-    twl[threadIdx.x >> 3][threadIdx.x & 7u] = tv;
-  }
-  __syncthreads();
-  unsigned char *const reg = region[w];
-  const uint32_t N = a.pos.S * a.pos.G;
-  const uint32_t Ka = N / a.D, Nr = N - Ka * a.D;
-  const v2f *__restrict__ ph = reinterpret_cast<const v2f *>(a.phtab);
-  const uint32_t o0 = xli8_load(w, j, 0u);
-  constexpr uint32_t os = 8u * CW;
-  // tile t -> its first element in Y, its first column, its segment
-  auto tile_of = [&](const uint32_t t, uint32_t &col0, uint32_t &seg) __attribute__((always_inline)) {
-    const uint32_t sub = t % NSUB, q = t / NSUB;
-    const uint32_t cg = q % a.ncg;
-    seg = q / a.ncg;
-    col0 = cg * XLP_COLS + sub * CW + 8u * w;
-    return reinterpret_cast<v2f *>(a.Y) + ((((size_t)cg * a.nseg_cap + seg) * NSUB + sub) * M) * CW;
-  };
-  // what the lane needs of its column in a tile: bounds, shift, the output index of the first phase it expands
-  struct Duty {
-    XlBnd bnd;
-    uint32_t esh, ibeg, m0;
-    bool eok;
-  };
-  auto duty_of = [&](const XlpCol &c, const uint32_t seg) __attribute__((always_inline)) {
-    Duty d;
-    d.bnd.j0 = xl_merge_j0(a.j0_ref, c.delta, a.D), d.bnd.D = a.D, d.bnd.S = a.pos.S, d.bnd.G = a.pos.G, d.bnd.flags = a.pos.pad;
-    d.bnd.K = Ka + (d.bnd.j0 < Nr ? 1u : 0u);
-    d.esh = xl_merge_shift(a.j0_ref, c.delta, a.D);
-    const uint32_t q0 = seg * a.V + u * XL_PH_STRIDE;
-    d.ibeg = q0 < d.esh ? 1u : 0u;
-    d.m0 = q0 + d.ibeg - d.esh;
-    d.eok = c.out_off != 0xFFFFFFFFu && u * XL_PH_STRIDE < a.V && d.m0 < d.bnd.K;
-    return d;
-  };
-  uint32_t t = bid, col0, seg;
-  v2f *tile = tile_of(t, col0, seg);
-  XlpCol ce = a.cols[col0 + c8];
-  v2f z[16];
-#pragma unroll
-  for (int m2 = 0; m2 < 16; ++m2) z[m2] = tile[o0 + m2 * os];
-  v2f pe;
-  {
-    const Duty d = duty_of(ce, seg);
-    pe = ph[d.eok ? (ce.out_off >> XL_PH_SHIFT) + (d.m0 >> XL_PH_SHIFT) : 0u];
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered with nothing in flight
-#pragma unroll 1
-  for (;;) {
-    const bool last = t + stride >= ntiles;
-    const uint32_t tn = last ? t : t + stride;  // (the last round requests its own tile again: no branch around the loads)
-    const Duty d = duty_of(ce, seg);
-    v2f *const dump = tile + o0;  // this lane's first element of the tile: consumed, nobody else's
-    // ---- roles 1 - 3 (writer)
-    xl_fft16_inverse<v2f, XlpFftOps>(z);
-    {
-      const uint32_t m1 = xli8_load_m1(j);
-      const v2f *__restrict__ twp = &twl[0][m1];
-      unsigned char *const wr = reg + xli8_exch(xli8_load_c8(j), 0u, m1);
-      *reinterpret_cast<v2f *>(wr) = z[xli8_slot16(0)];
-#pragma unroll
-      for (int tt = 1; tt < 16; ++tt) *reinterpret_cast<v2f *>(wr + tt * XLI8_XROW) = xlp_cmul_v(z[xli8_slot16(tt)], twp[tt * 8]);
-    }
-    // ---- the next tile: column record, then the 16 values per lane (into the registers just freed)
-    uint32_t col0n, segn;
-    v2f *const tilen = tile_of(tn, col0n, segn);
-    const XlpCol cen = a.cols[col0n + c8];
-#pragma unroll
-    for (int m2 = 0; m2 < 16; ++m2) z[m2] = tilen[o0 + m2 * os];
-    __builtin_amdgcn_wave_barrier();
-    // ---- role 3 (reader), role 4
-    v2f y[2][8];
-    {
-      const unsigned char *const rd = reg + xli8_exch(c8, u, 0u);
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const v4f pr = *reinterpret_cast<const v4f *>(rd + e * 8 * XLI8_XROW + i * 16);
-          y[e][2 * i] = (v2f){pr.x, pr.y};
-          y[e][2 * i + 1] = (v2f){pr.z, pr.w};
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    xl_fft8_inverse<v2f, XlpFftOps>(y[0]);
-    xl_fft8_inverse<v2f, XlpFftOps>(y[1]);
-    // ---- phases of this tile
-    if (d.eok) {
-      const uint32_t left = d.bnd.K - d.m0, span = XL_PH_STRIDE - d.ibeg;
-      unsigned char *const pw = reg + xli8_phase(c8, u * XL_PH_STRIDE + d.ibeg);
-      xl_phase_walk(pe, d.m0, left < span ? left : span, (v2f){ce.incr.x, ce.incr.y}, d.bnd,
-                    [&](uint32_t i, v2f phs) { *reinterpret_cast<v2f *>(pw + i * 8u) = phs; });
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- the next tile's phase-table entry (its column record has been back for a while: it was requested ahead of the tile)
-    const Duty dn = duty_of(cen, segn);
-    const v2f pen = ph[dn.eok ? (cen.out_off >> XL_PH_SHIFT) + (dn.m0 >> XL_PH_SHIFT) : 0u];
-    // ---- epilogue, branch-free
-    {
-      v2f *const out = reinterpret_cast<v2f *>(a.out) + (ce.out_off != 0xFFFFFFFFu ? ce.out_off : 0u);
-      const bool colok = ce.out_off != 0xFFFFFFFFu;
-      const unsigned char *const pr = reg + xli8_phase(c8, u);
-      const uint32_t qs0 = seg * a.V + u;
-#pragma unroll
-      for (int g = 0; g < 8; ++g)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const uint32_t qo = 16u * g + 8u * e + u, qs = qs0 + 16u * g + 8u * e;
-          const bool ok = colok && qo < a.V && qs >= d.esh && qs - d.esh < d.bnd.K;
-          const v2f val = y[e][xli8_slot8(g)] * (1.0f / (float)M);
-          // (a point without a phase in the region reads whatever is there: its product goes to the dump)
-          const v2f r = xl_rotate<1>(val, *reinterpret_cast<const v2f *>(pr + g * XLI8_PROW + e * 64));
-          v2f *const dst = ok ? out + (qs - d.esh) : dump;
-          *dst = r;
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0x4F70);  // vmcnt(16): the next tile and its table entry are here, the sixteen stores may still fly
-    if (last) break;
-    t = tn, tile = tilen, seg = segn, ce = cen, pe = pen;
-  }
-}
-
 void xlp_inverse8_launch(const XlpArgs &a, const dim3 grid, hipStream_t s, hipEvent_t done) {
-  void (*kern)(const XlpArgs) = a.inv_wgs ? xlp_inverse8p_kernel : xlp_inverse8_kernel;
-  if (done) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, s, nullptr, done, 0, a);
-  else hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);
+  if (done) hipExtLaunchKernelGGL(xlp_inverse8_kernel, grid, dim3(256), 0, s, nullptr, done, 0, a);
+  else hipLaunchKernelGGL(xlp_inverse8_kernel, grid, dim3(256), 0, s, a);
 }

@@ -1,15 +1,20 @@
 // xl_mixf32.hip -- the mix launch of the polyphase path on the matrix cores with FLOAT32 operands (PolyClass::mix_kind 3).
 //
-// Same sums as xlp_mix_kernel / xlp_mix_mfma_kernel (xl_polyphase.hip): Y[c][s][m] = sum_b X[s][b][m] R[c][b][m], the per-client
-// multiply-accumulate of xlating.c:66-71 evaluated per spectrum bin of the D polyphase branches (xl_polyphase.h) -- here as one
-// real matrix product per bin on v_mfma_f32_32x32x2_f32: float32 in, float32 accumulate, bit for bit a chain of fmaf in branch
-// order (the very chain xlp_mix_kernel issues as packed FMAs; nothing is split or scaled, so cf32 streams -- whose spectra have
-// no bound -- and any branch count take it).  rows = (segment of the pass, re / im), columns = 32 clients, one instruction =
-// one branch (k = 0: the "re" factor, k = 1: the "im" factor): xl_mixf_layout.h.
+// Same sums as xlp_mix_mfma_kernel (xl_polyphase.hip): Y[c][s][m] = sum_b X[s][b][m] R[c][b][m], the per-client multiply-accumulate of
+// xlating.c:66-71 evaluated per spectrum bin of the D polyphase branches (xl_polyphase.h) -- here as one real matrix product per bin on
+// v_mfma_f32_32x32x2_f32: float32 in, float32 accumulate, bit for bit a chain of fmaf in branch order (the chain rounds 1-4 issued as
+// packed FMAs on the vector ALUs: xlp_mix_kernel, retired in round 5).  Nothing is split or scaled, so cf32 streams -- whose spectra
+// have no bound -- and any branch count take it, and option "mix_kernel" = 3 gives every class the all-float32 arithmetic.
+// rows = (segment of the pass, re / im): the 16 segments of a pass fill the 32 rows; columns = 32 clients; one instruction = one branch
+// (k = 0: the "re" factor, k = 1: the "im" factor): xl_mixf_layout.h, checked on the host by tests/c/test_mixf_layout.cpp.
 //
-// Why it beats the packed-FMA kernel although the two have the same peak (64 flop per cycle and SIMD): the matrix pipe takes one
-// instruction per 4096 flop and reads two registers for it; the vector pipe needed 16 packed FMAs, each reading three 64-bit
-// operands, and everything else the wave does (addresses, waits, stores) competed with them for the same issue slots.
+// What to expect of it: the float32 matrix instruction has the SAME peak as the packed FP32 FMAs (64 flop per cycle and SIMD).  It
+// takes one instruction per 4096 flop where the vector pipe needed 16, so everything else a wave does stops competing with the
+// arithmetic -- measured (profiles/r05_mix_f32.txt, 4096 clients, us per block): 57.4 with 16-segment passes against 56.9 for the
+// packed-FMA kernel; ~80 % of the matrix pipe's rate on the CUs the launch gets, at a chain-checked clock of 2.3 GHz, and no faster
+// with its global loads compiled out: it is bound by the FP32 rate of the chip like its predecessor.  Gauss's three-product form of
+// the complex product (3 D / 2 instructions instead of 2 D) was built to parity and measured too: -5 % at D = 42, +20 % at D = 100 --
+// its three accumulators cost the occupancy it needs (profiles/r05_mix_f32_gauss_form.txt; tools/experiments/gauss_mix/).
 //
 // Workgroup = 4 waves = (bin m, column group of 128 clients, a run of passes); wave w = the group's columns 32 w .. 32 w + 31.
 //   B operands: the wave's branch spectra of bin m in operand form (Rf: xlmf_rf_slot), ONE float per lane and branch, read once per
@@ -21,7 +26,7 @@
 //               xlp_mix_mfma_kernel) and a matrix instruction's operand is one conflict-free ds_read_b32 (64 lanes, 32 distinct
 //               floats of one row) -- no conversion, no transposition.  (Round 5's first build loaded the operand straight from
 //               the image, one 4-byte load per lane and branch and no LDS: parity-equal, but 42 single-line requests per wave and
-//               pass ran the launch at 58 % of the matrix pipe's rate -- profiles/r05_mix_f32.txt; kept as -DXLMF_DIRECT.)
+//               pass ran 20 % slower -- profiles/r05_mix_f32.txt.)
 // This launch never hosts the NCO role (no launch that issues matrix instructions does: DESIGN 3.6).
 #include "xl_poly_dev.h"
 
@@ -48,15 +53,20 @@ XL_DEV XlmfJob xlmf_job(const XlpArgs &a, const uint32_t bid) {
 }
 
 // the wave's results of one pass -> Y image [cg][segment][sub][bin][CW columns] (the inverse workgroups' tiles): registers g, g + 1
-// (g even) = (re, im) of the pass's segment xlmf_result_row(g, h) / 2, column c
+// (g even) = (re, im) of the pass's segment xlmf_result_row(g, h) / 2 = 2 h + (g >> 1 & 1) + 4 (g >> 2), column c.  One 64-bit
+// product per lane (its first segment), then wave-uniform steps; the bounds test is per lane only in the call's last pass.
 XL_DEV void xlmf_store_pass(const XlpArgs &a, const v16f32 &acc, v2f *__restrict__ Yc, const size_t ystride, const uint32_t pass,
                             const uint32_t h) {
+  static_assert(XLP_SEG == 16u, "the 16 segments of a pass fill the 32 rows of the instruction");
   const uint32_t s0 = pass * XLP_SEG;
+  char *__restrict__ const base = reinterpret_cast<char *>(Yc + (size_t)(s0 + 2u * h) * ystride);
+  const size_t sb = ystride * sizeof(v2f);  // bytes from a segment's tile to the next one's (wave-uniform)
+  const bool whole = s0 + XLP_SEG <= a.nseg;  // (wave-uniform)
 #pragma unroll
   for (int g2 = 0; g2 < 16; g2 += 2) {
-    const uint32_t sl = xlmf_result_row((uint32_t)g2, h) >> 1;
+    const uint32_t cs = (uint32_t)(((g2 >> 1) & 1) + 4 * (g2 >> 2));  // (a constant after unrolling; = xlmf_result_row(g2, 0) / 2)
     // (written once, read once by the next launch: streamed past the L2 lines that hold the operands)
-    if (sl < XLP_SEG && s0 + sl < a.nseg) __builtin_nontemporal_store((v2f){acc[g2], acc[g2 + 1]}, &Yc[(size_t)(s0 + sl) * ystride]);
+    if (whole || s0 + 2u * h + cs < a.nseg) __builtin_nontemporal_store((v2f){acc[g2], acc[g2 + 1]}, reinterpret_cast<v2f *>(base + cs * sb));
   }
 }
 
@@ -147,71 +157,6 @@ __global__ __launch_bounds__(256) void xlp_mix_f32_kernel(const XlpArgs a) {
     __syncthreads();  // the other buffer is staged; everybody is done with this one
   }
 }
-
-#ifdef XLMF_DIRECT  // (A/B builds only: every lane loads its A operands straight from the image, one 4-byte load per branch)
-template <int NB8>
-__global__ __launch_bounds__(256) void xlp_mix_f32_direct_kernel(const XlpArgs a) {
-  constexpr int NJ = 8 * NB8;
-  const XlmfJob job = xlmf_job(a, blockIdx.x);
-  if (job.p0 >= job.p1) return;
-  const uint32_t tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-  const uint32_t M = a.M, m = job.m, cg = job.cg;
-  // ---- B operands of this wave: 2 NB8 runs of 1 KB
-  float bq[NJ];
-  {
-    const v4f32 *__restrict__ Rp = reinterpret_cast<const v4f32 *>(a.Rh);
-#pragma unroll
-    for (int jb = 0; jb < NB8; ++jb)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const v4f32 v = Rp[xlmf_rf_slot(cg, M, m, w, (uint32_t)NB8, (uint32_t)jb, (uint32_t)q, lane)];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bq[8 * jb + 4 * q + e] = v[e];
-      }
-  }
-  // ---- A operands: image row (pass, branch j, bin m) = 128 bytes at X + ((pass Dpad + j) M + m) 128; this lane's float of it
-  const uint32_t h = lane >> 5, c = lane & 31u;
-  const uint32_t sgn = xlmf_a_negate(lane) << 31;
-  const uint32_t loff = xlmf_a_float(lane) * 4u;
-  const char *__restrict__ xb = reinterpret_cast<const char *>(a.X) + (size_t)m * (XLP_XS * sizeof(float2));
-  const size_t xrow = (size_t)M * (XLP_XS * sizeof(float2));  // bytes from one branch's row of a bin to the next one's
-  const uint32_t D = a.D;
-  auto xload = [&](const uint32_t pass, const int j) __attribute__((always_inline)) {
-    return *reinterpret_cast<const float *>(xb + ((size_t)pass * a.Dpad + (uint32_t)j) * xrow + loff);
-  };
-  float av[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) av[j] = (j < NJ - 8 || (uint32_t)j < D) ? xload(job.p0, j) : 0.0f;  // (only the last k-block may be short)
-  // (the B operands are waited for HERE, once, with the first pass's A operands still in flight behind them: left to itself the
-  // compiler puts those waits into the pass loop -- `vmcnt(12)` ahead of every pass's first products, which also drains all but
-  // twelve of the operand loads the previous pass has just issued)
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(bq[j]));
-  // ---- Y: this lane's column of segment s
-  const uint32_t CW = M == 256u ? 16u : 32u, NSUB = XLP_COLS / CW;
-  const uint32_t col = w * 32u + c;
-  v2f *__restrict__ Yc = reinterpret_cast<v2f *>(a.Y) + ((((size_t)cg * a.nseg_cap) * NSUB + col / CW) * M + m) * CW + col % CW;
-  const size_t ystride = (size_t)NSUB * M * CW;  // v2f per segment
-  for (uint32_t pass = job.p0; pass < job.p1; ++pass) {
-    const uint32_t nxt = pass + 1u < job.p1 ? pass + 1u : pass;  // (the last pass requests its own rows again: no branch around the loads)
-    v16f32 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      if (j < NJ - 8 || (uint32_t)j < D) {  // (wave-uniform)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xlmf_flip(av[j], sgn), bq[j], acc, 0, 0, 0);
-        av[j] = xload(nxt, j);
-        // (nothing crosses: left alone, the scheduler gathers the sign flips of ALL branches -- and with them the waits for all
-        // their loads -- in front of the first matrix instruction of the pass)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    xlmf_store_pass(a, acc, Yc, ystride, pass, h);
-  }
-}
-
-#endif
 
 // Any branch count (D > 112: huge decimations, few segments per call): the B operands do not fit a wave's registers for all its
 // passes, so every pass streams them again, one k-block of 8 branches ahead of the products (they come from L2 after the first
@@ -308,11 +253,7 @@ static uint32_t xlmf_default_pp(const XlpArgs &a, uint32_t passes) {
 
 template <int NB8>
 static void xlmf_launch_n(const XlpArgs &a, const dim3 grid, hipStream_t s) {
-#ifdef XLMF_DIRECT
-  hipLaunchKernelGGL(xlp_mix_f32_direct_kernel<NB8>, grid, dim3(256), 0, s, a);
-#else
   hipLaunchKernelGGL(xlp_mix_f32_kernel<NB8>, grid, dim3(256), 0, s, a);
-#endif
 }
 
 // (called by xlp_launch_mix for mix_kind 3, with a.mix_passes set)

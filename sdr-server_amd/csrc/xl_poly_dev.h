@@ -1,13 +1,13 @@
 // xl_poly_dev.h -- device helpers shared by the polyphase kernels (xl_polyphase.hip: forward / mix / inverse launches;
 // xl_fused.hip: the fused mix + inverse launch): complex products, the M-point Stockham transform staged in LDS, the
-// packed-instruction arithmetic policy of the register transforms (xl_fft64.h), the two-half split of float32 values for
+// packed-instruction arithmetic policy of the register transforms (xl_fft16.h), the two-half split of float32 values for
 // the matrix cores, and the branch spectra of a client column.  Include only from .hip files compiled -ffp-contract=off.
 #ifndef XL_POLY_DEV_H_
 #define XL_POLY_DEV_H_
 #include "xl_polyphase.h"
 
 #include "xl_dev_inline.h"
-#include "xl_fft64.h"
+#include "xl_fft16.h"
 
 XL_DEV v2f xlp_cmul(const v2f a, const v2f b) {
   return (v2f){__builtin_fmaf(-a.y, b.y, a.x * b.x), __builtin_fmaf(a.y, b.x, a.x * b.y)};

@@ -27,16 +27,15 @@
 #include "xl_device.h"
 
 #define XLP_M_MAX 256u  // transform length M (branch samples per segment): 256 or 128, chosen per class
-#ifndef XLP_SEG
-#define XLP_SEG 14u    // segments accumulated per lane in one pass of the mix kernel
-#endif
-#define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: XLP_SEG padded to 128 bytes
+#define XLP_SEG 16u    // segments per pass of the mix launches: with (re, im) the 32 rows of a matrix instruction (round 5; 14 before: the
+                       // packed-FMA mix kernel's register budget -- 16 took 7 % off the two-half mix launch, profiles/r05_mix_f32.txt)
+#define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: the XLP_SEG segments of a pass = 128 bytes
 #define XLP_COLS 128u  // client columns per column group (= one mix workgroup: a wave with two columns per lane)
 #define XLP_NKB_MAX 8u // matrix-core mix: at most 8 k-blocks of 8 branches (D <= 64)
 #define XLP_H_XSCALE 128.0f  // matrix-core mix: the shared spectra are multiplied by this before the split in halves: integer input
                              // formats give |X| <= M sqrt(2) <= 363, so the first half stays below 46 400 < 65 504
 #define XLP_H_RMAX 8192.0f   // ... and a column's spectra by the power of two that brings their bound max_b sum_a |r_b[a]| under this
-#define XLP_BSTEP 6u   // rows per trip of the mix kernel's row loop (even; the branch count is padded to a multiple in the images)
+#define XLP_BSTEP 2u   // the branch count is padded to a multiple of this in the shared-spectrum image (rows D .. Dpad - 1: zeros)
 
 // One client column of a class: 16 bytes, one load.
 struct XlpCol {
@@ -60,70 +59,55 @@ struct XlpArgs {
   uint32_t D, Dpad;    // decimation = number of branches; padded to a multiple of XLP_BSTEP in the images
   uint32_t T, A, V;    // taps, taps per branch of the delayed filters, valid outputs per segment = M - A + 1
   uint32_t M;          // transform length: 256 or 128
-  uint32_t mix_passes; // (set by xlp_launch_mix) passes of 14 segments = ceil(nseg / 14)
+  uint32_t mix_passes; // (set by xlp_launch_mix) passes of XLP_SEG segments = ceil(nseg / XLP_SEG)
   uint32_t nseg;       // segments of this call = ceil(Kq / V)
   uint32_t nseg_cap;   // segment capacity of the Y image
   uint32_t ncg;        // column groups of XLP_COLS client columns
   uint32_t exp;        // tuning switches (XL_TUNING builds only; 0 otherwise)
-  uint32_t inv_reg;    // M = 128: the inverse launch's transform: 0 = staged in LDS, 1 = registers of a lane pair, 2 = of a lane quad,
-                       // 3 / 4 = staged in LDS on swizzled rows, 5 = registers of eight lanes per column (xl_inv8.hip)
-  uint32_t mix_kind;   // the mix launch: 0 = packed FP32 FMAs (xlp_mix_kernel), 1 = matrix cores on two-term half splits (xlp_mix_mfma_kernel),
-                       // 2 = mix + inverse as ONE launch with the mixed spectra on chip (xl_fused.hip: no Y image, X and Rh in that launch's operand forms),
-                       // 3 = matrix cores with float32 operands (xl_mixf32.hip: xlp_mix_f32_kernel; any input format, any branch count)
-  uint32_t nkb;        // mix_kind 1, 3: k-blocks of 8 branches = ceil(D / 8) (kind 1: <= XLP_NKB_MAX); mix_kind 2: k-blocks of 16 branches, <= 4
-  uint32_t mix_pp;     // mix_kind 1: passes per workgroup (0 = default)
-  uint32_t inv_wgs;    // inv_reg 5: work workgroups of the PERSISTENT form of that launch (each walks tiles bid, bid + inv_wgs, ..; option
-                       // "inverse_persistent"); 0 = one workgroup per tile
-  uint32_t y6;         // mix_kind 1 + LDS-transform inverse kernels: Y holds 48-bit values (xl_y6.h) instead of float32 pairs
+  uint32_t inv_reg;    // M = 128: the inverse launch's transform: 5 = registers of eight lanes per column (xl_inv8.hip; default), 3 = staged
+                       // in LDS on swizzled rows (xlp_inverse_kernel<128>)
+  uint32_t mix_kind;   // the mix launch: 1 = matrix cores on two-term half splits (xlp_mix_mfma_kernel), 3 = matrix cores with float32
+                       // operands (xl_mixf32.hip: xlp_mix_f32_kernel; any input format, any branch count)
+  uint32_t nkb;        // k-blocks of 8 branches = ceil(D / 8) (mix_kind 1: <= XLP_NKB_MAX)
+  uint32_t mix_pp;     // passes per workgroup of the mix launch (0 = the launcher's default)
   unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
-  const float2 *R;     // branch spectra   [cg][M][Dpad][XLP_COLS] (+ XLP_BSTEP rows of tail padding)
-  const void *Rh;      // mix_kind 1: the same, scaled per column and split in two halves, in MFMA operand order
+  const void *Rh;      // branch spectra in the mix launch's B-operand order.  mix_kind 1: scaled per column and split in two halves,
                        //   [cg][M][32-column quarter][term 2][k-block nkb][lane 64][8 halves] (see xlp_mix_mfma_kernel)
                        // mix_kind 3: the same values as float32 (R.re, -R.im) in v_mfma_f32_32x32x2_f32's B-operand order
                        //   [cg][M][32-column quarter][k-block nkb][half 2][lane 64][4 branches] (xl_mixf_layout.h)
   const float *cscale; // mix_kind 1: per column, what the sums are multiplied by = 1 / (column scale * XLP_H_XSCALE)
   float2 *Y;           // mixed spectra    [cg][nseg_cap][sub][M][CW], CW = 32 (M = 128) / 16 (M = 256) columns: one inverse tile contiguous
-                       //   (y6: the same tiles, 6 bytes per value in two planes: xl_y6.h)
   const XlpCol *cols;  // per column
   const float2 *phtab;
   float2 *out;
   // raw-history roll, carried by the forward launch (as XlFirArgs): null / 0 = none
   void *hist_out;
   uint32_t hist_units, block_units, roll_blocks;
-  // NCO role pieces (see XlFirArgs): each of the three launches of a call carries a slice [nco_k0, nco_k1) of the
+  // NCO role pieces (see XlFirArgs): the forward and the inverse launch of a call each carry a slice [nco_k0, nco_k1) of the
   // NEXT call's phase recurrence (stream position xl_grid_next(pos)); block ends inside a slice renormalise
   // (xlating.c:73).
   const XlNcoClient *nco_clients;
   uint32_t nco_nclients;
   uint32_t nco_blocks;
   uint32_t nco_prio;        // wave priority of the role (0..3)
-  uint32_t nco_skip_at, nco_skip;  // mix launch: workgroups [nco_skip_at, nco_skip_at + nco_skip) exit at once (see the kernel)
+  uint32_t nco_skip_at, nco_skip;  // inverse launch: workgroups [nco_skip_at, nco_skip_at + nco_skip) exit at once (a slot kept empty on the role's CUs)
   uint32_t nco_k0, nco_k1;  // in 1/65536 of the call's outputs: slice = [K*k0 >> 16, K*k1 >> 16) rounded down to pairs of table entries
   const float2 *nco_state_src;  // phases at the start of the slice (committed phases for the first slice)
   float2 *nco_state_dst;        // phases after the slice (committed post-call phases for the last slice)
   float2 *nco_tab;
 };
 
-// reversed band-pass taps of a LIST of columns -> their branch spectra in R (double arithmetic, rounded once to float)
+// reversed band-pass taps of a LIST of columns -> their branch spectra (double arithmetic, rounded once to float) in the two-half
+// mix's operand form (XlpArgs::Rh)
 //   rt: [T][nlist] float2 (tap-major); delta[j]: delay of entry j's taps in samples (xl_grid.h: merged classes);
-//   colidx[j]: the column of R the entry goes to; A = ceil((T + max delta) / D); branches >= D get 0
-hipError_t xlp_launch_tables(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, uint32_t nlist, uint32_t T,
-                             uint32_t D, uint32_t Dpad, uint32_t A, uint32_t M, float2 *R, hipStream_t s);
-// the same in the matrix-core mix's operand form (XlpArgs::Rh); scale[j]: the entry's power-of-two column scale
+//   colidx[j]: the column the entry goes to; scale[j]: the entry's power-of-two column scale; A = ceil((T + max delta) / D)
 hipError_t xlp_launch_tables_h(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, const float *scale,
                                uint32_t nlist, uint32_t T, uint32_t D, uint32_t A, uint32_t M, uint32_t nkb, void *Rh,
                                hipStream_t s);
-// bytes of the operand-form image per column group
+// bytes of that image per column group
 static inline size_t xlp_rh_bytes_per_group(uint32_t M, uint32_t nkb) { return (size_t)M * 4u * 2u * nkb * 64u * 16u; }
-// mix_kind 2 (xl_fused.hip; M = 128, integer input formats, D <= 64): the branch spectra in the fused launch's operand form
-// (xl_fused_layout.h: xlf_rh_slot), the forward launch that writes the shared spectra in its operand form (a.X = that image,
-// xlf_xh_slot) and the fused mix + inverse launch itself
-hipError_t xlp_launch_tables_h16(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, const float *scale,
-                                 uint32_t nlist, uint32_t T, uint32_t D, uint32_t A, uint32_t nk, void *Rh, hipStream_t s);
-hipError_t xlp_launch_forward_h(const XlpArgs &a, hipStream_t s);
-hipError_t xlp_launch_fused(const XlpArgs &a, hipStream_t s, hipEvent_t done);
 // mix_kind 3 (xl_mixf32.hip): the branch spectra as float32 B operands, and the mix launch itself (called by xlp_launch_mix)
 hipError_t xlp_launch_tables_f(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, uint32_t nlist, uint32_t T, uint32_t D,
                                uint32_t A, uint32_t M, uint32_t nb8, void *Rf, hipStream_t s);

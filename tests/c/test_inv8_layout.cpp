@@ -1,5 +1,5 @@
 // tests/c/test_inv8_layout.cpp -- host check of sdr-server_amd/csrc/xl_inv8_layout.h + the 16- / 8-point register transforms of
-// xl_fft64.h (the index bookkeeping of xlp_inverse8_kernel, xl_inv8.hip):
+// xl_fft16.h (the index bookkeeping of xlp_inverse8_kernel, xl_inv8.hip):
 //   1. a wave's data flow -- tile [bin][column] -> role-1 lanes (16-point transforms) -> twiddles -> exchange through a
 //      byte-addressed LDS image -> role-4 lanes (8-point transforms) -> output n of column c in lane (c, n & 7) -- against a
 //      double-precision DFT of every column;
@@ -16,7 +16,7 @@
 #include <set>
 #include <vector>
 
-#include "../../sdr-server_amd/csrc/xl_fft64.h"
+#include "../../sdr-server_amd/csrc/xl_fft16.h"
 #include "../../sdr-server_amd/csrc/xl_inv8_layout.h"
 
 typedef float V __attribute__((ext_vector_type(2)));

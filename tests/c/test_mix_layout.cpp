@@ -113,7 +113,7 @@ int main() {
     }
   }
   const uint32_t shapes[][2] = {{42, 3}, {5, 2}, {21, 2}, {8, 1}, {50, 2}, {64, 2}, {1, 1}};
-  for (auto &sh : shapes) bad |= run(sh[0], sh[1], 2, 14);
+  for (auto &sh : shapes) bad |= run(sh[0], sh[1], 2, 16);
   if (!bad) printf("matrix-core mix layout: ok\n");
   return bad ? 1 : 0;
 }

@@ -293,27 +293,17 @@ def test_1000_clients_split_group_riders():
 # that the oracle can check every client.
 # The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
 # the forced-path tests run with both.
-@pytest.fixture(params=[(128, 0, 1, 0), (128, 1, 1, 0), (128, 2, 1, 0), (128, 3, 1, 0), (256, 0, 1, 0), (128, 3, 0, 0), (256, 0, 0, 0), (128, 3, 2, 0),
-                        (128, 3, 1, 1), (256, 0, 1, 1), (128, 5, 1, 0), (128, 5, 0, 0), (128, 5, 1, 1), (128, 5, 3, 0), (256, 0, 3, 0)],
-                ids=["M128", "M128-register-inverse", "M128-quad-register-inverse", "M128-swizzled-inverse", "M256",
-                     "M128-fma-mix", "M256-fma-mix", "M128-fused", "M128-swizzled-inverse-48bit-Y", "M256-48bit-Y",
-                     "M128-8-lane-inverse", "M128-8-lane-inverse-fma-mix", "M128-8-lane-inverse-asked-with-48bit-Y",
-                     "M128-8-lane-inverse-f32-matrix-mix", "M256-f32-matrix-mix"])
+@pytest.fixture(params=[(128, 5, 1), (128, 3, 1), (256, 5, 1), (128, 5, 3), (256, 5, 3), (128, 3, 3)],
+                ids=["M128", "M128-lds-inverse", "M256", "M128-f32-mix", "M256-f32-mix", "M128-lds-inverse-f32-mix"])
 def poly_m(request, monkeypatch):
-    """Transform length of the forced polyphase plan; at M = 128 also with the inverse launch's transform in registers
-    (option "inverse_kernel" = 1: xlp_inverse_reg_kernel, a lane pair per column; 2: xlp_inverse_quad_kernel, a lane quad; 5:
-    xlp_inverse8_kernel, eight lanes per column with 16- and 8-point transforms in registers -- with 48-bit Y the engine falls back
-    to the swizzled LDS transform);
-    the mix launch on the matrix cores (option "mix_kernel" = 1, the default: two-half float16 operands where the class allows them --
-    integer input, D <= 64 --, float32 operands elsewhere; 3: float32 operands for every class)
-    or as packed FP32 FMAs (0), or mix + inverse as ONE launch with the mixed spectra on chip (2: xl_fused.hip); the mixed spectra
-    between the matrix-core mix and an LDS-staged inverse launch as float32 pairs (option "y_format" = 0, the default) or as
-    48-bit values (1: xl_y6.h)."""
-    m, inv, mix, y6 = request.param
+    """Transform length of the forced polyphase plan; at M = 128 the inverse launch's transform in the registers of eight lanes per
+    column (option "inverse_kernel" = 5, the default: xlp_inverse8_kernel) or staged in LDS on swizzled rows (3: xlp_inverse_kernel);
+    the mix launch on the matrix cores with two-half float16 operands where the class allows them and float32 operands elsewhere
+    (option "mix_kernel" = 1, the default) or with float32 operands for every class (3)."""
+    m, inv, mix = request.param
     monkeypatch.setenv("XL_EXP_POLY_M", str(m))
     monkeypatch.setenv("XL_EXP_INV", str(inv))
     monkeypatch.setenv("XL_EXP_MIX", str(mix))
-    monkeypatch.setenv("XL_EXP_Y6", str(y6))
     return m
 
 
@@ -432,7 +422,7 @@ def test_polyphase_forced_other_shapes(shape, monkeypatch, poly_m):
     eng.close()
 
 
-@pytest.mark.parametrize("m,mix", [(128, 1), (256, 1), (128, 2)], ids=["M128", "M256", "M128-fused"])
+@pytest.mark.parametrize("m,mix", [(128, 1), (256, 1), (128, 3)], ids=["M128", "M256", "M128-f32-mix"])
 def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, mix, monkeypatch):
     """The matrix-core mix carries every operand as two halves after a power-of-two scale (per column for the branch
     spectra, fixed for the shared spectra): one class whose members' taps differ by 10^8 in gain (column scales 2^-2 ..
@@ -453,7 +443,7 @@ def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, mix, monke
         for fc in (-600000 + 170000 * c, 250000 - 31000 * c):
             t = [float(v) for v in taps]
             oracles[eng.add_client(42, t, fc)] = Oracle(42, t, fc, FS, 262144)
-    assert ("mix=fused" if mix == 2 else "mix=mfma") in eng.describe(), eng.describe()
+    assert ("mix=mf32" if mix == 3 else "mix=mfma") in eng.describe(), eng.describe()
     n = 262144
     full = np.full(n, 255, dtype=np.uint8)
     square = np.where((np.arange(n) // 2) % 84 < 42, 255, 0).astype(np.uint8)
@@ -462,28 +452,26 @@ def test_polyphase_matrix_core_mix_tap_scales_and_full_scale_input(m, mix, monke
     eng.close()
 
 
-@pytest.mark.parametrize("mix", [1, 2, 3], ids=["mfma", "fused", "f32-mfma"])
+@pytest.mark.parametrize("mix", [1, 3], ids=["mfma", "f32-mfma"])
 @pytest.mark.parametrize("D,fs", [(12, 576000), (33, 1584000), (50, 2400000), (64, 3072000)])
 def test_polyphase_matrix_core_mix_other_branch_counts(D, fs, mix, monkeypatch):
-    """The matrix-core mix is built per number of k-blocks of 8 branches (1..8): the server default is 6 (D = 42), the
-    fixture shapes cover 1 (D = 5) and 3 (D = 21); here 2, 5, 7 and 8 (the last two keep a few operand registers in
-    scratch) -- 48 kHz clients off other sample rates, 12 taps per branch, both transform lengths by the size rule's
-    forcing, every client vs the oracle.  The fused launch (mix = 2) is built per number of k-blocks of SIXTEEN branches (1..4;
-    128-point segments only): 1, 3, 4 and 4 here, 1 (D = 5), 2 (D = 21) and 3 (D = 42) in the fixture shapes.  The float32 matrix-core
-    mix (mix = 3, xl_mixf32.hip) is built per number of k-blocks of 8 branches whose operands stay in registers (1..14; D = 100 and
-    D = 400 -- the streaming kernel -- run in test_polyphase_forced_other_shapes)."""
+    """The two-half matrix-core mix is built per number of k-blocks of 8 branches (1..8): the server default is 6 (D = 42), the
+    fixture shapes cover 1 (D = 5) and 3 (D = 21); here 2, 5, 7 and 8 (the last two keep a few operand registers in scratch) -- 48 kHz
+    clients off other sample rates, 12 taps per branch, both transform lengths by the size rule's forcing, every client vs the
+    oracle.  The float32 matrix-core mix (mix = 3, xl_mixf32.hip) is built per number of k-blocks whose operands stay in registers
+    (1..14; D = 100 and D = 400 -- the streaming kernel -- run in test_polyphase_forced_other_shapes)."""
     monkeypatch.setenv("XL_EXP_MIX", str(mix))
     taps = lpf(fs, 24000, fs // 210)
     assert len(taps) >= 9 * D // 2
     n = 131072
-    for m in ((128,) if mix == 2 else (128, 256)):
+    for m in (128, 256):
         monkeypatch.setenv("XL_EXP_POLY_M", str(m))
         eng = _poly_engine(monkeypatch, max_input=2 * n, fs=fs)
         oracles = {}
         for c in range(37):
             fc = int(-0.4 * fs + c * 0.021 * fs)
             oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, fs, 2 * n)
-        assert {2: "mix=fused", 3: "mix=mf32"}.get(mix, "mix=mfma") in eng.describe() and " M%d " % m in eng.describe(), eng.describe()
+        assert ("mix=mf32" if mix == 3 else "mix=mfma") in eng.describe() and " M%d " % m in eng.describe(), eng.describe()
         for k in range(3):
             check_clients(eng, oracles, "cu8", siggen.xs_u8(5300 + k, 2 * n if k != 1 else 2 * n - 1234), "optimized")
         eng.close()
@@ -491,11 +479,11 @@ def test_polyphase_matrix_core_mix_other_branch_counts(D, fs, mix, monkeypatch):
             o.close()
 
 
-def test_size_rule_of_matrix_core_classes():
+def test_size_rule_of_matrix_core_classes(monkeypatch):
     """The engine's own plan (no forcing): classes whose mix launch runs on the matrix cores take the polyphase path from 32
     clients and 2 taps per branch on (101 taps at D = 42: 3 per branch) -- cf32 streams too, since their mix launch multiplies
-    float32 operands on the matrix cores (round 5; before: 128 clients, 4.5 taps per branch) --, a given "polyphase_min_clients"
-    holds for every class -- and the 101-tap class and the cf32 class match the oracle."""
+    float32 operands on the matrix cores (round 5; before: 128 clients, 4.5 taps per branch) --, the tuning knob XL_EXP_POLY_MIN
+    moves the client threshold -- and the 101-tap class and the cf32 class match the oracle."""
     t101 = lpf(FS, 24000, 48000)
     assert len(t101) == 101
     eng = xl.BatchEngine(FS, "cu8", 262144, group_blocks=2)
@@ -511,10 +499,15 @@ def test_size_rule_of_matrix_core_classes():
         _check_group(eng, oracles, "cu8", x, 2, "optimized")
     d = eng.describe()
     assert "polyphase: cls0 D42 T101 cols40 " in d and "mix=mfma" in d and "cls1" not in d and "optimized-mode direct: h" in d, d
-    eng.set_option("polyphase_min_clients", 64)
-    _check_group(eng, oracles, "cu8", siggen.xs_u8(5410, 2 * 262144), 2, "optimized")
+    eng.close()
+    monkeypatch.setenv("XL_EXP_POLY_MIN", "64")  # (a tuning knob, read when an engine is created: the smallest class that takes the path)
+    eng = xl.BatchEngine(FS, "cu8", 262144, group_blocks=2)
+    for c in range(40):
+        eng.add_client(42, t101, -800000 + 41000 * c)
+    eng.process_host_group(siggen.xs_u8(5410, 2 * 262144), 2, "optimized")
     assert "polyphase: none" in eng.describe(), eng.describe()
     eng.close()
+    monkeypatch.delenv("XL_EXP_POLY_MIN")
     eng = xl.BatchEngine(FS, "cf32", 8 * 65536)
     taps = lpf(FS, 24000, 9600)
     oracles = {}
@@ -527,20 +520,20 @@ def test_size_rule_of_matrix_core_classes():
 
 
 def test_matrix_core_mix_role_phases_bit_exact(monkeypatch):
-    """One-block calls with the recurrence INSIDE the launches (option nco_side_stream = 0): with the FMA mix each of the three
-    polyphase launches carries a slice of the NEXT call's NCO recurrence; with the matrix-core mix only the forward and the
-    inverse launch do, with the fused launch only the forward launch (round 4: no launch that issues matrix instructions hosts
-    the role -- a first build of xlp_mix_mfma_kernel corrupted the phases of role waves riding in it, see its header).  Three
-    engines on the same stream of 120 blocks: the committed phases of all 1024 clients agree bit for bit after every call."""
+    """One-block calls with the recurrence INSIDE the launches (option nco_side_stream = 0): the forward and the inverse launch carry a
+    slice each of the NEXT call's NCO recurrence, the mix launch none (round 4: no launch that issues matrix instructions hosts the
+    role -- a first build of xlp_mix_mfma_kernel corrupted the phases of role waves riding in it).  Three engines on the
+    same stream of 120 blocks -- two-half mix, float32 mix, and the side-stream chain kernel as the reference -- : the committed
+    phases of all 1024 clients agree bit for bit after every call."""
     t48 = lpf(FS, 24000, 9600)
     engs = []
-    for mix in (0, 1, 2):
+    for mix, side in ((1, 0), (3, 0), (1, 1)):
         monkeypatch.setenv("XL_EXP_MIX", str(mix))
         e = xl.BatchEngine(FS, "cu8", 262144)
-        e.set_option("nco_side_stream", 0)  # the recurrence inside the launches (one-block calls default to the side stream now)
+        e.set_option("nco_side_stream", side)
         ids = [e.add_client(42, t48, -984000 + 1920 * c) for c in range(1024)]
         engs.append((e, ids))
-    assert "mix=fma" in engs[0][0].describe() and "mix=mfma" in engs[1][0].describe() and "mix=fused" in engs[2][0].describe()
+    assert "mix=mfma" in engs[0][0].describe() and "mix=mf32" in engs[1][0].describe() and "mix=mfma" in engs[2][0].describe()
     for k in range(120):
         x = siggen.xs_u8(7000 + k, 262144)
         ph = []
@@ -556,19 +549,20 @@ def test_matrix_core_mix_role_phases_bit_exact(monkeypatch):
 
 
 def test_role_phases_soak_4096_clients_2000_one_block_calls(monkeypatch):
-    """VERDICT r3 item 3's soak: 4096 clients, 2000 one-block calls with the recurrence INSIDE the launches (nco_side_stream = 0) --
-    the packed-FMA mix engine (role in all three launches) against the matrix-core mix engine (role in the forward and inverse
-    launches only: no launch that issues matrix instructions hosts it any more); all 4096 committed phases compared bit for bit
-    every 100 calls (a corrupted phase never heals: the recurrence carries it on)."""
+    """VERDICT r3 item 3's soak: 4096 clients, 2000 one-block calls with the recurrence INSIDE the launches (nco_side_stream = 0), two
+    engines in one process whose launches interleave on the chip -- one with the float32 matrix-core mix, one with the two-half mix;
+    both host the role in their forward and inverse launches only, stepping with scalar instructions (the packed step is what other
+    launches' matrix instructions corrupted: DESIGN 3.6).  All 4096 committed phases compared bit for bit every 100 calls (a
+    corrupted phase never heals: the recurrence carries it on)."""
     t48 = lpf(FS, 24000, 9600)
     engs = []
-    for mix in (0, 1):
+    for mix in (3, 1):
         monkeypatch.setenv("XL_EXP_MIX", str(mix))
         e = xl.BatchEngine(FS, "cu8", 262144)
         e.set_option("nco_side_stream", 0)
         ids = [e.add_client(42, t48, -984000 + 480 * c) for c in range(4096)]
         engs.append((e, ids))
-    assert "mix=fma" in engs[0][0].describe() and "mix=mfma" in engs[1][0].describe()
+    assert "mix=mf32" in engs[0][0].describe() and "mix=mfma" in engs[1][0].describe()
     blocks = [siggen.xs_u8(7300 + k, 262144) for k in range(4)]
     for k in range(2000):
         for e, _ in engs:
@@ -603,13 +597,13 @@ def test_polyphase_class_next_to_direct_classes():
 
 
 def test_polyphase_100_block_drift(monkeypatch, poly_m):
-    """100 consecutive blocks on the polyphase path (NCO recurrence cut into three slices per block, renormalised per
-    block, tabulated one block ahead): the float32 phase drift must stay the reference's own -- every 10th
+    """100 consecutive blocks on the polyphase path (NCO recurrence renormalised per block, tabulated one block ahead -- on the side
+    stream, or cut into two slices inside the launches): the float32 phase drift must stay the reference's own -- every 10th
     block of 8 clients against the oracle, plus the committed phases at the end."""
     taps = lpf(FS, 24000, 9600)
     eng = _poly_engine(monkeypatch)
-    if os.environ.get("XL_EXP_INV") == "0":  # (fixtures "M128", "M256", "M256-fma-mix": the recurrence inside the launches, as three
-        eng.set_option("nco_side_stream", 0)  # slices per block; the others: on the side stream, the default for these calls now)
+    if os.environ.get("XL_EXP_INV") == "3" or poly_m == 256:  # (these fixtures: the recurrence inside the launches, two slices per
+        eng.set_option("nco_side_stream", 0)                   # block; the others: on the side stream, the default for these calls)
     oracles = {}
     for c in range(8):
         fc = -800000 + c * 213000 + 17
@@ -915,13 +909,11 @@ def test_group_of_blocks_equals_successive_calls_direct(variant):
     eng.close()
 
 
-@pytest.mark.parametrize("m,inv,mix", [(128, 0, 1), (128, 1, 1), (128, 2, 1), (128, 3, 1), (128, 4, 1), (256, 0, 1),
-                                       (128, 3, 0), (256, 0, 0), (128, 3, 2), (128, 5, 3), (256, 0, 3)])
+@pytest.mark.parametrize("m,inv,mix", [(128, 5, 1), (128, 3, 1), (256, 5, 1), (128, 5, 3), (256, 5, 3)])
 def test_group_of_blocks_polyphase(m, inv, mix, monkeypatch):
     """Forced polyphase path, G = 4 server-default blocks per call (108 segments at M = 128): every client vs the
     oracle's four successive calls; a native group in between (shared history and phases); ragged group.  mix = 1: the mix
-    launch on the matrix cores (8 passes of 14 segments = two runs of 4 per workgroup), 0: packed FP32 FMAs, 3: the matrix cores
-    with float32 operands (runs of 2 passes per workgroup at this size)."""
+    launch on the matrix cores with two-half operands (7 passes of 16 segments), 3: with float32 operands."""
     monkeypatch.setenv("XL_EXP_INV", str(inv))
     monkeypatch.setenv("XL_EXP_MIX", str(mix))
     t48 = lpf(FS, 24000, 9600)
@@ -1045,6 +1037,12 @@ def test_set_option_and_unknown_option():
     assert e.value.code == -2
     with pytest.raises(xl.XlatingError):
         eng.set_option("polyphase_m", 100)
+    for name, bad in (("inverse_kernel", 1), ("mix_kernel", 0), ("mix_kernel", 2), ("nco_side_stream", 2)):
+        with pytest.raises(xl.XlatingError):
+            eng.set_option(name, bad)
+    with pytest.raises(xl.XlatingError) as e:  # (round 1-4 tuning names are no options any more: XL_EXP_* at create)
+        eng.set_option("riders", 0)
+    assert e.value.code == -2
     eng.set_option("polyphase", 1)
     eng.set_option("polyphase_m", 256)
     t48 = lpf(FS, 24000, 9600)
@@ -1237,16 +1235,16 @@ def test_q15_mode_rejected_for_cf32_engines():
 
 @pytest.mark.parametrize("ncalls", [1, 2, 3, 4])
 @pytest.mark.parametrize("poly", [0, 1])
-def test_chain_launch_covers_several_calls(ncalls, poly):
-    """One side-stream chain launch tabulates `nco_calls_per_launch` calls ahead (rings of phase tables and phase buffers
-    in the engine).  Runs of equal calls long enough to consume whole launches, a shape change and a client joining while
+def test_chain_launch_covers_several_calls(ncalls, poly, monkeypatch):
+    """One side-stream chain launch tabulates up to four calls ahead (rings of phase tables and phase buffers in the engine; the
+    tuning knob XL_EXP_CHAIN_CALLS, read at create, makes it fewer).  Runs of equal calls long enough to consume whole launches, a shape change and a client joining while
     look-ahead tables are pending (both drop them), a native call in between (fused launches when the direct FIR is
     heavy): native outputs and the committed phases bit-exact, optimized within tolerance."""
     t48 = lpf(FS, 24000, 9600)
     clients = [(42, t48, -700000 + 47000 * c) for c in range(70)]
+    monkeypatch.setenv("XL_EXP_CHAIN_CALLS", str(ncalls))
     eng, oracles = _group_engine("cu8", 100002, 4, clients, poly=poly)
     eng.set_option("nco_side_stream", 1)
-    eng.set_option("nco_calls_per_launch", ncalls)
     seq = [(4, 100002, "native")] * 5 + [(2, 65536, "native")] + [(4, 100002, "optimized")] * 3 + [(4, 100002, "native")] * 2
     for k, (g, n, variant) in enumerate(seq):
         if k == 8:  # a join while look-ahead tables are pending
@@ -1255,8 +1253,6 @@ def test_chain_launch_covers_several_calls(ncalls, poly):
         _check_group(eng, oracles, "cu8", x, g, variant)
     for cid, o in oracles.items():
         assert tuple(np.float32(v).tobytes() for v in eng.phase(cid)) == tuple(np.float32(v).tobytes() for v in o.phase)
-    with pytest.raises(xl.XlatingError):
-        eng.set_option("nco_calls_per_launch", 5)
     eng.close()
 
 
@@ -1290,18 +1286,18 @@ def test_describe_after_a_change_keeps_the_latest_outputs():
 
 
 @pytest.mark.parametrize("ncalls", [1, 2, 4])
-def test_side_and_fused_calls_mixed_while_the_host_runs_ahead(ncalls):
+def test_side_and_fused_calls_mixed_while_the_host_runs_ahead(ncalls, monkeypatch):
     """Calls whose NCO chain runs on the side stream (optimized, polyphase) alternate with calls that carry it inside their
     launches (native, heavy direct launches), enqueued back to back WITHOUT host synchronisation, with chain launches
-    shorter than the table ring (nco_calls_per_launch < 4): a chain launch must wait for the readers of every table slot
+    shorter than the table ring (XL_EXP_CHAIN_CALLS < 4): a chain launch must wait for the readers of every table slot
     it overwrites, whichever kind of call read it last.  Outputs of the final calls and the committed phases vs the oracle."""
     import torch
 
     t48 = lpf(FS, 24000, 9600)
     n, G = 100002, 4
     clients = [(42, t48, -900000 + 12000 * c) for c in range(150)]
+    monkeypatch.setenv("XL_EXP_CHAIN_CALLS", str(ncalls))
     eng, oracles = _group_engine("cu8", n, G, clients)
-    eng.set_option("nco_calls_per_launch", ncalls)
     keep = sorted(oracles)[::15]
     seq = ["optimized", "optimized", "native", "optimized", "native", "native", "optimized", "optimized", "optimized", "native",
            "optimized", "optimized"]
@@ -1329,30 +1325,20 @@ def _engine_outputs(eng, ids):
     return [eng.output(i) for i in ids]
 
 
-@pytest.mark.parametrize("variant", ["native", "optimized", "optimized-register-inverse", "optimized-quad-register-inverse",
-                                     "optimized-swizzled-inverse", "optimized-fma-mix", "optimized-fused", "optimized-48bit-Y",
-                                     "optimized-f32-mfma"])
+@pytest.mark.parametrize("variant", ["native", "optimized", "optimized-lds-inverse", "optimized-f32-mix"])
 def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
     server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
     the oracle population, after a first call that loads every filter's history and phase: native bit for bit,
-    optimized max|d| / max|y| <= 1e-5 per client (fixture semantics: test/test_xlating.c:24-61, test/utils.c:176-196)."""
+    optimized max|d| / max|y| <= 1e-5 per client (fixture semantics: test/test_xlating.c:24-61, test/utils.c:176-196) -- with the
+    default launches, with the alternate inverse launch, and with float32 operands in the mix launch."""
     from pyoracle import population
 
-    if variant.endswith("-inverse"):
-        monkeypatch.setenv("XL_EXP_INV", "3" if "swizzled" in variant else ("2" if "quad" in variant else "1"))
+    if variant.endswith("-lds-inverse"):
+        monkeypatch.setenv("XL_EXP_INV", "3")
         variant = "optimized"
-    if variant.endswith("-fma-mix"):
-        monkeypatch.setenv("XL_EXP_MIX", "0")
-        variant = "optimized"
-    if variant.endswith("-fused"):
-        monkeypatch.setenv("XL_EXP_MIX", "2")
-        variant = "optimized"
-    if variant.endswith("-f32-mfma"):  # float32 operands on the matrix cores: the all-float32 arithmetic of the path
+    if variant.endswith("-f32-mix"):  # float32 operands on the matrix cores: the all-float32 arithmetic of the path
         monkeypatch.setenv("XL_EXP_MIX", "3")
-        variant = "optimized"
-    if variant.endswith("-48bit-Y"):
-        monkeypatch.setenv("XL_EXP_Y6", "1")
         variant = "optimized"
     t48 = lpf(FS, 24000, 9600)
     G, nb = 8, 262144
@@ -1365,9 +1351,8 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     got = _engine_outputs(eng, ids)
     if variant == "optimized":
         assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
-        assert {"0": "mix=fma", "2": "mix=fused", "3": "mix=mf32"}.get(os.environ.get("XL_EXP_MIX"), "mix=mfma") in eng.describe(), eng.describe()
-        y48 = os.environ.get("XL_EXP_MIX") in (None, "1") and os.environ.get("XL_EXP_Y6") == "1" and os.environ.get("XL_EXP_INV") not in ("1", "2")
-        assert ("Y=48bit" in eng.describe()) == y48, eng.describe()
+        assert ("mix=mf32" if os.environ.get("XL_EXP_MIX") == "3" else "mix=mfma") in eng.describe(), eng.describe()
+        assert ("inv=lanes8" in eng.describe()) == (os.environ.get("XL_EXP_INV") != "3"), eng.describe()
     want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
     worst = 0.0
     for c in range(1024):
@@ -1380,19 +1365,16 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("pipeline", [1, 0])
-def test_one_block_calls_pipelined_on_the_engine_streams(pipeline):
-    """The reference's call granularity on the engine's own streams (XL_STREAM_ENGINE, what include/xlating_multi.h feeds):
-    1024 clients, one 262144-byte block per call, 40 calls enqueued back to back without a host wait.  With "pipeline_calls"
-    (an option; off by default) consecutive calls alternate between two compute streams and only their forward launches are ordered; the
-    outputs of the calls that are looked at -- sampled clients after calls 9, 10 and 39, a native call and a host-path
-    call in between (both must wait for BOTH streams) -- match the oracle, and the committed phases are the oracle's bit for bit."""
+def test_one_block_calls_on_the_engine_stream():
+    """The reference's call granularity on the engine's own stream (XL_STREAM_ENGINE, what include/xlating_multi.h feeds):
+    1024 clients, one 262144-byte block per call, 40 calls enqueued back to back without a host wait; the outputs of the calls that
+    are looked at -- sampled clients after calls 9, 10 and 39, a native call and a host-path call in between -- match the oracle,
+    and the committed phases are the oracle's bit for bit."""
     import torch
 
     t48 = lpf(FS, 24000, 9600)
     nb = 262144
     eng = xl.BatchEngine(FS, "cu8", nb)
-    eng.set_option("pipeline_calls", pipeline)
     fcs = [-984000 + 1920 * c for c in range(1024)]
     ids = [eng.add_client(42, t48, fc) for fc in fcs]
     sample = [0, 1, 63, 64, 500, 777, 1022, 1023]
@@ -1402,7 +1384,7 @@ def test_one_block_calls_pipelined_on_the_engine_streams(pipeline):
     look = {9, 10, 20, 39}
     for k in range(40):
         x = blocks[k % 6]
-        if k == 20:    # a native call in the middle of the pipelined run: ordered behind both compute streams
+        if k == 20:    # a native call in the middle of the run
             eng.process_device_group(dev[k % 6].data_ptr(), nb, 1, "native", "engine")
         elif k == 30:  # ... and a host-path call (the engine's plain stream)
             eng.process_host(x, "optimized")
@@ -1410,7 +1392,7 @@ def test_one_block_calls_pipelined_on_the_engine_streams(pipeline):
             eng.process_device_group(dev[k % 6].data_ptr(), nb, 1, "optimized", "engine")
         want = {cid: o.process("cu8", x) for cid, o in oracles.items()}
         if k in look:
-            eng.fetch()  # (xlating_batch_sync inside: both streams)
+            eng.fetch()  # (xlating_batch_sync inside)
             for cid in oracles:
                 got = eng.output(cid)
                 if k == 20:
@@ -1424,21 +1406,14 @@ def test_one_block_calls_pipelined_on_the_engine_streams(pipeline):
     eng.close()
 
 
-@pytest.mark.parametrize("mix", [1, 2, 3, 4], ids=["mfma-mix", "fused", "mfma-mix-persistent-inverse", "f32-mfma-mix"])
-@pytest.mark.parametrize("variant", ["native", "optimized"])
+@pytest.mark.parametrize("variant,mix", [("native", 1), ("optimized", 1), ("optimized", 3)], ids=["native", "optimized", "optimized-f32-mix"])
 def test_group_2048_clients_all(variant, mix, monkeypatch):
     """The shape the >= 50 % claim of DESIGN 6 rests on (the launches, not the recurrence, bound the call): 2048 x 48 kHz
     clients (16 column groups), one whole 8-block call after a warm-up call, ALL clients against the oracle population --
     native bit for bit, optimized <= 1e-5 per client (fixture semantics: test/test_xlating.c:24-61, test/utils.c:176-196)."""
     from pyoracle import population
 
-    if variant == "native" and mix >= 2:
-        pytest.skip("native calls do not depend on the mix or the inverse kernel")
-    persist = mix == 3  # option "inverse_persistent": the 8-lane inverse launch as 4 workgroups per CU walking the 13 824 tiles
-    mix = 1 if persist else (3 if mix == 4 else mix)  # (4: option "mix_kernel" = 3, float32 operands on the matrix cores)
     monkeypatch.setenv("XL_EXP_MIX", str(mix))
-    if persist:
-        monkeypatch.setenv("XL_EXP_INV_PERSIST", "4")
     t48 = lpf(FS, 24000, 9600)
     G, nb, n = 8, 262144, 2048
     fcs = [-984000 + 960 * c for c in range(n)]
@@ -1449,7 +1424,7 @@ def test_group_2048_clients_all(variant, mix, monkeypatch):
         eng.process_host_group(x[k * G * nb:(k + 1) * G * nb], G, variant)
     got = _engine_outputs(eng, ids)
     if variant == "optimized":
-        assert "polyphase: cls0 D42 T505 cols2048" in eng.describe() and {2: "mix=fused", 3: "mix=mf32"}.get(mix, "mix=mfma") in eng.describe(), eng.describe()
+        assert "polyphase: cls0 D42 T505 cols2048" in eng.describe() and ("mix=mf32" if mix == 3 else "mix=mfma") in eng.describe(), eng.describe()
     want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
     worst = 0.0
     for c in range(n):
@@ -1462,10 +1437,10 @@ def test_group_2048_clients_all(variant, mix, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("mix", [1, 2], ids=["mfma-mix", "fused"])
+@pytest.mark.parametrize("mix", [1, 3], ids=["mfma-mix", "f32-mix"])
 def test_group_4096_clients_sampled(mix, monkeypatch):
     """4096 x 48 kHz clients (32 column groups), 8 blocks per call, optimized: every 16th column and the first and last column
-    of every group of 128 (and of 16: the fused launch's tiles) against oracle filters over two calls; a one-block call on the
+    of every group of 128 (and of 16) against oracle filters over two calls; a one-block call on the
     same engine afterwards (the reference's call granularity)."""
     monkeypatch.setenv("XL_EXP_MIX", str(mix))
     t48 = lpf(FS, 24000, 9600)
@@ -1477,7 +1452,7 @@ def test_group_4096_clients_sampled(mix, monkeypatch):
     oracles = {ids[c]: Oracle(42, t48, fcs[c], FS, nb) for c in sample}
     for k in range(2):
         _check_group(eng, oracles, "cu8", siggen.xs_u8(8400 + k, G * nb), G, "optimized")
-    assert "polyphase: cls0 D42 T505 cols4096" in eng.describe() and ("mix=fused" if mix == 2 else "mix=mfma") in eng.describe(), eng.describe()
+    assert "polyphase: cls0 D42 T505 cols4096" in eng.describe() and ("mix=mf32" if mix == 3 else "mix=mfma") in eng.describe(), eng.describe()
     check_clients(eng, oracles, "cu8", siggen.xs_u8(8410, nb), "optimized")
     eng.close()
 

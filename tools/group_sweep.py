@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--decimations", default="42", help="client decimations to time (input rate = 48 kHz x decimation), e.g. 42,50,64")
     ap.add_argument("--blocks", type=int, default=320, help="blocks in the timed region")
     ap.add_argument("--poly3", action="store_true", help="also time the three polyphase launches separately")
-    ap.add_argument("--slices", default="")
+    ap.add_argument("--slices", default="", help="forward | inverse boundary of the in-launch NCO role, in 1/65536 of a call")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable), e.g. mix_kernel=2")
     ap.add_argument("--shape", default="server", choices=["server", "config5"], help="config5: BASELINE configs[4] -- cf32 input at 10 Msps, D = 100, 257 explicit taps")
     ap.add_argument("--engine-stream", type=int, default=1, help="1: XL_STREAM_ENGINE (the engine's own, CU-masked compute stream); 0: torch's stream")
@@ -55,15 +55,22 @@ def sweep(args, D, data, sarg):
         for m in [int(v) for v in args.m.split(",")]:
             for n in [int(c) for c in args.clients.split(",")]:
                 for G in [int(g) for g in args.groups.split(",")]:
+                    # (tuning knobs are no engine options: XL_EXP_* environment variables read when the engine is created)
+                    tuning = {"mix_passes_per_workgroup": "XL_EXP_MIX_PP", "polyphase_min_clients": "XL_EXP_POLY_MIN", "tile_height": "XL_EXP_H",
+                              "riders": "XL_EXP_RIDERS", "riders_min_workgroups": "XL_EXP_RIDERS_MIN", "nco_calls_per_launch": "XL_EXP_CHAIN_CALLS",
+                              "nco_slice": "XL_EXP_NCO_SLICE"}
+                    opts = [kv.split("=") for kv in args.opt]
+                    if args.slices:
+                        opts.append(("nco_slice", args.slices))
+                    for name, val in opts:
+                        if name in tuning:
+                            os.environ[tuning[name]] = val
                     eng = xl.BatchEngine(FS, fmt, BLOCK, group_blocks=G)
                     if m:
                         eng.set_option("polyphase_m", m)
-                    if args.slices:
-                        a, b = (int(v) for v in args.slices.split(","))
-                        eng.set_option("nco_slices", (a << 16) | b)
-                    for kv in args.opt:
-                        name, val = kv.split("=")
-                        eng.set_option(name, int(val))
+                    for name, val in opts:
+                        if name not in tuning:
+                            eng.set_option(name, int(val))
                     for c in range(n):
                         if args.shape == "config5":
                             eng.add_client(D, taps, -4000000 + (8000000 // n) * c)
