@@ -76,8 +76,12 @@ int xlating_multi_feed(xlating_multi *multi, const void *d_src, size_t input_len
  * / make `hip_stream` (a hipStream_t of GPU 0's device; NULL = the default stream) wait for that moment, so that an
  * asynchronous refill of d_src enqueued there afterwards is safe.  With a communicator the event sits behind the root's
  * broadcast only -- the filtering of the receive buffers goes on -- so a streaming host refills ONE buffer per feed and
- * the broadcast of super-block k+1 still overlaps the filtering of k.  Processes that do not drive GPU 0 hold no source:
- * 0 / 1 / 0 at once.  0 (query: 0 or 1), -EINVAL, -EIO. */
+ * the broadcast of super-block k+1 still overlaps the filtering of k.  WITHOUT a communicator (one GPU, the blocks are filtered
+ * in place) "no longer read" means "the engine's launches of that feed have run": stricter than behind a broadcast, since the
+ * launches themselves read d_src.  Processes that do not drive GPU 0 hold no source: 0 / 1 / 0 at once.
+ * Threading: a host object is driven by ONE thread -- these three calls read the state xlating_multi_feed() writes (which stream
+ * the latest feed used) without a lock, so they belong to the feeding thread, like every other call on the object.
+ * 0 (query: 0 or 1), -EINVAL, -EIO. */
 int xlating_multi_feed_done(xlating_multi *multi);
 int xlating_multi_feed_query(xlating_multi *multi);
 int xlating_multi_feed_wait_on_stream(xlating_multi *multi, void *hip_stream);

@@ -2120,16 +2120,18 @@ extern "C" int xlating_batch_fetch(xlating_batch *b) {
     b->fetched = true;
     return 0;
   }
-  if (b->out_total > b->h_out_alloc) {
+  // (clients that joined since the latest call have rows -- assigned at add_client -- that may lie beyond what the device images hold:
+  // those grow with the next plan.  Only what exists is copied; such a client has no outputs yet.)
+  const size_t n = std::min(b->out_total, b->out_alloc);
+  if (n > b->h_out_alloc) {
     if (b->h_out) (void)hipHostFree(b->h_out);
     b->h_out = nullptr;
     b->h_out_alloc = 0;
-    if (hipHostMalloc((void **)&b->h_out, b->out_total * sizeof(float2), hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc((void **)&b->h_out, n * sizeof(float2), hipHostMallocDefault) != hipSuccess)
       return -ENOMEM;
-    b->h_out_alloc = b->out_total;
+    b->h_out_alloc = n;
   }
-  if (hipMemcpyAsync(b->h_out, b->d_out[b->ocur], b->out_total * sizeof(float2), hipMemcpyDeviceToHost,
-                     b->own_stream) != hipSuccess)
+  if (hipMemcpyAsync(b->h_out, b->d_out[b->ocur], n * sizeof(float2), hipMemcpyDeviceToHost, b->own_stream) != hipSuccess)
     return -EIO;
   if (hipStreamSynchronize(b->own_stream) != hipSuccess) return -EIO;
   b->fetched = true;
@@ -2141,6 +2143,11 @@ extern "C" int xlating_batch_output_host_cs16(xlating_batch *b, int id, const in
       output == nullptr || output_len == nullptr || !b->last_q15)
     return -EINVAL;
   const Client &c = b->clients[id];
+  if (c.last_K == 0 || (size_t)c.out_off + c.last_K > b->h_out_alloc) {  // (joined since the latest call: a row, but nothing in it yet)
+    *output = nullptr;
+    *output_len = 0;
+    return c.last_K == 0 ? 0 : -EINVAL;
+  }
   *output = b->h_out ? reinterpret_cast<const int16_t *>(b->h_out + c.out_off) : nullptr;
   *output_len = c.last_K;
   return 0;
