@@ -75,8 +75,10 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                       exactly the float32 FMA chain, nothing split or scaled); 3: float32 operands for EVERY class -- the
  *                       all-float32 arithmetic of the path, ~40 % slower in the mix launch.  Same 1e-5 bar in both cases
  *   "inverse_kernel"    128-point polyphase classes: the inverse launch's transform -- in the registers of EIGHT lanes per client
- *                       column as 16 x 8 points with one exchange through LDS (5, default: xl_inv8.hip), or staged in LDS on dense
- *                       XOR-swizzled rows (3: round 3's default; within 2 % on 8-block calls, 7 % behind on one-block calls)
+ *                       column as 16 x 8 points with one exchange through LDS (5: xl_inv8.hip), or staged in LDS on dense
+ *                       XOR-swizzled rows (3).  0 (default): by the size of the launch -- the 8-lane kernel for launches of up to 2048
+ *                       tiles (one block per call: 5 % ahead), the LDS transform beyond (8 blocks per call at >= 2048 clients: 3-5 %
+ *                       ahead); measured alternating in one process (bench.py "inverse launch A/B")
  *   "nco_side_stream"   -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light, and one-block polyphase
  *                       calls of up to 2048 clients), 0 never, 1 always: the NCO phase recurrence of the following calls runs as a
  *                       kernel of its own on a side stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE) instead of

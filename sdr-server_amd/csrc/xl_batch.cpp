@@ -124,6 +124,7 @@ struct PolyClass {
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
   float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
   XlpCol *d_cols = nullptr;  // per column: output row, grid offset, NCO increment
+  int last_lanes8 = -1;      // which inverse kernel the class's latest launch took (describe): 1 = eight lanes per column, 0 = LDS, -1 = none yet
 };
 
 }  // namespace
@@ -204,10 +205,9 @@ struct xlating_batch_t {
   uint32_t poly_min_clients = 32;   // XL_EXP_POLY_MIN (tuning): smallest class that takes the polyphase path under the size rule
   uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
   int num_cus = 256;
-  uint32_t inv_reg = 5;       // option "inverse_kernel", M = 128 classes: 5 = eight lanes per column, 16- and 8-point transforms in registers
-                              // (xl_inv8.hip; default since round 4), 3 = staged in LDS on dense rows with an XOR swizzle (round 3's
-                              // default).  The two are within 2 % of each other on 8-block calls (profiles/r05_inverse_ab_same_box.txt;
-                              // bench.py runs both in its process), 5 is 7 % ahead on one-block calls (profiles/r04_inverse8.txt)
+  uint32_t inv_reg = 0;       // option "inverse_kernel", M = 128 classes: 0 (default) = by the launch's size (xlp_inverse_lanes8: the 8-lane kernel
+                              // for launches of up to 2048 tiles, the LDS transform beyond), 5 = always eight lanes per column, 16- and
+                              // 8-point transforms in registers (xl_inv8.hip), 3 = always staged in LDS on dense rows with an XOR swizzle
   uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = two-half float16 operands on the matrix cores where the class allows them
                               // (integer input format, D <= 64), float32 operands on the matrix cores everywhere else (cf32 input,
                               // D > 64); 3 = float32 operands for every class (the all-float32 arithmetic of the path)
@@ -256,7 +256,11 @@ struct xlating_batch_t {
   bool waited_valid = false;  // stream waited_stream has waited for ev_chain[waited_ev] since that event was last recorded
   int waited_ev = 0;
   hipStream_t waited_stream = nullptr;
-  int chain_calls = 4;  // option "nco_calls_per_launch": calls one side-stream chain launch tabulates (1 .. XL_CHAIN_MAXCALLS)
+  int chain_calls = 4;  // XL_EXP_CHAIN_CALLS (tuning): most calls one side-stream chain launch tabulates ahead (1 .. XL_CHAIN_MAXCALLS)
+  int chain_ahead = 4;  // ... and how many the NEXT launch does: 1 after a wrong shape guess (the look-ahead it drops is then one call of
+                        // chain work the call has to wait out, not four), doubled by every launch whose calls were all consumed.
+                        // A stream of irregular block lengths, one block per call, 1024 clients: 134 us per call with four calls
+                        // ahead every time (profiles/r05_ragged_blocks.txt), against 39.5 us for constant lengths
   bool exp_nofuse = false;  // XL_TUNING: keep the NCO tabulation a launch of its own
 
   uint32_t exp_flags = 0;  // tuning knobs
@@ -453,7 +457,7 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     if (value != 0 && value != 128 && value != 256) return -EINVAL;
     b->poly_m = (uint32_t)value;
   } else if (n == "inverse_kernel") {
-    if (value != 3 && value != 5) return -EINVAL;
+    if (value != 0 && value != 3 && value != 5) return -EINVAL;
     b->inv_reg = (uint32_t)value;
   } else if (n == "mix_kernel") {
     if (value != 1 && value != 3) return -EINVAL;
@@ -1631,6 +1635,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
     } else {
       // (a look-ahead of the wrong shape may still be running on the side stream, on these very buffers)
       if (b->spec_n > 0 && b->spec_on_side) XL_TRY(hipStreamWaitEvent(s, b->ev_chain[chain_ev], 0));
+      if (b->spec_n > 0) b->chain_ahead = 1;  // (a wrong guess: look less far ahead until the guesses hold again)
       if (b->ev_done_valid[tab]) XL_TRY(hipStreamWaitEvent(s, b->ev_done[tab], 0));  // (same stream normally: a no-op)
       XL_TRY(xl_batch_nco(b, pos, tab, s));
     }
@@ -1665,7 +1670,8 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
       }
       XlChainCalls cc;
       memset(&cc, 0, sizeof(cc));
-      cc.n = (uint32_t)std::min<int>(std::max(b->chain_calls, 1), (int)XL_CHAIN_MAXCALLS);
+      cc.n = (uint32_t)std::min<int>(std::max(std::min(b->chain_calls, b->chain_ahead), 1), (int)XL_CHAIN_MAXCALLS);
+      b->chain_ahead = std::min(2 * b->chain_ahead, (int)XL_CHAIN_MAXCALLS);  // (this launch is made because the previous one's calls were all used)
       int tt[XL_CHAIN_MAXCALLS];
       for (int i = 0, t = tab, pp = pcur; i < (int)cc.n; ++i) {
         t = xl_nx(t), pp = xl_nx(pp);
@@ -1916,6 +1922,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
 #endif
                 ;
             XL_TRY(xlp_launch_inverse(pa, s, attach ? (want_done ? b->ev_done[tab] : record_ev) : nullptr));
+            pc.last_lanes8 = xlp_inverse_lanes8(pa.M, pa.inv_reg, pa.nseg * pa.ncg * 4u) ? 1 : 0;
             done_attached = attach && want_done;
             record_attached = attach && !want_done && record_ev != nullptr;
           }
@@ -2014,7 +2021,7 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
          std::to_string(pc.members.size()) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
     if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
     d += pc.mix_kind == 3u ? " mix=mf32" : " mix=mfma";
-    if (pc.M == 128u && b->inv_reg == 5u) d += " inv=lanes8";
+    if (pc.M == 128u) d += b->inv_reg == 5u || (b->inv_reg == 0u && pc.last_lanes8 == 1) ? " inv=lanes8" : (b->inv_reg == 3u || pc.last_lanes8 == 0 ? " inv=lds" : " inv=auto");
   }
   if (!b->poly.empty()) {
     d += " | optimized-mode direct:";

@@ -64,8 +64,8 @@ struct XlpArgs {
   uint32_t nseg_cap;   // segment capacity of the Y image
   uint32_t ncg;        // column groups of XLP_COLS client columns
   uint32_t exp;        // tuning switches (XL_TUNING builds only; 0 otherwise)
-  uint32_t inv_reg;    // M = 128: the inverse launch's transform: 5 = registers of eight lanes per column (xl_inv8.hip; default), 3 = staged
-                       // in LDS on swizzled rows (xlp_inverse_kernel<128>)
+  uint32_t inv_reg;    // M = 128: the inverse launch's transform: 5 = registers of eight lanes per column (xl_inv8.hip), 3 = staged in LDS on
+                       // swizzled rows (xlp_inverse_kernel<128>), 0 = by the launch's size (xlp_inverse_lanes8)
   uint32_t mix_kind;   // the mix launch: 1 = matrix cores on two-term half splits (xlp_mix_mfma_kernel), 3 = matrix cores with float32
                        // operands (xl_mixf32.hip: xlp_mix_f32_kernel; any input format, any branch count)
   uint32_t nkb;        // k-blocks of 8 branches = ceil(D / 8) (mix_kind 1: <= XLP_NKB_MAX)
@@ -115,7 +115,16 @@ hipError_t xlp_launch_mix_f32(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);
-// (xl_inv8.hip: the kernel behind inv_reg 5; called by xlp_launch_inverse with the checked arguments and the launch's grid)
+// Which of the two 128-point inverse kernels a launch of `tiles` workgroups takes (option "inverse_kernel": 0 = this rule, 3 / 5 = one
+// of them).  Measured alternating in one process on every box of round 5 (profiles/r05_inverse_ab_same_box.txt, bench.py's
+// "inverse launch A/B"): launches of a few hundred to ~2000 tiles -- one block per call at up to 2048 clients -- run 5 % faster on the
+// 8-lane kernel (no fill pass, no workgroup barrier: it is the launch's latency that counts there), launches of >= 13 000 tiles -- 8
+// blocks per call at >= 2048 clients -- 3-5 % faster on the LDS transform (it keeps more bytes in flight per CU); in between the
+// call is bound by the NCO recurrence either way.
+static inline bool xlp_inverse_lanes8(uint32_t M, uint32_t inv_reg, uint32_t tiles) {
+  return M == 128u && (inv_reg == 5u || (inv_reg != 3u && tiles <= 2048u));
+}
+// (xl_inv8.hip: the 8-lane kernel; called by xlp_launch_inverse with the checked arguments and the launch's grid)
 void xlp_inverse8_launch(const XlpArgs &a, const dim3 grid, hipStream_t s, hipEvent_t done);
 
 #endif  // XL_POLYPHASE_H_

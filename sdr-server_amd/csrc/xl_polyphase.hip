@@ -472,10 +472,11 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
 // `done` (optional): recorded with the launch's own completion signal -- one queue packet instead of launch + event record
 hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done) {
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
-  // 128-point classes: 5 = eight lanes per column, transforms of 16 and 8 points in registers (xl_inv8.hip; the default), 3 = staged
-  // in LDS on dense XOR-swizzled rows; 256-point classes: staged in LDS on padded rows.  Workgroup = one tile of 32 (16) columns.
-  const bool lanes8 = a0.M == 128u && a0.inv_reg != 3u;
+  // 128-point classes: eight lanes per column, transforms of 16 and 8 points in registers (xl_inv8.hip), or staged in LDS on dense
+  // XOR-swizzled rows -- xlp_inverse_lanes8() picks; 256-point classes: staged in LDS on padded rows.  Workgroup = one tile of 32 (16)
+  // columns.
   const uint32_t work = a0.nseg * a0.ncg * (a0.M == 256u ? 8u : 4u);
+  const bool lanes8 = xlp_inverse_lanes8(a0.M, a0.inv_reg, work);
   const XlpArgs a = xlp_checked_skip(a0, work);
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
   if (lanes8) {

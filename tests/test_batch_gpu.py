@@ -293,11 +293,12 @@ def test_1000_clients_split_group_riders():
 # that the oracle can check every client.
 # The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
 # the forced-path tests run with both.
-@pytest.fixture(params=[(128, 5, 1), (128, 3, 1), (256, 5, 1), (128, 5, 3), (256, 5, 3), (128, 3, 3)],
+@pytest.fixture(params=[(128, 0, 1), (128, 3, 1), (256, 0, 1), (128, 5, 3), (256, 0, 3), (128, 3, 3)],
                 ids=["M128", "M128-lds-inverse", "M256", "M128-f32-mix", "M256-f32-mix", "M128-lds-inverse-f32-mix"])
 def poly_m(request, monkeypatch):
     """Transform length of the forced polyphase plan; at M = 128 the inverse launch's transform in the registers of eight lanes per
-    column (option "inverse_kernel" = 5, the default: xlp_inverse8_kernel) or staged in LDS on swizzled rows (3: xlp_inverse_kernel);
+    column (option "inverse_kernel" = 5: xlp_inverse8_kernel -- what the default, 0, picks for launches as small as these) or staged in
+    LDS on swizzled rows (3: xlp_inverse_kernel);
     the mix launch on the matrix cores with two-half float16 operands where the class allows them and float32 operands elsewhere
     (option "mix_kernel" = 1, the default) or with float32 operands for every class (3)."""
     m, inv, mix = request.param
@@ -909,7 +910,7 @@ def test_group_of_blocks_equals_successive_calls_direct(variant):
     eng.close()
 
 
-@pytest.mark.parametrize("m,inv,mix", [(128, 5, 1), (128, 3, 1), (256, 5, 1), (128, 5, 3), (256, 5, 3)])
+@pytest.mark.parametrize("m,inv,mix", [(128, 0, 1), (128, 3, 1), (256, 0, 1), (128, 5, 3), (256, 0, 3)])
 def test_group_of_blocks_polyphase(m, inv, mix, monkeypatch):
     """Forced polyphase path, G = 4 server-default blocks per call (108 segments at M = 128): every client vs the
     oracle's four successive calls; a native group in between (shared history and phases); ragged group.  mix = 1: the mix
@@ -1037,7 +1038,7 @@ def test_set_option_and_unknown_option():
     assert e.value.code == -2
     with pytest.raises(xl.XlatingError):
         eng.set_option("polyphase_m", 100)
-    for name, bad in (("inverse_kernel", 1), ("mix_kernel", 0), ("mix_kernel", 2), ("nco_side_stream", 2)):
+    for name, bad in (("inverse_kernel", 1), ("inverse_kernel", 4), ("mix_kernel", 0), ("mix_kernel", 2), ("nco_side_stream", 2)):
         with pytest.raises(xl.XlatingError):
             eng.set_option(name, bad)
     with pytest.raises(xl.XlatingError) as e:  # (round 1-4 tuning names are no options any more: XL_EXP_* at create)
@@ -1325,17 +1326,18 @@ def _engine_outputs(eng, ids):
     return [eng.output(i) for i in ids]
 
 
-@pytest.mark.parametrize("variant", ["native", "optimized", "optimized-lds-inverse", "optimized-f32-mix"])
+@pytest.mark.parametrize("variant", ["native", "optimized", "optimized-lanes8-inverse", "optimized-f32-mix"])
 def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
     server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
     the oracle population, after a first call that loads every filter's history and phase: native bit for bit,
     optimized max|d| / max|y| <= 1e-5 per client (fixture semantics: test/test_xlating.c:24-61, test/utils.c:176-196) -- with the
-    default launches, with the alternate inverse launch, and with float32 operands in the mix launch."""
+    default launches (the inverse launch of this size: the LDS transform), with the 8-lane inverse kernel, and with float32 operands in
+    the mix launch."""
     from pyoracle import population
 
-    if variant.endswith("-lds-inverse"):
-        monkeypatch.setenv("XL_EXP_INV", "3")
+    if variant.endswith("-lanes8-inverse"):
+        monkeypatch.setenv("XL_EXP_INV", "5")
         variant = "optimized"
     if variant.endswith("-f32-mix"):  # float32 operands on the matrix cores: the all-float32 arithmetic of the path
         monkeypatch.setenv("XL_EXP_MIX", "3")
@@ -1352,7 +1354,7 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     if variant == "optimized":
         assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
         assert ("mix=mf32" if os.environ.get("XL_EXP_MIX") == "3" else "mix=mfma") in eng.describe(), eng.describe()
-        assert ("inv=lanes8" in eng.describe()) == (os.environ.get("XL_EXP_INV") != "3"), eng.describe()
+        assert ("inv=lanes8" if os.environ.get("XL_EXP_INV") == "5" else "inv=lds") in eng.describe(), eng.describe()
     want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
     worst = 0.0
     for c in range(1024):

@@ -6,7 +6,7 @@
 # into sdr-server_amd/build/sanitize/libxlating_host_{asan,tsan}.so and drives them with the EXISTING CPU tests
 # (tests/test_sinks.py, test_wire.py, test_grid.py, the lpf / tap-preparation tests of test_capi_boundary.py).  Symbols of
 # the library that live in HIP translation units are stubbed with abort() (generated here from the real library's export
-# list), so a test that strays onto the GPU path fails loudly.  Logs: profiles/r03_sanitize_{asan_ubsan,tsan}.txt.
+# list), so a test that strays onto the GPU path fails loudly.  Logs: profiles/r05_sanitize_{asan_ubsan,tsan}.txt.
 # CPU only.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -47,12 +47,12 @@ run() {  # $1 = tag, $2 = runtime library, $3 = log, $4 = test files, $5... = en
 }
 rc=0
 build asan "-fsanitize=address,undefined -fno-sanitize-recover=undefined" || { echo "asan build failed"; exit 1; }
-run asan "$(gcc -print-file-name=libasan.so)" $ROOT/profiles/r03_sanitize_asan_ubsan.txt "$TESTS" \
+run asan "$(gcc -print-file-name=libasan.so)" $ROOT/profiles/r05_sanitize_asan_ubsan.txt "$TESTS" \
     ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1:log_path=$B/report_asan UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1:log_path=$B/report_asan \
     XL_SANITIZE_CFLAGS="-fsanitize=address,undefined" || rc=1
 build tsan "-fsanitize=thread" || { echo "tsan build failed"; exit 1; }
 # (tests/test_grid.py forks gcc, which does not return under a preloaded libtsan; xl_grid.h is single-threaded integer code)
-run tsan "$(gcc -print-file-name=libtsan.so)" $ROOT/profiles/r03_sanitize_tsan.txt "tests/test_sinks.py tests/test_wire.py tests/test_capi_boundary.py" \
+run tsan "$(gcc -print-file-name=libtsan.so)" $ROOT/profiles/r05_sanitize_tsan.txt "tests/test_sinks.py tests/test_wire.py tests/test_capi_boundary.py" \
     TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0:log_path=$B/report_tsan XL_SANITIZE_CFLAGS="" || rc=1
-cat $ROOT/profiles/r03_sanitize_asan_ubsan.txt $ROOT/profiles/r03_sanitize_tsan.txt
+cat $ROOT/profiles/r05_sanitize_asan_ubsan.txt $ROOT/profiles/r05_sanitize_tsan.txt
 exit $rc
