@@ -38,6 +38,15 @@ Prints ONE JSON line (rank 0): value = input IQ Msamples/s summed over all clien
                 only, then one real super-block to load the history, the next one compared).
 "native":       the same workload with the reference's default arithmetic (cpu_optimization NATIVE_CF32,
                 src/config.c:252-264): bit-exact scalar order, direct FIR kernel.
+"variants":     context for the headline, each a short run of its own on this box: other filter lengths / call granularities / client
+                counts (2048 and 4096: where the launches, not the recurrence, bound the call -- the 2048 one with its own counters
+                and EVERY client checked); "polyphase, float32 matrix-core mix": the all-float32 arithmetic (option mix_kernel = 3),
+                every client checked; "inverse launch A/B in this process": the two inverse kernels alternating on this box;
+                "config 5 ...": BASELINE configs[4] (cf32 10 Msps, D = 100, 257 taps, 1024 clients) with its own roofline block
+                (counter bytes, shared-read algorithmic fraction, FP32 / matrix-f32 fractions) and every client checked;
+                "host-delivered outputs": process_host + fetch per call (PCIe-inclusive; never `value`).
+"roofline.frac_algorithmic_shared": SURVEY 8(d)'s shared-read minimum (2/N B in + 8/D B out per (client, sample)) over the launches' own
+                time / 8 TB/s -- the USEFUL fraction, next to the counter fraction `frac`.
 "cpu_baseline": the reference itself (oracle/_ref, unmodified sources, -O3 -ffast-math AVX2) -- or the repo's CPU
                 restatement when that build is absent -- timed on this box's host cores on a bounded sample.
 """

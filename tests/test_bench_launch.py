@@ -76,3 +76,52 @@ def test_a_rank_without_engine_stops_every_rank_within_the_deadline():
     assert r.returncode != 0
     assert "could not be created on every rank" in (r.stderr + r.stdout)
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # no measurement line
+
+
+def test_counter_pass_rows_are_split_per_workload(tmp_path):
+    """bench.py replays several workloads in ONE rocprofv3 process per counter and splits the rows by the stand-alone phase-table
+    launches only a fresh engine makes (two per engine: its first and its second call): a synthetic counter file with three
+    workloads -- template arguments in the kernel names, rows out of dispatch order, foreign kernels in between -- comes apart into
+    the three workloads, each with its steady-state kernels and none of the other workloads' rows."""
+    import csv
+    import random
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    rows, did = [], 0
+
+    def emit(name, value):
+        nonlocal did
+        did += 1
+        rows.append({"Dispatch_Id": did, "Kernel_Name": name, "Counter_Name": "FETCH_SIZE", "Counter_Value": value})
+
+    shapes = [("void xlp_mix_mfma_kernel<6>(XlpArgs)", "xlp_inverse8_kernel(XlpArgs)", 100.0),
+              ("void xlp_mix_mfma_kernel<6>(XlpArgs)", "void xlp_inverse_kernel<128, XlpPosSwz>(XlpArgs)", 200.0),
+              ("void xlp_mix_f32_kernel<13>(XlpArgs)", "xlp_inverse8_kernel(XlpArgs)", 300.0)]
+    for mix, inv, v in shapes:
+        emit("xl_nco_table_kernel(XlNcoClient const*, unsigned int)", 1.0)
+        emit("void xl_fir_kernel<10, 1, true>(XlFirArgs)", 5.0)  # the fresh engine's first call: clients still inside their zero history
+        emit("__amd_rocclr_copyBuffer", 7.0)
+        emit("xl_nco_table_kernel(XlNcoClient const*, unsigned int)", 1.0)
+        for c in range(16):
+            emit("void xlp_forward_kernel<128>(XlpArgs)", v)
+            emit(mix, 2 * v)
+            emit(inv, 3 * v)
+            if c % 4 == 0:
+                emit("xl_nco_chain_kernel(XlNcoClient const*)", 4 * v)
+    random.Random(3).shuffle(rows)
+    path = tmp_path / "counter_collection.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    parsed = bench._pmc_rows(str(path), lambda row: float(row["Counter_Value"]))
+    assert [r[0] for r in parsed] == sorted(r[0] for r in parsed) and all("rocclr" not in r[1] for r in parsed)
+    segs = bench._split_workloads(parsed, 3)
+    assert segs is not None and len(segs) == 3
+    for (mix, inv, v), seg in zip(shapes, segs):
+        assert len(seg["xlp_forward_kernel"]) == 16 and set(seg["xlp_forward_kernel"]) == {v}
+        assert len(seg[mix.split("(")[0].replace("void ", "").split("<")[0]]) == 16
+        assert len(seg["xl_nco_chain_kernel"]) == 4 and len(seg["xl_nco_table_kernel"]) == 2 and len(seg["xl_fir_kernel"]) == 1
+    assert bench._split_workloads(parsed, 2) is None  # (a pass that does not show the workloads it was asked for is not used)
