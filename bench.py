@@ -1031,8 +1031,8 @@ def main():
                 variants["polyphase, float32 matrix-core mix (all-float32 products)"] = e
             if m["polyphase"] and total_clients == 1024:
                 # the inverse launch's two kernels in THIS process on THIS box, alternating (box-to-box differences
-                # are larger than the difference between them): option inverse_kernel = 5 (eight lanes per column; the default) / 3 (LDS
-                # transform on swizzled rows)
+                # are larger than the difference between them): option inverse_kernel = 5 (eight lanes per column) / 3 (LDS transform on
+                # swizzled rows); the default, 0, picks by launch size (xl_polyphase.h, xlp_inverse_lanes8: 3 for these two shapes)
                 ab = {}
                 for big in (2048, 4096):
                     rows = []
@@ -1044,7 +1044,7 @@ def main():
                                          "inverse_launch_ms_per_call": inv_ms, "launches_ms_per_call": round(mi["call_ms_avg"], 4)})
                     best = {inv: min(r["us_per_block"] for r in rows if r["inverse_kernel"] == inv) for inv in (5, 3)}
                     ab[f"{big} clients"] = {"runs": rows, "best_us_per_block": best, "faster": 5 if best[5] <= best[3] else 3}
-                variants["inverse launch A/B in this process (inverse_kernel 5 = default, 3 = LDS transform)"] = ab
+                variants["inverse launch A/B in this process (inverse_kernel 5 = eight lanes per column, 3 = LDS transform; default 0 = by launch size)"] = ab
                 # BASELINE configs[4]: cf32 input at 10 Msps, D = 100, 257 taps (the 'HBM-roofline run'): 1024 clients, every client checked
                 m5 = run_config5(ctx, 1024, vs, spot=not args.no_spot, blocks_per_step=VB)
                 variants["config 5: cf32 10 Msps, D=100, 257 taps, 1024 clients"] = m5  # (finished below, once the counters are in)
