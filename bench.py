@@ -468,7 +468,7 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
         eng.timing(False)
         if n3 > 0:
             mix_name = "xlp_mix_mfma_kernel" if "mix=mfma" in plan else "xlp_mix_f32_kernel"
-            inv_name = "xlp_inverse8_kernel" if "inv=lanes8" in plan else "xlp_inverse_kernel"
+            inv_name = "xlp_inverse8_kernel" if "inv=lanes8" in plan else ("xlp_inverse32_kernel" if "inv=cut32" in plan else "xlp_inverse_kernel")
             kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), mix_name: round(ms3[1] / n3, 4), inv_name: round(ms3[2] / n3, 4)}
     feed_name = host.name
     host.close()
@@ -558,7 +558,7 @@ def run_config5(ctx, nclients, steps, spot=True, blocks_per_step=320, replay_cal
         eng.timing(False)
         if n3 > 0:
             mix_name = "xlp_mix_mfma_kernel" if "mix=mfma" in plan else "xlp_mix_f32_kernel"
-            inv_name = "xlp_inverse8_kernel" if "inv=lanes8" in plan else "xlp_inverse_kernel"
+            inv_name = "xlp_inverse8_kernel" if "inv=lanes8" in plan else ("xlp_inverse32_kernel" if "inv=cut32" in plan else "xlp_inverse_kernel")
             kernels_ms = {"xlp_forward_kernel": round(ms3[0] / n3, 4), mix_name: round(ms3[1] / n3, 4), inv_name: round(ms3[2] / n3, 4)}
     eng.close()
     blocks = steps * blocks_per_step
@@ -1031,20 +1031,20 @@ def main():
                 variants["polyphase, float32 matrix-core mix (all-float32 products)"] = e
             if m["polyphase"] and total_clients == 1024:
                 # the inverse launch's two kernels in THIS process on THIS box, alternating (box-to-box differences
-                # are larger than the difference between them): option inverse_kernel = 5 (eight lanes per column) / 3 (LDS transform on
-                # swizzled rows); the default, 0, picks by launch size (xl_polyphase.h, xlp_inverse_lanes8: 3 for these two shapes)
+                # are larger than the difference between them): option inverse_kernel = 6 (the 32 x 4 cut: what the default, 0, picks for
+                # launches of this size, xl_polyphase.h: xlp_inverse_pick) / 3 (LDS transform on swizzled rows: round 4's pick there)
                 ab = {}
                 for big in (2048, 4096):
                     rows = []
                     for rnd in range(2):
-                        for inv in (5, 3):
+                        for inv in (6, 3):
                             mi = run_workload(ctx, big, args.lpf_cutoff_rate, 2, 1, args.mode, options={"inverse_kernel": inv}, blocks_per_step=VB)
                             inv_ms = next((v for k, v in (mi["kernels_ms"] or {}).items() if k.startswith("xlp_inverse")), None)
                             rows.append({"inverse_kernel": inv, "us_per_block": round(mi["seconds"] / (mi["steps"] * mi["blocks_per_step"]) * 1e6, 3),
                                          "inverse_launch_ms_per_call": inv_ms, "launches_ms_per_call": round(mi["call_ms_avg"], 4)})
-                    best = {inv: min(r["us_per_block"] for r in rows if r["inverse_kernel"] == inv) for inv in (5, 3)}
-                    ab[f"{big} clients"] = {"runs": rows, "best_us_per_block": best, "faster": 5 if best[5] <= best[3] else 3}
-                variants["inverse launch A/B in this process (inverse_kernel 5 = eight lanes per column, 3 = LDS transform; default 0 = by launch size)"] = ab
+                    best = {inv: min(r["us_per_block"] for r in rows if r["inverse_kernel"] == inv) for inv in (6, 3)}
+                    ab[f"{big} clients"] = {"runs": rows, "best_us_per_block": best, "faster": 6 if best[6] <= best[3] else 3}
+                variants["inverse launch A/B in this process (inverse_kernel 6 = the 32 x 4 cut, the size rule's pick here; 3 = LDS transform)"] = ab
                 # BASELINE configs[4]: cf32 input at 10 Msps, D = 100, 257 taps (the 'HBM-roofline run'): 1024 clients, every client checked
                 m5 = run_config5(ctx, 1024, vs, spot=not args.no_spot, blocks_per_step=VB)
                 variants["config 5: cf32 10 Msps, D=100, 257 taps, 1024 clients"] = m5  # (finished below, once the counters are in)
@@ -1151,7 +1151,7 @@ def main():
         flops = {"xlp_forward_kernel": 5.0 * M * lg * D * nseg, "xlp_mix_f32_kernel": 8.0 * nloc * nseg * M * D,
                  "xlp_mix_mfma_kernel": 8.0 * nloc * nseg * M * D,
                  "xlp_inverse_kernel": nloc * nseg * (5.0 * M * lg + 8.0 * (M - A + 1))}
-        flops["xlp_inverse8_kernel"] = flops["xlp_inverse_kernel"]
+        flops["xlp_inverse8_kernel"] = flops["xlp_inverse32_kernel"] = flops["xlp_inverse_kernel"]
         # matrix-core mix: half-precision flops the launch EXECUTES = 3 products x (32 rows x 32 columns x 16 k x 2) per k-block of
         # 8 branches, per (bin, 32 columns, pass of 16 segments = 32 rows)
         mfma_flops = 3.0 * 32 * 32 * 16 * 2 * -(-D // 8) * M * -(-nloc // 32) * -(-nseg // 16)
@@ -1162,6 +1162,9 @@ def main():
                    "xlp_inverse_kernel": "hbm (reads the mixed spectra, writes the outputs)"}
         binding["xlp_inverse8_kernel"] = ("hbm access pattern: with transform and phases compiled out the launch is no faster (profiles/r04_inverse8.txt); "
                                           "reads 4.7 TB/s, the output pieces of 928 bytes per (segment, client) 3.0-4.3 TB/s, and the two do not overlap")
+        binding["xlp_inverse32_kernel"] = ("hbm, and how much of it a CU keeps in flight: the launch's traffic alone -- whole-line tile loads, 256-byte "
+                                           "store runs, nothing else -- takes 0.82 of this kernel's time (tools/ubench_tile_copy.hip, "
+                                           "profiles/r05_inverse_cut32.txt); vector ALUs 36 % busy")
         pk = {}
         trace_ms = {k: v.get("ms_per_dispatch_kernel_trace") for k, v in (pmc["per_kernel"] if pmc else {}).items()}
         for kname, ms_ev in (m["kernels_ms"] or {}).items():

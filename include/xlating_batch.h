@@ -75,16 +75,19 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                       exactly the float32 FMA chain, nothing split or scaled); 3: float32 operands for EVERY class -- the
  *                       all-float32 arithmetic of the path, ~40 % slower in the mix launch.  Same 1e-5 bar in both cases
  *   "inverse_kernel"    128-point polyphase classes: the inverse launch's transform -- in the registers of EIGHT lanes per client
- *                       column as 16 x 8 points with one exchange through LDS (5: xl_inv8.hip), or staged in LDS on dense
- *                       XOR-swizzled rows (3).  0 (default): by the size of the launch -- the 8-lane kernel for launches of up to 2048
- *                       tiles (one block per call: 5 % ahead), the LDS transform beyond (8 blocks per call at >= 2048 clients: 3-5 %
- *                       ahead); measured alternating in one process (bench.py "inverse launch A/B")
+ *                       column as 16 x 8 points with one exchange through LDS (5: xl_inv8.hip), in the registers of FOUR lanes per
+ *                       column as 32 x 4 points -- whole-line loads, 256-byte store runs (6: xl_inv32.hip) --, or staged in LDS on
+ *                       dense XOR-swizzled rows (3).  0 (default): by the size of the launch -- the 8-lane kernel for launches of up
+ *                       to 2048 tiles (one block per call: 5-9 % ahead), the 32 x 4 cut beyond (8 blocks per call at >= 2048 clients:
+ *                       6-10 % ahead of the LDS transform, round 4's pick there); measured alternating in one process (bench.py
+ *                       "inverse launch A/B")
  *   "nco_side_stream"   -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light, and one-block polyphase
  *                       calls of up to 2048 clients), 0 never, 1 always: the NCO phase recurrence of the following calls runs as a
  *                       kernel of its own on a side stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE) instead of
  *                       riding inside the call's launches
  *   "expected_clients"  0 (default) .. 8192: the CUs of that side kernel are reserved for this many clients from the first plan on
- *                       (64 clients per CU), not for the clients joined so far -- the reservation then never grows while clients
+ *                       (64 clients per CU up to 3071 clients; from 3072 on the side kernel runs in rounds on half, a third, ... as
+ *                       many), not for the clients joined so far -- the reservation then never grows while clients
  *                       join up to that number (growing it re-creates two streams: ~25 ms, once per 512 clients); until then the
  *                       launches run on correspondingly fewer CUs
  * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call.

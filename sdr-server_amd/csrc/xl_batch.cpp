@@ -124,7 +124,7 @@ struct PolyClass {
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
   float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
   XlpCol *d_cols = nullptr;  // per column: output row, grid offset, NCO increment
-  int last_lanes8 = -1;      // which inverse kernel the class's latest launch took (describe): 1 = eight lanes per column, 0 = LDS, -1 = none yet
+  int last_inv = -1;         // which inverse kernel the class's latest launch took (describe; xlp_inverse_pick): 3 / 5 / 6, -1 = none yet
 };
 
 }  // namespace
@@ -205,9 +205,10 @@ struct xlating_batch_t {
   uint32_t poly_min_clients = 32;   // XL_EXP_POLY_MIN (tuning): smallest class that takes the polyphase path under the size rule
   uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
   int num_cus = 256;
-  uint32_t inv_reg = 0;       // option "inverse_kernel", M = 128 classes: 0 (default) = by the launch's size (xlp_inverse_lanes8: the 8-lane kernel
-                              // for launches of up to 2048 tiles, the LDS transform beyond), 5 = always eight lanes per column, 16- and
-                              // 8-point transforms in registers (xl_inv8.hip), 3 = always staged in LDS on dense rows with an XOR swizzle
+  uint32_t inv_reg = 0;       // option "inverse_kernel", M = 128 classes: 0 (default) = by the launch's size (xlp_inverse_pick: the 8-lane kernel
+                              // for launches of up to 2048 tiles, the 32 x 4 cut beyond), 5 = always eight lanes per column, 16- and
+                              // 8-point transforms in registers (xl_inv8.hip), 6 = always the 32 x 4 cut (xl_inv32.hip: 32-point transforms
+                              // in registers, whole-line loads, 256-byte store runs), 3 = always staged in LDS on dense rows with an XOR swizzle
   uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = two-half float16 operands on the matrix cores where the class allows them
                               // (integer input format, D <= 64), float32 operands on the matrix cores everywhere else (cf32 input,
                               // D > 64); 3 = float32 operands for every class (the all-float32 arithmetic of the path)
@@ -457,7 +458,7 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     if (value != 0 && value != 128 && value != 256) return -EINVAL;
     b->poly_m = (uint32_t)value;
   } else if (n == "inverse_kernel") {
-    if (value != 0 && value != 3 && value != 5) return -EINVAL;
+    if (value != 0 && value != 3 && value != 5 && value != 6) return -EINVAL;
     b->inv_reg = (uint32_t)value;
   } else if (n == "mix_kernel") {
     if (value != 1 && value != 3) return -EINVAL;
@@ -1322,9 +1323,16 @@ static int xl_batch_plan(xlating_batch *b) {
     // (a server that knows how many clients it admits says so -- option "expected_clients" --, and the reservation is made for
     // that many at once: the 25 ms of a stream re-creation then never fall on a call between two joins)
     const uint32_t nwg_res = std::max(nwg, (b->expected_clients + 63u) / 64u);
-    uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? (nwg_res + 7u) / 8u : 0u;
-    if (want > 16u) want = (nwg + 7u) / 8u > 16u ? 0u : 16u;  // (more than half the chip for the chain: such engines are bound by the filtering anyway)
+    // Round 5: one CU per chain workgroup is a quarter of the chip at 4096 clients, held for a kernel that is busy a third of the
+    // call there (the chain's time per client does not grow with the client count, the launches' does).  From 3072 clients on the chain
+    // launch runs in ROUNDS on fewer CUs -- its workgroups queue on the mask -- as long as the rounds fit the calls they look ahead
+    // of: measured (profiles/r05_chain_reservation.txt) 2 rounds from 3072 clients (4096: 82.3 against 87.5 us per block; 3 rounds
+    // there make the chain the bound again: 85.1), by the same ratio 3 from 5120, 4 from 7168.
+    const uint32_t rounds = std::max(1u, (64u * nwg_res + 1024u) / 2048u);
+    uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? (nwg_res + 8u * rounds - 1u) / (8u * rounds) : 0u;
+    if (want > 16u) want = 0u;  // (more than half the chip for the chain: such engines are bound by the filtering anyway)
     if (getenv("XL_EXP_NOMASK")) want = 0u;
+    if (want > 0u && getenv("XL_EXP_RESERVE")) want = std::min(want, (uint32_t)atoi(getenv("XL_EXP_RESERVE")));  // (tuning: fewer CUs, more rounds)
     // (creating a masked stream pair takes ~25 ms: grow at once, shrink only when two CUs per XCD too many are held, so that
     // a client count hovering around a multiple of 512 does not recreate the streams at every join and leave)
     if (want > b->reserve_r || want + 2u <= b->reserve_r || (want == 0u && b->reserve_r != 0u)) {
@@ -1922,7 +1930,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
 #endif
                 ;
             XL_TRY(xlp_launch_inverse(pa, s, attach ? (want_done ? b->ev_done[tab] : record_ev) : nullptr));
-            pc.last_lanes8 = xlp_inverse_lanes8(pa.M, pa.inv_reg, pa.nseg * pa.ncg * 4u) ? 1 : 0;
+            pc.last_inv = (int)xlp_inverse_pick(pa.M, pa.inv_reg, pa.nseg * pa.ncg * 4u);
             done_attached = attach && want_done;
             record_attached = attach && !want_done && record_ev != nullptr;
           }
@@ -2021,7 +2029,10 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
          std::to_string(pc.members.size()) + " V" + std::to_string(pc.V) + " M" + std::to_string(pc.M);
     if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
     d += pc.mix_kind == 3u ? " mix=mf32" : " mix=mfma";
-    if (pc.M == 128u) d += b->inv_reg == 5u || (b->inv_reg == 0u && pc.last_lanes8 == 1) ? " inv=lanes8" : (b->inv_reg == 3u || pc.last_lanes8 == 0 ? " inv=lds" : " inv=auto");
+    if (pc.M == 128u) {
+      const int k = b->inv_reg ? (int)b->inv_reg : pc.last_inv;
+      d += k == 6 ? " inv=cut32" : (k == 5 ? " inv=lanes8" : (k == 3 ? " inv=lds" : " inv=auto"));
+    }
   }
   if (!b->poly.empty()) {
     d += " | optimized-mode direct:";

@@ -1,7 +1,8 @@
-// xl_fft16.h -- the 16-point and 8-point inverse DFTs one lane runs in its registers in the inverse launch of the polyphase path
-// (xl_inv8.hip: the 128-point transform cut 16 x 8, xl_inv8_layout.h).  Written so that the same text compiles for the device
-// (V = float ext_vector_type(2), packed instructions placed by hand: XlpFftOps in xl_poly_dev.h) and for the host
-// (tests/c/test_inv8_layout.cpp: an emulation of the lanes checked against a double-precision DFT), because the index bookkeeping
+// xl_fft16.h -- the 32-, 16-, 8- and 4-point inverse DFTs one lane runs in its registers in the inverse launches of the polyphase
+// path (xl_inv8.hip: the 128-point transform cut 16 x 8, xl_inv8_layout.h; xl_inv32.hip: cut 32 x 4, xl_inv32_layout.h).  Written so
+// that the same text compiles for the device (V = float ext_vector_type(2), packed instructions placed by hand: XlpFftOps in
+// xl_poly_dev.h) and for the host (tests/c/test_inv8_layout.cpp, test_inv32_layout.cpp: an emulation of the lanes checked against a
+// double-precision DFT), because the index bookkeeping
 // of a register FFT is the kind of thing that is either exactly right or silently wrong.  All indices are compile-time constants:
 // the "arrays" are named registers.  (Rounds 3-4 also held 64- and 32-point transforms here for inverse kernels that kept a whole
 // column in one lane pair / quad; they measured slower and live in tools/experiments/retired/xl_fft64.h.txt.)
@@ -104,6 +105,28 @@ XL_FFT_FN void xl_fft8_inverse(V (&u)[8]) {
     u[2 * q] = a + b;
     u[2 * q + 1] = a - b;
   }
+}
+
+// 32-point inverse transform for the 32 x 4 split of xl_inv32_layout.h: x[t] = sum_{k<32} v[k] e^{+2 pi j k t / 32}: radix-4 (span 8,
+// twiddles W_32^{i q} = W_128^{4 i q}), radix-4 (span 2, W_8^{i q}), radix-2 on the slot pairs; output t = q + 4 q' + 16 r in slot
+// 8 q + 2 q' + r
+template <class V, class Ops>
+XL_FFT_FN void xl_fft32_inverse(V (&u)[32]) {
+  XlFftNStage<V, Ops, 32, 8, 0, 0>::run(u);
+  XlFftNStage<V, Ops, 32, 2, 0, 0>::run(u);
+#if defined(__clang__)
+#pragma unroll
+#endif
+  for (int q = 0; q < 16; ++q) {
+    const V a = u[2 * q], b = u[2 * q + 1];
+    u[2 * q] = a + b;
+    u[2 * q + 1] = a - b;
+  }
+}
+// 4-point inverse transform, natural order in and out: x[g] = sum_{k<4} v[k] (+j)^{k g}
+template <class V, class Ops>
+XL_FFT_FN void xl_fft4_inverse(V (&u)[4]) {
+  xl_fft_bfly4<V, Ops, 0, 1, 2, 3, 0, 4>(u);
 }
 
 #endif  // XL_FFT16_H_

@@ -64,8 +64,9 @@ struct XlpArgs {
   uint32_t nseg_cap;   // segment capacity of the Y image
   uint32_t ncg;        // column groups of XLP_COLS client columns
   uint32_t exp;        // tuning switches (XL_TUNING builds only; 0 otherwise)
-  uint32_t inv_reg;    // M = 128: the inverse launch's transform: 5 = registers of eight lanes per column (xl_inv8.hip), 3 = staged in LDS on
-                       // swizzled rows (xlp_inverse_kernel<128>), 0 = by the launch's size (xlp_inverse_lanes8)
+  uint32_t inv_reg;    // M = 128: the inverse launch's transform: 5 = registers of eight lanes per column (xl_inv8.hip), 6 = cut 32 x 4
+                       // (xl_inv32.hip), 3 = staged in LDS on swizzled rows (xlp_inverse_kernel<128>), 0 = by the launch's size
+                       // (xlp_inverse_pick)
   uint32_t mix_kind;   // the mix launch: 1 = matrix cores on two-term half splits (xlp_mix_mfma_kernel), 3 = matrix cores with float32
                        // operands (xl_mixf32.hip: xlp_mix_f32_kernel; any input format, any branch count)
   uint32_t nkb;        // k-blocks of 8 branches = ceil(D / 8) (mix_kind 1: <= XLP_NKB_MAX)
@@ -115,16 +116,23 @@ hipError_t xlp_launch_mix_f32(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);
-// Which of the two 128-point inverse kernels a launch of `tiles` workgroups takes (option "inverse_kernel": 0 = this rule, 3 / 5 = one
-// of them).  Measured alternating in one process on every box of round 5 (profiles/r05_inverse_ab_same_box.txt, bench.py's
-// "inverse launch A/B"): launches of a few hundred to ~2000 tiles -- one block per call at up to 2048 clients -- run 5 % faster on the
-// 8-lane kernel (no fill pass, no workgroup barrier: it is the launch's latency that counts there), launches of >= 13 000 tiles -- 8
-// blocks per call at >= 2048 clients -- 3-5 % faster on the LDS transform (it keeps more bytes in flight per CU); in between the
-// call is bound by the NCO recurrence either way.
-static inline bool xlp_inverse_lanes8(uint32_t M, uint32_t inv_reg, uint32_t tiles) {
-  return M == 128u && (inv_reg == 5u || (inv_reg != 3u && tiles <= 2048u));
+// Which inverse kernel a launch of `tiles` tiles (of 32 columns x one segment) takes: 3 = the transform staged in LDS
+// (xlp_inverse_kernel: the only one for 256-point classes), 5 = eight lanes per column (xl_inv8.hip), 6 = the 32 x 4 cut
+// (xl_inv32.hip).  Option "inverse_kernel": 0 = this rule, 3 / 5 / 6 = that kernel for every 128-point launch.  Measured alternating
+// in one process on every box of round 5 (profiles/r05_inverse_ab_same_box.txt, r05_inverse_cut32.txt, bench.py's "inverse launch
+// A/B"): launches of up to ~2000 tiles -- one block per call at up to 2048 clients -- run 5-9 % faster on the 8-lane kernel (no table
+// fill, the least work per tile: it is the launch's latency that counts there); 8 blocks per call at >= 2048 clients (>= 13 000 tiles)
+// run 6-10 % faster on the 32 x 4 cut than on the LDS transform, which in turn beat the 8-lane kernel by 3-5 % there; in between
+// (1024 clients x 8 blocks: 6912 tiles) the three are within 2 % and the call is bound by the NCO recurrence.
+static inline uint32_t xlp_inverse_pick(uint32_t M, uint32_t inv_reg, uint32_t tiles) {
+  if (M != 128u) return 3u;
+  if (inv_reg == 3u || inv_reg == 5u || inv_reg == 6u) return inv_reg;
+  return tiles <= 2048u ? 5u : 6u;
 }
 // (xl_inv8.hip: the 8-lane kernel; called by xlp_launch_inverse with the checked arguments and the launch's grid)
 void xlp_inverse8_launch(const XlpArgs &a, const dim3 grid, hipStream_t s, hipEvent_t done);
+// (xl_inv32.hip: the 32 x 4 cut; its workgroups take half tiles)
+uint32_t xlp_inverse32_work(uint32_t tiles);
+void xlp_inverse32_launch(const XlpArgs &a, const dim3 grid, hipStream_t s, hipEvent_t done);
 
 #endif  // XL_POLYPHASE_H_

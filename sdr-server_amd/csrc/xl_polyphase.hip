@@ -9,9 +9,9 @@
 //                       halves, v_mfma_f32_32x32x16_f16, FP32 accumulation.  Integer input formats, D <= 64 (the default there).
 //   xlp_mix_f32_kernel  (xl_mixf32.hip) the same sums with float32 operands on v_mfma_f32_32x32x2_f32 -- the float32 FMA chain itself:
 //                       cf32 input, D > 64, and every class on request (option "mix_kernel" = 3).
-//   xlp_inverse8_kernel (xl_inv8.hip; 128-point classes) / xlp_inverse_kernel (256-point classes; 128-point ones on request): per
-//                       (segment, 32 or 16 columns): Y tile -> M-point inverse DFT per column -> scale, NCO rotate (xlating.c:70) with
-//                       the tabulated float32 phase -> out[k], k < K.
+//   xlp_inverse8_kernel (xl_inv8.hip) / xlp_inverse32_kernel (xl_inv32.hip) (128-point classes: small / big launches) /
+//   xlp_inverse_kernel  (256-point classes; 128-point ones on request): per (segment, 32 or 16 columns): Y tile -> M-point inverse DFT
+//                       per column -> scale, NCO rotate (xlating.c:70) with the tabulated float32 phase -> out[k], k < K.
 // M = 256 or 128 per class (xl_polyphase.h).  When the NCO phases of the next call are not tabulated by the side-stream
 // chain kernel (xl_kernels.hip), the forward and the inverse launch each carry a slice of that recurrence ("NCO role").
 // Rounds 1-4 also shipped a packed-FMA mix kernel, a fused mix + inverse launch, 48-bit mixed spectra and three more inverse
@@ -472,14 +472,19 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
 // `done` (optional): recorded with the launch's own completion signal -- one queue packet instead of launch + event record
 hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done) {
   if (!xlp_valid_m(a0.M)) return hipErrorInvalidValue;
-  // 128-point classes: eight lanes per column, transforms of 16 and 8 points in registers (xl_inv8.hip), or staged in LDS on dense
-  // XOR-swizzled rows -- xlp_inverse_lanes8() picks; 256-point classes: staged in LDS on padded rows.  Workgroup = one tile of 32 (16)
-  // columns.
-  const uint32_t work = a0.nseg * a0.ncg * (a0.M == 256u ? 8u : 4u);
-  const bool lanes8 = xlp_inverse_lanes8(a0.M, a0.inv_reg, work);
+  // 128-point classes: eight lanes per column, transforms of 16 and 8 points in registers (xl_inv8.hip), the 32 x 4 cut (xl_inv32.hip),
+  // or staged in LDS on dense XOR-swizzled rows -- xlp_inverse_pick() says which; 256-point classes: staged in LDS on padded rows.
+  // Workgroup = one tile of 32 (16) columns.
+  const uint32_t tiles = a0.nseg * a0.ncg * (a0.M == 256u ? 8u : 4u);
+  const uint32_t kind = xlp_inverse_pick(a0.M, a0.inv_reg, tiles);
+  const uint32_t work = kind == 6u ? xlp_inverse32_work(tiles) : tiles;
   const XlpArgs a = xlp_checked_skip(a0, work);
   const dim3 grid(a.nco_blocks + a.nco_skip + work);
-  if (lanes8) {
+  if (kind == 6u) {
+    xlp_inverse32_launch(a, grid, s, done);
+    return hipGetLastError();
+  }
+  if (kind == 5u) {
     xlp_inverse8_launch(a, grid, s, done);
     return hipGetLastError();
   }

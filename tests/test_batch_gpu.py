@@ -293,12 +293,13 @@ def test_1000_clients_split_group_riders():
 # that the oracle can check every client.
 # The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
 # the forced-path tests run with both.
-@pytest.fixture(params=[(128, 0, 1), (128, 3, 1), (256, 0, 1), (128, 5, 3), (256, 0, 3), (128, 3, 3)],
-                ids=["M128", "M128-lds-inverse", "M256", "M128-f32-mix", "M256-f32-mix", "M128-lds-inverse-f32-mix"])
+@pytest.fixture(params=[(128, 0, 1), (128, 3, 1), (256, 0, 1), (128, 5, 3), (256, 0, 3), (128, 3, 3), (128, 6, 1), (128, 6, 3)],
+                ids=["M128", "M128-lds-inverse", "M256", "M128-f32-mix", "M256-f32-mix", "M128-lds-inverse-f32-mix", "M128-cut32-inverse",
+                     "M128-cut32-inverse-f32-mix"])
 def poly_m(request, monkeypatch):
     """Transform length of the forced polyphase plan; at M = 128 the inverse launch's transform in the registers of eight lanes per
-    column (option "inverse_kernel" = 5: xlp_inverse8_kernel -- what the default, 0, picks for launches as small as these) or staged in
-    LDS on swizzled rows (3: xlp_inverse_kernel);
+    column (option "inverse_kernel" = 5: xlp_inverse8_kernel -- what the default, 0, picks for launches as small as these), cut 32 x 4
+    (6: xlp_inverse32_kernel, the default's pick for big launches) or staged in LDS on swizzled rows (3: xlp_inverse_kernel);
     the mix launch on the matrix cores with two-half float16 operands where the class allows them and float32 operands elsewhere
     (option "mix_kernel" = 1, the default) or with float32 operands for every class (3)."""
     m, inv, mix = request.param
@@ -603,7 +604,7 @@ def test_polyphase_100_block_drift(monkeypatch, poly_m):
     block of 8 clients against the oracle, plus the committed phases at the end."""
     taps = lpf(FS, 24000, 9600)
     eng = _poly_engine(monkeypatch)
-    if os.environ.get("XL_EXP_INV") == "3" or poly_m == 256:  # (these fixtures: the recurrence inside the launches, two slices per
+    if os.environ.get("XL_EXP_INV") in ("3", "6") or poly_m == 256:  # (these fixtures: the recurrence inside the launches, two slices per
         eng.set_option("nco_side_stream", 0)                   # block; the others: on the side stream, the default for these calls)
     oracles = {}
     for c in range(8):
@@ -910,7 +911,7 @@ def test_group_of_blocks_equals_successive_calls_direct(variant):
     eng.close()
 
 
-@pytest.mark.parametrize("m,inv,mix", [(128, 0, 1), (128, 3, 1), (256, 0, 1), (128, 5, 3), (256, 0, 3)])
+@pytest.mark.parametrize("m,inv,mix", [(128, 0, 1), (128, 3, 1), (256, 0, 1), (128, 5, 3), (256, 0, 3), (128, 6, 1)])
 def test_group_of_blocks_polyphase(m, inv, mix, monkeypatch):
     """Forced polyphase path, G = 4 server-default blocks per call (108 segments at M = 128): every client vs the
     oracle's four successive calls; a native group in between (shared history and phases); ragged group.  mix = 1: the mix
@@ -1038,7 +1039,7 @@ def test_set_option_and_unknown_option():
     assert e.value.code == -2
     with pytest.raises(xl.XlatingError):
         eng.set_option("polyphase_m", 100)
-    for name, bad in (("inverse_kernel", 1), ("inverse_kernel", 4), ("mix_kernel", 0), ("mix_kernel", 2), ("nco_side_stream", 2)):
+    for name, bad in (("inverse_kernel", 1), ("inverse_kernel", 4), ("inverse_kernel", 7), ("mix_kernel", 0), ("mix_kernel", 2), ("nco_side_stream", 2)):
         with pytest.raises(xl.XlatingError):
             eng.set_option(name, bad)
     with pytest.raises(xl.XlatingError) as e:  # (round 1-4 tuning names are no options any more: XL_EXP_* at create)
@@ -1326,7 +1327,7 @@ def _engine_outputs(eng, ids):
     return [eng.output(i) for i in ids]
 
 
-@pytest.mark.parametrize("variant", ["native", "optimized", "optimized-lanes8-inverse", "optimized-f32-mix"])
+@pytest.mark.parametrize("variant", ["native", "optimized", "optimized-lanes8-inverse", "optimized-lds-inverse", "optimized-f32-mix"])
 def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
     server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
@@ -1338,6 +1339,9 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
 
     if variant.endswith("-lanes8-inverse"):
         monkeypatch.setenv("XL_EXP_INV", "5")
+        variant = "optimized"
+    if variant.endswith("-lds-inverse"):
+        monkeypatch.setenv("XL_EXP_INV", "3")
         variant = "optimized"
     if variant.endswith("-f32-mix"):  # float32 operands on the matrix cores: the all-float32 arithmetic of the path
         monkeypatch.setenv("XL_EXP_MIX", "3")
@@ -1354,7 +1358,8 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     if variant == "optimized":
         assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
         assert ("mix=mf32" if os.environ.get("XL_EXP_MIX") == "3" else "mix=mfma") in eng.describe(), eng.describe()
-        assert ("inv=lanes8" if os.environ.get("XL_EXP_INV") == "5" else "inv=lds") in eng.describe(), eng.describe()
+        # (6912 tiles per launch: the size rule takes the 32 x 4 cut)
+        assert {"5": "inv=lanes8", "3": "inv=lds"}.get(os.environ.get("XL_EXP_INV"), "inv=cut32") in eng.describe(), eng.describe()
     want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
     worst = 0.0
     for c in range(1024):
@@ -1443,7 +1448,8 @@ def test_group_2048_clients_all(variant, mix, monkeypatch):
 def test_group_4096_clients_sampled(mix, monkeypatch):
     """4096 x 48 kHz clients (32 column groups), 8 blocks per call, optimized: every 16th column and the first and last column
     of every group of 128 (and of 16) against oracle filters over two calls; a one-block call on the
-    same engine afterwards (the reference's call granularity)."""
+    same engine afterwards (the reference's call granularity).  Also: the plan's choices at this size (inverse kernel by the size
+    rule, the side kernel's CU reservation in rounds)."""
     monkeypatch.setenv("XL_EXP_MIX", str(mix))
     t48 = lpf(FS, 24000, 9600)
     G, nb, n = 8, 262144, 4096
@@ -1455,6 +1461,9 @@ def test_group_4096_clients_sampled(mix, monkeypatch):
     for k in range(2):
         _check_group(eng, oracles, "cu8", siggen.xs_u8(8400 + k, G * nb), G, "optimized")
     assert "polyphase: cls0 D42 T505 cols4096" in eng.describe() and ("mix=mf32" if mix == 3 else "mix=mfma") in eng.describe(), eng.describe()
+    # (27 648 tiles per launch: the 32 x 4 inverse kernel; the side-stream recurrence kernel's 64 workgroups run in two rounds on 32
+    # reserved CUs -- one CU each would be a quarter of the chip)
+    assert "inv=cut32" in eng.describe() and "side kernel: 32 CUs reserved" in eng.describe(), eng.describe()
     check_clients(eng, oracles, "cu8", siggen.xs_u8(8410, nb), "optimized")
     eng.close()
 
