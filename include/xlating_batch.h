@@ -78,9 +78,9 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                       column as 16 x 8 points with one exchange through LDS (5: xl_inv8.hip), in the registers of FOUR lanes per
  *                       column as 32 x 4 points -- whole-line loads, 256-byte store runs (6: xl_inv32.hip) --, or staged in LDS on
  *                       dense XOR-swizzled rows (3).  0 (default): by the size of the launch -- the 8-lane kernel for launches of up
- *                       to 2048 tiles (one block per call: 5-9 % ahead), the 32 x 4 cut beyond (8 blocks per call at >= 2048 clients:
- *                       6-10 % ahead of the LDS transform, round 4's pick there); measured alternating in one process (bench.py
- *                       "inverse launch A/B")
+ *                       to 2048 tiles (one block per call: 5-9 % ahead), the 32 x 4 cut from 8193 (8 blocks per call at >= 2048
+ *                       clients: 6-10 % ahead of the LDS transform, round 4's pick there), the LDS transform in between (up to
+ *                       10 % ahead of both); measured alternating in one process (bench.py "inverse launch A/B")
  *   "nco_side_stream"   -1 by rule (default: calls of >= 2 blocks whose launches are polyphase or light, and one-block polyphase
  *                       calls of up to 2048 clients), 0 never, 1 always: the NCO phase recurrence of the following calls runs as a
  *                       kernel of its own on a side stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE) instead of

@@ -206,7 +206,7 @@ struct xlating_batch_t {
   uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
   int num_cus = 256;
   uint32_t inv_reg = 0;       // option "inverse_kernel", M = 128 classes: 0 (default) = by the launch's size (xlp_inverse_pick: the 8-lane kernel
-                              // for launches of up to 2048 tiles, the 32 x 4 cut beyond), 5 = always eight lanes per column, 16- and
+                              // for launches of up to 2048 tiles, the LDS transform up to 8192, the 32 x 4 cut beyond), 5 = always eight lanes per column, 16- and
                               // 8-point transforms in registers (xl_inv8.hip), 6 = always the 32 x 4 cut (xl_inv32.hip: 32-point transforms
                               // in registers, whole-line loads, 256-byte store runs), 3 = always staged in LDS on dense rows with an XOR swizzle
   uint32_t mix_kernel = 1;    // option "mix_kernel": 1 (default) = two-half float16 operands on the matrix cores where the class allows them

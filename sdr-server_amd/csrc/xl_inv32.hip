@@ -1,5 +1,5 @@
 // xl_inv32.hip -- the inverse launch of the polyphase path with the 128-point transform cut 32 x 4 (option "inverse_kernel" = 6; what
-// the default, 0, takes for launches of more than 2048 tiles: xlp_inverse_pick).
+// the default, 0, takes for launches of more than 8192 tiles: xlp_inverse_pick).
 //
 // Same job as xlp_inverse_kernel (xl_polyphase.hip) and xlp_inverse8_kernel (xl_inv8.hip): per (segment, client column) the 128-point
 // inverse transform of the mixed spectra, the valid outputs scaled, rotated by the client's NCO phases and stored (xlating.c:70

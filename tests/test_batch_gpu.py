@@ -652,6 +652,7 @@ def test_polyphase_default_rule_1024_clients():
                 assert bits_equal(outs[c], want), c
             else:
                 assert rel_err(outs[c], want) <= REL_TOL, (c, rel_err(outs[c], want))
+    assert "inv=lanes8" in eng.describe(), eng.describe()  # (864 tiles per launch: the size rule takes the 8-lane inverse kernel)
     eng.close()
 
 
@@ -1327,7 +1328,7 @@ def _engine_outputs(eng, ids):
     return [eng.output(i) for i in ids]
 
 
-@pytest.mark.parametrize("variant", ["native", "optimized", "optimized-lanes8-inverse", "optimized-lds-inverse", "optimized-f32-mix"])
+@pytest.mark.parametrize("variant", ["native", "optimized", "optimized-lanes8-inverse", "optimized-cut32-inverse", "optimized-f32-mix"])
 def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     """The headline shape (bench.py / BASELINE configs[3] on one GPU): 1024 x 48 kHz clients, 505 taps, calls of 8
     server-default blocks.  ALL 1024 clients x one whole 8-block call (1.07 G client-samples, 25.6 M outputs) against
@@ -1340,8 +1341,8 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     if variant.endswith("-lanes8-inverse"):
         monkeypatch.setenv("XL_EXP_INV", "5")
         variant = "optimized"
-    if variant.endswith("-lds-inverse"):
-        monkeypatch.setenv("XL_EXP_INV", "3")
+    if variant.endswith("-cut32-inverse"):
+        monkeypatch.setenv("XL_EXP_INV", "6")
         variant = "optimized"
     if variant.endswith("-f32-mix"):  # float32 operands on the matrix cores: the all-float32 arithmetic of the path
         monkeypatch.setenv("XL_EXP_MIX", "3")
@@ -1358,8 +1359,8 @@ def test_group_bench_shape_1024_clients_all(variant, monkeypatch):
     if variant == "optimized":
         assert "polyphase: cls0 D42 T505 cols1024" in eng.describe(), eng.describe()
         assert ("mix=mf32" if os.environ.get("XL_EXP_MIX") == "3" else "mix=mfma") in eng.describe(), eng.describe()
-        # (6912 tiles per launch: the size rule takes the 32 x 4 cut)
-        assert {"5": "inv=lanes8", "3": "inv=lds"}.get(os.environ.get("XL_EXP_INV"), "inv=cut32") in eng.describe(), eng.describe()
+        # (6912 tiles per launch: the size rule takes the LDS transform)
+        assert {"5": "inv=lanes8", "6": "inv=cut32"}.get(os.environ.get("XL_EXP_INV"), "inv=lds") in eng.describe(), eng.describe()
     want = population(42, t48, fcs, FS, nb, "cu8", x, G, nwarm=G)
     worst = 0.0
     for c in range(1024):
