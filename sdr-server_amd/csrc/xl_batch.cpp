@@ -1323,14 +1323,8 @@ static int xl_batch_plan(xlating_batch *b) {
     // (a server that knows how many clients it admits says so -- option "expected_clients" --, and the reservation is made for
     // that many at once: the 25 ms of a stream re-creation then never fall on a call between two joins)
     const uint32_t nwg_res = std::max(nwg, (b->expected_clients + 63u) / 64u);
-    // Round 5: one CU per chain workgroup is a quarter of the chip at 4096 clients, held for a kernel that is busy a third of the
-    // call there (the chain's time per client does not grow with the client count, the launches' does).  From 3072 clients on the chain
-    // launch runs in ROUNDS on fewer CUs -- its workgroups queue on the mask -- as long as the rounds fit the calls they look ahead
-    // of: measured (profiles/r05_chain_reservation.txt) 2 rounds from 3072 clients (4096: 82.3 against 87.5 us per block; 3 rounds
-    // there make the chain the bound again: 85.1), by the same ratio 3 from 5120, 4 from 7168.
-    const uint32_t rounds = std::max(1u, (64u * nwg_res + 1024u) / 2048u);
-    uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? (nwg_res + 8u * rounds - 1u) / (8u * rounds) : 0u;
-    if (want > 16u) want = 0u;  // (more than half the chip for the chain: such engines are bound by the filtering anyway)
+    // (one CU per chain workgroup up to 3071 clients; beyond, the chain launch runs in rounds on fewer: xl_plan_rules.h)
+    uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? xl_chain_reserve_per_xcd(nwg_res) : 0u;
     if (getenv("XL_EXP_NOMASK")) want = 0u;
     if (want > 0u && getenv("XL_EXP_RESERVE")) want = std::min(want, (uint32_t)atoi(getenv("XL_EXP_RESERVE")));  // (tuning: fewer CUs, more rounds)
     // (creating a masked stream pair takes ~25 ms: grow at once, shrink only when two CUs per XCD too many are held, so that

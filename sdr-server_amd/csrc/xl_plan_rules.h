@@ -1,0 +1,43 @@
+/* xl_plan_rules.h -- the two SIZE RULES of the engine's plan that were set from measurements of round 5, as plain C so that the
+ * CPU suite can pin them (tests/test_plan_rules.py): which inverse kernel a polyphase launch takes, and how many CUs the side-stream
+ * recurrence kernel gets.  No HIP types. */
+#ifndef XL_PLAN_RULES_H_
+#define XL_PLAN_RULES_H_
+#include <stdint.h>
+
+/* Which inverse kernel a launch of `tiles` tiles (of 32 columns x one segment) takes: 3 = the transform staged in LDS
+ * (xlp_inverse_kernel: the only one for 256-point classes), 5 = eight lanes per column (xl_inv8.hip), 6 = the 32 x 4 cut
+ * (xl_inv32.hip).  Option "inverse_kernel": 0 = this rule, 3 / 5 / 6 = that kernel for every 128-point launch.  Measured alternating
+ * in one process on every box of round 5 (profiles/r05_inverse_ab_same_box.txt, r05_inverse_cut32.txt, bench.py's "inverse launch
+ * A/B"):
+ *   up to ~2000 tiles (one block per call at up to 2048 clients): the 8-lane kernel, 5-9 % ahead -- no table fill, the least work per
+ *     tile: it is the launch's latency that counts there;
+ *   from ~13 000 tiles (8 blocks per call at >= 2048 clients): the 32 x 4 cut, 6-10 % ahead of the LDS transform, which beat the
+ *     8-lane kernel by 3-5 % there -- whole-line loads, 256-byte store runs and a third fewer instructions;
+ *   in between: the LDS transform -- 10 % ahead of both others at 2688 tiles (BASELINE config 5 at 1024 clients: 45.4 against
+ *     49.8 / 50.2 us per launch), 3 % at 3456 (4096 clients, one block), level with the 32 x 4 cut at 6912 (1024 clients x 8 blocks,
+ *     where the NCO recurrence bounds the call anyway). */
+static inline uint32_t xlp_inverse_pick(uint32_t M, uint32_t inv_reg, uint32_t tiles) {
+  if (M != 128u) return 3u;
+  if (inv_reg == 3u || inv_reg == 5u || inv_reg == 6u) return inv_reg;
+  return tiles <= 2048u ? 5u : (tiles <= 8192u ? 3u : 6u);
+}
+
+/* CUs per XCD reserved for the side-stream recurrence (chain) kernel, whose workgroups -- one per 64 clients -- each own a CU
+ * (xl_kernels.hip: one chain wave per SIMD by register exhaustion).  One CU per workgroup is a quarter of the chip at 4096 clients,
+ * held for a kernel that is busy a third of the call there: the chain's time per client does not grow with the client count, the
+ * launches' does.  So from 3072 clients on the chain launch runs in ROUNDS on fewer CUs (its workgroups queue on the stream's CU
+ * mask), as many as fit the calls it looks ahead of -- measured (profiles/r05_chain_reservation.txt): 2 rounds from 3072 clients
+ * (4096: 82.3 against 87.5 us per block; 3 rounds there make the chain the bound again: 85.1), by the same ratio 3 from 5120, 4 from
+ * 7168.  `chain_wgs` = ceil(clients / 64).  More than 16 CUs per XCD (half the chip) is never reserved: 0 then. */
+static inline uint32_t xl_chain_rounds(uint32_t chain_wgs) {
+  const uint32_t r = (64u * chain_wgs + 1024u) / 2048u;
+  return r < 1u ? 1u : r;
+}
+static inline uint32_t xl_chain_reserve_per_xcd(uint32_t chain_wgs) {
+  const uint32_t per_round = 8u * xl_chain_rounds(chain_wgs);
+  const uint32_t want = (chain_wgs + per_round - 1u) / per_round;
+  return want > 16u ? 0u : want;
+}
+
+#endif /* XL_PLAN_RULES_H_ */

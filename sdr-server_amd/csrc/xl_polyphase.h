@@ -25,6 +25,7 @@
 #ifndef XL_POLYPHASE_H_
 #define XL_POLYPHASE_H_
 #include "xl_device.h"
+#include "xl_plan_rules.h"
 
 #define XLP_M_MAX 256u  // transform length M (branch samples per segment): 256 or 128, chosen per class
 #define XLP_SEG 16u    // segments per pass of the mix launches: with (re, im) the 32 rows of a matrix instruction (round 5; 14 before: the
@@ -116,23 +117,7 @@ hipError_t xlp_launch_mix_f32(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);
-// Which inverse kernel a launch of `tiles` tiles (of 32 columns x one segment) takes: 3 = the transform staged in LDS
-// (xlp_inverse_kernel: the only one for 256-point classes), 5 = eight lanes per column (xl_inv8.hip), 6 = the 32 x 4 cut
-// (xl_inv32.hip).  Option "inverse_kernel": 0 = this rule, 3 / 5 / 6 = that kernel for every 128-point launch.  Measured alternating
-// in one process on every box of round 5 (profiles/r05_inverse_ab_same_box.txt, r05_inverse_cut32.txt, bench.py's "inverse launch
-// A/B"):
-//   up to ~2000 tiles (one block per call at up to 2048 clients): the 8-lane kernel, 5-9 % ahead -- no table fill, the least work per
-//     tile: it is the launch's latency that counts there;
-//   from ~13 000 tiles (8 blocks per call at >= 2048 clients): the 32 x 4 cut, 6-10 % ahead of the LDS transform, which beat the
-//     8-lane kernel by 3-5 % there -- whole-line loads, 256-byte store runs and a third fewer instructions;
-//   in between: the LDS transform -- 10 % ahead of both others at 2688 tiles (BASELINE config 5 at 1024 clients: 45.4 against
-//     49.8 / 50.2 us per launch), 3 % at 3456 (4096 clients, one block), level with the 32 x 4 cut at 6912 (1024 clients x 8 blocks,
-//     where the NCO recurrence bounds the call anyway).
-static inline uint32_t xlp_inverse_pick(uint32_t M, uint32_t inv_reg, uint32_t tiles) {
-  if (M != 128u) return 3u;
-  if (inv_reg == 3u || inv_reg == 5u || inv_reg == 6u) return inv_reg;
-  return tiles <= 2048u ? 5u : (tiles <= 8192u ? 3u : 6u);
-}
+// Which inverse kernel a launch takes (option "inverse_kernel" = 0): xlp_inverse_pick, xl_plan_rules.h.
 // (xl_inv8.hip: the 8-lane kernel; called by xlp_launch_inverse with the checked arguments and the launch's grid)
 void xlp_inverse8_launch(const XlpArgs &a, const dim3 grid, hipStream_t s, hipEvent_t done);
 // (xl_inv32.hip: the 32 x 4 cut; its workgroups take half tiles)
