@@ -36,17 +36,15 @@
 
 typedef float v4f32 __attribute__((ext_vector_type(4)));
 
-// where workgroup `bid` works: bin, column group, passes [p0, p1) -- the pass runs of one (bin, column group) sit 8 positions
-// apart in the grid: same XCD, dispatched together, so that the group's operands come from HBM once (as in xlp_mix_mfma_kernel)
+// where workgroup `bid` works: bin, column group, passes [p0, p1) (xlp_mix_place: XCD-aware, as in xlp_mix_mfma_kernel)
 struct XlmfJob {
   uint32_t m, cg, p0, p1;
 };
 XL_DEV XlmfJob xlmf_job(const XlpArgs &a, const uint32_t bid) {
   const uint32_t pp = a.mix_pp, runs = (a.mix_passes + pp - 1u) / pp;
-  const uint32_t grp = bid / (8u * runs), rr = bid - grp * 8u * runs;
-  const uint32_t run = rr >> 3, pair = grp * 8u + (rr & 7u);
+  uint32_t run;
   XlmfJob j;
-  j.m = pair & (a.M - 1u), j.cg = pair / a.M;
+  xlp_mix_place(bid, a.M, runs, j.m, j.cg, run);
   j.p0 = run * pp;
   j.p1 = j.p0 + pp < a.mix_passes ? j.p0 + pp : a.mix_passes;
   return j;

@@ -200,6 +200,27 @@ XL_DEV void xlp_branch_spectrum(const float2 *__restrict__ rt, const uint32_t nl
   }
 }
 
+// Where workgroup `bid` of a mix launch works: bin m, column group cg, pass run `run` (of `runs`).  Workgroups go to the 8 XCDs round
+// robin (bid % 8), so
+//   * the pass runs of one (bin, column group) sit 8 positions apart in the grid: same XCD, dispatched together -- the group's operands
+//     come from HBM once;
+//   * XCD x takes the bins x M/8 .. (x + 1) M/8 - 1 of every column group, in order (round 5): the 16 (32) workgroups an XCD runs side
+//     by side for a column group write ADJACENT 256-byte runs of the Y tiles -- 4 KB contiguous from one L2 at about the same time
+//     instead of runs 2 KB apart from eight --, and an XCD's L2 holds an eighth of the shared spectra X instead of all of them.  The
+//     launch's store pattern alone (tools/ubench_tile_copy.hip, 4096 clients): 148 against 169 us per launch; the launches:
+//     profiles/r05_mix_xcd_bins.txt.
+XL_DEV void xlp_mix_place(const uint32_t bid, const uint32_t M, const uint32_t runs, uint32_t &m, uint32_t &cg, uint32_t &run) {
+  const uint32_t grp = bid / (8u * runs), rr = bid - grp * 8u * runs;
+  run = rr >> 3;
+#ifdef XLP_MIX_BINS_STRIDED  // (experiment: round 3's placement -- XCD x takes the bins = x mod 8)
+  const uint32_t pair = grp * 8u + (rr & 7u);
+  m = pair & (M - 1u), cg = pair / M;
+#else
+  const uint32_t per = M >> 3;
+  m = (rr & 7u) * per + grp % per, cg = grp / per;
+#endif
+}
+
 // NCO role of a launch: the first a.nco_blocks workgroups carry XL_NCO_LANES clients each (first wave only) through
 // this launch's slice of the NEXT call's phase recurrence.
 XL_DEV void xlp_nco_role(const XlpArgs &a) {

@@ -136,12 +136,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const uint32_t bid = blockIdx.x;
   const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
   const uint32_t M = a.M;
-  // the pass runs of one (bin, column group) sit 8 positions apart in the grid: same XCD, dispatched together -- the
-  // group's operands come from HBM once (as in xlp_mix_kernel)
+  // bin, column group and pass run of this workgroup: XCD-aware (xlp_mix_place)
   const uint32_t pp = a.mix_pp, runs = (a.mix_passes + pp - 1u) / pp;
-  const uint32_t grp = bid / (8u * runs), rr = bid - grp * 8u * runs;
-  const uint32_t run = rr >> 3, pair = grp * 8u + (rr & 7u);
-  const uint32_t m = pair & (M - 1u), cg = pair / M;
+  uint32_t m, cg, run;
+  xlp_mix_place(bid, M, runs, m, cg, run);
   const uint32_t p0 = run * pp, p1 = p0 + pp < a.mix_passes ? p0 + pp : a.mix_passes;
   if (p0 >= p1) return;
   // ---- B operands of this wave: 2 NKB runs of 1 KB

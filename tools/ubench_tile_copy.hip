@@ -121,6 +121,38 @@ __global__ __launch_bounds__(256) void tile_stores(char *__restrict__ out, const
   store_pieces<WINDOWS>(out, blockIdx.x % nsub, blockIdx.x / nsub, row_bytes, z);
 }
 
+// The MIX launch's store pattern: workgroup = (bin m, column group of 128 columns), wave = 32 columns (one tile column block), all
+// passes of 16 segments: per pass and wave 8 store instructions of two 256-byte runs (segments 2 h + cs, lanes = 32 columns x 8 bytes)
+// into Y[cg][segment][sub][bin][32]: runs of 256 bytes, 32 KB apart.  MAP 0: workgroup index = bin fastest (adjacent bins on
+// different XCDs, as the launch has it); MAP 1: XCD x (= index % 8) takes bins 16 x .. 16 x + 15 of a column group: adjacent runs
+// come from one XCD's CUs at about the same time.  NT: non-temporal stores (the launch's) or plain.
+template <int MAP, bool NT>
+__global__ __launch_bounds__(256) void mix_stores(v2f *__restrict__ Y, const uint32_t ncg, const uint32_t nseg) {
+  const uint32_t bid = blockIdx.x;
+  uint32_t m, cg;
+  if (MAP == 0) m = bid & 127u, cg = bid >> 7;
+  else {
+    const uint32_t x = bid & 7u, idx = bid >> 3;
+    m = 16u * x + (idx & 15u), cg = idx >> 4;
+  }
+  if (cg >= ncg) return;
+  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, h = lane >> 5, c = lane & 31u;
+  v2f *__restrict__ Yc = Y + ((((size_t)cg * nseg) * 4u + w) * 128u + m) * 32u + c;
+  const size_t ystride = 4u * 128u * 32u;  // v2f per segment
+  for (uint32_t s0 = 0; s0 < nseg; s0 += 16u) {
+#pragma unroll
+    for (int g2 = 0; g2 < 8; ++g2) {
+      const uint32_t cs = (uint32_t)((g2 & 1) + 4 * (g2 >> 1));
+      const uint32_t sg = s0 + 2u * h + cs;
+      const v2f y = {(float)sg, (float)m};
+      if (sg < nseg) {
+        if (NT) __builtin_nontemporal_store(y, Yc + (size_t)sg * ystride);
+        else Yc[(size_t)sg * ystride] = y;
+      }
+    }
+  }
+}
+
 int main(int argc, char **argv) {
   const uint32_t ncols = argc > 1 ? (uint32_t)atoi(argv[1]) : 4096u;
   const size_t lds = argc > 2 ? (size_t)atoi(argv[2]) : 0u;
@@ -166,6 +198,15 @@ int main(int argc, char **argv) {
     time(name, rd + wr, [&] { hipLaunchKernelGGL(tile_pieces_pipe<0>, dim3(256u * per_cu), dim3(256), 0, st, in4, out, nsub, row_bytes, ntiles); });
     snprintf(name, sizeof name, "tile -> pieces, persistent (%u workgroups per CU), next tile's loads in flight, aligned windows", per_cu);
     time(name, rd + wr, [&] { hipLaunchKernelGGL(tile_pieces_pipe<1>, dim3(256u * per_cu), dim3(256), 0, st, in4, out, nsub, row_bytes, ntiles); });
+  }
+  {
+    const uint32_t ncg = ncols / 128u;
+    v2f *Y = reinterpret_cast<v2f *>(in);  // (the tile image: 906 MB at 4096 rows)
+    printf("the mix launch's store pattern alone (%u workgroups, each all %u segments of one bin and 128 columns):\n", 128u * ncg, NSEG);
+    time("mix stores, bin fastest across the grid (adjacent bins on different XCDs), non-temporal", rd, [&] { hipLaunchKernelGGL((mix_stores<0, true>), dim3(128u * ncg), dim3(256), lds, st, Y, ncg, NSEG); });
+    time("mix stores, bin fastest across the grid, plain stores", rd, [&] { hipLaunchKernelGGL((mix_stores<0, false>), dim3(128u * ncg), dim3(256), lds, st, Y, ncg, NSEG); });
+    time("mix stores, 16 adjacent bins per XCD, non-temporal", rd, [&] { hipLaunchKernelGGL((mix_stores<1, true>), dim3(128u * ncg), dim3(256), lds, st, Y, ncg, NSEG); });
+    time("mix stores, 16 adjacent bins per XCD, plain stores", rd, [&] { hipLaunchKernelGGL((mix_stores<1, false>), dim3(128u * ncg), dim3(256), lds, st, Y, ncg, NSEG); });
   }
   return 0;
 }
