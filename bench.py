@@ -41,7 +41,7 @@ Prints ONE JSON line (rank 0): value = input IQ Msamples/s summed over all clien
 "variants":     context for the headline, each a short run of its own on this box: other filter lengths / call granularities / client
                 counts (2048 and 4096: where the launches, not the recurrence, bound the call -- the 2048 one with its own counters
                 and EVERY client checked); "polyphase, float32 matrix-core mix": the all-float32 arithmetic (option mix_kernel = 3),
-                every client checked; "inverse launch A/B in this process": the two inverse kernels alternating on this box;
+                every client checked; "inverse launch A/B in this process": the size rule's inverse kernel and its alternate alternating on this box;
                 "config 5 ...": BASELINE configs[4] (cf32 10 Msps, D = 100, 257 taps, 1024 clients) with its own roofline block
                 (counter bytes, shared-read algorithmic fraction, FP32 / matrix-f32 fractions) and every client checked;
                 "host-delivered outputs": process_host + fetch per call (PCIe-inclusive; never `value`).
