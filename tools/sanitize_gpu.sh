@@ -7,7 +7,7 @@
 #           C++ over the HIP headers), linked with the normal kernel objects into sdr-server_amd/build/sanitize_gpu/libxlating_hip_asan.so
 #           (travels with gpurun; the plain build under sdr-server_amd/build/ must be current)
 #   run     (GPU box) drives it with GPU tests that stay off torch (host-path calls): churn with a join and a leave per block, CU
-#           reservation, options, re-plans, groups of blocks, config 5, the drop-in filter's create / process / destroy cycles
+#           reservation (also in rounds: 4096 clients), options, re-plans, groups of blocks, config 5, the drop-in filter's create / process / destroy cycles
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CS=$ROOT/sdr-server_amd/csrc; B=$ROOT/sdr-server_amd/build; S=$B/sanitize_gpu
@@ -23,7 +23,7 @@ build)
   echo built $S/libxlating_hip_asan.so ;;
 run)
   OUT=${2:-$ROOT/gpurun_out/sanitize}; mkdir -p $OUT; rm -f $S/report.*
-  K="churn or expected_clients or set_option or describe_after or size_rule or group_of_blocks_polyphase or config5_cf32_10msps_all_clients or polyphase_forced_server_default or chain_launch_covers"
+  K="churn or expected_clients or set_option or describe_after or size_rule or group_of_blocks_polyphase or config5_cf32_10msps_all_clients or polyphase_forced_server_default or chain_launch_covers or group_4096_clients_sampled"
   ( cd $ROOT && timeout 1200 env LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:protect_shadow_gap=0:log_path=$S/report UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=$S/report \
       XL_TESTING=1 XL_LIBRARY_PATH=$S/libxlating_hip_asan.so python -m pytest tests/test_batch_gpu.py tests/test_c_dropin.py -m gpu -q -p no:cacheprovider -k "$K" ) > $OUT/asan_gpu.tmp 2>&1
   rc=$?
