@@ -86,8 +86,8 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                       kernel of its own on a side stream (on CUs reserved for it when the call uses XL_STREAM_ENGINE) instead of
  *                       riding inside the call's launches
  *   "expected_clients"  0 (default) .. 8192: the CUs of that side kernel are reserved for this many clients from the first plan on
- *                       (64 clients per CU up to 3071 clients; from 3072 on the side kernel runs in rounds on half, a third, ... as
- *                       many), not for the clients joined so far -- the reservation then never grows while clients
+ *                       (64 clients per CU up to 2048 clients; none from there to 3008 -- the side kernel then shares the chip --; beyond,
+ *                       it runs in rounds on half, a third, ... as many CUs), not for the clients joined so far -- the reservation then never grows while clients
  *                       join up to that number (growing it re-creates two streams: ~25 ms, once per 512 clients); until then the
  *                       launches run on correspondingly fewer CUs
  * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call.

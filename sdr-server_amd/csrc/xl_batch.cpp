@@ -1323,9 +1323,10 @@ static int xl_batch_plan(xlating_batch *b) {
     // (a server that knows how many clients it admits says so -- option "expected_clients" --, and the reservation is made for
     // that many at once: the 25 ms of a stream re-creation then never fall on a call between two joins)
     const uint32_t nwg_res = std::max(nwg, (b->expected_clients + 63u) / 64u);
-    // (one CU per chain workgroup up to 3071 clients; beyond, the chain launch runs in rounds on fewer: xl_plan_rules.h)
+    // (one CU per chain workgroup up to 2048 clients, none up to 3008, beyond that the chain launch runs in rounds on fewer: xl_plan_rules.h)
     uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? xl_chain_reserve_per_xcd(nwg_res) : 0u;
     if (getenv("XL_EXP_NOMASK")) want = 0u;
+    if (want > 0u && getenv("XL_EXP_ROUNDS1")) want = std::min(16u, (nwg_res + 7u) / 8u);  // (tuning: round 3's rule, one CU per chain workgroup)
     if (want > 0u && getenv("XL_EXP_RESERVE")) want = std::min(want, (uint32_t)atoi(getenv("XL_EXP_RESERVE")));  // (tuning: fewer CUs, more rounds)
     // (creating a masked stream pair takes ~25 ms: grow at once, shrink only when two CUs per XCD too many are held, so that
     // a client count hovering around a multiple of 512 does not recreate the streams at every join and leave)

@@ -24,18 +24,27 @@ static inline uint32_t xlp_inverse_pick(uint32_t M, uint32_t inv_reg, uint32_t t
 }
 
 /* CUs per XCD reserved for the side-stream recurrence (chain) kernel, whose workgroups -- one per 64 clients -- each own a CU
- * (xl_kernels.hip: one chain wave per SIMD by register exhaustion).  One CU per workgroup is a quarter of the chip at 4096 clients,
- * held for a kernel that is busy a third of the call there: the chain's time per client does not grow with the client count, the
- * launches' does.  So from 3072 clients on the chain launch runs in ROUNDS on fewer CUs (its workgroups queue on the stream's CU
- * mask), as many as fit the calls it looks ahead of -- measured (profiles/r05_chain_reservation.txt): 2 rounds from 3072 clients
- * (4096: 82.3 against 87.5 us per block; 3 rounds there make the chain the bound again: 85.1), by the same ratio 3 from 5120, 4 from
- * 7168.  `chain_wgs` = ceil(clients / 64).  More than 16 CUs per XCD (half the chip) is never reserved: 0 then. */
+ * (xl_kernels.hip: one chain wave per SIMD by register exhaustion).  `chain_wgs` = ceil(clients / 64).
+ *   up to 32 workgroups (2048 clients): one CU per workgroup (round 3's rule).  The recurrence bounds or nearly bounds the call there
+ *     (1024 clients: 194 of 198 us; 1536: 212 of 280), and without CUs of its own it runs 25-35 % slower.
+ *   33 .. 47 workgroups (2049 .. 3008 clients): NONE -- the chain workgroups take whole CUs as the launches' tails free them.  One
+ *     CU each would be 40-48 CUs (a sixth of the chip) for a kernel that is busy half the call, and two rounds on half as many do
+ *     not fit the calls yet: measured (profiles/r05_chain_reservation.txt (3)) 2304 / 2560 / 2816 clients 49.1-49.9 / 53.9-54.7 /
+ *     58.2-58.6 us per block without against 53.7-54.2 / 57.2-58.1 / 62.3-63.2 with the reservation (2048: level).
+ *   from 48 workgroups (3009+ clients): the chain launch runs in ROUNDS on fewer CUs (its workgroups queue on the stream's CU mask),
+ *     as many as fit the calls it looks ahead of -- the chain's time per client does not grow with the client count, the launches'
+ *     does: 2 rounds from 3072 clients (4096: 82.3 against 87.5 us per block with one CU per workgroup; 3 rounds there make the
+ *     chain the bound again: 85.1), 3 from 5120, 4 from 7168 (5120 / 6144 / 8192 clients: 100-102 / 118-121 / 155-160 against
+ *     115-119 / 138-142 / 217-226; no reservation: 103 / 119-123 / 160-163).
+ * More than 16 CUs per XCD (half the chip) is never reserved: 0 then. */
 static inline uint32_t xl_chain_rounds(uint32_t chain_wgs) {
   const uint32_t r = (64u * chain_wgs + 1024u) / 2048u;
   return r < 1u ? 1u : r;
 }
 static inline uint32_t xl_chain_reserve_per_xcd(uint32_t chain_wgs) {
-  const uint32_t per_round = 8u * xl_chain_rounds(chain_wgs);
+  const uint32_t rounds = xl_chain_rounds(chain_wgs);
+  if (rounds == 1u && chain_wgs > 32u) return 0u;
+  const uint32_t per_round = 8u * rounds;
   const uint32_t want = (chain_wgs + per_round - 1u) / per_round;
   return want > 16u ? 0u : want;
 }

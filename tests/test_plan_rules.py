@@ -41,8 +41,8 @@ def test_inverse_kernel_by_launch_size(tmp_path):
 def test_chain_kernel_cu_reservation(tmp_path):
     lib = _lib(tmp_path)
     wgs = lambda clients: -(-clients // 64)
-    # one CU per chain workgroup (8 XCDs) up to 47 workgroups (3008 clients)
-    for clients, per_xcd in ((64, 1), (512, 1), (513, 2), (1024, 2), (2048, 4), (3008, 6)):
+    # one CU per chain workgroup (8 XCDs) up to 32 workgroups (2048 clients); none from there to 47 workgroups (3008 clients)
+    for clients, per_xcd in ((64, 1), (512, 1), (513, 2), (1024, 2), (1536, 3), (2048, 4), (2049, 0), (2560, 0), (3008, 0)):
         assert lib.rounds(wgs(clients)) == 1 and lib.reserve(wgs(clients)) == per_xcd, clients
     # in rounds beyond: 2 from 48 workgroups (3009 .. 3072 clients), 3 from 80 (5120), 4 from 112 (7168)
     for clients, rounds, per_xcd in ((3009, 2, 3), (3072, 2, 3), (4096, 2, 4), (5056, 2, 5), (5120, 3, 4), (7168, 4, 4), (8192, 4, 4)):
@@ -50,4 +50,4 @@ def test_chain_kernel_cu_reservation(tmp_path):
     # the reservation never needs more rounds than the rule allows, and never more than half the chip
     for n in range(1, 1025):
         r, c = lib.rounds(n), lib.reserve(n)
-        assert c <= 16 and (c == 0 or 8 * c * r >= n), n
+        assert c <= 16 and (c == 0 or 8 * c * r >= n) and (c > 0 or 32 < n < 48 or n > 512), n
