@@ -147,8 +147,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   v8h r1[NKB], r2[NKB];
 #pragma unroll
   for (int j = 0; j < NKB; ++j) {
+#ifdef XLP_MIX_EXP_NOOPERANDS
+    r1[j] = __builtin_bit_cast(v8h, (uint4){lane, tid, (uint32_t)j, m});
+    r2[j] = __builtin_bit_cast(v8h, (uint4){m, lane, tid, (uint32_t)j});
+#else
     r1[j] = __builtin_bit_cast(v8h, Rp[xlm_rh_slot(cg, M, m, w, 0u, NKB, (uint32_t)j, lane)]);
     r2[j] = __builtin_bit_cast(v8h, Rp[xlm_rh_slot(cg, M, m, w, 1u, NKB, (uint32_t)j, lane)]);
+#endif
   }
   const uint32_t h = lane >> 5, c = lane & 31u;
   const float cs_ = a.cscale[cg * XLP_COLS + w * 32u + c];
@@ -210,12 +215,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int j = 0; j < NKB; ++j) {
       const v8h a1 = __builtin_bit_cast(v8h, xs[buf][0][j][xlm_lds_slot(lane)]);
       const v8h a2 = __builtin_bit_cast(v8h, xs[buf][1][j][xlm_lds_slot(lane)]);
+#ifdef XLP_MIX_EXP_NOMFMA  // (experiments, wrong results: what is the launch's time made of?  profiles/r05_mix_anatomy.txt)
+      hi[j] += a1[0] * r1[j][0], lo[j] += a2[1] * r2[j][1];
+#else
       lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, r1[j], lo, 0, 0, 0);
       hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r1[j], hi, 0, 0, 0);
       lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r2[j], lo, 0, 0, 0);
+#endif
     }
+#ifndef XLP_MIX_EXP_NOSTAGE
     if (pass + 1u < p1) stage(buf ^ 1u);
     if (pass + 2u < p1) request(pass + 2u);
+#endif
     // this lane's rows: registers g, g + 1 (g even) = (re, im) of the pass's segment xlm_result_row(g, h) / 2 = 2 h + (g >> 1 & 1) +
     // 4 (g >> 2): one 64-bit product per lane (its first segment), then wave-uniform steps; the bounds test is per lane only in the
     // call's last pass
@@ -229,7 +240,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const uint32_t cs = (uint32_t)(((g2 >> 1) & 1) + 4 * (g2 >> 2));  // (a constant after unrolling)
         const v2f y = {(hi[g2] + lo[g2]) * cs_, (hi[g2 + 1] + lo[g2 + 1]) * cs_};
         v2f *const dst = reinterpret_cast<v2f *>(base + cs * sb);
-#ifdef XLP_Y_TEMPORAL  // (tools/mall_calibration.sh: the same stores with the default cache policy)
+#ifdef XLP_MIX_EXP_NOSTORE
+        if ((whole || s0 + 2u * h + cs < a.nseg) && y.x == 1.2345e-33f) __builtin_nontemporal_store(y, dst);
+#elif defined(XLP_Y_TEMPORAL)  // (tools/mall_calibration.sh: the same stores with the default cache policy)
         if (whole || s0 + 2u * h + cs < a.nseg) *dst = y;
 #else
         if (whole || s0 + 2u * h + cs < a.nseg) __builtin_nontemporal_store(y, dst);
