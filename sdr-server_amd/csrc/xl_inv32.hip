@@ -7,8 +7,8 @@
 // and 256-byte store runs the traffic alone takes 43.6 us per block at 4096 clients; in the 8-lane kernel's 64-byte runs, 58):
 //   * a wave owns 16 client columns = one 128-byte line of every bin row of the tile: a load instruction reads four whole lines, and
 //     the values land in the registers of the lane that transforms them (32-point transform over m2 in registers: no fill pass);
-//   * one exchange through the wave's private LDS region -- in two rounds of 8 columns, so that the region is 8.5 KB and sixteen waves
-//     fit a CU -- then 4-point transforms in registers; lane (cc, t) ends up with outputs t + 32 g of column 2 k + cc: a store
+//   * one exchange through the wave's private LDS region -- in two rounds of 8 columns, so that a wave needs 10 KB of LDS, not 18.7: the
+//     twelve waves per CU its 154 registers allow, not eight (-9 % launch time) -- then 4-point transforms in registers; lane (cc, t) ends up with outputs t + 32 g of column 2 k + cc: a store
 //     instruction covers 256 consecutive bytes of each of two client rows;
 //   * every LDS address is "one register per lane + an immediate" (xl_inv32_layout.h; tests/c/test_inv32_layout.cpp runs the same
 //     index functions through an emulation of the lanes and a model of the banks);

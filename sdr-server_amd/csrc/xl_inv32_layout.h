@@ -14,8 +14,8 @@
 //      transform over m2 in registers: Z_m1[t]          (radix 4, 4, 2 with compile-time twiddles: xl_fft16.h)
 //   2. Z'_m1[t] = Z_m1[t] * w^{m1 t} / 128              (the lane's 32 factors from a 1 KB table in LDS, [t][m1]: one address per
 //                                                        lane, t in the instruction's offset field; the exact scaling rides along)
-//   3. one exchange through the wave's own LDS region, [column][m1][t], in TWO ROUNDS of 8 columns (a region of 8.5 KB: sixteen
-//      waves per CU): the writer lanes of the round's columns store (t, t + 1) pairs (ds_write_b128), reader lane (cc, t) of pass
+//   3. one exchange through the wave's own LDS region, [column][m1][t], in TWO ROUNDS of 8 columns (a region of 8.5 KB: LDS for
+//      sixteen waves per CU; the kernel's registers allow twelve): the writer lanes of the round's columns store (t, t + 1) pairs (ds_write_b128), reader lane (cc, t) of pass
 //      k < 4 fetches row t of column 8 r + 2 k + cc (4 x ds_read_b64) -- every address = lane base + immediate
 //   4. a 4-point inverse transform over m1 in registers: y[t + 32 g], g < 4 -- a store instruction (fixed pass, g) covers 32
 //      consecutive outputs of each of two columns
@@ -65,7 +65,7 @@ XLI32_FN uint32_t xli32_phase(uint32_t c8, uint32_t p) { return c8 * XLI32_PCOL 
 XLI32_FN uint32_t xli32_tw(uint32_t t, uint32_t m1) { return XLI32_TW + t * 32u + m1 * 8u; }
 #define XLI32_META (XLI32_TW + 1024u)
 XLI32_FN uint32_t xli32_meta(uint32_t c) { return XLI32_META + c * 16u; }
-#define XLI32_WAVE_BYTES (XLI32_META + 16u * XLI32_COLS)  // 9984: sixteen waves per CU
+#define XLI32_WAVE_BYTES (XLI32_META + 16u * XLI32_COLS)  // 9984: sixteen waves' worth per CU
 
 // slot of output t of the in-place 32-point register transform (xl_fft32_inverse, xl_fft16.h): radix 4 (span 8), radix 4 (span 2),
 // radix 2
