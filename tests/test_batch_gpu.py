@@ -1469,6 +1469,27 @@ def test_group_4096_clients_sampled(mix, monkeypatch):
     eng.close()
 
 
+def test_group_2304_clients_sampled_no_cu_reservation():
+    """2304 x 48 kHz clients, 8 blocks per call, optimized: between 2049 and 3008 clients the side-stream recurrence kernel gets no CUs of
+    its own (xl_plan_rules.h: its 36 workgroups take whole CUs as the launches' tails free them) -- every 16th column and the last one
+    against oracle filters over three calls, the committed phases of the sampled clients bit for bit at the end."""
+    t48 = lpf(FS, 24000, 9600)
+    G, nb, n = 8, 262144, 2304
+    fcs = [-984000 + 850 * c for c in range(n)]
+    eng = xl.BatchEngine(FS, "cu8", nb, group_blocks=G)
+    ids = [eng.add_client(42, t48, fc) for fc in fcs]
+    sample = sorted(set(range(0, n, 16)) | {n - 1})
+    oracles = {ids[c]: Oracle(42, t48, fcs[c], FS, nb) for c in sample}
+    for k in range(3):
+        _check_group(eng, oracles, "cu8", siggen.xs_u8(8600 + k, G * nb), G, "optimized")
+    d = eng.describe()
+    assert "polyphase: cls0 D42 T505 cols2304" in d and "inv=cut32" in d and "side kernel:" not in d, d
+    for cid, o in oracles.items():
+        pr, pi = eng.phase(cid)
+        assert (np.float32(pr), np.float32(pi)) == tuple(np.float32(v) for v in o.phase), cid
+    eng.close()
+
+
 @pytest.mark.parametrize("nclients", [64, 256, 1024])
 def test_config5_cf32_10msps_all_clients(nclients):
     """BASELINE config 5 at the client counts SURVEY 8(d) lists (N = 64, 256; N = 1 runs in
