@@ -1323,8 +1323,22 @@ static int xl_batch_plan(xlating_batch *b) {
     // (a server that knows how many clients it admits says so -- option "expected_clients" --, and the reservation is made for
     // that many at once: the 25 ms of a stream re-creation then never fall on a call between two joins)
     const uint32_t nwg_res = std::max(nwg, (b->expected_clients + 63u) / 64u);
-    // (one CU per chain workgroup up to 2048 clients, none up to 3008, beyond that the chain launch runs in rounds on fewer: xl_plan_rules.h)
-    uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? xl_chain_reserve_per_xcd(nwg_res) : 0u;
+    // (one CU per chain workgroup while the recurrence bounds the call, none in a band above that, beyond it the chain launch runs in
+    // rounds on fewer CUs -- by the plan's load: launch time per unit of chain time, in clients of the measured shape: xl_plan_rules.h)
+    uint32_t load_wgs = nwg_res;
+    if (!b->poly.empty()) {
+      double ps = b->macs_rest * (double)b->max_samples * 72.0;  // (direct-kernel clients of an optimized call: ~0.072 ns per complex MAC)
+      uint32_t kmax = 1u;
+      for (const PolyClass &pc : b->poly) {
+        const uint32_t K = (b->max_samples + pc.D - 1u) / pc.D;
+        ps += (double)pc.members.size() * xl_client_launch_ps(pc.M, K, pc.V, 8u * pc.nkb, pc.mix_kind, b->gcap);
+        kmax = std::max(kmax, K);
+      }
+      for (const DirectClass &cs : b->classes_rest) kmax = std::max(kmax, (b->max_samples + cs.D - 1u) / cs.D);
+      // (scaled to the population the CUs are reserved for: option "expected_clients")
+      load_wgs = xl_plan_load_wgs(ps * (double)nwg_res / (double)std::max(nwg, 1u), kmax);
+    }
+    uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? xl_chain_reserve_per_xcd(nwg_res, load_wgs) : 0u;
     if (getenv("XL_EXP_NOMASK")) want = 0u;
     if (want > 0u && getenv("XL_EXP_ROUNDS1")) want = std::min(16u, (nwg_res + 7u) / 8u);  // (tuning: round 3's rule, one CU per chain workgroup)
     if (want > 0u && getenv("XL_EXP_RESERVE")) want = std::min(want, (uint32_t)atoi(getenv("XL_EXP_RESERVE")));  // (tuning: fewer CUs, more rounds)

@@ -1463,8 +1463,9 @@ def test_group_4096_clients_sampled(mix, monkeypatch):
         _check_group(eng, oracles, "cu8", siggen.xs_u8(8400 + k, G * nb), G, "optimized")
     assert "polyphase: cls0 D42 T505 cols4096" in eng.describe() and ("mix=mf32" if mix == 3 else "mix=mfma") in eng.describe(), eng.describe()
     # (27 648 tiles per launch: the 32 x 4 inverse kernel; the side-stream recurrence kernel's 64 workgroups run in two rounds on 32
-    # reserved CUs -- one CU each would be a quarter of the chip)
-    assert "inv=cut32" in eng.describe() and "side kernel: 32 CUs reserved" in eng.describe(), eng.describe()
+    # reserved CUs -- one CU each would be a quarter of the chip; with the float32 mix a client weighs 1.5 x as much launch time and
+    # the plan reserves none: xl_plan_rules.h)
+    assert "inv=cut32" in eng.describe() and (mix == 3 or "side kernel: 32 CUs reserved" in eng.describe()), eng.describe()
     check_clients(eng, oracles, "cu8", siggen.xs_u8(8410, nb), "optimized")
     eng.close()
 

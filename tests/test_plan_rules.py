@@ -11,7 +11,11 @@ SHIM = r"""
 #include "xl_plan_rules.h"
 unsigned pick(unsigned M, unsigned opt, unsigned tiles) { return xlp_inverse_pick(M, opt, tiles); }
 unsigned rounds(unsigned wgs) { return xl_chain_rounds(wgs); }
-unsigned reserve(unsigned wgs) { return xl_chain_reserve_per_xcd(wgs); }
+unsigned reserve(unsigned wgs) { return xl_chain_reserve_per_xcd(wgs, wgs); }
+unsigned reserve2(unsigned wgs, unsigned load_wgs) { return xl_chain_reserve_per_xcd(wgs, load_wgs); }
+unsigned launch_ps(unsigned M, unsigned K, unsigned V, unsigned Dpad, unsigned mix, unsigned G) { return xl_client_launch_ps(M, K, V, Dpad, mix, G); }
+unsigned chain_ns(unsigned K) { return xl_chain_block_ns(K); }
+unsigned load_wgs(double ps_sum, unsigned kmax) { return xl_plan_load_wgs(ps_sum, kmax); }
 """
 
 
@@ -20,7 +24,9 @@ def _lib(tmp_path):
     src.write_text(SHIM)
     so = str(tmp_path / "rules.so")
     subprocess.run(["gcc", "-std=c11", "-O1", "-shared", "-fPIC", "-I", os.path.join(ROOT, "sdr-server_amd", "csrc"), str(src), "-o", so], check=True)
-    return ctypes.CDLL(so)
+    lib = ctypes.CDLL(so)
+    lib.load_wgs.argtypes = [ctypes.c_double, ctypes.c_uint]
+    return lib
 
 
 def test_inverse_kernel_by_launch_size(tmp_path):
@@ -51,3 +57,29 @@ def test_chain_kernel_cu_reservation(tmp_path):
     for n in range(1, 1025):
         r, c = lib.rounds(n), lib.reserve(n)
         assert c <= 16 and (c == 0 or 8 * c * r >= n) and (c > 0 or 32 < n < 48 or n > 512), n
+
+
+def test_chain_reservation_follows_the_plans_load(tmp_path):
+    """The bands are measured on the server-default shape; a plan of another shape enters them with its launch time per unit of chain
+    time, expressed as the default-shape client count that has the same ratio (xl_plan_load_wgs)."""
+    lib = _lib(tmp_path)
+    # the default shape (2.016 Msps cu8 -> 48 kHz, 505 taps: M = 128, K = 3121, V = 116, 48 padded branches, two-half mix, 8 blocks per
+    # call): per client 18.7 ns of launches against 25.7 us of chain per block -- the measured 7.1 (mix) + 11.7 (inverse) ns and 24.6 us
+    d = lib.launch_ps(128, 3121, 116, 48, 1, 8)
+    assert 18000 <= d <= 19500 and 25000 <= lib.chain_ns(3121) <= 26500, (d, lib.chain_ns(3121))
+    for clients in (64, 1000, 1024, 2048, 2049, 3008, 3009, 4096, 8192):
+        assert lib.load_wgs(float(clients) * d, 3121) == -(-clients // 64), clients  # its own client count
+    # BASELINE config 5 (cf32 10 Msps, D = 100, 257 taps: K = 1311, V = 126, 104 padded branches, float32 mix): 2.2 x the load per client
+    c5 = lib.launch_ps(128, 1311, 126, 104, 3, 8)
+    assert 17000 <= c5 <= 20500, c5  # measured: mix 14.0 + inverse 5.6 ns per (client, block)
+    ratio = (c5 / lib.chain_ns(1311)) / (d / lib.chain_ns(3121))
+    assert 2.0 <= ratio <= 2.5, ratio
+    want = {512: 1, 1024: 0, 2048: 0, 4096: 0}  # CUs per XCD: reserved at 512 clients (measured better), none beyond (measured better)
+    for clients, per_xcd in want.items():
+        wgs, load = -(-clients // 64), lib.load_wgs(float(clients) * c5, 1311)
+        assert lib.reserve2(wgs, load) == per_xcd, (clients, load)
+    # rounds are for plans whose clients weigh about what the measured shape's do
+    assert lib.reserve2(64, 64) == 4 and lib.reserve2(64, 95) == 3 and lib.reserve2(64, 97) == 0
+    # a plan whose launches are short against the recurrence (few taps, small decimation) keeps one CU per chain workgroup
+    light = lib.launch_ps(128, 3121, 126, 8, 1, 8)
+    assert lib.reserve2(16, lib.load_wgs(1024.0 * light, 3121)) == 2
