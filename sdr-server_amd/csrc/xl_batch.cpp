@@ -1326,7 +1326,7 @@ static int xl_batch_plan(xlating_batch *b) {
     // (one CU per chain workgroup while the recurrence bounds the call, none in a band above that, beyond it the chain launch runs in
     // rounds on fewer CUs -- by the plan's load: launch time per unit of chain time, in clients of the measured shape: xl_plan_rules.h)
     uint32_t load_wgs = nwg_res;
-    if (!b->poly.empty()) {
+    if (!b->poly.empty() && b->gcap >= 2) {  // (engines of one-block calls: the bands as measured by client count -- their calls are short, and nothing else was measured)
       double ps = b->macs_rest * (double)b->max_samples * 72.0;  // (direct-kernel clients of an optimized call: ~0.072 ns per complex MAC)
       uint32_t kmax = 1u;
       for (const PolyClass &pc : b->poly) {
