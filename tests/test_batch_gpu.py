@@ -1470,6 +1470,51 @@ def test_group_4096_clients_sampled(mix, monkeypatch):
     eng.close()
 
 
+def test_chain_kernel_placement_does_not_change_the_phases(monkeypatch):
+    """The side-stream recurrence kernel of a 4096-client plan under its three placements -- in two rounds on 32 reserved CUs (the rule),
+    one CU per workgroup (XL_EXP_ROUNDS1, round 3's rule), no reservation (XL_EXP_NOMASK: the chain workgroups wait for whole free CUs)
+    -- is the same arithmetic at different times: three engines fed the same 96 calls of 8 blocks must hold bit-identical phases for all
+    4096 clients every 16 calls -- and bit-identical outputs --, whatever the look-ahead, the event order and the queueing did in between."""
+    t48 = lpf(FS, 24000, 9600)
+    G, nb, n = 8, 65536, 4096
+    fcs = [-984000 + 480 * c for c in range(n)]
+    engs = []
+    x0 = siggen.xs_u8(8700, G * nb)
+    for env in (None, "XL_EXP_ROUNDS1", "XL_EXP_NOMASK"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        e = xl.BatchEngine(FS, "cu8", nb, group_blocks=G)
+        ids = [e.add_client(42, t48, fc) for fc in fcs]
+        e.process_host_group(x0, G, "optimized")  # (the plan, and with it the reservation, is made by the first call)
+        e.sync()
+        if env:
+            monkeypatch.delenv(env)
+        engs.append((e, ids))
+    d = [e.describe() for e, _ in engs]
+    assert "side kernel: 32 CUs reserved" in d[0] and "side kernel: 64 CUs reserved" in d[1] and "side kernel:" not in d[2], d
+    for k in range(1, 96):
+        x = siggen.xs_u8(8700 + k, G * nb)
+        for e, _ in engs:
+            e.process_host_group(x, G, "optimized")
+        if k % 16 == 15:
+            ph = []
+            for e, ids in engs:
+                e.sync()
+                ph.append(np.array([e.phase(i) for i in ids], dtype=np.float32))
+            for other in (1, 2):
+                bad = np.flatnonzero((ph[0].view(np.uint32) != ph[other].view(np.uint32)).any(axis=1))
+                assert len(bad) == 0, (k, other, bad[:32])
+    outs = []
+    for e, ids in engs:  # ... and so are the outputs of the last call (sampled columns of the first, a middle and the last column group)
+        e.fetch()
+        outs.append([np.array(e.output(ids[c])) for c in (0, 77, 2047, 2048, 4000, 4095)])
+    for other in (1, 2):
+        for a, b_ in zip(outs[0], outs[other]):
+            assert len(a) > 0 and bits_equal(a, b_), other
+    for e, _ in engs:
+        e.close()
+
+
 def test_group_2304_clients_sampled_no_cu_reservation():
     """2304 x 48 kHz clients, 8 blocks per call, optimized: between 2049 and 3008 clients the side-stream recurrence kernel gets no CUs of
     its own (xl_plan_rules.h: its 36 workgroups take whole CUs as the launches' tails free them) -- every 16th column and the last one
