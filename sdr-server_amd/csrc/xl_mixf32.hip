@@ -243,10 +243,13 @@ hipError_t xlp_launch_tables_f(const float2 *rt, const uint32_t *delta, const ui
 // Passes per workgroup when the caller names none: the launch is bound by the matrix pipe, so what matters is that every SIMD gets
 // the same number of (wave, pass) jobs -- runs of 16 passes (operands fetched once) while that still makes >= 4096 workgroups
 // (four rounds of the chip), shorter runs (the operands then come from L2 again) for smaller classes.
+// The runs are then made EQUAL: 6 passes cut 4 + 2 leave half the workgroups with twice the work of the others (BASELINE config 5 at
+// 2048 clients: 30.8 us per block against 26.0 cut 3 + 3; profiles/r05_mix_f32.txt "balanced runs").
 static uint32_t xlmf_default_pp(const XlpArgs &a, uint32_t passes) {
   uint32_t pp = 16u;
   while (pp > 2u && (size_t)a.M * a.ncg * ((passes + pp - 1u) / pp) < 4096u) pp >>= 1;
-  return pp;
+  const uint32_t runs = (passes + pp - 1u) / pp;
+  return runs ? (passes + runs - 1u) / runs : pp;
 }
 
 template <int NB8>
