@@ -68,6 +68,10 @@ XL_DEV void xlmf_store_pass(const XlpArgs &a, const v16f32 &acc, v2f *__restrict
   }
 }
 
+// Workgroup barrier for LDS hand-offs only: this wave's LDS writes are done (lgkmcnt), everybody arrives.  __syncthreads() also fences
+// global memory, which on this target is `s_waitcnt vmcnt(0)`: a wait for every store of the pass and for the rows requested for the
+// pass after next, once per pass.
+XL_DEV void xlmf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 XL_DEV float xlmf_flip(const float v, const uint32_t sgn) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) ^ sgn); }
 
 template <int NB8>
@@ -80,19 +84,7 @@ __global__ __launch_bounds__(256) void xlp_mix_f32_kernel(const XlpArgs a) {
   if (job.p0 >= job.p1) return;
   const uint32_t tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
   const uint32_t M = a.M, m = job.m, cg = job.cg;
-  // ---- B operands of this wave: 2 NB8 runs of 1 KB
   float bq[NJ];
-  {
-    const v4f32 *__restrict__ Rp = reinterpret_cast<const v4f32 *>(a.Rh);
-#pragma unroll
-    for (int jb = 0; jb < NB8; ++jb)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const v4f32 v = Rp[xlmf_rf_slot(cg, M, m, w, (uint32_t)NB8, (uint32_t)jb, (uint32_t)q, lane)];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bq[8 * jb + 4 * q + e] = v[e];
-      }
-  }
   // ---- staging role of this thread: 16 bytes (part) of the image rows jr, jr + 32, .. of the bin: row (pass, branch j, bin m) = 128
   // bytes at X + ((pass Dpad + j) M + m) 128 -- a wave instruction covers 8 whole rows
   const uint32_t D = a.D;
@@ -103,12 +95,14 @@ __global__ __launch_bounds__(256) void xlp_mix_f32_kernel(const XlpArgs a) {
   auto request = [&](const uint32_t pass) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < ROUNDS; ++q) {
-      const uint32_t j = jr + 32u * (uint32_t)q;
-      // (rows D .. Dpad - 1 of the image are zeros; beyond Dpad there is nothing to read)
+      // (rows D .. Dpad - 1 of the image are zeros; beyond Dpad there is nothing to read: those lanes re-read the last row and stage()
+      // drops it.  Unconditional on purpose: a load under `j < D` comes with a branch and a register copy behind it that waits for
+      // EVERYTHING in flight -- the operands included)
+      const uint32_t j = jr + 32u * (uint32_t)q, jc = j < a.Dpad ? j : a.Dpad - 1u;
 #ifdef XLMF_EXP_NOLOAD
       g[q] = (v4f32){0.25f, -0.5f, 0.125f, 1.0f};
 #else
-      g[q] = j < D ? *reinterpret_cast<const v4f32 *>(xb + ((size_t)pass * a.Dpad + j) * xrow) : (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+      g[q] = *reinterpret_cast<const v4f32 *>(xb + ((size_t)pass * a.Dpad + jc) * xrow);
 #endif
     }
   };
@@ -131,16 +125,23 @@ __global__ __launch_bounds__(256) void xlp_mix_f32_kernel(const XlpArgs a) {
   // Software pipeline (as xlp_mix_mfma_kernel): the rows of pass p + 1 go into the other buffer AFTER pass p's products and BEFORE
   // its stores, so that the wait for them finds no store younger than pass p - 1's.
   request(job.p0);
+  // ---- B operands of this wave: 2 NB8 runs of 1 KB -- requested BEHIND the first pass's rows, so that staging those rows is not a wait
+  // for the operands (loads return in order)
+  {
+    const v4f32 *__restrict__ Rp = reinterpret_cast<const v4f32 *>(a.Rh);
+#pragma unroll
+    for (int jb = 0; jb < NB8; ++jb)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const v4f32 v = Rp[xlmf_rf_slot(cg, M, m, w, (uint32_t)NB8, (uint32_t)jb, (uint32_t)q, lane)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[8 * jb + 4 * q + e] = v[e];
+      }
+  }
   stage(0u);
   if (job.p0 + 1u < job.p1) request(job.p0 + 1u);
-  // (the B operands are waited for HERE, once -- they were requested first, the second pass's rows stay in flight behind them: left to
-  // itself the compiler puts those waits into the pass loop, `vmcnt(5)` ahead of every pass's first products, which also waits for the
-  // rows the previous pass has just requested)
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(bq[j]));
-  __syncthreads();
-  for (uint32_t pass = job.p0; pass < job.p1; ++pass) {
-    const uint32_t buf = (pass - job.p0) & 1u;
+  xlmf_lds_barrier();
+  auto products = [&](const uint32_t pass, const uint32_t buf) __attribute__((always_inline)) {
     v16f32 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -152,8 +153,24 @@ __global__ __launch_bounds__(256) void xlp_mix_f32_kernel(const XlpArgs a) {
     if (pass + 1u < job.p1) stage(buf ^ 1u);
     if (pass + 2u < job.p1) request(pass + 2u);
     xlmf_store_pass(a, acc, Yc, ystride, pass, h);
-    __syncthreads();  // the other buffer is staged; everybody is done with this one
-  }
+    xlmf_lds_barrier();  // the other buffer is staged; everybody is done with this one
+  };
+#ifndef XLMF_EXP_NO_PEEL
+  // The FIRST pass runs its products as the B operands arrive (they were requested first and return in order: the compiler's waits
+  // before product j let the later operands -- and the second pass's rows behind them -- stay in flight): a workgroup of a short run
+  // (2-3 passes for small classes) no longer sits out the operands' whole latency before its first matrix instruction.
+  products(job.p0, 0u);
+  if (job.p0 + 1u >= job.p1) return;
+  // (for the other passes the operands are waited for HERE, once: left to itself the compiler puts those waits into the pass loop,
+  // `vmcnt(5)` ahead of every pass's first products, which also waits for the rows the previous pass has just requested)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(bq[j]));
+  for (uint32_t pass = job.p0 + 1u; pass < job.p1; ++pass) products(pass, (pass - job.p0) & 1u);
+#else
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(bq[j]));
+  for (uint32_t pass = job.p0; pass < job.p1; ++pass) products(pass, (pass - job.p0) & 1u);
+#endif
 }
 
 // Any branch count (D > 112: huge decimations, few segments per call): the B operands do not fit a wave's registers for all its
