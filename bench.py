@@ -454,8 +454,8 @@ def run_workload(ctx, total_clients, ntaps_rate, steps, warmup, mode, group=GROU
     klen = eng.output_len(ids[mine[0]]) if mine else 0
 
     spot_res = None
-    if spot and cuda and mine and group == GROUP and not staggered and world == 1:
-        spot_res = parity_spot(ctx, eng, ids, mine, taps, mode, host.k, call)
+    if spot and cuda and mine and group in (1, GROUP) and not staggered and world == 1:
+        spot_res = parity_spot(ctx, eng, ids, mine, taps, mode, host.k, call, last_blocks=group)
 
     kernels_ms = None
     if polyphase and poly3 and cuda:  # separate durations of the three launches: a short extra pass, OUTSIDE the timed region
@@ -614,10 +614,26 @@ def config5_entry(m5, pmc5):
     return e
 
 
-def run_host_delivered(ctx, nclients, ntaps_rate, calls=12):
+def _oracle_population():
+    odir = os.path.join(ROOT, "oracle")  # the checker (test infrastructure): never on a timed path
+    if odir not in sys.path:
+        sys.path.insert(0, odir)
+    from pyoracle import population
+
+    return population
+
+
+def _rel_err(got, want):
+    if got.shape != want.shape or want.size == 0:
+        return float("inf")
+    return float(np.abs(got.astype(np.complex128) - want).max() / np.abs(want).max())
+
+
+def run_host_delivered(ctx, nclients, ntaps_rate, calls=12, spot=True):
     """What the reference's dsp_worker does with every block (src/dsp_worker.c:57-77: process, then write the output): host blocks
     in (xlating_batch_process_host_group: pinned staging + H2D), every client's outputs back on the host (xlating_batch_fetch: D2H of
-    the whole output image) before the next call -- synchronous, PCIe-inclusive, never `value`."""
+    the whole output image) before the next call -- synchronous, PCIe-inclusive, never `value`.  After the timed loop every client's
+    delivered outputs of the last call are compared with the oracle population."""
     xl = ctx["xl"]
     code, taps = ctx["lpf"](1.0, FS, RATE // 2, RATE // ntaps_rate)
     eng = xl.BatchEngine(FS, "cu8", BLOCK_BYTES, device=ctx["torch"].cuda.current_device(), group_blocks=GROUP)
@@ -633,15 +649,123 @@ def run_host_delivered(ctx, nclients, ntaps_rate, calls=12):
         eng.fetch()
     dt = time.perf_counter() - t0
     out_bytes = sum(eng.output_len(c) for c in range(nclients)) * 8
+    spot_res = None
+    if spot:  # (calls + 2 calls so far; the last one filtered xs[(calls + 1) % 2] after xs[calls % 2])
+        done = calls + 2
+        x = np.concatenate([xs[(done - 2) % 2], xs[(done - 1) % 2]])
+        want = _oracle_population()(D, taps, [client_center_freq(c) for c in range(nclients)], FS, BLOCK_BYTES, "cu8", x, GROUP, nwarm=GROUP,
+                                    skip_fresh=S, skip_calls=(done - 2) * GROUP)
+        errs = [_rel_err(eng.output(c), w) for c, w in enumerate(want)]
+        spot_res = {"clients": nclients, "clients_failing": int(sum(e > 1e-5 for e in errs)), "max_rel": max(errs), "ok": bool(max(errs) <= 1e-5)}
     eng.close()
     return {"value": round(nclients * S * GROUP * calls / dt / 1e6, 1), "us_per_block": round(dt / (calls * GROUP) * 1e6, 2), "blocks_per_call": GROUP,
             "host_bytes_in_per_call": GROUP * BLOCK_BYTES, "host_bytes_out_per_call": int(out_bytes),
-            "pcie_GBs_out": round(out_bytes * calls / dt / 1e9, 2),
+            "pcie_GBs_out": round(out_bytes * calls / dt / 1e9, 2), "parity_spot": spot_res,
             "note": "process_host_group + fetch per call, synchronous: every client's outputs of every block delivered to host memory "
                     "(src/dsp_worker.c:74-77 writes them out).  PCIe-inclusive; the headline keeps outputs in HBM"}
 
 
-def parity_spot(ctx, eng, ids, mine, taps, mode, calls_done, call):
+def config3_clients(ctx):
+    """BASELINE configs[2] as SURVEY 8(d) defines it: 32 x 48 kHz (D = 42, 505 taps) + 32 x 96 kHz (D = 21, 253 taps), fc = -900 kHz + c x 28 kHz."""
+    t48 = ctx["lpf"](1.0, FS, 24000, 9600)[1]
+    t96 = ctx["lpf"](1.0, FS, 48000, 19200)[1]
+    return [((42, t48) if c % 2 == 0 else (21, t96)) + (-900000 + c * 28000,) for c in range(64)]
+
+
+def run_config3_mixed(ctx, steps=40, spot=True):
+    """BASELINE configs[2]: 64 concurrent clients at mixed 48 / 96 kHz sharing one 2.016 Msps block stream, GROUP blocks per call, inputs
+    resident in HBM, engine's own stream.  Every client of the call after the timed loop is compared with the oracle population."""
+    xl, torch = ctx["xl"], ctx["torch"]
+    cl = config3_clients(ctx)
+    eng = xl.BatchEngine(FS, "cu8", BLOCK_BYTES, device=torch.cuda.current_device(), group_blocks=GROUP)
+    ids = [eng.add_client(dd, tt, fc) for dd, tt, fc in cl]
+    xs = [make_group(g) for g in range(2)]
+    dev = [torch.from_numpy(x).cuda() for x in xs]
+    n = [0]
+
+    def call():
+        eng.process_device_group(dev[n[0] % 2].data_ptr(), BLOCK_BYTES, GROUP, "optimized", "engine")
+        n[0] += 1
+
+    for _ in range(4):
+        call()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call()
+    eng.sync()
+    dt = time.perf_counter() - t0
+    plan = eng.describe()
+    spot_res = None
+    if spot:
+        done = n[0]
+        call()
+        call()
+        eng.fetch()
+        x = np.concatenate([xs[done % 2], xs[(done + 1) % 2]])
+        errs = {}
+        for dd in (42, 21):
+            sel = [i for i, c in enumerate(cl) if c[0] == dd]
+            want = _oracle_population()(dd, cl[sel[0]][1], [cl[i][2] for i in sel], FS, BLOCK_BYTES, "cu8", x, GROUP, nwarm=GROUP,
+                                        skip_fresh=S, skip_calls=done * GROUP)
+            for i, w in zip(sel, want):
+                errs[i] = _rel_err(eng.output(ids[i]), w)
+        worst = max(errs.values())
+        spot_res = {"clients": len(cl), "clients_failing": int(sum(e > 1e-5 for e in errs.values())), "max_rel": worst, "ok": bool(worst <= 1e-5)}
+    eng.close()
+    blocks = steps * GROUP
+    return {"value": round(len(cl) * S * blocks / dt / 1e6, 1), "us_per_block": round(dt / blocks * 1e6, 3), "blocks_per_call": GROUP,
+            "plan": plan, "parity_spot": spot_res,
+            "workload": "BASELINE configs[2]: 32 x 48 kHz (D=42, 505 taps) + 32 x 96 kHz (D=21, 253 taps) clients off one 2.016 Msps cu8 stream"}
+
+
+def run_config2_dropin(ctx, calls=300, spot=True):
+    """BASELINE configs[1]: ONE client through the drop-in C API (include/xlating.h: create / process_optimized_cu8_cf32 / destroy), host
+    block in, host-visible output back per call -- what dsp_worker.c:57-77 does; latency-bound (us per 262144-byte block).  The outputs
+    of three further calls are compared with one oracle filter fed the same blocks from the start."""
+    import gc
+
+    xl = ctx["xl"]
+    taps = ctx["lpf"](1.0, FS, RATE // 2, 9600)[1]
+    xs = [make_group(g)[:BLOCK_BYTES] for g in range(2)]
+    f = xl.XlatingFilter(D, taps, -12000, FS, BLOCK_BYTES)
+    for k in range(20):
+        f.process("optimized", "cu8", "cf32", xs[k % 2])
+    gc_was = gc.isenabled()
+    gc.disable()  # (a generation-2 collection inside the ctypes wrapper is a 1-35 ms outlier: tools/dropin_python_stall.py)
+    ts = []
+    for k in range(calls):
+        t0 = time.perf_counter()
+        f.process("optimized", "cu8", "cf32", xs[k % 2])
+        ts.append(time.perf_counter() - t0)
+    if gc_was:
+        gc.enable()
+    spot_res = None
+    if spot:
+        odir = os.path.join(ROOT, "oracle")
+        if odir not in sys.path:
+            sys.path.insert(0, odir)
+        from pyoracle import Oracle
+
+        o = Oracle(D, taps, -12000, FS, BLOCK_BYTES)
+        done = 20 + calls
+        o.skip_calls(S, done - 1)
+        o.process("cu8", xs[(done - 1) % 2])  # (loads the oracle's sample history; the filter under test runs this block too)
+        f.process("optimized", "cu8", "cf32", xs[(done - 1) % 2])
+        worst = 0.0
+        for k in range(done, done + 3):
+            worst = max(worst, _rel_err(f.process("optimized", "cu8", "cf32", xs[k % 2]), o.process("cu8", xs[k % 2])))
+        o.close()
+        spot_res = {"clients": 1, "clients_failing": int(worst > 1e-5), "max_rel": worst, "ok": bool(worst <= 1e-5)}
+    f.close()
+    ts.sort()
+    mean = sum(ts) / len(ts)
+    return {"value": round(S / mean / 1e6, 1), "us_per_block": round(mean * 1e6, 2), "median_us": round(ts[len(ts) // 2] * 1e6, 2),
+            "p99_us": round(ts[int(len(ts) * 0.99) - 1] * 1e6, 2), "blocks_per_call": 1, "parity_spot": spot_res,
+            "workload": "BASELINE configs[1]: one client, create_frequency_xlating_filter + process_optimized_cu8_cf32 per 262144-byte host block, 505 taps, D=42"}
+
+
+def parity_spot(ctx, eng, ids, mine, taps, mode, calls_done, call, last_blocks=GROUP):
     """EVERY client of the engine the timed region just ran, vs a population of oracle filters on the host cores
     (oracle/population.c, one reference-model filter per client over pthreads).  The oracles' stream state (phase
     recurrence with per-block renormalisation, history counter) is fast-forwarded over the blocks processed so far
@@ -657,7 +781,8 @@ def parity_spot(ctx, eng, ids, mine, taps, mode, calls_done, call):
     call()
     call()
     eng.fetch()
-    want = population(D, taps, [client_center_freq(c) for c in mine], FS, BLOCK_BYTES, "cu8", x, GROUP, nwarm=GROUP,
+    # (an engine driven one block per call holds the outputs of the last BLOCK only: last_blocks = 1)
+    want = population(D, taps, [client_center_freq(c) for c in mine], FS, BLOCK_BYTES, "cu8", x, last_blocks, nwarm=2 * GROUP - last_blocks,
                       skip_fresh=S, skip_calls=calls_done * GROUP)
     t_oracle = time.perf_counter() - t0
     worst, exact, want_len, bad = 0.0, True, 0, 0
@@ -721,6 +846,8 @@ def cpu_baseline(ntaps_rate, seconds=12.0):
     return {
         "value": round(allc["msps"], 1), "unit": "Msamples/s", "cores": cores, "threads": threads, "kind": kind,
         "single_thread_value": round(one["msps"], 1),
+        "sample_short": f"{'reference AVX2 -O3 -ffast-math build' if kind == 'reference' else 'scalar oracle port'}, {allc['ntaps']} taps D={D}, one filter per thread over a shared "
+                        f"{BLOCK_BYTES}-byte block: {allc['calls']} calls / {threads} threads / {allc['seconds']:.1f} s (+ {one['seconds']:.1f} s on 1 thread); {model}",
         "sample": f"{what}; lpf_cutoff_rate={ntaps_rate} -> {allc['ntaps']} taps, D={D}, {BLOCK_BYTES}-byte cu8 blocks, one "
                   f"filter per thread over a shared block; {allc['calls']} calls on {threads} threads ({cores} physical cores) in "
                   f"{allc['seconds']:.1f} s wall (+ {one['calls']} calls on 1 thread in {one['seconds']:.1f} s); host CPU: {model}",
@@ -905,6 +1032,95 @@ EXPECTED_STRONG = {"clients_total": 1024, "Msamples_per_s": {"1": 5.39e6, "2": 5
 EXPECTED_WEAK = {"clients_per_gpu": 1024, "Msamples_per_s_per_gpu": "5.3e6 - 5.5e6", "efficiency": "~1.0 (no data-path collective besides one 2 MB broadcast per call)"}
 
 
+COMPACT_MAX_BYTES = 4096  # the driver keeps an 8 KB tail of stdout: the one line it parses must fit with room to spare
+FULL_JSON_DEFAULT = os.path.join(ROOT, "profiles", "bench_last_full.json")
+
+# compact `configs` keys <- prefix of the full record's variants[...] key
+CONFIG_KEYS = (("one_block_per_call", "one block per call"), ("config3_64_mixed_clients", "config 3"), ("config2_dropin_single_filter", "config 2"),
+               ("clients_2048", "2048 clients"), ("clients_4096", "4096 clients"), ("config5_cf32_10msps_1024_clients", "config 5"),
+               ("all_f32", "polyphase, float32 matrix-core mix"), ("host_delivered", "host-delivered outputs"))
+
+
+def _sig(x, n=4):
+    return None if x is None else (float(f"{x:.{n}g}") if isinstance(x, float) else x)
+
+
+def _spot_compact(sp):
+    if not sp:
+        return None
+    return {"clients": sp.get("clients"), "clients_failing": sp.get("clients_failing"), "max_rel": _sig(sp.get("max_rel"), 3), "ok": sp.get("ok")}
+
+
+def compact_line(full):
+    """The ONE stdout line: the bench contract's keys + roofline + cpu_baseline + parity + one short entry per BASELINE config, nothing else;
+    <= COMPACT_MAX_BYTES.  Everything descriptive (per-kernel tables, plans, notes, expected scaling) stays in the full record
+    (`--full-json`, default profiles/bench_last_full.json; also printed to stderr)."""
+    rl = full.get("roofline") or {}
+    cfg = full.get("config") or {}
+    c = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                  "data")}
+    c["dtype"] = "f32"
+    c["config"] = {"workload": f"{cfg.get('clients_total')} clients x 48 kHz off one 2.016 Msps cu8 stream, D={D}, {cfg.get('ntaps')} taps, {BLOCK_BYTES}-byte blocks "
+                               f"(BASELINE configs[3]; N=1: the >=1000-client single-GPU target)",
+                   "clients_total": cfg.get("clients_total"), "clients_per_gpu": cfg.get("clients_per_gpu"), "blocks_per_call": cfg.get("blocks_per_call"),
+                   "us_per_block": cfg.get("us_per_block"), "mode": cfg.get("mode"), "mix_products": cfg.get("mix_products"),
+                   "parallelism": "single GPU" if full.get("n_gpus") == 1 else f"clients c%{full.get('n_gpus')}, one RCCL broadcast per {GROUP} blocks",
+                   "rccl_ranks": cfg.get("rccl_ranks"),
+                   "feed": ("xlating_multi (C host)" if (cfg.get("feed") or "").startswith("xlating_multi") else
+                            "torch.distributed feeder" if (cfg.get("feed") or "").startswith("torch") else "other")}
+    r = {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_algorithmic_shared", "traffic", "kernel_ms", "units_per_launch",
+                                "call_period_ms", "step_bound", "chain_ms_per_call", "frac_of_recurrence_floor")}
+    r["kernel"] = rl.get("kernel_short")
+    r["traffic_measured_in_run"] = bool(rl.get("traffic_source") == "measured in this run")
+    pk = {}
+    for k, v in (rl.get("per_kernel") or {}).items():
+        pk[k.replace("_kernel", "")] = {"ms": _sig(v.get("ms")), "frac_hbm": v.get("frac_hbm")}
+    if pk:
+        r["per_kernel"] = pk
+    c["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "threads", "kind", "single_thread_value")}
+        c["cpu_baseline"]["sample"] = cb.get("sample_short")
+    c["parity_spot"] = _spot_compact(full.get("parity_spot"))
+    configs = {}
+    vs = full.get("variants") or {}
+    for key, prefix in CONFIG_KEYS:
+        v = next((vv for kk, vv in vs.items() if kk.startswith(prefix)), None)
+        if isinstance(v, dict) and v.get("value") is not None:
+            sp = v.get("parity_spot")
+            e = {"value": _sig(float(v["value"]), 5), "us_per_block": _sig(float(v["us_per_block"])), "parity_ok": (sp or {}).get("ok")}
+            vr = v.get("roofline") or {}
+            if vr.get("frac") is not None:
+                e["frac"] = vr["frac"]
+            if vr.get("frac_algorithmic_shared") is not None:
+                e["frac_shared"] = vr["frac_algorithmic_shared"]
+            configs[key] = e
+    nat = full.get("native")
+    if nat:
+        configs["native"] = {"value": _sig(float(nat["value"]), 5), "us_per_block": _sig(float(nat["us_per_block"])),
+                             "parity_ok": (nat.get("parity_spot") or {}).get("ok")}
+    for kk, vv in vs.items():  # N > 1: the other way to use the GPUs
+        if kk.startswith(("strong scaling", "weak scaling")):
+            configs[kk.split(" (")[0].replace(" ", "_")] = {"value": _sig(float(vv["value"]), 5), "us_per_block": _sig(float(vv["us_per_block"])), "parity_ok": None}
+    if configs:
+        c["configs"] = configs
+    mg = (full.get("multi_gpu") or {}).get(full.get("scaling")) if full.get("multi_gpu") else None
+    if mg:
+        ft = mg.get("feed_timing") or {}
+        c["multi_gpu"] = {"per_rank_seconds_last_repeat": (mg.get("per_rank_seconds") or [None])[-1], "rccl_comm_count": mg.get("rccl_comm_count"),
+                          "broadcast_us": ft.get("broadcast_us"), "feed_overlap_frac": ft.get("feed_overlap_frac")}
+    c["full_record"] = full.get("full_record")
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) > COMPACT_MAX_BYTES:  # (cannot happen with the fields above; never let a long line cost the driver its record again)
+        for k in ("multi_gpu", "configs"):
+            c.pop(k, None)
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) <= COMPACT_MAX_BYTES:
+                break
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -923,6 +1139,7 @@ def main():
     ap.add_argument("--replay-calls", type=int, default=0, help=argparse.SUPPRESS)  # the counter passes profile this: no timing, N calls
     ap.add_argument("--replay-set", default="", help=argparse.SUPPRESS)  # ... of each of these workloads, back to back ("server:1024,config5:1024")
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_launch.py only
+    ap.add_argument("--full-json", default=None, help="where the full record goes (default profiles/bench_last_full.json; the stdout line is the compact one)")
     args = ap.parse_args()
 
     if "RANK" not in os.environ and args.gpus > 1:
@@ -1004,8 +1221,9 @@ def main():
             other_rate = 1 if args.lpf_cutoff_rate != 1 else 5
             mv = run_workload(ctx, total_clients, other_rate, vs, 1, args.mode, poly3=False, blocks_per_step=VB)
             variants[f"lpf_cutoff_rate={other_rate} ({mv['ntaps']} taps)"] = variant_entry(mv)
-            m1 = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, group=1, poly3=False, blocks_per_step=VB)
+            m1 = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, group=1, poly3=False, blocks_per_step=VB, spot=not args.no_spot)
             variants["one block per call (the reference's call granularity)"] = variant_entry(m1)
+            variants["one block per call (the reference's call granularity)"]["parity_spot"] = m1["parity_spot"]
             ms = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, staggered=True, poly3=False, blocks_per_step=VB)
             variants["staggered joins (clients joined over 21 consecutive blocks: 21 output grids, one polyphase class)"] = variant_entry(ms)
             if total_clients >= 8 * 64:  # what each GPU of an 8-GPU strong-scaling run holds (c mod 8)
@@ -1013,8 +1231,8 @@ def main():
                 variants[f"one GPU's share at 8 GPUs ({total_clients // 8} clients): aggregate = 8 x this value minus the feed"] = variant_entry(m8)
             for big in (2048, 4096):  # where the launches, not the NCO recurrence, bound the engine
                 if total_clients == 1024:
-                    # (2048: EVERY client against the oracle population after the timed region, like the headline)
-                    mb = run_workload(ctx, big, args.lpf_cutoff_rate, 2, 1, args.mode, blocks_per_step=VB, spot=(big == 2048 and not args.no_spot))
+                    # (EVERY client against the oracle population after the timed region, like the headline)
+                    mb = run_workload(ctx, big, args.lpf_cutoff_rate, 2, 1, args.mode, blocks_per_step=VB, spot=not args.no_spot)
                     e = variant_entry(mb)
                     e["kernels_ms_per_call"] = mb["kernels_ms"]
                     e["parity_spot"] = mb["parity_spot"]
@@ -1049,7 +1267,10 @@ def main():
                 m5 = run_config5(ctx, 1024, vs, spot=not args.no_spot, blocks_per_step=VB)
                 variants["config 5: cf32 10 Msps, D=100, 257 taps, 1024 clients"] = m5  # (finished below, once the counters are in)
                 # what the reference's dsp_worker does with every block: outputs delivered to host memory
-                variants["host-delivered outputs (process_host + fetch per call)"] = run_host_delivered(ctx, total_clients, args.lpf_cutoff_rate)
+                variants["host-delivered outputs (process_host + fetch per call)"] = run_host_delivered(ctx, total_clients, args.lpf_cutoff_rate, spot=not args.no_spot)
+                # BASELINE configs[2] (64 mixed clients) and configs[1] (one client through the drop-in C API), re-measured in every run
+                variants["config 3: 64 clients at mixed 48 / 96 kHz"] = run_config3_mixed(ctx, spot=not args.no_spot)
+                variants["config 2: one client, drop-in process_optimized_cu8_cf32"] = run_config2_dropin(ctx, spot=not args.no_spot)
             if m["polyphase"]:  # the same workload through the direct FIR kernels: the FP32-bound design
                 md = run_workload(ctx, total_clients, args.lpf_cutoff_rate, vs, 1, args.mode, options={"polyphase": 0}, poly3=False, blocks_per_step=VB)
                 variants[f"process_{args.mode}_cu8_cf32 through the direct FIR kernel ({md['ntaps']} taps)"] = variant_entry(
@@ -1194,6 +1415,16 @@ def main():
         roofline["kernel"] = ("xlp_forward_kernel + " + ("xlp_mix_mfma_kernel" if "mix=mfma" in m["plan"] else "xlp_mix_f32_kernel") + " + " + next((k for k in (m["kernels_ms"] or {}) if k.startswith("xlp_inverse")), "xlp_inverse_kernel") + ": the three launches of one call on the polyphase "
                               "overlap-save path (the next call's NCO phase recurrence runs beside them on a side stream)")
         roofline["per_kernel"] = pk
+        roofline["kernel_short"] = "+".join(k.replace("_kernel", "") for k in (m["kernels_ms"] or {})) + " (the 3 launches of one call)"
+        # what bounds the STEP at this client count: the next call's float32 NCO phase recurrence (the reference's own p *= incr chain,
+        # src/xlating.c:70-73: 3121 dependent steps per block and client) runs beside the launches on reserved CUs; one chain launch
+        # tabulates CHAIN_CALLS calls.  frac_of_recurrence_floor = its share of the call period: ~1 = the step IS the recurrence
+        # (<= ~1500 clients); well below 1 = the launches (HBM) bound the step (2048 / 4096 clients: configs.clients_*)
+        ck = pk.get("xl_nco_chain_kernel") or {}
+        if ck.get("ms_per_call_profiled"):
+            roofline["chain_ms_per_call"] = ck["ms_per_call_profiled"]
+            roofline["frac_of_recurrence_floor"] = round(min(1.0, ck["ms_per_call_profiled"] / period_ms), 4) if period_ms > 0 else None
+            roofline["step_bound"] = "nco_recurrence" if roofline["frac_of_recurrence_floor"] and roofline["frac_of_recurrence_floor"] >= 0.9 else "hbm"
         roofline["per_kernel_note"] = ("ms: the kernel's own duration from a rocprofv3 --kernel-trace pass of this run over `bench.py --replay-calls` -- a "
                                        "separate, profiled pass, not the timed region (ms_hip_events: event pairs around "
                                        "each launch, 16 extra calls after the timed region -- they include the event records and forbid the overlap "
@@ -1203,6 +1434,7 @@ def main():
         kname = next((k for k in per_kernel_bytes if k.startswith("xl_fir_kernel")), "xl_fir_kernel")
         roofline["kernel"] = (f"xl_fir_kernel<H,{1 if args.mode == 'optimized' else 0},wide> (H = register-tile height chosen by the "
                               "engine; one launch per call: history roll + FIR + next call's NCO phase table)")
+        roofline["kernel_short"] = "xl_fir (one launch per call)"
         roofline["per_kernel"] = {kname: {"ms": round(m["call_ms_avg"], 4), "hbm_bytes": per_kernel_bytes.get(kname),
                                           "frac_hbm": round(ach / HBM_PEAK_GBS, 4), "frac_fp32": round(ach_tf / FP32_PEAK_TFLOPS, 4),
                                           "binding": "fp32 vector issue (native: 4 packed unfused ops per complex MAC -> ceiling 0.5; optimized: 2 packed FMAs)"}}
@@ -1258,7 +1490,9 @@ def main():
                         + ("weak scaling: 1024 clients per GPU -- configs[3]'s 1024 in total is variants['strong scaling ...']" if args.scaling == "weak" else
                            "strong scaling: the total is fixed") + ")",
             "step": f"{m['blocks_per_step']} consecutive blocks = {calls_per_step} calls = {m['blocks_per_step'] * S} stream samples per client",
-            "clients_total": total_clients, "block_samples": S, "blocks_per_call": GROUP,
+            "clients_total": total_clients, "clients_per_gpu": nloc, "ntaps": m["ntaps"], "mode": args.mode, "block_samples": S, "blocks_per_call": GROUP,
+            "mix_products": ("2xf16 split operands on the matrix cores, f32 accumulate (every client <= 1e-5 vs the f32 reference: parity_spot; "
+                             "exact-f32 number: configs.all_f32)" if (m["polyphase"] and "mix=mfma" in m["plan"]) else "f32"),
             "outputs_per_client_per_call": m["K_call"], "us_per_block": round(m["seconds"] / (args.steps * m["blocks_per_step"]) * 1e6, 3),
             "parallelism": (f"clients sharded c%{world}; one RCCL broadcast per {GROUP} raw IQ blocks ({GROUP * BLOCK_BYTES} bytes) "
                             "on a separate stream (overlaps the previous call's filtering), no other collective") if world > 1 else "single GPU",
@@ -1277,7 +1511,21 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline and cuda:
         out["cpu_baseline"] = cpu_baseline(args.lpf_cutoff_rate, args.cpu_seconds)
-    print(json.dumps(out), flush=True)
+    # the full record goes to a file; stdout gets ONE compact line (<= 4 KB) the driver can parse
+    full_path = args.full_json or (FULL_JSON_DEFAULT if cuda else os.path.join("/tmp", f"xl_bench_full_{os.getpid()}.json"))
+    out["full_record"] = os.path.relpath(full_path, ROOT) if full_path.startswith(ROOT) else full_path
+    try:
+        os.makedirs(os.path.dirname(full_path), exist_ok=True)
+        with open(full_path, "w") as fh:
+            json.dump(out, fh, indent=1)
+        gout = os.path.join(ROOT, "gpurun_out")  # (on a gpurun box only this directory travels back)
+        if cuda and os.path.isdir(gout):
+            with open(os.path.join(gout, "bench_last_full.json"), "w") as fh:
+                json.dump(out, fh, indent=1)
+    except OSError as e:
+        out["full_record"] = f"not written ({e})"
+    print(f"bench.py: full record ({len(json.dumps(out))} bytes) -> {out['full_record']}", file=sys.stderr, flush=True)
+    print(compact_line(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
