@@ -122,6 +122,10 @@ struct PolyClass {
   std::vector<float> col_scale;
   float *d_cscale = nullptr;
   float2 *d_X = nullptr;     // shared spectra [passes][Dpad][M][16]
+  // two-half mix of a cf32 stream: per segment the largest component of its shared spectra, found by the forward launch (XlpArgs::segmax):
+  // two buffers of seg_cap entries, a call uses buffer seg_par; lives and dies with d_X
+  uint32_t *d_segmax = nullptr;
+  uint32_t seg_cap = 0, seg_par = 0;
   float2 *d_Y = nullptr;     // mixed spectra  [ncg][nseg_cap][M][128]
   XlpCol *d_cols = nullptr;  // per column: output row, grid offset, NCO increment
   int last_inv = -1;         // which inverse kernel the class's latest launch took (describe; xlp_inverse_pick): 3 / 5 / 6, -1 = none yet
@@ -344,9 +348,10 @@ static void xl_plan_trim(xlating_batch *b) {
 }
 
 static void xl_poly_release(xlating_batch *b, PolyClass &pc) {
-  void *dev[] = {pc.d_X, pc.d_Y, pc.d_cols, pc.d_Rh, pc.d_cscale};
+  void *dev[] = {pc.d_X, pc.d_Y, pc.d_cols, pc.d_Rh, pc.d_cscale, pc.d_segmax};
   for (void *q : dev) xl_plan_release(b, q);
   pc.d_X = pc.d_Y = nullptr;
+  pc.d_segmax = nullptr;
   pc.d_cols = nullptr;
   pc.d_Rh = nullptr;
   pc.d_cscale = nullptr;
@@ -529,20 +534,20 @@ extern "C" int xlating_batch_create_grouped(uint32_t sampling_freq, int input_fo
                  {"XL_EXP_RIDERS_MIN", "riders_min_workgroups", false}, {"XL_EXP_CHAIN_CALLS", "nco_calls_per_launch", false},
                  {"XL_EXP_NCO_SLICE", "nco_slice", false}};
     for (const auto &k : knobs)
-      if (const char *v = getenv(k.env)) {
+      if (const char *v = xl_exp_getenv(k.env)) {
         const int rc = k.documented ? xlating_batch_set_option(b, k.opt, atol(v)) : xl_batch_set_tuning(b, k.opt, atol(v));
         if (rc != 0) XL_LOG_ERR("%s=%s is not a value of \"%s\" (ignored)", k.env, v, k.opt);
       }
   }
-  if (getenv("XL_EXP_CHAIN_STATS")) (void)hipMalloc((void **)&b->d_chain_stats, 4096 * 4 * sizeof(unsigned long long));
-  if (getenv("XL_EXP_INVSKIP")) b->inv_skip_at = (uint32_t)atoi(getenv("XL_EXP_INVSKIP"));
-  if (getenv("XL_EXP_NCOPRIO")) b->nco_prio = (uint32_t)atoi(getenv("XL_EXP_NCOPRIO")) & 3u;
-  if (getenv("XL_EXP_FLATPRIO")) b->exp_flags |= 2u;
+  if (xl_exp_getenv("XL_EXP_CHAIN_STATS")) (void)hipMalloc((void **)&b->d_chain_stats, 4096 * 4 * sizeof(unsigned long long));
+  if (xl_exp_getenv("XL_EXP_INVSKIP")) b->inv_skip_at = (uint32_t)atoi(xl_exp_getenv("XL_EXP_INVSKIP"));
+  if (xl_exp_getenv("XL_EXP_NCOPRIO")) b->nco_prio = (uint32_t)atoi(xl_exp_getenv("XL_EXP_NCOPRIO")) & 3u;
+  if (xl_exp_getenv("XL_EXP_FLATPRIO")) b->exp_flags |= 2u;
 #ifdef XL_TUNING
-  b->exp_trace = getenv("XL_EXP_TRACE");
-  b->exp_nofuse = getenv("XL_EXP_NOFUSE") != nullptr;
-  b->poly_trace = getenv("XL_EXP_POLY_TRACE");
-  if (getenv("XL_EXP_POLY_EXP")) b->poly_exp = (uint32_t)atoi(getenv("XL_EXP_POLY_EXP"));
+  b->exp_trace = xl_exp_getenv("XL_EXP_TRACE");
+  b->exp_nofuse = xl_exp_getenv("XL_EXP_NOFUSE") != nullptr;
+  b->poly_trace = xl_exp_getenv("XL_EXP_POLY_TRACE");
+  if (xl_exp_getenv("XL_EXP_POLY_EXP")) b->poly_exp = (uint32_t)atoi(xl_exp_getenv("XL_EXP_POLY_EXP"));
 #endif
   b->last_stream = b->own_stream;
   b->dirty = true;
@@ -936,10 +941,11 @@ static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t A, size_t member
 }
 
 // Which mix launch a class of D branches takes (PolyClass::mix_kind): the two-half kernel (1) carries the spectra as pairs of halves
-// and needs them bounded -- integer input formats -- and at most XLP_NKB_MAX k-blocks of 8 branches; the float32 matrix instruction
-// (3) has no such conditions: it is what cf32 streams and D > 64 take, and every class on request.
+// -- bounded by the input format, or (cf32 streams) scaled per segment by what the forward launch found (PolyClass::d_segmax) -- and
+// holds at most XLP_NKB_MAX k-blocks of 8 branches (D <= 112); the float32 matrix instruction (3) has no such condition: it is what
+// D > 112 takes, and every class on request (option "mix_kernel" = 3: all-float32 products).
 static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D) {
-  const bool halves_ok = b->fmt != XL_FMT_CF32 && D <= 8u * XLP_NKB_MAX;
+  const bool halves_ok = D <= 8u * XLP_NKB_MAX;
   return (b->mix_kernel == 3u || !halves_ok) ? 3u : 1u;
 }
 
@@ -996,6 +1002,13 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
       const size_t xbytes = (size_t)passes * pc.Dpad * pc.M * XLP_XS * sizeof(float2);
       XL_TRY(xl_plan_alloc(b, (void **)&pc.d_X, xbytes));
       XL_TRY(hipMemsetAsync(pc.d_X, 0, xbytes, b->own_stream));
+      xl_plan_release(b, pc.d_segmax);
+      pc.d_segmax = nullptr;
+      pc.seg_cap = passes * XLP_SEG, pc.seg_par = 0;
+      if (pc.mix_kind == 1u && b->fmt == XL_FMT_CF32) {
+        XL_TRY(xl_plan_alloc(b, (void **)&pc.d_segmax, 2u * (size_t)pc.seg_cap * sizeof(uint32_t)));
+        XL_TRY(hipMemsetAsync(pc.d_segmax, 0, 2u * (size_t)pc.seg_cap * sizeof(uint32_t), b->own_stream));
+      }
     }
     pc.nseg_cap = nseg_cap;
   }
@@ -1024,7 +1037,7 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
       for (uint32_t j : new_cols) pc.col_scale[j] = xl_poly_col_scale(b->clients[pc.col_client[j]], pc.D, pc.T);
       for (size_t j = 0; j < pc.col_client.size(); ++j) {
         if (pc.col_client[j] < 0) continue;
-        cs[j] = 1.0f / (pc.col_scale[j] * XLP_H_XSCALE);
+        cs[j] = b->fmt == XL_FMT_CF32 ? 1.0f / pc.col_scale[j] : 1.0f / (pc.col_scale[j] * XLP_H_XSCALE);  // (cf32: the segments' own scales, in the kernel)
       }
     }
     XL_TRY(hipMemcpy(pc.d_cscale, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1078,7 +1091,7 @@ fail : {
 // small per-client records.
 static int xl_batch_plan(xlating_batch *b) {
   // tuning: XL_EXP_PLAN_TIMING=1 prints where a re-plan spends its time
-  static const bool plan_timing = getenv("XL_EXP_PLAN_TIMING") != nullptr;
+  static const bool plan_timing = xl_exp_getenv("XL_EXP_PLAN_TIMING") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (!plan_timing) return;
@@ -1187,6 +1200,7 @@ static int xl_batch_plan(xlating_batch *b) {
         pc = std::move(*old);
         old->keep = true;
         old->d_X = old->d_Y = nullptr;
+        old->d_segmax = nullptr;
         old->d_cols = nullptr;
         old->d_Rh = nullptr;
         old->d_cscale = nullptr;
@@ -1339,9 +1353,9 @@ static int xl_batch_plan(xlating_batch *b) {
       load_wgs = xl_plan_load_wgs(ps * (double)nwg_res / (double)std::max(nwg, 1u), kmax);
     }
     uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? xl_chain_reserve_per_xcd(nwg_res, load_wgs) : 0u;
-    if (getenv("XL_EXP_NOMASK")) want = 0u;
-    if (want > 0u && getenv("XL_EXP_ROUNDS1")) want = std::min(16u, (nwg_res + 7u) / 8u);  // (tuning: round 3's rule, one CU per chain workgroup)
-    if (want > 0u && getenv("XL_EXP_RESERVE")) want = std::min(want, (uint32_t)atoi(getenv("XL_EXP_RESERVE")));  // (tuning: fewer CUs, more rounds)
+    if (xl_exp_getenv("XL_EXP_NOMASK")) want = 0u;
+    if (want > 0u && xl_exp_getenv("XL_EXP_ROUNDS1")) want = std::min(16u, (nwg_res + 7u) / 8u);  // (tuning: round 3's rule, one CU per chain workgroup)
+    if (want > 0u && xl_exp_getenv("XL_EXP_RESERVE")) want = std::min(want, (uint32_t)atoi(xl_exp_getenv("XL_EXP_RESERVE")));  // (tuning: fewer CUs, more rounds)
     // (creating a masked stream pair takes ~25 ms: grow at once, shrink only when two CUs per XCD too many are held, so that
     // a client count hovering around a multiple of 512 does not recreate the streams at every join and leave)
     if (want > b->reserve_r || want + 2u <= b->reserve_r || (want == 0u && b->reserve_r != 0u)) {
@@ -1854,6 +1868,10 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           pa.mix_pp = b->mix_pp;
           pa.Rh = pc.d_Rh;
           pa.cscale = pc.d_cscale;
+          pa.segmax = pc.d_segmax;
+          pa.seg_par = pc.seg_par;
+          pa.seg_cap = pc.seg_cap;
+          pc.seg_par ^= 1u;  // (a failed call leaves stale maxima behind at worst: a smaller scale than necessary, never a wrong one)
           pa.W = b->d_W;
           pa.X = pc.d_X;
           pa.Y = pc.d_Y;
@@ -1891,7 +1909,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           pa.roll_blocks = 0;
           pa.nco_blocks = 0;  // (no role in the mix launch)
 #ifdef XL_TUNING
-          const bool trace_inv = b->poly_trace && getenv("XL_EXP_POLY_TRACE_INV");  // (the inverse launch instead)
+          const bool trace_inv = b->poly_trace && xl_exp_getenv("XL_EXP_POLY_TRACE_INV");  // (the inverse launch instead)
           if (b->poly_trace && !trace_inv) {  // timeline of the mix launch (work waves' span + each NCO wave)
             if (!b->d_ptrace) XL_TRY(hipMalloc((void **)&b->d_ptrace, 32768 * sizeof(unsigned long long)));
             XL_TRY(hipMemsetAsync(b->d_ptrace, 0, 32768 * sizeof(unsigned long long), s));

@@ -3,6 +3,7 @@
 
 #include <errno.h>
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/xlating.h"
@@ -27,6 +28,29 @@ int xl_errno_of_last_hip_error(void) {
     default:
       return -EIO;
   }
+}
+
+static std::once_flag g_exp_once;
+static bool g_exp_enabled = false;
+
+extern char **environ;
+
+extern "C" const char *xl_exp_getenv(const char *name) {
+  std::call_once(g_exp_once, [] {
+#ifdef XL_TUNING
+    g_exp_enabled = true;
+#else
+    const char *t = getenv("XL_TESTING");
+    g_exp_enabled = t != nullptr && strcmp(t, "1") == 0;
+    if (!g_exp_enabled)
+      for (char **e = environ; e != nullptr && *e != nullptr; ++e)
+        if (strncmp(*e, "XL_EXP_", 7) == 0) {
+          XL_LOG_WARN("XL_EXP_* tuning variables are set but ignored (they are honoured only next to XL_TESTING=1): first one %.40s", *e);
+          break;
+        }
+#endif
+  });
+  return g_exp_enabled ? getenv(name) : nullptr;
 }
 
 static std::once_flag g_probe_once;

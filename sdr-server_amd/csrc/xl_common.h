@@ -29,6 +29,19 @@ int xl_errno_of_last_hip_error(void);
     }                                                                                      \
   } while (0)
 
+// journald "warning" line
+#define XL_LOG_WARN(...)                \
+  do {                                  \
+    fprintf(stderr, "<4>xlating-hip: "); \
+    fprintf(stderr, __VA_ARGS__);       \
+    fprintf(stderr, "\n");              \
+  } while (0)
+
+// Tuning / test knobs from the environment (XL_EXP_*): honoured ONLY when the process also sets XL_TESTING=1 (tests/ and tools/ do)
+// or in -DXL_TUNING builds.  A plain process ignores them -- its plan must not depend on stray environment (the reference's only
+// switch is the config file's cpu_optimization, src/config.c:252-264) -- and says so once on stderr if any is set.
+extern "C" const char *xl_exp_getenv(const char *name);
+
 // Thread-safe lazy probe.  Returns the device ordinal to use (>= 0) or -1 when no usable HIP device exists.
 // `requested` < 0 selects the calling thread's current device.
 int xl_hip_select_device(int requested);

@@ -156,10 +156,10 @@ extern "C" int create_frequency_xlating_filter(uint32_t decimation, float *taps,
   XL_TRY(hipStreamCreateWithFlags(&f->stream_nco, hipStreamNonBlocking));
   XL_TRY(hipEventCreateWithFlags(&f->ev_nco, hipEventDisableTiming));
   XL_TRY(hipEventCreateWithFlags(&f->ev_qnco, hipEventDisableTiming));
-  f->lookahead = getenv("XL_EXP_NOLOOKAHEAD") == nullptr;
+  f->lookahead = xl_exp_getenv("XL_EXP_NOLOOKAHEAD") == nullptr;
   f->x86 = getenv("XLATING_OPTIMIZED_X86") != nullptr ? atoi(getenv("XLATING_OPTIMIZED_X86")) : 0;
   if (f->x86 < 0 || f->x86 > 2) f->x86 = 0;
-  f->zero_copy = getenv("XL_EXP_DROPIN_COPY") == nullptr;
+  f->zero_copy = xl_exp_getenv("XL_EXP_DROPIN_COPY") == nullptr;
   XL_TRY(hipMalloc(&f->d_raw, f->max_samples * 8 + 16));
   XL_TRY(hipMalloc((void **)&f->d_work_f, work_n * sizeof(float2)));
   XL_TRY(hipMalloc((void **)&f->d_work_q, work_n * sizeof(short2)));

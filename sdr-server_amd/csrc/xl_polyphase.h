@@ -32,9 +32,13 @@
                        // packed-FMA mix kernel's register budget -- 16 took 7 % off the two-half mix launch, profiles/r05_mix_f32.txt)
 #define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: the XLP_SEG segments of a pass = 128 bytes
 #define XLP_COLS 128u  // client columns per column group (= one mix workgroup: a wave with two columns per lane)
-#define XLP_NKB_MAX 8u // matrix-core mix: at most 8 k-blocks of 8 branches (D <= 64)
+#define XLP_NKB_MAX 14u // matrix-core mix: at most 14 k-blocks of 8 branches (D <= 112): a wave keeps its B operands in registers
+#define XLP_NKB_4W 8u   // ... up to 8 k-blocks (D <= 64) at four waves per SIMD, above that at two (xlp_mix_mfma_kernel)
 #define XLP_H_XSCALE 128.0f  // matrix-core mix: the shared spectra are multiplied by this before the split in halves: integer input
-                             // formats give |X| <= M sqrt(2) <= 363, so the first half stays below 46 400 < 65 504
+                             // formats give |X| <= M sqrt(2) <= 363, so the first half stays below 46 400 < 65 504.
+                             // A cf32 stream has no such bound: its spectra are scaled per SEGMENT by the power of two that brings the
+                             // segment's largest component (XlpArgs::segmax, found by the forward launch) under 2^15 -- a row scale of
+                             // the per-bin matrix product, undone exactly in the mix launch's epilogue (xlp_seg_scale)
 #define XLP_H_RMAX 8192.0f   // ... and a column's spectra by the power of two that brings their bound max_b sum_a |r_b[a]| under this
 #define XLP_BSTEP 2u   // the branch count is padded to a multiple of this in the shared-spectrum image (rows D .. Dpad - 1: zeros)
 
@@ -72,6 +76,11 @@ struct XlpArgs {
                        // operands (xl_mixf32.hip: xlp_mix_f32_kernel; any input format, any branch count)
   uint32_t nkb;        // k-blocks of 8 branches = ceil(D / 8) (mix_kind 1: <= XLP_NKB_MAX)
   uint32_t mix_pp;     // passes per workgroup of the mix launch (0 = the launcher's default)
+  // two-half mix of a cf32 stream: per segment the largest |component| of its shared spectra (float bits; all branches, all bins),
+  // gathered by the forward launch with one atomicMax per (segment, branch).  Two buffers of seg_cap entries: a call uses buffer
+  // seg_par, and its forward launch clears the other one for the next call.  nullptr: integer formats (constant scale XLP_H_XSCALE)
+  uint32_t *segmax;
+  uint32_t seg_par, seg_cap;
   unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
   const float2 *W;     // e^{-2 pi j n / 256}, n < 256
   float2 *X;           // shared spectra   [pass][Dpad][M][XLP_XS]
@@ -79,7 +88,7 @@ struct XlpArgs {
                        //   [cg][M][32-column quarter][term 2][k-block nkb][lane 64][8 halves] (see xlp_mix_mfma_kernel)
                        // mix_kind 3: the same values as float32 (R.re, -R.im) in v_mfma_f32_32x32x2_f32's B-operand order
                        //   [cg][M][32-column quarter][k-block nkb][half 2][lane 64][4 branches] (xl_mixf_layout.h)
-  const float *cscale; // mix_kind 1: per column, what the sums are multiplied by = 1 / (column scale * XLP_H_XSCALE)
+  const float *cscale; // mix_kind 1: per column, what the sums are multiplied by = 1 / (column scale * XLP_H_XSCALE) (segmax: 1 / column scale)
   float2 *Y;           // mixed spectra    [cg][nseg_cap][sub][M][CW], CW = 32 (M = 128) / 16 (M = 256) columns: one inverse tile contiguous
   const XlpCol *cols;  // per column
   const float2 *phtab;

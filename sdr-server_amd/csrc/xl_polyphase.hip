@@ -77,6 +77,18 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
   v2f *const bufs[1] = {lds[h]};
   const uint32_t rs0[1] = {0u};
   xlp_dft<-1, 1, M>(u, bufs, tw, l, rs0);
+  if (a.segmax != nullptr) {
+    // cf32 stream on the two-half mix: the segment's largest spectrum component, over all branches -- this transform's share of it
+    // (NaNs drop out of fmaxf: a stream that carries them has no parity to keep)
+    float mx = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fmaxf(fabsf(u[0][r].x), fabsf(u[0][r].y)));
+#pragma unroll
+    for (uint32_t o = L / 2u; o > 0u; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, (int)o));
+    if (l == 0u && live) atomicMax(a.segmax + (size_t)a.seg_par * a.seg_cap + s, __float_as_uint(mx));
+    if (bid == 0u)  // the next call's buffer (last read by the previous call's mix launch)
+      for (uint32_t i = j; i < a.seg_cap; i += NT) a.segmax[(size_t)(a.seg_par ^ 1u) * a.seg_cap + i] = 0u;
+  }
   // the transform's row, natural order (its own scratch: the LDS operations of a wave execute in order)
 #pragma unroll
   for (int r = 0; r < 4; ++r) lds[h][l + L * r] = u[0][r];
@@ -127,11 +139,29 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
 // was never found, so the combination was designed out (round 4): the recurrence rides in the forward and inverse launches or
 // runs on the side stream (xl_batch.cpp), xlp_launch_mix refuses a role for this kernel, and
 // tests/test_batch_gpu.py::test_matrix_core_mix_role_phases_bit_exact keeps comparing all phases of two engines bit for bit.
-template <int NKB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void xlp_mix_mfma_kernel(const XlpArgs a) {
+// Round 6: (1) up to XLP_NKB_MAX = 14 k-blocks (D <= 112): above XLP_NKB_4W the B operands (8 NKB registers) take the kernel to a
+// two-waves-per-SIMD budget -- the launch is bound by its operand and Y streams either way; (2) SEG: cf32 streams, whose spectra have no
+// a-priori bound, are scaled per SEGMENT -- rows of the per-bin product are (segment, re / im), so a power-of-two row scale factors out
+// of the sums exactly: the forward launch leaves every segment's largest spectrum component in XlpArgs::segmax, the staging multiplies
+// the segment's rows by 2^(14 - floor(log2 max)) (every scaled component < 2^15), and the epilogue multiplies the segment's sums by the
+// inverse.  The float32 matrix instruction (xl_mixf32.hip) remains for D > 112 and as the exact-float32 option (mix_kernel = 3).
+XL_DEV uint32_t xlp_seg_exp(const uint32_t maxbits) {  // biased exponent of the segment's largest component, kept where both powers are normal
+  const uint32_t ex = maxbits >> 23;
+  return ex < 27u ? 27u : (ex > 254u ? 254u : ex);
+}
+XL_DEV float xlp_seg_scale(const uint32_t maxbits) { return __uint_as_float((268u - xlp_seg_exp(maxbits)) << 23); }  // 2^(14 - e)
+XL_DEV float xlp_seg_unscale(const uint32_t maxbits) { return __uint_as_float((xlp_seg_exp(maxbits) - 14u) << 23); }  // 2^(e - 14)
+
+// waves per SIMD: 4 up to XLP_NKB_4W k-blocks (124-128 VGPRs; with the segment scales only up to 4 k-blocks, then 3), 2 above
+constexpr int xlp_mix_waves(const int nkb, const bool seg) { return nkb > (int)XLP_NKB_4W ? 2 : (seg && nkb > 4 ? 3 : 4); }
+
+template <int NKB, bool SEG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xlp_mix_waves(NKB, SEG), xlp_mix_waves(NKB, SEG))))
+void xlp_mix_mfma_kernel(const XlpArgs a) {
   // A operands of one pass: [term][k-block][lane][8 halves]; two buffers (one barrier per pass: a buffer is rewritten two
   // barriers after it was read)
   __shared__ uint4 xs[2][2][NKB][64];
+  __shared__ float sinv[2][XLP_SEG];  // SEG: what undoes the segments' scales, per buffer
   const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;
   const uint32_t bid = blockIdx.x;
   const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
@@ -163,7 +193,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const v4f *__restrict__ Xm = reinterpret_cast<const v4f *>(a.X) + (size_t)m * (XLP_XS / 2u) + sp;
   const size_t xrow = (size_t)M * (XLP_XS / 2u);  // v4f per branch row
   v4f g[ROUNDS];
+  uint32_t smx[2] = {0u, 0u};  // SEG: the largest components of this lane's two segments of the requested pass
+  const uint32_t *__restrict__ segmax = SEG ? a.segmax + (size_t)a.seg_par * a.seg_cap + 2u * sp : nullptr;
   auto request = [&](const uint32_t pass) __attribute__((always_inline)) {
+    if (SEG) smx[0] = segmax[pass * XLP_SEG], smx[1] = segmax[pass * XLP_SEG + 1u];
 #pragma unroll
     for (int q = 0; q < ROUNDS; ++q) {
       const uint32_t b = 8u * xlm_stage_kblock(w, (uint32_t)q) + bb;
@@ -172,13 +205,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
   };
   auto stage = [&](const uint32_t buf) __attribute__((always_inline)) {
+    const float sx0 = SEG ? xlp_seg_scale(smx[0]) : XLP_H_XSCALE, sx1 = SEG ? xlp_seg_scale(smx[1]) : XLP_H_XSCALE;
+    if (SEG && tid < 8u) sinv[buf][2u * sp] = xlp_seg_unscale(smx[0]), sinv[buf][2u * sp + 1u] = xlp_seg_unscale(smx[1]);
 #pragma unroll
     for (int q = 0; q < ROUNDS; ++q) {
       const uint32_t j = xlm_stage_kblock(w, (uint32_t)q);
       if (j < (uint32_t)NKB) {  // (wave-uniform)
         _Float16 f1[4], f2[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xlp_split_h(g[q][e] * XLP_H_XSCALE, f1[e], f2[e]);
+        for (int e = 0; e < 4; ++e) xlp_split_h(g[q][e] * (e < 2 ? sx0 : sx1), f1[e], f2[e]);
         // branch bb of the k-block: dword xlm_dword(bb) of the lane slots (half xlm_half(bb), row) of its two segments' rows
 #pragma unroll
         for (int u = 0; u < 2; ++u) {  // segment 2 sp + u: (re, im) = f[2 u], f[2 u + 1]
@@ -238,7 +273,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
       for (int g2 = 0; g2 < 16; g2 += 2) {
         const uint32_t cs = (uint32_t)(((g2 >> 1) & 1) + 4 * (g2 >> 2));  // (a constant after unrolling)
-        const v2f y = {(hi[g2] + lo[g2]) * cs_, (hi[g2 + 1] + lo[g2 + 1]) * cs_};
+        v2f y = {(hi[g2] + lo[g2]) * cs_, (hi[g2 + 1] + lo[g2 + 1]) * cs_};
+        if (SEG) {
+          const float si = sinv[buf][2u * h + cs];
+          y.x *= si, y.y *= si;
+        }
         v2f *const dst = reinterpret_cast<v2f *>(base + cs * sb);
 #ifdef XLP_MIX_EXP_NOSTORE
         if ((whole || s0 + 2u * h + cs < a.nseg) && y.x == 1.2345e-33f) __builtin_nontemporal_store(y, dst);
@@ -449,7 +488,8 @@ static XlpArgs xlp_checked_skip(const XlpArgs &a, uint32_t work_blocks) {
 
 template <int NKB>
 static void xlp_launch_mix_mfma_n(const XlpArgs &a, const dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(xlp_mix_mfma_kernel<NKB>, grid, dim3(256), 0, s, a);
+  if (a.segmax != nullptr) hipLaunchKernelGGL((xlp_mix_mfma_kernel<NKB, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((xlp_mix_mfma_kernel<NKB, false>), grid, dim3(256), 0, s, a);
 }
 
 hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
@@ -459,8 +499,9 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
   a.nco_skip_at = 0xFFFFFFFFu;
   a.mix_passes = (a0.nseg + XLP_SEG - 1) / XLP_SEG;
   if (a0.mix_kind == 3u) return xlp_launch_mix_f32(a, s);  // float32 operands (xl_mixf32.hip)
+  // (a cf32 stream's spectra are unbounded: only with the per-segment scales)
   if (a0.mix_kind != 1u || a0.nkb == 0u || a0.nkb > XLP_NKB_MAX || a0.D > 8u * a0.nkb || a0.Rh == nullptr || a0.cscale == nullptr ||
-      a0.fmt == XLF_CF32)
+      (a0.fmt == XLF_CF32 && a0.segmax == nullptr) || (a0.segmax != nullptr && a0.seg_cap < a.mix_passes * XLP_SEG))
     return hipErrorInvalidValue;
   // (all passes of an 8-block call in one workgroup: the operands are fetched once; A/B at 4096 clients, passes per
   // workgroup 4 / 8 / 16: 42.5 / 38.5 / 34.8 us per block, at 1024 clients 10.3 / 9.3 / 10.0)
@@ -475,7 +516,13 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
     case 5: xlp_launch_mix_mfma_n<5>(a, grid, s); break;
     case 6: xlp_launch_mix_mfma_n<6>(a, grid, s); break;
     case 7: xlp_launch_mix_mfma_n<7>(a, grid, s); break;
-    default: xlp_launch_mix_mfma_n<8>(a, grid, s); break;
+    case 8: xlp_launch_mix_mfma_n<8>(a, grid, s); break;
+    case 9: xlp_launch_mix_mfma_n<9>(a, grid, s); break;
+    case 10: xlp_launch_mix_mfma_n<10>(a, grid, s); break;
+    case 11: xlp_launch_mix_mfma_n<11>(a, grid, s); break;
+    case 12: xlp_launch_mix_mfma_n<12>(a, grid, s); break;
+    case 13: xlp_launch_mix_mfma_n<13>(a, grid, s); break;
+    default: xlp_launch_mix_mfma_n<14>(a, grid, s); break;
   }
   return hipGetLastError();
 }

@@ -12,6 +12,10 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The library honours its XL_EXP_* tuning variables (and XL_LIBRARY_PATH) only next to XL_TESTING=1: the tests force plans through them
+# (monkeypatch.setenv("XL_EXP_POLY", ...)); a plain process ignores them (tests/test_option_docs.py checks that side).
+os.environ.setdefault("XL_TESTING", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

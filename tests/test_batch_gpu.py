@@ -12,6 +12,7 @@ import sdr_server_amd as xl
 from conftest import bits_equal
 from pyoracle import Oracle
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-5
 FS = 2016000
@@ -394,11 +395,13 @@ def test_polyphase_forced_other_formats(fmt, monkeypatch, poly_m):
     eng.close()
 
 
-@pytest.mark.parametrize("shape", ["perf_2429_taps", "cf32_d100_257_taps", "d400_4819_taps"])
+@pytest.mark.parametrize("shape", ["perf_2429_taps", "cf32_d100_257_taps", "cs16_d100_257_taps", "cu8_d112_569_taps", "d400_4819_taps"])
 def test_polyphase_forced_other_shapes(shape, monkeypatch, poly_m):
     """Other branch counts / taps per branch on the path: the reference's perf shape (test/perf_xlating.c: 2429 taps,
     D=42 -> 58 taps per branch, 199 valid outputs per segment), BASELINE config 5 (cf32 in, D=100, 257 taps -> 3 taps
-    per branch) and a huge decimation (20 Msps -> 50 kHz: D=400, 4819 taps)."""
+    per branch: 13 k-blocks on the two-half mix, segment scales), the same shape off an Airspy-style cs16 stream (src/xlating.c:374-382)
+    and D = 112 (14 k-blocks: the most the two-half kernel holds), and a huge decimation (20 Msps -> 50 kHz: D=400, 4819 taps: float32
+    operands streamed per pass)."""
     if shape == "perf_2429_taps":
         fs, D, fmt, nbytes = FS, 42, "cu8", 262144
         taps = lpf(fs, 24000, 2000)
@@ -408,6 +411,15 @@ def test_polyphase_forced_other_shapes(shape, monkeypatch, poly_m):
         fs, D, fmt, nbytes = 10000000, 100, "cf32", 262144
         taps = siggen.hamming_sinc(257, 0.004)
         x = [(siggen.xs_s16(300 + k, 131072).astype(np.float32) / np.float32(32768)).astype(np.float32) for k in range(2)]
+    elif shape == "cs16_d100_257_taps":
+        fs, D, fmt, nbytes = 10000000, 100, "cs16", 262144
+        taps = siggen.hamming_sinc(257, 0.004)
+        x = [siggen.xs_s16(310 + k, 131072) for k in range(2)]
+    elif shape == "cu8_d112_569_taps":
+        fs, D, fmt, nbytes = 5376000, 112, "cu8", 262144
+        taps = lpf(fs, 24000, 22000)
+        assert len(taps) == 569
+        x = [siggen.xs_u8(320 + k, nbytes) for k in range(2)]
     else:
         fs, D, fmt, nbytes = 20000000, 400, "cu8", 1048576
         taps = lpf(fs, 25000, 10000)
@@ -419,6 +431,8 @@ def test_polyphase_forced_other_shapes(shape, monkeypatch, poly_m):
         fc = int(-0.3 * fs + c * 0.15 * fs)
         oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, fs, nbytes)
     assert "polyphase: cls0 D%d T%d cols5" % (D, len(taps)) in eng.describe(), eng.describe()
+    want_mix = "mix=mf32" if (D > 112 or os.environ.get("XL_EXP_MIX") == "3") else "mix=mfma"
+    assert want_mix in eng.describe(), eng.describe()
     for xb in x:
         check_clients(eng, oracles, fmt, xb, "optimized")
     eng.close()
@@ -517,7 +531,8 @@ def test_size_rule_of_matrix_core_classes(monkeypatch):
         oracles[eng.add_client(42, taps, -800000 + 41000 * c)] = Oracle(42, taps, -800000 + 41000 * c, FS, 262144)
     for k in range(2):
         check_clients(eng, oracles, "cf32", (siggen.xs_s16(5420 + k, 2 * 65536).astype(np.float32) / np.float32(32768)).astype(np.float32), "optimized")
-    assert "polyphase: cls0 D42 T505 cols40 " in eng.describe() and "mix=mf32" in eng.describe(), eng.describe()
+    # (round 6: a cf32 class takes the two-half matrix-core mix too, its spectra scaled per segment)
+    assert "polyphase: cls0 D42 T505 cols40 " in eng.describe() and "mix=mfma" in eng.describe(), eng.describe()
     eng.close()
 
 
@@ -1540,31 +1555,143 @@ def test_group_2304_clients_sampled_no_cu_reservation():
 def test_config5_cf32_10msps_all_clients(nclients):
     """BASELINE config 5 at the client counts SURVEY 8(d) lists (N = 64, 256; N = 1 runs in
     test_config5_cf32_10msps_257_taps's family): cf32 input at 10 Msps, D = 100, 257 explicit taps, S = 131072; every
-    client of two consecutive blocks vs the oracle population, native bit-exact and optimized <= 1e-5 (the optimized calls take
-    the polyphase path with the mix on the matrix cores, float32 operands: 13 k-blocks of 8 branches; 1024 clients = the
-    count bench.py's config-5 variant is quoted on)."""
+    client of two consecutive blocks vs the oracle population, PER BLOCK: native bit-exact and optimized <= 1e-5 -- the optimized
+    calls take the polyphase path with the mix on the matrix cores, by default on two-half operands (13 k-blocks of 8 branches, the
+    spectra scaled per segment: round 6), on request (option mix_kernel = 3) on float32 operands; 1024 clients = the count
+    bench.py's config-5 entry is quoted on."""
     from pyoracle import population
 
     taps = siggen.hamming_sinc(257, 0.004)
     nsamp = 131072
     fcs = [-4900000 + (9800000 // nclients) * c for c in range(nclients)]
     x = np.concatenate([siggen.sin_f32(0, 2 * nsamp), (siggen.xs_s16(91, 2 * nsamp).astype(np.float32) / np.float32(32768))]).astype(np.float32)
-    want = population(100, taps, fcs, 10000000, 2 * nsamp, "cf32", x, 1, nwarm=1)
-    for variant in ("native", "optimized"):
+    want0 = population(100, taps, fcs, 10000000, 2 * nsamp, "cf32", x[:2 * nsamp], 1)
+    want1 = population(100, taps, fcs, 10000000, 2 * nsamp, "cf32", x, 1, nwarm=1)
+    for variant, mix in (("native", 0), ("optimized", 0), ("optimized", 3)):
         eng = xl.BatchEngine(10000000, "cf32", 2 * nsamp)
+        if mix:
+            eng.set_option("mix_kernel", mix)
         ids = [eng.add_client(100, taps, fc) for fc in fcs]
-        for k in range(2):
+        for k, want in enumerate((want0, want1)):
             eng.process_host(x[k * 2 * nsamp:(k + 1) * 2 * nsamp], variant)
-        if variant == "optimized":
-            assert "polyphase: cls0 D100 T257 cols%d " % nclients in eng.describe() and "mix=mf32" in eng.describe(), eng.describe()
-        got = _engine_outputs(eng, ids)
-        for c in range(nclients):
-            assert len(got[c]) == len(want[c]), c
-            if variant == "native":
-                assert bits_equal(got[c], want[c]), c
-            else:
-                assert rel_err(got[c], want[c]) <= REL_TOL, (c, rel_err(got[c], want[c]))
+            if variant == "optimized" and k == 1:  # (block 0: the clients are inside their zero history -- a class of its own)
+                d = eng.describe()
+                assert "polyphase: cls0 D100 T257 cols%d " % nclients in d and ("mix=mf32" if mix == 3 else "mix=mfma") in d, d
+            got = _engine_outputs(eng, ids)
+            for c in range(nclients):
+                assert len(got[c]) == len(want[c]), c
+                if variant == "native":
+                    assert bits_equal(got[c], want[c]), (k, c)
+                else:
+                    assert rel_err(got[c], want[c]) <= REL_TOL, (variant, mix, k, c, rel_err(got[c], want[c]))
         eng.close()
+
+
+def _cf32_adversarial_blocks(nsamp):
+    """8 consecutive cf32 blocks (interleaved I,Q float32) whose levels and shapes differ wildly INSIDE one call: what the per-segment
+    scales of the two-half mix are for."""
+    rng = np.random.default_rng(606)
+    n = 2 * nsamp
+    noise = lambda a: (rng.standard_normal(n) * a).astype(np.float32)  # noqa: E731
+    loud = noise(0.3)
+    quiet = noise(0.3e-4)                                   # 10^4 x quieter than the block before it
+    square = np.where((np.arange(n) // 2) % 200 < 100, 1.0, -1.0).astype(np.float32)   # full-scale square wave on I and Q
+    tiny = noise(1e-6)
+    impulse = np.zeros(n, np.float32)
+    impulse[2 * 4321] = 1.0                                  # a lone impulse in an all-zero block
+    zeros = np.zeros(n, np.float32)
+    huge = noise(3e4)                                        # far above any integer format's range
+    ramp = (np.linspace(-1.0, 1.0, n) ** 3).astype(np.float32) * np.float32(1e-3)
+    return [loud, quiet, square, tiny, impulse, zeros, huge, ramp]
+
+
+@pytest.mark.parametrize("shape", ["config5_d100", "d42_505_taps"])
+def test_cf32_two_half_mix_adversarial_levels_in_one_call(shape):
+    """cf32 input has no a-priori bound, so the two-half matrix-core mix scales the shared spectra per SEGMENT (the forward launch finds
+    each segment's largest component; a row scale factors out of the per-bin matrix product exactly).  ONE 8-block call whose blocks are:
+    loud noise, noise 10^4 x quieter, a full-scale square wave, 1e-6-amplitude noise, a lone impulse, zeros, 3e4-amplitude noise, a
+    small cubic ramp -- every client, PER BLOCK, within 1e-5 of the block's own output scale against the oracle (the reference's
+    float32 direct form, src/xlating.c:52-83), on both the default plan (two-half operands) and the float32-operand option; then the
+    same eight blocks again as eight one-block calls (another segmentation of the same stream)."""
+    nsamp = 131072
+    if shape == "config5_d100":
+        fs, D, taps = 10000000, 100, siggen.hamming_sinc(257, 0.004)
+    else:
+        fs, D, taps = FS, 42, lpf(FS, 24000, 9600)
+    blocks = _cf32_adversarial_blocks(nsamp)
+    nclients = 40
+    fcs = [int(-0.45 * fs + (0.9 * fs / nclients) * c) for c in range(nclients)]
+    oracles = [Oracle(D, taps, fc, fs, 8 * nsamp) for fc in fcs]
+    warm = (siggen.xs_s16(17, 2 * nsamp).astype(np.float32) / np.float32(32768)).astype(np.float32)
+    want_warm = [o.process("cf32", warm) for o in oracles]
+    want = [[o.process("cf32", xb) for xb in blocks] for o in oracles]          # first pass over the eight blocks
+    want2 = [[o.process("cf32", xb) for xb in blocks] for o in oracles]         # second pass
+    for mix in (0, 3):
+        eng = xl.BatchEngine(fs, "cf32", 2 * nsamp, group_blocks=8)
+        if mix:
+            eng.set_option("mix_kernel", mix)
+        ids = [eng.add_client(D, taps, fc) for fc in fcs]
+        eng.process_host(warm, "optimized")  # (the clients leave their zero history)
+        eng.fetch()
+        for c in range(nclients):
+            assert rel_err(eng.output(ids[c]), want_warm[c]) <= REL_TOL
+        eng.process_host_group(np.concatenate(blocks), 8, "optimized")
+        d = eng.describe()
+        assert "polyphase: cls0 D%d " % D in d and ("mix=mf32" if mix == 3 else "mix=mfma") in d, d
+        eng.fetch()
+        worst = 0.0
+        for c in range(nclients):
+            got = eng.output(ids[c])
+            lens = [eng.output_len_block(ids[c], g) for g in range(8)]
+            assert lens == [len(w) for w in want[c]], (c, lens)
+            off = 0
+            for g in range(8):
+                gb, wb = got[off:off + lens[g]], want[c][g]
+                off += lens[g]
+                if not np.any(wb):  # (the all-zero block once the filter has run out of the impulse: exact zeros expected)
+                    assert not np.any(gb), (mix, c, g)
+                    continue
+                e = rel_err(gb, wb)
+                worst = max(worst, e)
+                assert e <= REL_TOL, (shape, mix, c, g, e)
+        for g in range(8):  # the same blocks, one per call
+            eng.process_host(blocks[g], "optimized")
+            eng.fetch()
+            for c in range(nclients):
+                wb = want2[c][g]
+                gb = eng.output(ids[c])
+                assert len(gb) == len(wb)
+                if np.any(wb):
+                    assert rel_err(gb, wb) <= REL_TOL, (shape, mix, c, g, "one block per call", rel_err(gb, wb))
+        eng.close()
+
+
+def test_plain_process_ignores_tuning_variables():
+    """With XL_EXP_* set but XL_TESTING unset (a production process), describe() equals the default plan; with XL_TESTING=1 the same
+    variables force the plan (what the tests above rely on)."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import siggen, sdr_server_amd as xl\n"
+            "t = xl.create_low_pass_filter(1.0, 2016000, 24000, 9600)[1]\n"
+            "e = xl.BatchEngine(2016000, 'cu8', 262144, group_blocks=2)\n"
+            "[e.add_client(42, t, -800000 + 41000 * c) for c in range(40)]\n"
+            "[e.process_host_group(siggen.xs_u8(9 + k, 2 * 262144), 2, 'optimized') for k in range(2)]\n"
+            "print('PLAN', e.describe())\n" % (ROOT, os.path.join(ROOT, "tests")))
+    base = {k: v for k, v in os.environ.items() if not k.startswith("XL_")}
+    knobs = {"XL_EXP_POLY": "0", "XL_EXP_MIX": "3", "XL_EXP_POLY_M": "256", "XL_EXP_NOMASK": "1", "XL_EXP_RESERVE": "1"}
+
+    def plan(env):
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1000:]
+        return next(l for l in r.stdout.splitlines() if l.startswith("PLAN")), r.stderr
+
+    default, _ = plan(base)
+    stray, err = plan(dict(base, **knobs))
+    forced, _ = plan(dict(base, XL_TESTING="1", **knobs))
+    assert "polyphase: cls0 D42 T505 cols40 " in default and "mix=mfma" in default, default
+    assert stray == default and "tuning variables are set but ignored" in err, (stray, err[-300:])
+    assert "polyphase: none" in forced, forced
 
 
 def test_expected_clients_reserves_the_side_kernels_cus_once():

@@ -3,6 +3,8 @@
 Run on the GPU box:  python tools/group_sweep.py [--clients 128,1024] [--groups 1,2,4,8] [--modes optimized,native] [--m 0,128,256]"""
 import argparse
 import os
+
+os.environ.setdefault("XL_TESTING", "1")  # (a tuning tool: the library honours XL_EXP_* only next to this)
 import sys
 import time
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/poly_check.py -- GPU: polyphase path vs direct path on the same stream (accuracy + time)."""
 import os, sys, time
+os.environ.setdefault("XL_TESTING", "1")  # (a tuning tool: the library honours XL_EXP_* only next to this)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch

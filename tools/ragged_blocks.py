@@ -3,6 +3,8 @@
 phase table tabulated ahead and redoes it with a stand-alone xl_nco_table_kernel launch, which claims whole SIMDs).  Native and
 optimized mode, one block per call, constant 262144-byte blocks against lengths alternating 262144 / 262100 / 131072 bytes."""
 import os
+
+os.environ.setdefault("XL_TESTING", "1")  # (a tuning tool: the library honours XL_EXP_* only next to this)
 import sys
 import time
 

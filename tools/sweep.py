@@ -3,6 +3,8 @@
 Run on the GPU box:  python tools/sweep.py [--clients 256,512,...] [--rates 5,1] [--modes optimized,native]"""
 import argparse
 import os
+
+os.environ.setdefault("XL_TESTING", "1")  # (a tuning tool: the library honours XL_EXP_* only next to this)
 import sys
 import time
 
