@@ -158,6 +158,7 @@ struct xlating_batch_t {
   unsigned long long *d_chain_stats = nullptr;  // tuning (XL_EXP_CHAIN_STATS): per chain workgroup cycles / ticks of the latest launch
   hipStream_t nco_masked = nullptr;  // the side stream that goes with cs_masked; nco_stream (unmasked) serves callers' own streams
   uint32_t reserve_r = 0;
+  int reserve_band = -1;  // band of the reservation rule the latest plan was in (xl_chain_band; -1: none yet): hysteresis at the band edges
   uint32_t expected_clients = 0;  // option "expected_clients": the CUs are reserved for this many clients from the first plan on
   hipEvent_t ev_chain[XL_NTAB] = {}, ev_done[XL_NTAB] = {};  // per phase table
   bool ev_done_valid[XL_NTAB] = {};
@@ -1006,8 +1007,9 @@ static int xl_poly_sync_device(xlating_batch *b, PolyClass &pc, const std::vecto
       pc.d_segmax = nullptr;
       pc.seg_cap = passes * XLP_SEG, pc.seg_par = 0;
       if (pc.mix_kind == 1u && b->fmt == XL_FMT_CF32) {
-        XL_TRY(xl_plan_alloc(b, (void **)&pc.d_segmax, 2u * (size_t)pc.seg_cap * sizeof(uint32_t)));
-        XL_TRY(hipMemsetAsync(pc.d_segmax, 0, 2u * (size_t)pc.seg_cap * sizeof(uint32_t), b->own_stream));
+        const size_t sbytes = 2u * (size_t)pc.seg_cap * XLP_SEGMAX_STRIDE * sizeof(uint32_t);
+        XL_TRY(xl_plan_alloc(b, (void **)&pc.d_segmax, sbytes));
+        XL_TRY(hipMemsetAsync(pc.d_segmax, 0, sbytes, b->own_stream));
       }
     }
     pc.nseg_cap = nseg_cap;
@@ -1190,8 +1192,11 @@ static int xl_batch_plan(xlating_batch *b) {
       // recurrence in small classes (A/B at 8 blocks per call, direct kernel -> polyphase, us per block: 101 taps 37.3 -> 28.2 at
       // 1024 clients, 124.8 -> 88.7 at 4096, 23.3 -> 22.9 at 128; 505 taps 24.8 -> 22.9 at 96 clients, 23.1 -> 22.7 at 32; cf32 10
       // Msps, D = 100, 257 taps: 38.4 -> 23.4 at 1024 clients, 12.8 -> 11.8 at 256, 11.4 -> 11.3 at 64): 2 taps per branch, 32 clients
-      const size_t min_clients = b->poly_min_set ? b->poly_min_clients : 32u;
-      const bool pays = m.size() >= min_clients && T >= 2 * D;
+      // Classes of more than XLMF_NB8_MAX k-blocks (D > 112: float32 operands re-streamed every pass, xlp_mix_f32_stream_kernel) keep
+      // round 4's crossover -- 128 clients, 4.5 taps per branch: the only one a measurement of that kernel stands behind
+      const bool streamed = (D + 7u) / 8u > XLMF_NB8_MAX;
+      const size_t min_clients = b->poly_min_set ? b->poly_min_clients : (streamed ? 128u : 32u);
+      const bool pays = m.size() >= min_clients && (streamed ? 2 * T >= 9 * D : T >= 2 * D);
       if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
       PolyClass pc;
       Pending pd;
@@ -1352,7 +1357,20 @@ static int xl_batch_plan(xlating_batch *b) {
       // (scaled to the population the CUs are reserved for: option "expected_clients")
       load_wgs = xl_plan_load_wgs(ps * (double)nwg_res / (double)std::max(nwg, 1u), kmax);
     }
-    uint32_t want = ((b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0) ? xl_chain_reserve_per_xcd(nwg_res, load_wgs) : 0u;
+    // (the bands have edges where the reservation jumps: stay in the band of the previous plan until the load is two workgroups past one)
+    load_wgs = xl_chain_load_with_hysteresis(load_wgs, b->reserve_band);
+    b->reserve_band = xl_chain_band(load_wgs);
+    const bool side_plan = (b->gcap >= 2 || one_block_side) && (!b->poly.empty() || light || b->nco_side > 0) && b->nco_side != 0;
+    // (the no-reservation band and the rounds were measured on polyphase plans only; a direct-only plan -- whose side-stream chain needs
+    // the masked pair, see side_call -- keeps one CU per chain workgroup, up to half the chip)
+    uint32_t want = !side_plan ? 0u : (b->poly.empty() ? ((nwg_res + 7u) / 8u <= 16u ? (nwg_res + 7u) / 8u : 0u) : xl_chain_reserve_per_xcd(nwg_res, load_wgs));
+    // A wide two-half class (9 .. 14 k-blocks: xl_mixh2.hip) runs two workgroups per CU and launches M x column groups of them -- a
+    // multiple of 512 at every 512 clients: on the 240 CUs a reservation of 16 leaves, BASELINE config 5 at 1024 clients took a third,
+    // quarter-full round of workgroups (56 us per mix launch; the launch's own timeline: profiles/r06_mix_wide_timeline.txt) -- and its
+    // forward and inverse launches lose a sixteenth of the chip as well.  No reservation for such plans: the chain workgroups take CUs as
+    // the launches' tails free them (as in the 33..47 band of the rule).
+    for (const PolyClass &pc : b->poly)
+      if (pc.mix_kind == 1u && pc.nkb > XLP_NKB_4W) want = 0u;
     if (xl_exp_getenv("XL_EXP_NOMASK")) want = 0u;
     if (want > 0u && xl_exp_getenv("XL_EXP_ROUNDS1")) want = std::min(16u, (nwg_res + 7u) / 8u);  // (tuning: round 3's rule, one CU per chain workgroup)
     if (want > 0u && xl_exp_getenv("XL_EXP_RESERVE")) want = std::min(want, (uint32_t)atoi(xl_exp_getenv("XL_EXP_RESERVE")));  // (tuning: fewer CUs, more rounds)
@@ -2057,7 +2075,10 @@ extern "C" int xlating_batch_describe(xlating_batch *b, char *buf, size_t n) {
     if (pc.dmax) d += " offsets<=" + std::to_string(pc.dmax);
     d += pc.mix_kind == 3u ? " mix=mf32" : " mix=mfma";
     if (pc.M == 128u) {
-      const int k = b->inv_reg ? (int)b->inv_reg : pc.last_inv;
+      // (before the class's first launch: what the size rule picks for a call of the plan's full size -- gcap blocks of max_samples)
+      const uint32_t kq_full = (uint32_t)(((uint64_t)b->max_samples * b->gcap + pc.D - 1u) / pc.D) + 1u;
+      const int k = b->inv_reg ? (int)b->inv_reg
+                               : (pc.last_inv >= 0 ? pc.last_inv : (int)xlp_inverse_pick(pc.M, 0u, ((kq_full + pc.V - 1u) / pc.V) * pc.ncg * 4u));
       d += k == 6 ? " inv=cut32" : (k == 5 ? " inv=lanes8" : (k == 3 ? " inv=lds" : " inv=auto"));
     }
   }

@@ -21,6 +21,13 @@
 
 #include "xl_grid.h"
 
+// The kernels are hand-written for CDNA3/4 wave64 targets: inline `s_waitcnt lgkmcnt(0); s_barrier` LDS-only barriers (gfx9 wait-counter
+// encodings, in-order LDS), v_pk_*_f32 with op_sel, v_mfma_f32_32x32x16_f16 / 32x32x2_f32 operand maps, CU-masked streams of 8 XCDs.
+// Nothing here was written for, or tested on, another target: refuse it instead of mis-compiling quietly.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "sdr-server_amd kernels target gfx950 (MI355X; gfx942 builds for comparison only): build with --offload-arch=gfx950"
+#endif
+
 #define XL_NW_MAX 4      // waves (tiles) per workgroup: one per SIMD (5..7 measured slower: unbalanced SIMDs; 8 ties)
 #define XL_NW_DEFAULT 4
 #define XL_CT_MAX 12     // most clients per tile (register-tile height: 1, 2, 4, 8, 9, 10 or 12)

@@ -56,6 +56,23 @@ static inline uint32_t xl_chain_reserve_per_xcd(uint32_t chain_wgs, uint32_t loa
   return want > 16u ? 0u : want;
 }
 
+/* Which band of the rule above a load falls in: 0 = one CU per chain workgroup, 1 = none, 2 = rounds.  The rule is NOT monotonic in the
+ * client count (CUs up to 32 workgroups, none for 33..47, rounds from 48) and re-creating the CU-masked stream pair costs ~25 ms plus a
+ * full synchronisation, so the plan keeps the band it is in until the load has moved XL_BAND_HYST workgroups past an edge: a population
+ * hovering at 2048 / 2049 or 3008 / 3009 clients then stays where it is instead of destroying and re-creating the streams at every
+ * crossing.  `last_band` < 0: no history.  Returns the load to evaluate the rule at (the load itself, or the nearest load of the band
+ * the plan stays in). */
+#define XL_BAND_HYST 2u
+static inline int xl_chain_band(uint32_t load_wgs) { return xl_chain_rounds(load_wgs) > 1u ? 2 : (load_wgs > 32u ? 1 : 0); }
+static inline uint32_t xl_chain_load_with_hysteresis(uint32_t load_wgs, int last_band) {
+  if (last_band < 0 || xl_chain_band(load_wgs) == last_band) return load_wgs;
+  for (uint32_t d = 1u; d <= XL_BAND_HYST; ++d) {
+    if (load_wgs >= d && xl_chain_band(load_wgs - d) == last_band) return load_wgs - d;
+    if (xl_chain_band(load_wgs + d) == last_band) return load_wgs + d;
+  }
+  return load_wgs;
+}
+
 /* The load of a plan, for the rule above.  What decides between the bands is the ratio of the launches' time to the chain kernel's,
  * and a client of another shape brings another ratio: BASELINE config 5 (cf32 10 Msps, D = 100: 1311 recurrence steps per block
  * instead of 3121, a float32 mix of 100 branches) has 2.2 x the default's, and indeed does better WITHOUT reserved CUs from 1024

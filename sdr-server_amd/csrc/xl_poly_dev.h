@@ -137,6 +137,24 @@ typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef float v16f32 __attribute__((ext_vector_type(16)));
 
 // v * scale as two halves; (lo, hi) of the returned pairs: first terms, second terms
+// Workgroup barrier for LDS hand-offs only: this wave's LDS operations are done (lgkmcnt), everybody arrives.  __syncthreads() also
+// fences global memory, which on this target is `s_waitcnt vmcnt(0)`: a wait for every load and store the wave has in flight.
+#ifdef XLP_EXP_SYNCTHREADS  // (A/B builds only, tools/experiments/build_variant.sh: the barrier of rounds 3-5)
+XL_DEV void xlp_lds_barrier() { __syncthreads(); }
+#else
+XL_DEV void xlp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
+// Two-half mix of a cf32 stream: the power-of-two scale of a segment's rows from the float bits of its largest spectrum component
+// (XlpArgs::segmax): 2^(14 - e), e = floor(log2 max) -- every scaled component < 2^15 --, and what undoes it.
+XL_DEV uint32_t xlp_seg_exp(const uint32_t maxbits) {  // biased exponent of the segment's largest component, kept where both powers are normal
+  const uint32_t ex = maxbits >> 23;
+  return ex < 27u ? 27u : (ex > 254u ? 254u : ex);
+}
+XL_DEV float xlp_seg_scale(const uint32_t maxbits) { return __uint_as_float((268u - xlp_seg_exp(maxbits)) << 23); }  // 2^(14 - e)
+XL_DEV float xlp_seg_unscale(const uint32_t maxbits) { return __uint_as_float((xlp_seg_exp(maxbits) - 14u) << 23); }  // 2^(e - 14)
+
+
 XL_DEV void xlp_split_h(const float v, _Float16 &h1, _Float16 &h2) {
   h1 = (_Float16)v;
   h2 = (_Float16)(v - (float)h1);

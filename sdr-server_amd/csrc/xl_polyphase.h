@@ -40,6 +40,7 @@
                              // segment's largest component (XlpArgs::segmax, found by the forward launch) under 2^15 -- a row scale of
                              // the per-bin matrix product, undone exactly in the mix launch's epilogue (xlp_seg_scale)
 #define XLP_H_RMAX 8192.0f   // ... and a column's spectra by the power of two that brings their bound max_b sum_a |r_b[a]| under this
+#define XLP_SEGMAX_STRIDE 32u  // XlpArgs::segmax: one entry per 128-byte line (the forward launch's atomics spread over the L2 channels)
 #define XLP_BSTEP 2u   // the branch count is padded to a multiple of this in the shared-spectrum image (rows D .. Dpad - 1: zeros)
 
 // One client column of a class: 16 bytes, one load.
@@ -78,7 +79,7 @@ struct XlpArgs {
   uint32_t mix_pp;     // passes per workgroup of the mix launch (0 = the launcher's default)
   // two-half mix of a cf32 stream: per segment the largest |component| of its shared spectra (float bits; all branches, all bins),
   // gathered by the forward launch with one atomicMax per (segment, branch).  Two buffers of seg_cap entries: a call uses buffer
-  // seg_par, and its forward launch clears the other one for the next call.  nullptr: integer formats (constant scale XLP_H_XSCALE)
+  // seg_par, and its forward launch clears the other one for the next call; entry i at word i * XLP_SEGMAX_STRIDE.  nullptr: integer formats (constant scale XLP_H_XSCALE)
   uint32_t *segmax;
   uint32_t seg_par, seg_cap;
   unsigned long long *trace;  // tuning only: [0..2] min start / max end of the work waves, [8 + 4 i ..] per NCO wave: start, loaded, end
@@ -123,6 +124,8 @@ static inline size_t xlp_rh_bytes_per_group(uint32_t M, uint32_t nkb) { return (
 hipError_t xlp_launch_tables_f(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, uint32_t nlist, uint32_t T, uint32_t D,
                                uint32_t A, uint32_t M, uint32_t nb8, void *Rf, hipStream_t s);
 hipError_t xlp_launch_mix_f32(const XlpArgs &a, hipStream_t s);
+// (xl_mixh2.hip: the two-half mix of 9 .. XLP_NKB_MAX k-blocks; called by xlp_launch_mix with the checked arguments and the launch's grid)
+void xlp_mix_wide_launch(const XlpArgs &a, const dim3 grid, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);

@@ -34,6 +34,7 @@ template <int M>
 __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpArgs a) {
   constexpr uint32_t L = M / 4, NT = XLP_SEG * L;
   __shared__ v2f lds[XLP_SEG][XLP_ROW(M)];
+  __shared__ uint32_t tmax[XLP_SEG];  // (cf32 streams on the two-half mix: float bits of the largest |component| of each transform)
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a);
     return;
@@ -63,6 +64,13 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
   // branch sample n of segment s = stream sample base + (s V + n) D + b   (base: first tap of shared point 0)
   const uint32_t first = a.base + s * a.V * a.D + b;
   const uint32_t end = a.n0 + a.n1;
+  // (two-half mix of a cf32 stream: what the maximum of segment pass * 16 + j stands at, read by thread j < 16 ahead of the transforms
+  // -- stale is fine: one entry per 128-byte line (XLP_SEGMAX_STRIDE), and a global atomic only where this workgroup raises what it saw:
+  // a few of the D workgroups of a segment, not all -- D x nseg atomics on six cache lines cost the launch 1.6 us per block)
+  uint32_t *const smax = (a.segmax != nullptr && j < XLP_SEG && pass * XLP_SEG + j < a.nseg)
+                             ? a.segmax + ((size_t)a.seg_par * a.seg_cap + pass * XLP_SEG + j) * XLP_SEGMAX_STRIDE : nullptr;
+  const uint32_t seen = smax != nullptr ? __hip_atomic_load(smax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  if (l == 0u) tmax[h] = 0u;
   v2f u[1][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -79,20 +87,20 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
   xlp_dft<-1, 1, M>(u, bufs, tw, l, rs0);
   if (a.segmax != nullptr) {
     // cf32 stream on the two-half mix: the segment's largest spectrum component, over all branches -- this transform's share of it
-    // (NaNs drop out of fmaxf: a stream that carries them has no parity to keep)
+    // (NaNs drop out of fmaxf: a stream that carries them has no parity to keep), gathered with one LDS atomic per lane (the lanes of a
+    // transform sit in one wave, whose LDS operations execute in order: the clear above needs no barrier)
     float mx = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fmaxf(fabsf(u[0][r].x), fabsf(u[0][r].y)));
-#pragma unroll
-    for (uint32_t o = L / 2u; o > 0u; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, (int)o));
-    if (l == 0u && live) atomicMax(a.segmax + (size_t)a.seg_par * a.seg_cap + s, __float_as_uint(mx));
-    if (bid == 0u)  // the next call's buffer (last read by the previous call's mix launch)
-      for (uint32_t i = j; i < a.seg_cap; i += NT) a.segmax[(size_t)(a.seg_par ^ 1u) * a.seg_cap + i] = 0u;
+    atomicMax(&tmax[h], __float_as_uint(mx));
   }
   // the transform's row, natural order (its own scratch: the LDS operations of a wave execute in order)
 #pragma unroll
   for (int r = 0; r < 4; ++r) lds[h][l + L * r] = u[0][r];
   __syncthreads();
+  if (smax != nullptr && tmax[j] > seen) atomicMax(smax, tmax[j]);
+  if (a.segmax != nullptr && bid == 0u)  // the next call's buffer (last read by the previous call's mix launch)
+    for (uint32_t i = j; i < a.seg_cap; i += NT) a.segmax[((size_t)(a.seg_par ^ 1u) * a.seg_cap + i) * XLP_SEGMAX_STRIDE] = 0u;
   static_assert(XLP_XS == 16u && XLP_SEG <= XLP_XS, "image rows of 16 complex = 8 x 16 bytes");
   v4f *__restrict__ X = reinterpret_cast<v4f *>(a.X) + ((size_t)pass * a.Dpad + b) * M * (XLP_XS / 2u);
   for (uint32_t i = j; i < (uint32_t)M * (XLP_XS / 2u); i += NT) {
@@ -145,19 +153,14 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
 // of the sums exactly: the forward launch leaves every segment's largest spectrum component in XlpArgs::segmax, the staging multiplies
 // the segment's rows by 2^(14 - floor(log2 max)) (every scaled component < 2^15), and the epilogue multiplies the segment's sums by the
 // inverse.  The float32 matrix instruction (xl_mixf32.hip) remains for D > 112 and as the exact-float32 option (mix_kernel = 3).
-XL_DEV uint32_t xlp_seg_exp(const uint32_t maxbits) {  // biased exponent of the segment's largest component, kept where both powers are normal
-  const uint32_t ex = maxbits >> 23;
-  return ex < 27u ? 27u : (ex > 254u ? 254u : ex);
-}
-XL_DEV float xlp_seg_scale(const uint32_t maxbits) { return __uint_as_float((268u - xlp_seg_exp(maxbits)) << 23); }  // 2^(14 - e)
-XL_DEV float xlp_seg_unscale(const uint32_t maxbits) { return __uint_as_float((xlp_seg_exp(maxbits) - 14u) << 23); }  // 2^(e - 14)
-
-// waves per SIMD: 4 up to XLP_NKB_4W k-blocks (124-128 VGPRs; with the segment scales only up to 4 k-blocks, then 3), 2 above
-constexpr int xlp_mix_waves(const int nkb, const bool seg) { return nkb > (int)XLP_NKB_4W ? 2 : (seg && nkb > 4 ? 3 : 4); }
+// waves per SIMD: 4 up to 6 k-blocks (122-126 VGPRs; with the segment scales up to 4), 3 up to XLP_NKB_4W = 8 (no spills: at 4 waves
+// 7 / 8 k-blocks spilled 10 / 42 registers); wider classes: xlp_mix_mfma_wide_kernel (xl_mixh2.hip), 2 waves
+constexpr int xlp_mix_waves(const int nkb, const bool seg) { return nkb > (seg ? 4 : 6) ? 3 : 4; }
 
 template <int NKB, bool SEG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(xlp_mix_waves(NKB, SEG), xlp_mix_waves(NKB, SEG))))
 void xlp_mix_mfma_kernel(const XlpArgs a) {
+  static_assert(NKB <= (int)XLP_NKB_4W, "wider classes: xl_mixh2.hip");
   // A operands of one pass: [term][k-block][lane][8 halves]; two buffers (one barrier per pass: a buffer is rewritten two
   // barriers after it was read)
   __shared__ uint4 xs[2][2][NKB][64];
@@ -172,19 +175,6 @@ void xlp_mix_mfma_kernel(const XlpArgs a) {
   xlp_mix_place(bid, M, runs, m, cg, run);
   const uint32_t p0 = run * pp, p1 = p0 + pp < a.mix_passes ? p0 + pp : a.mix_passes;
   if (p0 >= p1) return;
-  // ---- B operands of this wave: 2 NKB runs of 1 KB
-  const uint4 *__restrict__ Rp = reinterpret_cast<const uint4 *>(a.Rh);
-  v8h r1[NKB], r2[NKB];
-#pragma unroll
-  for (int j = 0; j < NKB; ++j) {
-#ifdef XLP_MIX_EXP_NOOPERANDS
-    r1[j] = __builtin_bit_cast(v8h, (uint4){lane, tid, (uint32_t)j, m});
-    r2[j] = __builtin_bit_cast(v8h, (uint4){m, lane, tid, (uint32_t)j});
-#else
-    r1[j] = __builtin_bit_cast(v8h, Rp[xlm_rh_slot(cg, M, m, w, 0u, NKB, (uint32_t)j, lane)]);
-    r2[j] = __builtin_bit_cast(v8h, Rp[xlm_rh_slot(cg, M, m, w, 1u, NKB, (uint32_t)j, lane)]);
-#endif
-  }
   const uint32_t h = lane >> 5, c = lane & 31u;
   const float cs_ = a.cscale[cg * XLP_COLS + w * 32u + c];
   // ---- staging role of this lane: branch 8 j + bb of k-block j = w + 4 round, segments 2 sp, 2 sp + 1 of the pass
@@ -194,9 +184,9 @@ void xlp_mix_mfma_kernel(const XlpArgs a) {
   const size_t xrow = (size_t)M * (XLP_XS / 2u);  // v4f per branch row
   v4f g[ROUNDS];
   uint32_t smx[2] = {0u, 0u};  // SEG: the largest components of this lane's two segments of the requested pass
-  const uint32_t *__restrict__ segmax = SEG ? a.segmax + (size_t)a.seg_par * a.seg_cap + 2u * sp : nullptr;
+  const uint32_t *__restrict__ segmax = SEG ? a.segmax + ((size_t)a.seg_par * a.seg_cap + 2u * sp) * XLP_SEGMAX_STRIDE : nullptr;
   auto request = [&](const uint32_t pass) __attribute__((always_inline)) {
-    if (SEG) smx[0] = segmax[pass * XLP_SEG], smx[1] = segmax[pass * XLP_SEG + 1u];
+    if (SEG) smx[0] = segmax[(size_t)pass * XLP_SEG * XLP_SEGMAX_STRIDE], smx[1] = segmax[((size_t)pass * XLP_SEG + 1u) * XLP_SEGMAX_STRIDE];
 #pragma unroll
     for (int q = 0; q < ROUNDS; ++q) {
       const uint32_t b = 8u * xlm_stage_kblock(w, (uint32_t)q) + bb;
@@ -238,10 +228,26 @@ void xlp_mix_mfma_kernel(const XlpArgs a) {
   // "all") then finds nothing younger than the stores of pass p - 1, a whole pass old.  Waiting with pass p's stores just
   // issued made every pass sit out a write latency.
   request(p0);
+  // ---- B operands of this wave: 2 NKB runs of 1 KB -- requested BEHIND the first pass's rows, so that staging those rows is not a wait
+  // for the operands (loads return in order), and the first pass's products start as the operands arrive (round 6; as xlp_mix_f32_kernel)
+  const uint4 *__restrict__ Rp = reinterpret_cast<const uint4 *>(a.Rh);
+  v8h r1[NKB], r2[NKB];
+#pragma unroll
+  for (int j = 0; j < NKB; ++j) {
+#ifdef XLP_MIX_EXP_NOOPERANDS
+    r1[j] = __builtin_bit_cast(v8h, (uint4){lane, tid, (uint32_t)j, m});
+    r2[j] = __builtin_bit_cast(v8h, (uint4){m, lane, tid, (uint32_t)j});
+#else
+    r1[j] = __builtin_bit_cast(v8h, Rp[xlm_rh_slot(cg, M, m, w, 0u, NKB, (uint32_t)j, lane)]);
+    r2[j] = __builtin_bit_cast(v8h, Rp[xlm_rh_slot(cg, M, m, w, 1u, NKB, (uint32_t)j, lane)]);
+#endif
+  }
   stage(0u);
   if (p0 + 1u < p1) request(p0 + 1u);
-  __syncthreads();
-  for (uint32_t pass = p0; pass < p1; ++pass) {
+  // (LDS hand-offs only: __syncthreads() would also wait for every load and store in flight -- the operands, the next rows, the pass's
+  // stores)
+  xlp_lds_barrier();
+  auto products = [&](const uint32_t pass) __attribute__((always_inline)) {
     const uint32_t buf = (pass - p0) & 1u;
     v16f32 hi, lo;
 #pragma unroll
@@ -288,8 +294,15 @@ void xlp_mix_mfma_kernel(const XlpArgs a) {
 #endif
       }
     }
-    __syncthreads();  // the other buffer is staged; everybody is done with this one
-  }
+    xlp_lds_barrier();  // the other buffer is staged; everybody is done with this one
+  };
+  // The first pass's products run as the operands arrive (the compiler's waits before product j leave the later operands in flight);
+  // for the other passes the operands are waited for HERE, once -- left to itself the compiler puts those waits into the pass loop,
+  // where they would also wait for the rows the previous pass has just requested.
+  products(p0);
+#pragma unroll
+  for (int j = 0; j < NKB; ++j) asm volatile("" : "+v"(r1[j]), "+v"(r2[j]));
+  for (uint32_t pass = p0 + 1u; pass < p1; ++pass) products(pass);
   xlp_trace_work(a, t_begin);
 }
 
@@ -517,12 +530,7 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
     case 6: xlp_launch_mix_mfma_n<6>(a, grid, s); break;
     case 7: xlp_launch_mix_mfma_n<7>(a, grid, s); break;
     case 8: xlp_launch_mix_mfma_n<8>(a, grid, s); break;
-    case 9: xlp_launch_mix_mfma_n<9>(a, grid, s); break;
-    case 10: xlp_launch_mix_mfma_n<10>(a, grid, s); break;
-    case 11: xlp_launch_mix_mfma_n<11>(a, grid, s); break;
-    case 12: xlp_launch_mix_mfma_n<12>(a, grid, s); break;
-    case 13: xlp_launch_mix_mfma_n<13>(a, grid, s); break;
-    default: xlp_launch_mix_mfma_n<14>(a, grid, s); break;
+    default: xlp_mix_wide_launch(a, grid, s); break;  // 9 .. 14 k-blocks: xl_mixh2.hip
   }
   return hipGetLastError();
 }

@@ -16,6 +16,8 @@ unsigned reserve2(unsigned wgs, unsigned load_wgs) { return xl_chain_reserve_per
 unsigned launch_ps(unsigned M, unsigned K, unsigned V, unsigned Dpad, unsigned mix, unsigned G) { return xl_client_launch_ps(M, K, V, Dpad, mix, G); }
 unsigned chain_ns(unsigned K) { return xl_chain_block_ns(K); }
 unsigned load_wgs(double ps_sum, unsigned kmax) { return xl_plan_load_wgs(ps_sum, kmax); }
+int band(unsigned load_wgs) { return xl_chain_band(load_wgs); }
+unsigned hyst(unsigned load_wgs, int last_band) { return xl_chain_load_with_hysteresis(load_wgs, last_band); }
 """
 
 
@@ -83,3 +85,26 @@ def test_chain_reservation_follows_the_plans_load(tmp_path):
     # a plan whose launches are short against the recurrence (few taps, small decimation) keeps one CU per chain workgroup
     light = lib.launch_ps(128, 3121, 126, 8, 1, 8)
     assert lib.reserve2(16, lib.load_wgs(1024.0 * light, 3121)) == 2
+
+
+def test_reservation_bands_have_hysteresis(tmp_path):
+    """The rule is not monotonic (CUs up to 32 chain workgroups, none for 33..47, rounds from 48) and a change of the reservation
+    re-creates the CU-masked stream pair (~25 ms + a full synchronisation): a plan stays in the band of the previous plan until its load
+    is XL_BAND_HYST = 2 workgroups past an edge, so that a population hovering at 2048 / 2049 or 3008 / 3009 clients keeps its streams."""
+    lib = _lib(tmp_path)
+    assert [lib.band(n) for n in (1, 32, 33, 47, 48, 200)] == [0, 0, 1, 1, 2, 2]
+    for n in range(1, 300):
+        assert lib.hyst(n, -1) == n and lib.hyst(n, lib.band(n)) == n  # no history / no edge crossed: the load itself
+    # hovering at an edge: the band of the previous plan is kept
+    band = lib.band(32)
+    seen = []
+    for clients in (2048, 2049, 2048, 2112, 2049, 2176, 2048):  # 32, 33, 32, 33, 33, 34, 32 workgroups
+        load = lib.hyst(-(-clients // 64), band)
+        band = lib.band(load)
+        seen.append((band, lib.reserve2(-(-clients // 64), load)))
+    assert [b for b, _ in seen] == [0] * 7 and all(r >= 4 for _, r in seen), seen
+    # two workgroups past the edge: the band changes, and the way back has the same margin
+    assert lib.band(lib.hyst(35, 0)) == 1 and lib.band(lib.hyst(34, 0)) == 0
+    assert lib.band(lib.hyst(31, 1)) == 1 and lib.band(lib.hyst(30, 1)) == 0
+    assert lib.band(lib.hyst(48, 1)) == 1 and lib.band(lib.hyst(49, 1)) == 1 and lib.band(lib.hyst(50, 1)) == 2
+    assert lib.band(lib.hyst(47, 2)) == 2 and lib.band(lib.hyst(46, 2)) == 2 and lib.band(lib.hyst(45, 2)) == 1

@@ -1,9 +1,12 @@
 #!/bin/bash
-# two-half mix for cf32 / D <= 112 classes: parity subset + config 5 timing, default (two-half) against mix_kernel = 3 (float32 operands)
-OUT=$1
-timeout 1500 python -m pytest tests/test_batch_gpu.py -m gpu -q -x --timeout=900 -k "config5 or adversarial or forced_other_shapes or size_rule or forced_other_formats or plain_process or other_input_formats" > $OUT/pytest_mix.txt 2>&1
+# wide two-half mix (xl_mixh2.hip): parity subset + config 5 timing: the shipped schedule against variants of it and against mix_kernel = 3
+OUT=$1; V=sdr-server_amd/build/variants
+timeout 1500 python -m pytest tests/test_batch_gpu.py -m gpu -q -x --timeout=900 -k "config5 or adversarial or forced_other_shapes or size_rule or forced_other_formats or plain_process or other_input_formats or other_branch_counts or tap_scales or group_of_blocks_polyphase" > $OUT/pytest_mix.txt 2>&1
 tail -12 $OUT/pytest_mix.txt
 for rep in 1 2; do
-  timeout 200 python tools/group_sweep.py --shape config5 --clients 256,1024,2048 --groups 8 --modes optimized --poly3 --blocks 320 2>&1 | grep optimized | sed "s/^/two-half /"
-  timeout 200 python tools/group_sweep.py --shape config5 --clients 256,1024,2048 --groups 8 --modes optimized --poly3 --blocks 320 --opt mix_kernel=3 2>&1 | grep optimized | sed "s/^/float32  /"
+  timeout 200 python tools/group_sweep.py --shape config5 --clients 256,1024,2048 --groups 8 --modes optimized --poly3 --blocks 320 2>&1 | grep optimized | sed "s/^/two-half      /"
+  for v in NOSCHED NOINTERLEAVE PF2 PF3 PF6; do
+    XL_LIBRARY_PATH=$V/libmixh2_$v.so timeout 200 python tools/group_sweep.py --shape config5 --clients 1024,2048 --groups 8 --modes optimized --poly3 --blocks 320 2>&1 | grep optimized | sed "s/^/$(printf '%-14s' $v)/"
+  done
+  timeout 200 python tools/group_sweep.py --shape config5 --clients 1024 --groups 8 --modes optimized --poly3 --blocks 320 --opt mix_kernel=3 2>&1 | grep optimized | sed "s/^/float32       /"
 done | tee $OUT/config5_mix_ab.txt
