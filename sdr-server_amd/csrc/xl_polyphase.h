@@ -124,8 +124,8 @@ static inline size_t xlp_rh_bytes_per_group(uint32_t M, uint32_t nkb) { return (
 hipError_t xlp_launch_tables_f(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, uint32_t nlist, uint32_t T, uint32_t D,
                                uint32_t A, uint32_t M, uint32_t nb8, void *Rf, hipStream_t s);
 hipError_t xlp_launch_mix_f32(const XlpArgs &a, hipStream_t s);
-// (xl_mixh2.hip: the two-half mix of 9 .. XLP_NKB_MAX k-blocks; called by xlp_launch_mix with the checked arguments and the launch's grid)
-void xlp_mix_wide_launch(const XlpArgs &a, const dim3 grid, hipStream_t s);
+// (xl_mixh2.hip: the two-half mix of 9 .. XLP_NKB_MAX k-blocks; called by xlp_launch_mix with the checked arguments)
+void xlp_mix_wide_launch(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_mix(const XlpArgs &a, hipStream_t s);
 hipError_t xlp_launch_inverse(const XlpArgs &a, hipStream_t s, hipEvent_t done);

@@ -92,13 +92,21 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
     float mx = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fmaxf(fabsf(u[0][r].x), fabsf(u[0][r].y)));
+#ifdef XLP_EXP_FWD_SHUFFLE  // (experiment: the first form -- shuffles, one global atomic per transform)
+#pragma unroll
+    for (uint32_t o = L / 2u; o > 0u; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, (int)o));
+    if (l == 0u && live) atomicMax(a.segmax + ((size_t)a.seg_par * a.seg_cap + s) * XLP_SEGMAX_STRIDE, __float_as_uint(mx));
+#else
     atomicMax(&tmax[h], __float_as_uint(mx));
+#endif
   }
   // the transform's row, natural order (its own scratch: the LDS operations of a wave execute in order)
 #pragma unroll
   for (int r = 0; r < 4; ++r) lds[h][l + L * r] = u[0][r];
   __syncthreads();
+#ifndef XLP_EXP_FWD_SHUFFLE
   if (smax != nullptr && tmax[j] > seen) atomicMax(smax, tmax[j]);
+#endif
   if (a.segmax != nullptr && bid == 0u)  // the next call's buffer (last read by the previous call's mix launch)
     for (uint32_t i = j; i < a.seg_cap; i += NT) a.segmax[((size_t)(a.seg_par ^ 1u) * a.seg_cap + i) * XLP_SEGMAX_STRIDE] = 0u;
   static_assert(XLP_XS == 16u && XLP_SEG <= XLP_XS, "image rows of 16 complex = 8 x 16 bytes");
@@ -264,6 +272,11 @@ void xlp_mix_mfma_kernel(const XlpArgs a) {
       lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r2[j], lo, 0, 0, 0);
 #endif
     }
+    // (the staging below begins by overwriting registers the pass's last matrix instructions read; with several waves sharing a SIMD's
+    // matrix pipe an issued matrix instruction has not necessarily read its operands yet, and nothing interlocks a vector write under it
+    // -- measured on the wide kernel, xl_mixh2.hip "OPERAND HAZARD"; never observed here in three rounds of every-client checks, and
+    // 16 wait states per pass keep it that way)
+    asm volatile("s_nop 15" ::: "memory");
 #ifndef XLP_MIX_EXP_NOSTAGE
     if (pass + 1u < p1) stage(buf ^ 1u);
     if (pass + 2u < p1) request(pass + 2u);
@@ -530,7 +543,7 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
     case 6: xlp_launch_mix_mfma_n<6>(a, grid, s); break;
     case 7: xlp_launch_mix_mfma_n<7>(a, grid, s); break;
     case 8: xlp_launch_mix_mfma_n<8>(a, grid, s); break;
-    default: xlp_mix_wide_launch(a, grid, s); break;  // 9 .. 14 k-blocks: xl_mixh2.hip
+    default: xlp_mix_wide_launch(a, s); break;  // 9 .. 14 k-blocks: xl_mixh2.hip
   }
   return hipGetLastError();
 }

@@ -22,3 +22,4 @@ def test_matrix_core_mix_layout_against_plain_complex_sums(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "matrix-core mix layout: ok" in r.stdout
+

@@ -19,6 +19,11 @@ sec = ~first
 if sec.any():
     print(f"later rounds: {sec.sum()} waves; start med {np.median(st[sec]):.1f} (p10 {np.percentile(st[sec],10):.1f} p90 {np.percentile(st[sec],90):.1f}); first pass takes med {np.median((p1-st)[sec]):.1f}; whole wave med {np.median((en-st)[sec]):.1f}")
 print(f"all: first pass takes med {np.median(p1-st):.1f}; remaining passes take med {np.median(en-p1):.1f} us")
+sg = (w[:, 2].astype(np.int64) - t0) * 0.01
+if (sg > 0).all() and (sg < en.max() + 1).all():  # (wide kernel, k-block-major form: slot 2 = A operands staged, slot 3 = products over)
+    print(f"phases per wave (us): staging med {np.median(sg-st):.1f} p90 {np.percentile(sg-st,90):.1f} | products med {np.median(p1-sg):.1f} p90 {np.percentile(p1-sg,90):.1f} | stores med {np.median(en-p1):.1f} p90 {np.percentile(en-p1,90):.1f}")
+    print(f"  first round only: staging {np.median((sg-st)[first]):.1f} products {np.median((p1-sg)[first]):.1f} stores {np.median((en-p1)[first]):.1f}")
+    sys.exit(0)
 hw = w[:, 2]
 cu = [((int(v) >> 32) & 7, ((int(v) & 0xFFFFFFFF) >> 13) & 7, ((int(v) & 0xFFFFFFFF) >> 12) & 1, ((int(v) & 0xFFFFFFFF) >> 8) & 15) for v in hw]
 from collections import Counter
