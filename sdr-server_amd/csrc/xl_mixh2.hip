@@ -7,7 +7,12 @@
 // 32 columns' branch spectra of one bin, two half terms: 8 NKB registers) stay in registers for all passes of the call; at 13 k-blocks
 // that is 104 registers, so the kernel lives on a TWO-waves-per-SIMD budget, and with two waves nothing hides a wave's own latencies:
 // measured on the first form of this kernel (xlp_mix_mfma_kernel<13>: profiles/r06_mix_halves_cf32.txt) the launch's time was the SUM of
-// its phases -- operand arrival 16 us, matrix instructions 16, staging 14, the rest 21 per call.  Hence:
+// its phases -- operand arrival 16 us, matrix instructions 16, staging 14, the rest 21 per call.  Hence the points below.  What they do
+// NOT change is what bounds the launch (profiles/r06_mix_wide_timeline.txt): every workgroup of a round pulls its 104 KB of operands at
+// once, at the ~11 bytes per cycle a CU takes in, with idle matrix cores (10 of a workgroup's 25 us), then runs its passes with an idle
+// memory system.  A second form that streams the operands under the products of all passes (k-blocks outermost) was built, was no
+// faster (the intake per workgroup is the same) and produced wrong sums in a few workgroups per launch for a reason that was not found:
+// tools/experiments/mix_wide_kmajor/, profiles/r06_mix_wide_kmajor_wrong_sums.txt.  This form passes the same stress.
 //   * the two LDS buffers of staged A operands are two distinct arrays and the pass loop is unrolled by two, so that the compiler knows
 //     that the reads of one pass and the staging writes for the next never alias, and may interleave them;
 //   * a pass is ONE basic block -- no per-lane or per-round branch: rows beyond the class's branches are loaded from a clamped address and

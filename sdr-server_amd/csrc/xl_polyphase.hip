@@ -272,11 +272,6 @@ void xlp_mix_mfma_kernel(const XlpArgs a) {
       lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r2[j], lo, 0, 0, 0);
 #endif
     }
-    // (the staging below begins by overwriting registers the pass's last matrix instructions read; with several waves sharing a SIMD's
-    // matrix pipe an issued matrix instruction has not necessarily read its operands yet, and nothing interlocks a vector write under it
-    // -- measured on the wide kernel, xl_mixh2.hip "OPERAND HAZARD"; never observed here in three rounds of every-client checks, and
-    // 16 wait states per pass keep it that way)
-    asm volatile("s_nop 15" ::: "memory");
 #ifndef XLP_MIX_EXP_NOSTAGE
     if (pass + 1u < p1) stage(buf ^ 1u);
     if (pass + 2u < p1) request(pass + 2u);
