@@ -69,11 +69,13 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  *                       whenever the shape allows: which classes take the polyphase overlap-save path in XL_MODE_OPTIMIZED
  *   "polyphase_m"       0 by the size rule, 128, 256: its transform length
  *   "mix_kernel"        polyphase classes: the mix launch (spectra x branch spectra, summed over the branches) runs on the matrix
- *                       cores.  1 (default): classes of an integer input format with decimation <= 64 carry every float32 operand as
- *                       two halves (three v_mfma_f32_32x32x16_f16 per 8 branches, FP32 accumulation; as accurate as the float32 FMA
- *                       chain), every other class (cf32 input, decimation > 64) multiplies float32 operands (v_mfma_f32_32x32x2_f32:
- *                       exactly the float32 FMA chain, nothing split or scaled); 3: float32 operands for EVERY class -- the
- *                       all-float32 arithmetic of the path, ~40 % slower in the mix launch.  Same 1e-5 bar in both cases
+ *                       cores.  1 (default): every float32 operand is carried as two halves (three v_mfma_f32_32x32x16_f16 per 8
+ *                       branches, FP32 accumulation; as accurate as the float32 FMA chain) after a power-of-two scale -- per column for
+ *                       the branch spectra; for the shared spectra a constant where the input format bounds them (cu8 / cs8 / cs16)
+ *                       and, for cf32 streams, one per SEGMENT from the segment's largest spectrum value (a row scale of the per-bin
+ *                       product, undone exactly) -- for classes of up to 112 branches (decimation <= 112); larger decimations
+ *                       multiply float32 operands (v_mfma_f32_32x32x2_f32: exactly the float32 FMA chain).  3: float32 operands for
+ *                       EVERY class -- the all-float32 arithmetic of the path, ~40 % slower in the mix launch.  Same 1e-5 bar
  *   "inverse_kernel"    128-point polyphase classes: the inverse launch's transform -- in the registers of EIGHT lanes per client
  *                       column as 16 x 8 points with one exchange through LDS (5: xl_inv8.hip), in the registers of FOUR lanes per
  *                       column as 32 x 4 points -- whole-line loads, 256-byte store runs (6: xl_inv32.hip) --, or staged in LDS on
@@ -93,7 +95,9 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
  * Returns 0, -ENOENT (unknown name), -EINVAL.  The plan is rebuilt at the next call.
  * (Launch-shaping knobs of the tuning sessions -- tile heights, riders, slices, passes per workgroup, calls per chain launch, the
  * size rule's client threshold -- are not options: they are read from XL_EXP_* environment variables when an engine is created,
- * csrc/xl_batch.cpp; rounds 1-4's measured-and-lost kernel variants are gone from the library: tools/experiments/retired/.) */
+ * csrc/xl_batch.cpp, and ONLY when the process also sets XL_TESTING=1 (tests and tools do) or in -DXL_TUNING builds: a plain process
+ * ignores every XL_EXP_* variable and logs one "<4>" line if any is set; rounds 1-4's measured-and-lost kernel variants are gone from
+ * the library: tools/experiments/retired/.) */
 int xlating_batch_set_option(xlating_batch *batch, const char *name, long value);
 
 /* Add a client whose stream starts with the NEXT block (like dsp_worker_start, dsp_worker.c:90-108).
