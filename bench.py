@@ -603,10 +603,15 @@ def config5_entry(m5, pmc5):
             pk[kname] = {"ms": ms_k, "ms_hip_events": ms_ev, "hbm_bytes": (pkk or {}).get("hbm_bytes_per_call"),
                          "frac_hbm": round(pkk["hbm_bytes_per_call"] / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pkk and ms_k else None}
             if kname.startswith("xlp_mix") and ms_k:
-                # flops the launch EXECUTES on the matrix cores: one v_mfma_f32_32x32x2_f32 (4096 flop) per (branch, bin, 32 columns, pass)
                 passes = -(-nseg // 16)
-                pk[kname]["frac_matrix_f32"] = round(4096.0 * C5_D * M * -(-n // 32) * passes / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
-                pk[kname]["frac_fp32_useful"] = round(8.0 * n * nseg * M * C5_D / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
+                if "mfma" in kname:
+                    # two-half mix: half-precision flops the launch EXECUTES = 3 products x (32 x 32 x 16 x 2) per k-block of 8 branches, per
+                    # (bin, 32 columns, pass of 16 segments)
+                    pk[kname]["frac_mfma_f16"] = round(3.0 * 32 * 32 * 16 * 2 * -(-C5_D // 8) * M * -(-n // 32) * passes / (ms_k * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
+                else:
+                    # float32 mix: one v_mfma_f32_32x32x2_f32 (4096 flop) per (branch, bin, 32 columns, pass)
+                    pk[kname]["frac_matrix_f32"] = round(4096.0 * C5_D * M * -(-n // 32) * passes / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
+                    pk[kname]["frac_fp32_useful"] = round(8.0 * n * nseg * M * C5_D / (ms_k * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
         rl["per_kernel"] = pk
     else:
         rl["traffic"] = None

@@ -58,7 +58,23 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
   }
   const uint32_t h = j / L, l = j % L;  // transform (= segment of the pass) of this lane, lane within it
   const XlpTw tw = xlp_twiddles<-1, M>(reinterpret_cast<const v2f *>(a.W), l);
-  const uint32_t pass = bid / a.D, b = bid - pass * a.D;
+  // Which (pass, branch): branch-major over the XCDs.  Workgroup bid runs on XCD bid % 8; the transform workgroups of XCD x are given a
+  // CONTIGUOUS range of the branch-major list (branch, pass), so an XCD works on ~D/8 neighbouring branches -- with wide samples (cf32:
+  // 16 per 128-byte line, D = 100 branches per period) it then pulls a quarter of the block's lines through its L2 instead of all of
+  // them (with (pass, branch) = (bid / D, bid % D) every XCD fetched every line: 67 MB by the counters for an 8.4 MB super-block,
+  // profiles/r06_bench_full.json).  Narrow samples (cu8: 64 per line >= D) are unaffected either way.
+  uint32_t pass, b;
+  {
+#ifdef XLP_EXP_FWD_PASS_MAJOR
+    pass = bid / a.D, b = bid - pass * a.D;
+#else
+    const uint32_t x = bid & 7u, kx = bid >> 3;
+    uint32_t start = 0u;  // workgroups of the XCDs below x: XCD y holds the bids y, y + 8, .. < nwg
+    for (uint32_t y = 0u; y < x; ++y) start += (nwg - y + 7u) >> 3;
+    const uint32_t jj = start + kx;
+    b = jj / passes, pass = jj - b * passes;
+#endif
+  }
   const uint32_t s = pass * XLP_SEG + h;
   const bool live = s < a.nseg;  // (the last pass may hold fewer segments: zeros, never read by the mix kernel)
   // branch sample n of segment s = stream sample base + (s V + n) D + b   (base: first tap of shared point 0)

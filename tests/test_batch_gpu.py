@@ -1577,6 +1577,8 @@ def test_config5_cf32_10msps_all_clients(nclients):
             if variant == "optimized" and k == 1:  # (block 0: the clients are inside their zero history -- a class of its own)
                 d = eng.describe()
                 assert "polyphase: cls0 D100 T257 cols%d " % nclients in d and ("mix=mf32" if mix == 3 else "mix=mfma") in d, d
+                if mix != 3:  # (a plan with a wide two-half class reserves no CUs for the side-stream kernel: xl_batch.cpp)
+                    assert "CUs reserved" not in d, d
             got = _engine_outputs(eng, ids)
             for c in range(nclients):
                 assert len(got[c]) == len(want[c]), c

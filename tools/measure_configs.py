@@ -88,7 +88,7 @@ blocks = [siggen.xs_u8(100 + k, 262144) for k in range(4)]
 S = 131072
 # ---- [2] 64 mixed clients
 cl = [((42, t48) if c % 2 == 0 else (21, t96)) + (-900000 + c * 28000,) for c in range(64)]
-dt, fir = run_batch(FS, "cu8", 262144, cl, blocks)
+dt, fir = run_batch(FS, "cu8", 262144, cl, blocks, steps=320)
 out["config2_64_clients_mixed_48k_96k"] = {"us_per_block": round(dt * 1e6, 2), "launches_us_per_block": round(fir * 1e3, 2),
                                            "Msps_all_clients": round(64 * S / dt / 1e6, 0)}
 dt1, fir1 = run_batch(FS, "cu8", 262144, cl, blocks, group=1)
@@ -116,7 +116,7 @@ taps = siggen.hamming_sinc(257, 0.004)
 fblocks = [(siggen.xs_s16(300 + k, 2 * S).astype(np.float32) / np.float32(32768)) for k in range(3)]
 for n in (64, 256, 1024):
     cl = [(100, taps, -4000000 + (8000000 // n) * c) for c in range(n)]
-    dt, fir = run_batch(10000000, "cf32", 2 * S, cl, fblocks)
+    dt, fir = run_batch(10000000, "cf32", 2 * S, cl, fblocks, steps=640)
     bpu = 8 + 8 / 100
     out[f"config4_cf32_10Msps_D100_257taps_{n}_clients"] = {
         "us_per_block": round(dt * 1e6, 2), "launches_us_per_block": round(fir * 1e3, 2), "Msps_all_clients": round(n * S / dt / 1e6, 0),
