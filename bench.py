@@ -1029,12 +1029,12 @@ def measure_traffic(args, workloads):
     return results, "measured in this run"
 
 
-# the curve this workload is EXPECTED to follow (per-GPU step times measured on one GPU; the 2 MB
+# DESIGN.md section 8 (history: DESIGN_HISTORY.md section 7): the curve this workload is EXPECTED to follow (per-GPU step times measured on one GPU; the 2 MB
 # broadcast per call hides behind a 200+ us call).  Strong scaling saturates at once: below ~1000 clients per GPU every GPU
 # is bound by the float32 phase recurrence (3121 sequential steps per block and client).
 EXPECTED_STRONG = {"clients_total": 1024, "Msamples_per_s": {"1": 5.39e6, "2": 5.64e6, "4": 5.79e6, "8": 5.94e6},
                    "speedup": {"1": 1.0, "2": 1.05, "4": 1.07, "8": 1.10},
-                   "why": "DESIGN.md section 7: one GPU already runs 1024 clients at 24.9 us per block, within 10 % of the floor the NCO "
+                   "why": "DESIGN.md section 8 (history: DESIGN_HISTORY.md section 7): one GPU already runs 1024 clients at 24.9 us per block, within 10 % of the floor the NCO "
                           "phase recurrence sets for ANY client count (3121 dependent float32 steps per block and client: 22.6 us); 1024 "
                           "clients IN TOTAL leave 512 / 256 / 128 per GPU (23.8 / 23.2 / 22.6 us per block measured on one GPU), so "
                           "adding GPUs only pays with MORE clients (weak scaling)"}
@@ -1515,7 +1515,7 @@ def main():
         "multi_gpu": multi_gpu,
         "variants": variants,
         "expected_scaling": {"strong": EXPECTED_STRONG, "weak": EXPECTED_WEAK,
-                             "note": "what DESIGN.md section 7 predicts for --gpus 1/2/4/8, to judge a measured curve against"},
+                             "note": "what DESIGN.md section 8 (history: DESIGN_HISTORY.md section 7) predicts for --gpus 1/2/4/8, to judge a measured curve against"},
         "device": xl.device_info() if cuda else "none (plumbing test)",
     }
     if world == 1 and not args.no_cpu_baseline and cuda:

@@ -227,7 +227,7 @@ void xlp_mix_mfma_kernel(const XlpArgs a) {
       if (j < (uint32_t)NKB) {  // (wave-uniform)
         _Float16 f1[4], f2[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xlp_split_h(g[q][e] * (e < 2 ? sx0 : sx1), f1[e], f2[e]);
+        for (int e = 0; e < 4; ++e) xlp_split_h(xl_mul_s(g[q][e], e < 2 ? sx0 : sx1), f1[e], f2[e]);  // (no packed FP32 here: xl_mul_s)
         // branch bb of the k-block: dword xlm_dword(bb) of the lane slots (half xlm_half(bb), row) of its two segments' rows
 #pragma unroll
         for (int u = 0; u < 2; ++u) {  // segment 2 sp + u: (re, im) = f[2 u], f[2 u + 1]
@@ -303,10 +303,11 @@ void xlp_mix_mfma_kernel(const XlpArgs a) {
 #pragma unroll
       for (int g2 = 0; g2 < 16; g2 += 2) {
         const uint32_t cs = (uint32_t)(((g2 >> 1) & 1) + 4 * (g2 >> 2));  // (a constant after unrolling)
-        v2f y = {(hi[g2] + lo[g2]) * cs_, (hi[g2 + 1] + lo[g2 + 1]) * cs_};
+        // (no packed FP32 beside matrix instructions: xl_poly_dev.h, xl_mul_s)
+        v2f y = {xl_mul_s(xl_add_s(hi[g2], lo[g2]), cs_), xl_mul_s(xl_add_s(hi[g2 + 1], lo[g2 + 1]), cs_)};
         if (SEG) {
           const float si = sinv[buf][2u * h + cs];
-          y.x *= si, y.y *= si;
+          y.x = xl_mul_s(y.x, si), y.y = xl_mul_s(y.y, si);
         }
         v2f *const dst = reinterpret_cast<v2f *>(base + cs * sb);
 #ifdef XLP_MIX_EXP_NOSTORE

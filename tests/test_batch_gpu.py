@@ -1710,6 +1710,35 @@ def test_plain_process_ignores_tuning_variables():
     assert "polyphase: none" in forced, forced
 
 
+def test_config5_fresh_engines_tone_block_every_client_repeated():
+    """The stress that exposed the unshipped k-block-major wide mix (tools/experiments/mix_wide_kmajor/: wrong sums in a few workgroups
+    per launch, timing dependent, 50-100 % of fresh engines): BASELINE config 5 at 256 clients, the first block of a pure-tone stream --
+    most clients sit in the tone's stopband, so a single tile of a single bin off by 2^-11 of its value shows as 1e-4 of max|y| --, a
+    NEW engine per round right behind another engine's life in the same process, every client of every round within 1e-5.  The shipped
+    kernels pass it 12 of 12 (profiles/r06_mix_wide_kmajor_wrong_sums.txt (10)); six rounds here."""
+    from pyoracle import population
+
+    taps = siggen.hamming_sinc(257, 0.004)
+    nsamp, n = 131072, 256
+    fcs = [-4900000 + (9800000 // n) * c for c in range(n)]
+    x = siggen.sin_f32(0, 2 * nsamp).astype(np.float32)
+    want = population(100, taps, fcs, 10000000, 2 * nsamp, "cf32", x, 1)
+    for rnd in range(6):
+        other = xl.BatchEngine(10000000, "cf32", 2 * nsamp)  # (another engine's allocations and launches first)
+        for fc in fcs[:64]:
+            other.add_client(100, taps, fc)
+        other.process_host(x, "native" if rnd % 2 == 0 else "optimized")
+        other.close()
+        eng = xl.BatchEngine(10000000, "cf32", 2 * nsamp)
+        ids = [eng.add_client(100, taps, fc) for fc in fcs]
+        eng.process_host(x, "optimized")
+        assert "mix=mfma" in eng.describe(), eng.describe()
+        got = _engine_outputs(eng, ids)
+        bad = [(c, rel_err(got[c], want[c])) for c in range(n) if rel_err(got[c], want[c]) > REL_TOL]
+        assert not bad, (rnd, len(bad), bad[:8])
+        eng.close()
+
+
 def test_expected_clients_reserves_the_side_kernels_cus_once():
     """Option "expected_clients": the CUs of the side-stream recurrence kernel are reserved for the announced population at the
     first plan, so joins up to it never re-create the CU-masked streams (25 ms each time the count crosses a multiple of 512

@@ -1,4 +1,4 @@
-// tools/ubench_pk_mfma.hip -- a stand-alone reproducer for DESIGN.md 3.6: does a wave that steps a complex float32 recurrence
+// tools/ubench_pk_mfma.hip -- a stand-alone reproducer for DESIGN_HISTORY.md 3.6: does a wave that steps a complex float32 recurrence
 // with PACKED instructions (v_pk_mul_f32 x2, v_pk_add_f32: the NCO role's step, xl_dev_inline.h) compute different bits when
 // waves issuing MATRIX instructions are resident on the chip at the same time?
 //   chain kernel    256 workgroups of one wave; lane l of workgroup g rotates p <- p * inc_(g,l) for `steps` steps and stores p.
