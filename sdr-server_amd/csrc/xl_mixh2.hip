@@ -12,8 +12,8 @@
 // once, at the ~11 bytes per cycle a CU takes in, with idle matrix cores (10 of a workgroup's 25 us), then runs its passes with an idle
 // memory system.  A second form that streams the operands under the products of all passes (k-blocks outermost) was built and was no
 // faster at 1024 clients (the intake per workgroup is the same; 8 % faster at 2048+): tools/experiments/mix_wide_kmajor/.  Its wrong
-// sums in a few workgroups per launch led to the rule this file follows too: NO PACKED FP32 beside matrix instructions (xl_mul_s,
-// xl_poly_dev.h; profiles/r06_mix_wide_kmajor_wrong_sums.txt (11)).
+// sums in a few workgroups per launch led to the rule this file is compiled under: NO PACKED FP32 beside matrix instructions
+// (-fno-slp-vectorize: xl_mixh.hip's header; profiles/r06_mix_wide_kmajor_wrong_sums.txt (11)).
 //   * the two LDS buffers of staged A operands are two distinct arrays and the pass loop is unrolled by two, so that the compiler knows
 //     that the reads of one pass and the staging writes for the next never alias, and may interleave them;
 //   * a pass is ONE basic block -- no per-lane or per-round branch: rows beyond the class's branches are loaded from a clamped address and
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const uint32_t j = jq < (uint32_t)NKB ? jq : (uint32_t)NKB;  // (wave-uniform select: k-blocks beyond the class go to the dump slot)
       _Float16 f1[4], f2[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) xlp_split_h(xl_mul_s(g[q][e], e < 2 ? sx0 : sx1), f1[e], f2[e]);  // (no packed FP32 here: xl_mul_s)
+      for (int e = 0; e < 4; ++e) xlp_split_h(g[q][e] * (e < 2 ? sx0 : sx1), f1[e], f2[e]);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {  // segment 2 sp + u: (re, im) = f[2 u], f[2 u + 1]
         const uint32_t sre = xlm_lds_slot(xlm_lane(xlm_half(bb), xlm_row(2u * sp + (uint32_t)u, 0u)));
@@ -150,11 +150,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int g2 = 0; g2 < 16; g2 += 2) {
         const uint32_t cs = (uint32_t)(((g2 >> 1) & 1) + 4 * (g2 >> 2));  // (a constant after unrolling)
-        // (no packed FP32 beside matrix instructions: xl_poly_dev.h, xl_mul_s)
-        y[g2 >> 1] = (v2f){xl_mul_s(xl_add_s(hi[g2], lo[g2]), cs_), xl_mul_s(xl_add_s(hi[g2 + 1], lo[g2 + 1]), cs_)};
+        y[g2 >> 1] = (v2f){(hi[g2] + lo[g2]) * cs_, (hi[g2 + 1] + lo[g2 + 1]) * cs_};
         if (SEG) {
           const float si = cur.unscale[w][2u * h + cs];
-          y[g2 >> 1].x = xl_mul_s(y[g2 >> 1].x, si), y[g2 >> 1].y = xl_mul_s(y[g2 >> 1].y, si);
+          y[g2 >> 1].x *= si, y[g2 >> 1].y *= si;
         }
       }
       if (s0 + XLP_SEG <= a.nseg) {  // (wave-uniform: every pass but the call's last)

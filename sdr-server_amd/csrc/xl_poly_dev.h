@@ -155,33 +155,9 @@ XL_DEV float xlp_seg_scale(const uint32_t maxbits) { return __uint_as_float((268
 XL_DEV float xlp_seg_unscale(const uint32_t maxbits) { return __uint_as_float((xlp_seg_exp(maxbits) - 14u) << 23); }  // 2^(e - 14)
 
 
-// Single-lane-width FP32 arithmetic for waves that share a SIMD with matrix instructions.  PACKED FP32 (v_pk_mul_f32 / v_pk_add_f32 /
-// v_pk_fma_f32, which the compiler forms from any two adjacent float operations) loses the fourth quarter-wave of a result -- lanes
-// 48..63 keep what the registers held -- once in a while when matrix instructions are co-resident on the SIMD: pinned for the NCO
-// role's packed recurrence steps in rounds 3-4 (DESIGN_HISTORY.md 3.6: scalar FP32 is immune), and met again in round 6 in a mix
-// kernel's own epilogue -- `y = sum x scale` as v_pk_mul_f32 right behind the products, beside the SIMD's other wave still issuing
-// them: rows 4, 5 x columns 16..31 of a tile wrong by 1e-5 .. 1e-4 of max|y| in 6 of 10 fresh engines; the same build with these
-// helpers: 0 of 10 (profiles/r06_mix_wide_kmajor_wrong_sums.txt (11)).  The mix kernels therefore form every float32 product, sum and
-// difference through these (inline asm: the vectoriser cannot re-pack them); tests/test_mix_no_packed_fp32.py checks their code objects.
-XL_DEV float xl_mul_s(const float a, const float b) {
-  float r;
-  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-XL_DEV float xl_add_s(const float a, const float b) {
-  float r;
-  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-XL_DEV float xl_sub_s(const float a, const float b) {
-  float r;
-  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
 XL_DEV void xlp_split_h(const float v, _Float16 &h1, _Float16 &h2) {
   h1 = (_Float16)v;
-  h2 = (_Float16)xl_sub_s(v, (float)h1);
+  h2 = (_Float16)(v - (float)h1);
 }
 XL_DEV uint32_t xlp_pack_h(const _Float16 lo, const _Float16 hi) {
   const v2h p = {lo, hi};

@@ -20,7 +20,7 @@ PAT = re.compile(r"\s*(v_mfma_\S+)\s+[va]\[(\d+):(\d+)\], [va]\[(\d+):(\d+)\], [
 def scan(path):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        subprocess.run(["hipcc"] + FLAGS + [path, "-o", out], check=True, capture_output=True)
+        subprocess.run(["hipcc"] + FLAGS + ["-fno-slp-vectorize"] + [path, "-o", out], check=True, capture_output=True)  # (csrc/Makefile: MIX_FLAGS)
         total, bad, kernel = 0, [], "?"
         for line in open(out):
             if line.startswith("_Z") and line.rstrip().endswith(":") is False and ":" in line:
@@ -36,7 +36,7 @@ def scan(path):
 
 
 def main():
-    files = sys.argv[1:] or [os.path.join(ROOT, "sdr-server_amd", "csrc", f) for f in ("xl_mixh2.hip", "xl_polyphase.hip", "xl_mixf32.hip")]
+    files = sys.argv[1:] or [os.path.join(ROOT, "sdr-server_amd", "csrc", f) for f in ("xl_mixh.hip", "xl_mixh2.hip", "xl_mixf32.hip")]
     rc = 0
     for f in files:
         total, bad = scan(f)

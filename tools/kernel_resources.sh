@@ -11,8 +11,9 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fh
 {
 echo "# kernel resources of sdr-server_amd/csrc/*.hip for gfx950 (hipcc $FLAGS), from llvm-readelf --notes of the code objects"
 echo "# columns: vgpr agpr sgpr sgpr_spill vgpr_spill lds_bytes scratch_bytes  kernel"
-for f in xl_kernels xl_polyphase xl_mixf32 xl_mixh2 xl_inv8 xl_inv32; do
-  hipcc $FLAGS --cuda-device-only -c $ROOT/sdr-server_amd/csrc/$f.hip -o $W/$f.co
+for f in xl_kernels xl_polyphase xl_mixf32 xl_mixh xl_mixh2 xl_inv8 xl_inv32; do
+  case $f in xl_mixh|xl_mixh2|xl_mixf32) X="-fno-slp-vectorize";; *) X="";; esac   # (csrc/Makefile: MIX_FLAGS)
+  hipcc $FLAGS $X --cuda-device-only -c $ROOT/sdr-server_amd/csrc/$f.hip -o $W/$f.co
   $LLVM/clang-offload-bundler --unbundle --type=o --input=$W/$f.co --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$W/$f.elf
   echo "## $f.hip"
   $LLVM/llvm-readelf --notes $W/$f.elf | python3 -c '
@@ -33,7 +34,7 @@ done
 echo
 echo "## SGPR spill code placement (v_writelane_b32 / v_readlane_b32 per kernel: total, and inside loop bodies = between a label that is"
 echo "## the target of a backward branch and that branch)"
-for f in xl_kernels xl_polyphase xl_mixf32 xl_mixh2 xl_inv8 xl_inv32; do
+for f in xl_kernels xl_polyphase xl_mixf32 xl_mixh xl_mixh2 xl_inv8 xl_inv32; do
   $LLVM/llvm-objdump -d --no-show-raw-insn $W/$f.elf | python3 -c '
 import re, sys
 kern, lines = None, {}

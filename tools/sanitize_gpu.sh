@@ -17,7 +17,7 @@ build)
   mkdir -p $S
   FLAGS="-std=c++17 -O1 -g -fno-omit-frame-pointer -ffp-contract=off -fno-fast-math -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include"
   for f in xl_batch xl_filter xl_common xl_sinks; do g++ $FLAGS -c $CS/$f.cpp -o $S/$f.o || exit 1; done
-  OBJS="$B/xl_kernels.o $B/xl_polyphase.o $B/xl_inv8.o $B/xl_inv32.o $B/xl_mixf32.o $S/xl_filter.o $S/xl_batch.o $S/xl_sinks.o $S/xl_common.o $B/lpf.o $B/xl_taps.o $B/xl_wire.o"
+  OBJS="$B/xl_kernels.o $B/xl_polyphase.o $B/xl_inv8.o $B/xl_inv32.o $B/xl_mixf32.o $B/xl_mixh.o $B/xl_mixh2.o $S/xl_filter.o $S/xl_batch.o $S/xl_sinks.o $S/xl_common.o $B/lpf.o $B/xl_taps.o $B/xl_wire.o"
   g++ -shared -fPIC -fsanitize=address,undefined -o $S/libxlating_hip_asan.so $OBJS -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lm -lz -lpthread || exit 1
   rm -f $S/*.o
   echo built $S/libxlating_hip_asan.so ;;
