@@ -1922,13 +1922,27 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           }
           // the call's last launch carries the "table has been read" event the side stream waits for
           const bool last_launch = side && rolled && &pc == &b->poly.back();
+#ifdef XL_TUNING
+          const bool trace_fwd = b->poly_trace && xl_exp_getenv("XL_EXP_POLY_TRACE_FWD");  // (the forward launch instead)
+          if (trace_fwd) {
+            if (!b->d_ptrace) XL_TRY(hipMalloc((void **)&b->d_ptrace, 32768 * sizeof(unsigned long long)));
+            XL_TRY(hipMemsetAsync(b->d_ptrace, 0, 32768 * sizeof(unsigned long long), s));
+            pa.trace = b->d_ptrace;
+          }
+#endif
           XL_TRY(xlp_launch_forward(pa, s));
+#ifdef XL_TUNING
+          if (trace_fwd) {
+            pa.trace = nullptr;
+            XL_TRY(xl_dump_trace(b->poly_trace, b->d_ptrace, 32768, s));
+          }
+#endif
           if (pe[1]) XL_TRY(hipEventRecord(pe[1], s));
           pa.roll_blocks = 0;
           pa.nco_blocks = 0;  // (no role in the mix launch)
 #ifdef XL_TUNING
-          const bool trace_inv = b->poly_trace && xl_exp_getenv("XL_EXP_POLY_TRACE_INV");  // (the inverse launch instead)
-          if (b->poly_trace && !trace_inv) {  // timeline of the mix launch (work waves' span + each NCO wave)
+          const bool trace_inv = b->poly_trace && !trace_fwd && xl_exp_getenv("XL_EXP_POLY_TRACE_INV");  // (the inverse launch instead)
+          if (b->poly_trace && !trace_inv && !trace_fwd) {  // timeline of the mix launch (work waves' span + each NCO wave)
             if (!b->d_ptrace) XL_TRY(hipMalloc((void **)&b->d_ptrace, 32768 * sizeof(unsigned long long)));
             XL_TRY(hipMemsetAsync(b->d_ptrace, 0, 32768 * sizeof(unsigned long long), s));
             pa.trace = b->d_ptrace;
@@ -1937,7 +1951,7 @@ static int xl_batch_run(xlating_batch *b, const void *d_blocks, size_t input_len
           XL_TRY(xlp_launch_mix(pa, s));
           pa.nco_skip = 0;
 #ifdef XL_TUNING
-          if (b->poly_trace && !trace_inv) {
+          if (b->poly_trace && !trace_inv && !trace_fwd) {
             pa.trace = nullptr;
             XL_TRY(xl_dump_trace(b->poly_trace, b->d_ptrace, 32768, s));
           }

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
     xlp_nco_role(a);
     return;
   }
+  const unsigned long long t_begin = a.trace ? wall_clock64() : 0ull;  // (tuning builds: XL_EXP_POLY_TRACE_FWD)
   const uint32_t bid = blockIdx.x - a.nco_blocks;
   const uint32_t j = threadIdx.x;
   const uint32_t passes = (a.nseg + XLP_SEG - 1u) / XLP_SEG;
@@ -95,12 +96,23 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
                                                                // (those outputs lie beyond K and are never stored)
     const bool lo = idx < a.n0;
     const void *src = (lo || !ok) ? a.in0 : a.in1;
+#ifdef XLP_EXP_FWD_NOLOAD  // (anatomy: wrong results)
+    const v2f v = (v2f){(float)idx, 1.0f};
+#else
     const v2f v = xl_sample(src, (int)a.fmt, ok ? (lo ? idx : idx - a.n0) : 0u);
+#endif
     u[0][r] = ok ? v : (v2f){0.0f, 0.0f};
+  }
+  unsigned long long t_loaded = 0ull;
+  if (a.trace) {
+    __builtin_amdgcn_s_waitcnt(0);  // (tuning only: samples and twiddles have arrived)
+    t_loaded = wall_clock64();
   }
   v2f *const bufs[1] = {lds[h]};
   const uint32_t rs0[1] = {0u};
+#ifndef XLP_EXP_FWD_NODFT  // (anatomy: wrong results)
   xlp_dft<-1, 1, M>(u, bufs, tw, l, rs0);
+#endif
   if (a.segmax != nullptr) {
     // cf32 stream on the two-half mix: the segment's largest spectrum component, over all branches -- this transform's share of it
     // (NaNs drop out of fmaxf: a stream that carries them has no parity to keep), gathered with one LDS atomic per lane (the lanes of a
@@ -131,7 +143,21 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
     const uint32_t m = i >> 3, part = i & 7u;  // row m, segments 2 part and 2 part + 1
     const v2f x0 = 2u * part < XLP_SEG ? lds[2u * part][m] : (v2f){0.0f, 0.0f};
     const v2f x1 = 2u * part + 1u < XLP_SEG ? lds[2u * part + 1u][m] : (v2f){0.0f, 0.0f};
+#ifdef XLP_EXP_FWD_NOSTORE  // (anatomy: wrong results)
+    if (x0.x == 1.2345e-30f)
+#endif
     X[i] = (v4f){x0.x, x0.y, x1.x, x1.y};
+  }
+  if (a.trace && bid < 6000u) {  // tuning: start, end (stores issued and acknowledged), samples loaded, transforms in LDS
+    const unsigned long long t_xf = wall_clock64();
+    __builtin_amdgcn_s_waitcnt(0);
+    if (j == 0u) {
+      unsigned long long *t = a.trace + 4096 + 4 * (size_t)bid;
+      t[0] = t_begin;
+      t[1] = wall_clock64();
+      t[2] = t_loaded;
+      t[3] = t_xf;
+    }
   }
 }
 
