@@ -1192,11 +1192,15 @@ static int xl_batch_plan(xlating_batch *b) {
       // recurrence in small classes (A/B at 8 blocks per call, direct kernel -> polyphase, us per block: 101 taps 37.3 -> 28.2 at
       // 1024 clients, 124.8 -> 88.7 at 4096, 23.3 -> 22.9 at 128; 505 taps 24.8 -> 22.9 at 96 clients, 23.1 -> 22.7 at 32; cf32 10
       // Msps, D = 100, 257 taps: 38.4 -> 23.4 at 1024 clients, 12.8 -> 11.8 at 256, 11.4 -> 11.3 at 64): 2 taps per branch, 32 clients
-      // Classes of more than XLMF_NB8_MAX k-blocks (D > 112: float32 operands re-streamed every pass, xlp_mix_f32_stream_kernel) keep
-      // round 4's crossover -- 128 clients, 4.5 taps per branch: the only one a measurement of that kernel stands behind
+      // Classes of more than XLMF_NB8_MAX k-blocks (D > 112: float32 operands re-streamed every pass, xlp_mix_f32_stream_kernel): the
+      // same 2 taps per branch from 128 clients on -- measured in round 6 at D = 128 / 200 / 400, 1.2 / 2.4 / 4.8 / 12 taps per branch,
+      // 32 .. 1024 clients (profiles/r06_plan_rules_other_shapes.txt): the path costs 10.6-11.5 us per block up to 128 clients whatever
+      // the filter, the direct kernel 11.4-11.9 at 128 clients x 2.4 taps per branch (1.04-1.07 x) and 47-62 at 1024 (1.6-2.1 x; rounds
+      // 4-5 sent those to the direct kernel: 4.5 taps per branch was the only crossover a measurement of that kernel stood behind);
+      // at 64 clients the direct kernel is still ahead up to 4.8 taps per branch.
       const bool streamed = (D + 7u) / 8u > XLMF_NB8_MAX;
       const size_t min_clients = b->poly_min_set ? b->poly_min_clients : (streamed ? 128u : 32u);
-      const bool pays = m.size() >= min_clients && (streamed ? 2 * T >= 9 * D : T >= 2 * D);
+      const bool pays = m.size() >= min_clients && T >= 2 * D;
       if (b->poly_mode == 0 || !fits || (b->poly_mode < 0 && !pays)) continue;
       PolyClass pc;
       Pending pd;

@@ -41,6 +41,7 @@
                              // the per-bin matrix product, undone exactly in the mix launch's epilogue (xlp_seg_scale)
 #define XLP_H_RMAX 8192.0f   // ... and a column's spectra by the power of two that brings their bound max_b sum_a |r_b[a]| under this
 #define XLP_SEGMAX_STRIDE 32u  // XlpArgs::segmax: one entry per 128-byte line (the forward launch's atomics spread over the L2 channels)
+#define XLP_FWD_GROUP_MIN_WGS 96u  // forward launch, cf32 streams: groups of adjacent branches per workgroup from this many workgroups on
 #define XLP_BSTEP 2u   // the branch count is padded to a multiple of this in the shared-spectrum image (rows D .. Dpad - 1: zeros)
 
 // One client column of a class: 16 bytes, one load.

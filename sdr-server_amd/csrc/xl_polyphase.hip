@@ -24,17 +24,96 @@
 #include <hip/hip_ext.h>
 
 // ------------------------------------------------------------------------------------------- forward transforms
-// grid = nco_blocks + passes * D transform workgroups + a.roll_blocks history-roll workgroups.  A transform workgroup =
-// (pass, branch b): the XLP_SEG = 16 segments of the pass, one transform each on M / 4 lanes (16 * M / 4 threads: 512 or
-// 1024).  The spectra go through LDS once more so that the image rows X[pass][b][m][0..15] -- what the mix kernel fetches
-// as one 128-byte scalar row -- leave as whole lines: 8 lanes x 16 bytes per row, the workgroup's 16 KB (M = 128) back to
-// back.  (One wave per transform storing its 8-byte values 128 bytes apart wrote 40 MB for an 11 MB image and took 25 us
-// per call of 8 blocks at 1024 clients.)
-template <int M>
+// grid = nco_blocks + passes * ceil(D / NB) transform workgroups + a.roll_blocks history-roll workgroups.  A transform workgroup =
+// (pass, group of NB ADJACENT branches): the XLP_SEG = 16 segments of the pass on M / 4 lanes each (16 * M / 4 threads: 512 or 1024),
+// every lane running the NB branches' transforms of its segment side by side.  NB = 1 for the integer input formats; cf32 streams of
+// at least XLP_FWD_GROUP_MIN_WGS grouped workgroups: NB = 4 (M = 128) or 2 (M = 256), 80 KB of LDS.
+//
+// Why groups of branches for cf32 (round 6, second session): branch b of a segment is every D-th sample, so a lane's four points lie D
+// samples apart -- one cache line per lane and point --, but the NB branches' samples of one point are NB adjacent samples: ONE load of
+// NB x 8 bytes.  With one branch per workgroup a call of 8 cf32 blocks asked the L2s for 1.2 M lines of which it used 8 bytes each
+// (157 MB of L2 -> CU traffic for an 8.4 MB super-block), and the load phase was 5 us median / 9 us p90 of a 13.7 us launch by the
+// kernel's own clock stamps (profiles/r06_forward_anatomy.txt); four branches per load: a quarter of the requests, a quarter of the
+// workgroups, 13.7 -> 10.7 us (profiles/r06_forward_groups.txt).  The 2-byte formats gain nothing (a line holds 64 samples >= D: the
+// single-branch form already hits L1 / L2 with most requests; their load phase is 3.5-4 us either way) and lose the parallelism that
+// short calls need (one block per call: 84 workgroups -> 22, 8.7 -> 13.5 us): they keep NB = 1.
+// The spectra go through LDS once more so that the image rows X[pass][b][m][0..15] -- what the mix kernel fetches as one 128-byte
+// row -- leave as whole lines: 8 lanes x 16 bytes per row, a branch's 16 KB (M = 128) back to back.
+//
+// NB adjacent samples i .. i + NB - 1 of a raw buffer -> cf32 (xl_sample's maps, xlating.c:357-378: exact), one load (the address is
+// aligned to the SAMPLE, not to the load: global loads take any alignment on this target)
+typedef uint32_t xlp_u2 __attribute__((ext_vector_type(2)));
+typedef uint32_t xlp_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t xlp_u1_a2 __attribute__((aligned(2)));
+typedef xlp_u2 xlp_u2_a2 __attribute__((aligned(2)));
+typedef xlp_u2 xlp_u2_a4 __attribute__((aligned(4)));
+typedef xlp_u4 xlp_u4_a4 __attribute__((aligned(4)));
+typedef xlp_u4 xlp_u4_a8 __attribute__((aligned(8)));
+template <int NB>
+XL_DEV void xlp_samples(const void *__restrict__ p, const int fmt, const uint32_t i, v2f (&out)[NB]) {
+  static_assert(NB == 1 || NB == 2 || NB == 4, "one, two or four adjacent samples");
+  if (NB == 1) {
+    out[0] = xl_sample(p, fmt, i);
+    return;
+  }
+  uint32_t w[2 * NB];  // the raw bytes, as much as the format needs
+  if (fmt == XLF_CU8 || fmt == XLF_CS8) {
+    const char *q = reinterpret_cast<const char *>(p) + 2u * (size_t)i;
+    if (NB == 4) {
+      const xlp_u2 v = *reinterpret_cast<const xlp_u2_a2 *>(q);
+      w[0] = v.x, w[1] = v.y;
+    } else {
+      w[0] = *reinterpret_cast<const xlp_u1_a2 *>(q);
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const uint32_t v = (w[n >> 1] >> (16 * (n & 1))) & 0xFFFFu;
+      if (fmt == XLF_CU8) {
+        out[n].x = ((float)(v & 0xFFu) - 127.5f) / 128.0f;
+        out[n].y = ((float)(v >> 8) - 127.5f) / 128.0f;
+      } else {
+        out[n].x = (float)((int32_t)(int8_t)(v & 0xFFu)) / 128.0f;
+        out[n].y = (float)((int32_t)(int8_t)(v >> 8)) / 128.0f;
+      }
+    }
+  } else if (fmt == XLF_CS16) {
+    const char *q = reinterpret_cast<const char *>(p) + 4u * (size_t)i;
+    if (NB == 4) {
+      const xlp_u4 v = *reinterpret_cast<const xlp_u4_a4 *>(q);
+      w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+    } else {
+      const xlp_u2 v = *reinterpret_cast<const xlp_u2_a4 *>(q);
+      w[0] = v.x, w[1] = v.y;
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int32_t v = (int32_t)w[n];
+      out[n].x = (float)((int32_t)(int16_t)(v & 0xFFFF)) / 32768.0f;
+      out[n].y = (float)(v >> 16) / 32768.0f;
+    }
+  } else {
+    const char *q = reinterpret_cast<const char *>(p) + 8u * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < NB / 2; ++k) {
+      const xlp_u4 v = reinterpret_cast<const xlp_u4_a8 *>(q)[k];
+      w[4 * k] = v.x, w[4 * k + 1] = v.y, w[4 * k + 2] = v.z, w[4 * k + 3] = v.w;
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) out[n] = (v2f){__uint_as_float(w[2 * n]), __uint_as_float(w[2 * n + 1])};
+  }
+}
+
+template <int M, int NB>
 __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpArgs a) {
   constexpr uint32_t L = M / 4, NT = XLP_SEG * L;
-  __shared__ v2f lds[XLP_SEG][XLP_ROW(M)];
-  __shared__ uint32_t tmax[XLP_SEG];  // (cf32 streams on the two-half mix: float bits of the largest |component| of each transform)
+  static_assert(XLP_SEG * NB * XLP_ROW(M) * 8 <= 80 * 1024, "two workgroups' rows in a CU's LDS");
+  __shared__ v2f lds[XLP_SEG][NB][XLP_ROW(M)];
+  // (cf32 streams on the two-half mix: float bits of the largest |component| of each segment's transforms -- in the one element of a
+  // segment's first row that XLP_POS never addresses, so that two workgroups' 80 KB fit a CU's LDS exactly)
+  static_assert(XLP_POS(M - 1) < XLP_ROW(M) - 1, "the last element of a padded row is free");
+  auto tmax = [&](const uint32_t seg) __attribute__((always_inline)) -> uint32_t & {
+    return reinterpret_cast<uint32_t *>(&lds[seg][0][XLP_ROW(M) - 1])[0];
+  };
   if (blockIdx.x < a.nco_blocks) {
     xlp_nco_role(a);
     return;
@@ -43,7 +122,8 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
   const uint32_t bid = blockIdx.x - a.nco_blocks;
   const uint32_t j = threadIdx.x;
   const uint32_t passes = (a.nseg + XLP_SEG - 1u) / XLP_SEG;
-  const uint32_t nwg = passes * a.D;
+  const uint32_t ngrp = (a.D + (uint32_t)NB - 1u) / (uint32_t)NB;
+  const uint32_t nwg = passes * ngrp;
   if (bid >= nwg) {
     // raw-history roll (as in xl_fir_kernel): hist_out = the last hist_units 2-byte units of [in0 | in1]; nothing in
     // this block's launches reads hist_out
@@ -57,99 +137,120 @@ __global__ __launch_bounds__(XLP_SEG * M / 4) void xlp_forward_kernel(const XlpA
     }
     return;
   }
-  const uint32_t h = j / L, l = j % L;  // transform (= segment of the pass) of this lane, lane within it
+  const uint32_t h = j / L, l = j % L;  // segment of the pass this lane works on, lane within its transforms
   const XlpTw tw = xlp_twiddles<-1, M>(reinterpret_cast<const v2f *>(a.W), l);
-  // Which (pass, branch): branch-major over the XCDs.  Workgroup bid runs on XCD bid % 8; the transform workgroups of XCD x are given a
-  // CONTIGUOUS range of the branch-major list (branch, pass), so an XCD works on ~D/8 neighbouring branches -- with wide samples (cf32:
-  // 16 per 128-byte line, D = 100 branches per period) it then pulls a quarter of the block's lines through its L2 instead of all of
-  // them (with (pass, branch) = (bid / D, bid % D) every XCD fetched every line: 67 MB by the counters for an 8.4 MB super-block,
-  // profiles/r06_bench_full.json).  Narrow samples (cu8: 64 per line >= D) are unaffected either way.
-  uint32_t pass, b;
+  // Which (pass, group): group-major over the XCDs.  Workgroup bid runs on XCD bid % 8; the transform workgroups of XCD x are given a
+  // CONTIGUOUS range of the group-major list (group, pass), so an XCD works on neighbouring branches -- with wide samples (cf32: 16 per
+  // 128-byte line, D = 100 branches per period) it then pulls a fraction of the block's lines through its L2 instead of all of them.
+  uint32_t pass, grp;
   {
 #ifdef XLP_EXP_FWD_PASS_MAJOR
-    pass = bid / a.D, b = bid - pass * a.D;
+    pass = bid / ngrp, grp = bid - pass * ngrp;
 #else
     const uint32_t x = bid & 7u, kx = bid >> 3;
     uint32_t start = 0u;  // workgroups of the XCDs below x: XCD y holds the bids y, y + 8, .. < nwg
     for (uint32_t y = 0u; y < x; ++y) start += (nwg - y + 7u) >> 3;
     const uint32_t jj = start + kx;
-    b = jj / passes, pass = jj - b * passes;
+    grp = jj / passes, pass = jj - grp * passes;
 #endif
   }
+  const uint32_t b0 = grp * (uint32_t)NB;  // branches b0 .. b0 + NB - 1 (those >= D: computed from real samples, never stored)
   const uint32_t s = pass * XLP_SEG + h;
   const bool live = s < a.nseg;  // (the last pass may hold fewer segments: zeros, never read by the mix kernel)
   // branch sample n of segment s = stream sample base + (s V + n) D + b   (base: first tap of shared point 0)
-  const uint32_t first = a.base + s * a.V * a.D + b;
+  const uint32_t first = a.base + s * a.V * a.D + b0;
   const uint32_t end = a.n0 + a.n1;
   // (two-half mix of a cf32 stream: what the maximum of segment pass * 16 + j stands at, read by thread j < 16 ahead of the transforms
-  // -- stale is fine: one entry per 128-byte line (XLP_SEGMAX_STRIDE), and a global atomic only where this workgroup raises what it saw:
-  // a few of the D workgroups of a segment, not all -- D x nseg atomics on six cache lines cost the launch 1.6 us per block)
+  // -- stale is fine: one entry per 128-byte line (XLP_SEGMAX_STRIDE), and a global atomic only where this workgroup raises what it saw)
   uint32_t *const smax = (a.segmax != nullptr && j < XLP_SEG && pass * XLP_SEG + j < a.nseg)
                              ? a.segmax + ((size_t)a.seg_par * a.seg_cap + pass * XLP_SEG + j) * XLP_SEGMAX_STRIDE : nullptr;
   const uint32_t seen = smax != nullptr ? __hip_atomic_load(smax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  if (l == 0u) tmax[h] = 0u;
-  v2f u[1][4];
+  if (l == 0u) tmax(h) = 0u;
+  v2f u[NB][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const uint32_t idx = first + (l + L * r) * a.D;
-    const bool ok = live && idx >= a.zero_below && idx < end;  // late joiner: zeros below; past the block: zeros
-                                                               // (those outputs lie beyond K and are never stored)
-    const bool lo = idx < a.n0;
-    const void *src = (lo || !ok) ? a.in0 : a.in1;
+    const uint32_t idx = first + (l + L * r) * a.D;  // sample of branch b0; branch b0 + n: idx + n
+    v2f v[NB];
+    // all NB samples real and in ONE of the two buffers: one load.  Else (the window's edges: below the late joiners' zero line, across
+    // history | block, past the block's end -- those outputs lie beyond K and are never stored) sample by sample.
 #ifdef XLP_EXP_FWD_NOLOAD  // (anatomy: wrong results)
-    const v2f v = (v2f){(float)idx, 1.0f};
+#pragma unroll
+    for (int n = 0; n < NB; ++n) v[n] = (v2f){(float)(idx + n), 1.0f};
 #else
-    const v2f v = xl_sample(src, (int)a.fmt, ok ? (lo ? idx : idx - a.n0) : 0u);
+    const bool whole = NB > 1 && live && idx >= a.zero_below && idx + (uint32_t)NB <= end && (idx + (uint32_t)NB <= a.n0 || idx >= a.n0);
+    if (whole) {
+      const bool lo = idx < a.n0;
+      xlp_samples<NB>(lo ? a.in0 : a.in1, (int)a.fmt, lo ? idx : idx - a.n0, v);
+    } else {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const uint32_t in = idx + (uint32_t)n;
+        const bool ok = live && in >= a.zero_below && in < end;
+        const bool lo = in < a.n0;
+        const v2f t = xl_sample((lo || !ok) ? a.in0 : a.in1, (int)a.fmt, ok ? (lo ? in : in - a.n0) : 0u);
+        v[n] = ok ? t : (v2f){0.0f, 0.0f};
+      }
+    }
 #endif
-    u[0][r] = ok ? v : (v2f){0.0f, 0.0f};
+#pragma unroll
+    for (int n = 0; n < NB; ++n) u[n][r] = v[n];
   }
   unsigned long long t_loaded = 0ull;
   if (a.trace) {
     __builtin_amdgcn_s_waitcnt(0);  // (tuning only: samples and twiddles have arrived)
     t_loaded = wall_clock64();
   }
-  v2f *const bufs[1] = {lds[h]};
-  const uint32_t rs0[1] = {0u};
+  {
+    v2f *bufs[NB];
+    uint32_t rs0[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) bufs[n] = lds[h][n], rs0[n] = 0u;
+    v2f *const(&cb)[NB] = bufs;
+    const uint32_t(&crs)[NB] = rs0;
 #ifndef XLP_EXP_FWD_NODFT  // (anatomy: wrong results)
-  xlp_dft<-1, 1, M>(u, bufs, tw, l, rs0);
+    xlp_dft<-1, NB, M>(u, cb, tw, l, crs);
 #endif
+  }
   if (a.segmax != nullptr) {
-    // cf32 stream on the two-half mix: the segment's largest spectrum component, over all branches -- this transform's share of it
+    // cf32 stream on the two-half mix: the segment's largest spectrum component, over all branches -- these transforms' share of it
     // (NaNs drop out of fmaxf: a stream that carries them has no parity to keep), gathered with one LDS atomic per lane (the lanes of a
     // transform sit in one wave, whose LDS operations execute in order: the clear above needs no barrier)
     float mx = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fmaxf(fabsf(u[0][r].x), fabsf(u[0][r].y)));
-#ifdef XLP_EXP_FWD_SHUFFLE  // (experiment: the first form -- shuffles, one global atomic per transform)
+    for (int n = 0; n < NB; ++n)
+      if (b0 + (uint32_t)n < a.D) {
 #pragma unroll
-    for (uint32_t o = L / 2u; o > 0u; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, (int)o));
-    if (l == 0u && live) atomicMax(a.segmax + ((size_t)a.seg_par * a.seg_cap + s) * XLP_SEGMAX_STRIDE, __float_as_uint(mx));
-#else
-    atomicMax(&tmax[h], __float_as_uint(mx));
-#endif
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fmaxf(fabsf(u[n][r].x), fabsf(u[n][r].y)));
+      }
+    atomicMax(&tmax(h), __float_as_uint(mx));
   }
-  // the transform's row, natural order (its own scratch: the LDS operations of a wave execute in order)
+  // the transforms' rows, natural order (their own scratch: the LDS operations of a wave execute in order)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) lds[h][l + L * r] = u[0][r];
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds[h][n][l + L * r] = u[n][r];
   __syncthreads();
-#ifndef XLP_EXP_FWD_SHUFFLE
-  if (smax != nullptr && tmax[j] > seen) atomicMax(smax, tmax[j]);
-#endif
+  if (smax != nullptr && tmax(j) > seen) atomicMax(smax, tmax(j));
   if (a.segmax != nullptr && bid == 0u)  // the next call's buffer (last read by the previous call's mix launch)
     for (uint32_t i = j; i < a.seg_cap; i += NT) a.segmax[((size_t)(a.seg_par ^ 1u) * a.seg_cap + i) * XLP_SEGMAX_STRIDE] = 0u;
   static_assert(XLP_XS == 16u && XLP_SEG <= XLP_XS, "image rows of 16 complex = 8 x 16 bytes");
-  v4f *__restrict__ X = reinterpret_cast<v4f *>(a.X) + ((size_t)pass * a.Dpad + b) * M * (XLP_XS / 2u);
-  for (uint32_t i = j; i < (uint32_t)M * (XLP_XS / 2u); i += NT) {
-    const uint32_t m = i >> 3, part = i & 7u;  // row m, segments 2 part and 2 part + 1
-    const v2f x0 = 2u * part < XLP_SEG ? lds[2u * part][m] : (v2f){0.0f, 0.0f};
-    const v2f x1 = 2u * part + 1u < XLP_SEG ? lds[2u * part + 1u][m] : (v2f){0.0f, 0.0f};
+  unsigned long long t_xf = 0ull;
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    if (b0 + (uint32_t)n >= a.D) break;  // (workgroup-uniform; rows D .. Dpad - 1 of the image stay zero)
+    v4f *__restrict__ X = reinterpret_cast<v4f *>(a.X) + ((size_t)pass * a.Dpad + b0 + (uint32_t)n) * M * (XLP_XS / 2u);
+    for (uint32_t i = j; i < (uint32_t)M * (XLP_XS / 2u); i += NT) {
+      const uint32_t m = i >> 3, part = i & 7u;  // row m, segments 2 part and 2 part + 1
+      const v2f x0 = 2u * part < XLP_SEG ? lds[2u * part][n][m] : (v2f){0.0f, 0.0f};
+      const v2f x1 = 2u * part + 1u < XLP_SEG ? lds[2u * part + 1u][n][m] : (v2f){0.0f, 0.0f};
 #ifdef XLP_EXP_FWD_NOSTORE  // (anatomy: wrong results)
-    if (x0.x == 1.2345e-30f)
+      if (x0.x == 1.2345e-30f)
 #endif
-    X[i] = (v4f){x0.x, x0.y, x1.x, x1.y};
+      X[i] = (v4f){x0.x, x0.y, x1.x, x1.y};
+    }
   }
   if (a.trace && bid < 6000u) {  // tuning: start, end (stores issued and acknowledged), samples loaded, transforms in LDS
-    const unsigned long long t_xf = wall_clock64();
+    t_xf = wall_clock64();
     __builtin_amdgcn_s_waitcnt(0);
     if (j == 0u) {
       unsigned long long *t = a.trace + 4096 + 4 * (size_t)bid;
@@ -338,9 +439,17 @@ hipError_t xlp_launch_tables_h(const float2 *rt, const uint32_t *delta, const ui
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s) {
   if (!xlp_valid_m(a.M)) return hipErrorInvalidValue;
   const uint32_t passes = (a.nseg + XLP_SEG - 1u) / XLP_SEG;
-  const dim3 grid(a.nco_blocks + passes * a.D + a.roll_blocks);
-  if (a.M == 256u) hipLaunchKernelGGL(xlp_forward_kernel<256>, grid, dim3(XLP_SEG * 64u), 0, s, a);
-  else hipLaunchKernelGGL(xlp_forward_kernel<128>, grid, dim3(XLP_SEG * 32u), 0, s, a);
+  const uint32_t nb = a.M == 256u ? 2u : 4u;  // branches per workgroup of the grouped form
+  const uint32_t ngrp = (a.D + nb - 1u) / nb;
+  const bool grouped = a.fmt == XLF_CF32 && passes * ngrp >= XLP_FWD_GROUP_MIN_WGS;
+  const dim3 grid(a.nco_blocks + passes * (grouped ? ngrp : a.D) + a.roll_blocks);
+  if (a.M == 256u) {
+    if (grouped) hipLaunchKernelGGL((xlp_forward_kernel<256, 2>), grid, dim3(XLP_SEG * 64u), 0, s, a);
+    else hipLaunchKernelGGL((xlp_forward_kernel<256, 1>), grid, dim3(XLP_SEG * 64u), 0, s, a);
+  } else {
+    if (grouped) hipLaunchKernelGGL((xlp_forward_kernel<128, 4>), grid, dim3(XLP_SEG * 32u), 0, s, a);
+    else hipLaunchKernelGGL((xlp_forward_kernel<128, 1>), grid, dim3(XLP_SEG * 32u), 0, s, a);
+  }
   return hipGetLastError();
 }
 

@@ -945,6 +945,35 @@ def test_group_of_blocks_polyphase(m, inv, mix, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("m", [128, 256])
+@pytest.mark.parametrize("D", [50, 21])
+def test_forward_groups_of_branches_cf32(D, m):
+    """cf32 streams: the forward launch of a big call runs groups of adjacent branches per workgroup (four at M = 128, two at M = 256:
+    one load per group and point, xl_polyphase.hip) -- D = 50 / 21 leave the last group partial (2 of 4 / 1 of 4, 1 of 2), the first call
+    reads below the clients' zero line and across history | block, a client joins between two calls (its own zero line inside the next
+    call's window), the third call is ragged and short (the one-branch form again).  Calls of 8 blocks, every client per call against
+    the oracle's eight successive calls (src/xlating.c:374-382: cf32 input needs no conversion)."""
+    fs = 48000 * D
+    taps = lpf(fs, 24000, 9600)
+    nsamp = 98304
+    gen = lambda seed, n: (siggen.xs_s16(seed, 2 * n).astype(np.float32) / np.float32(32768)).astype(np.float32)  # noqa: E731
+    eng = xl.BatchEngine(fs, "cf32", 2 * nsamp, group_blocks=8)
+    eng.set_option("polyphase", 1)
+    eng.set_option("polyphase_m", m)
+    oracles = {}
+    for c in range(36):
+        fc = int(-0.42 * fs + 0.024 * fs * c)
+        oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, fs, 2 * nsamp)
+    for k, (G, n) in enumerate(((8, nsamp), (8, nsamp), (8, nsamp), (3, 50001), (8, nsamp))):
+        if k == 2:
+            oracles[eng.add_client(D, taps, 4321)] = Oracle(D, taps, 4321, fs, 2 * nsamp)
+        x = gen(7100 + k, G * n)
+        _check_group(eng, oracles, "cf32", x, G, "optimized")
+        if k == 1:
+            assert "polyphase: cls0 D%d " % D in eng.describe() and " M%d " % m in eng.describe(), eng.describe()
+    eng.close()
+
+
 def test_group_bench_shape_1024_clients_sampled():
     """The bench workload: 1024 x 48 kHz clients, 8 blocks per call, engine's own plan; 16 sampled clients."""
     t48 = lpf(FS, 24000, 9600)
