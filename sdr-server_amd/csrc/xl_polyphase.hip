@@ -439,7 +439,7 @@ hipError_t xlp_launch_tables_h(const float2 *rt, const uint32_t *delta, const ui
 hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s) {
   if (!xlp_valid_m(a.M)) return hipErrorInvalidValue;
   const uint32_t passes = (a.nseg + XLP_SEG - 1u) / XLP_SEG;
-  const uint32_t nb = a.M == 256u ? 2u : 4u;  // branches per workgroup of the grouped form
+  const uint32_t nb = a.M == 256u ? 2u : 4u;  // branches per workgroup of the grouped form (two: level, profiles/r06_forward_groups.txt)
   const uint32_t ngrp = (a.D + nb - 1u) / nb;
   const bool grouped = a.fmt == XLF_CF32 && passes * ngrp >= XLP_FWD_GROUP_MIN_WGS;
   const dim3 grid(a.nco_blocks + passes * (grouped ? ngrp : a.D) + a.roll_blocks);
