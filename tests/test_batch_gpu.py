@@ -536,6 +536,27 @@ def test_size_rule_of_matrix_core_classes(monkeypatch):
     eng.close()
 
 
+def test_size_rule_of_streamed_mix_classes():
+    """Classes of more than 14 k-blocks of 8 branches (D > 112: the float32 mix with operands streamed per pass) take the polyphase path
+    from 128 clients with 2 taps per branch on (round 6: measured at D = 128 / 200 / 400, profiles/r06_plan_rules_other_shapes.txt;
+    rounds 4-5 asked for 4.5 taps per branch) and the direct kernel below 128 clients; D = 200, 481 taps (2.4 per branch), every client of
+    two blocks against the oracle on either side of the rule."""
+    fs, D = 9600000, 200
+    taps = lpf(fs, 24000, 48000)
+    assert 2 * D <= len(taps) < 9 * D // 2, len(taps)
+    for nclients, poly in ((128, True), (96, False)):
+        eng = xl.BatchEngine(fs, "cu8", 262144)
+        oracles = {}
+        for c in range(nclients):
+            fc = int(-0.45 * fs + (0.9 * fs / nclients) * c)
+            oracles[eng.add_client(D, taps, fc)] = Oracle(D, taps, fc, fs, 262144)
+        for k in range(3):  # (block 0: the clients are inside their zero history -- a class of its own, direct)
+            check_clients(eng, oracles, "cu8", siggen.xs_u8(5460 + k, 262144), "optimized")
+        d = eng.describe()
+        assert (("polyphase: cls0 D200 T%d cols%d " % (len(taps), nclients)) in d and "mix=mf32" in d) if poly else "polyphase: none" in d, d
+        eng.close()
+
+
 def test_matrix_core_mix_role_phases_bit_exact(monkeypatch):
     """One-block calls with the recurrence INSIDE the launches (option nco_side_stream = 0): the forward and the inverse launch carry a
     slice each of the NEXT call's NCO recurrence, the mix launch none (round 4: no launch that issues matrix instructions hosts the
