@@ -9,7 +9,7 @@
 // measured on the first form of this kernel (xlp_mix_mfma_kernel<13>: profiles/r06_mix_halves_cf32.txt) the launch's time was the SUM of
 // its phases -- operand arrival 16 us, matrix instructions 16, staging 14, the rest 21 per call.  Hence the points below.  What they do
 // NOT change is what bounds the launch (profiles/r06_mix_wide_timeline.txt): every workgroup of a round pulls its 104 KB of operands at
-// once, at the ~11 bytes per cycle a CU takes in, with idle matrix cores (10 of a workgroup's 25 us), then runs its passes with an idle
+// once -- 53 MB per round at ~11 bytes per cycle and CU, i.e. the 5.3 TB/s the memory system gives --, with idle matrix cores (10 of a workgroup's 25 us), then runs its passes with an idle
 // memory system.  A second form that streams the operands under the products of all passes (k-blocks outermost) was built and was no
 // faster at 1024 clients (the intake per workgroup is the same; 8 % faster at 2048+): tools/experiments/mix_wide_kmajor/.  Its wrong
 // sums in a few workgroups per launch led to the rule this file is compiled under: NO PACKED FP32 beside matrix instructions
