@@ -208,7 +208,7 @@ struct xlating_batch_t {
   int poly_mode = -1;        // option "polyphase": 0 never, 1 whenever the shape allows, -1 (default) by the size rule
   bool poly_min_set = false;        // "polyphase_min_clients" was given: it holds for every class (else 32 where the mix runs on the matrix cores)
   uint32_t poly_min_clients = 32;   // XL_EXP_POLY_MIN (tuning): smallest class that takes the polyphase path under the size rule
-  uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (128 / 256); 0 = by the size rule
+  uint32_t poly_m = 0;        // option "polyphase_m": force the transform length (64 / 128 / 256); 0 = by the size rule
   int num_cus = 256;
   uint32_t inv_reg = 0;       // option "inverse_kernel", M = 128 classes: 0 (default) = by the launch's size (xlp_inverse_pick: the 8-lane kernel
                               // for launches of up to 2048 tiles, the LDS transform up to 8192, the 32 x 4 cut beyond), 5 = always eight lanes per column, 16- and
@@ -461,7 +461,7 @@ extern "C" int xlating_batch_set_option(xlating_batch *b, const char *name, long
     if (value < -1 || value > 1) return -EINVAL;
     b->poly_mode = (int)value;
   } else if (n == "polyphase_m") {
-    if (value != 0 && value != 128 && value != 256) return -EINVAL;
+    if (value != 0 && value != 64 && value != 128 && value != 256) return -EINVAL;
     b->poly_m = (uint32_t)value;
   } else if (n == "inverse_kernel") {
     if (value != 0 && value != 3 && value != 5 && value != 6) return -EINVAL;
@@ -933,22 +933,36 @@ fail:
   return xl_errno_of_last_hip_error();
 }
 
+static uint32_t xl_poly_mix_kind_of(const xlating_batch *b, uint32_t D) {  // (see xl_poly_mix_kind below)
+  const bool halves_ok = D <= 8u * XLP_NKB_MAX;
+  return (b->mix_kernel == 3u || !halves_ok) ? 3u : 1u;
+}
+
 // Transform length of a polyphase class: the mix launch streams D x M branch-spectrum values per client and call from HBM,
 // which is what bounds it with many clients and one block per call; M = 128 halves that for ~5-10 % more arithmetic
 // (valid outputs per segment M - A + 1) while the filter is short against the segment.  Measured at D = 42, 505 taps, one
 // block per call: x1.17 at 4096 clients, x1.08 at 2048, x1.015 at 1024, x0.99 at 512 and below.
-static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t A, size_t members) {
-  return A > 64 ? 256u : (b->poly_m ? b->poly_m : (A <= 32 && members >= 768 ? 128u : 256u));
+// M = 64 (round 6): classes on the WIDE two-half mix (9 .. 14 k-blocks: D = 65 .. 112) with up to 8 taps per branch (57+ of 64 outputs
+// per segment valid).  A wide workgroup holds 104 KB of operands for ONE bin of 128 columns, and half the bins is half the workgroups
+// and half the operand stream (config 5 at 1024 clients: 512 workgroups = ONE round instead of two): config 5 (cf32, D = 100, 3 taps
+// per branch) 8 blocks per call at 1024 / 2048 / 4096 clients 16.9 / 29.1 / 51.0 -> 16.0 / 26.2 / 47.4 us per block, ONE block per call
+// 48.4 -> 40.8 (4096 clients: 138 -> 94); D = 72 / 100 off cu8 streams with 3 / 5 / 8 taps per branch: ahead or level at 1024 and 4096
+// clients; at 128-768 clients level with 128 and ahead of 256 (which the rule above picked there: 12.0 / 39.4 against 11.9 / 29.1 us
+// per block at 256 clients x 8 / 1 blocks per call).  Narrow classes (D <= 64) LOSE with 64 points (D = 64, 4096 clients: 59.4 -> 65.6):
+// their workgroups hold less and the inverse launch, whose tiles stay 32 KB, gains nothing.  profiles/r06_transform_length_64.txt
+static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t A, size_t members, uint32_t D) {
+  if (A > 64) return 256u;
+  if (b->poly_m) return A > 32 && b->poly_m == 64u ? 128u : b->poly_m;  // (forced; a class needs A <= M / 2)
+  const uint32_t nkb = (D + 7u) / 8u;
+  if (xl_poly_mix_kind_of(b, D) == 1u && nkb > XLP_NKB_4W && A <= 8) return 64u;
+  return A <= 32 && members >= 768 ? 128u : 256u;
 }
 
 // Which mix launch a class of D branches takes (PolyClass::mix_kind): the two-half kernel (1) carries the spectra as pairs of halves
 // -- bounded by the input format, or (cf32 streams) scaled per segment by what the forward launch found (PolyClass::d_segmax) -- and
 // holds at most XLP_NKB_MAX k-blocks of 8 branches (D <= 112); the float32 matrix instruction (3) has no such condition: it is what
 // D > 112 takes, and every class on request (option "mix_kernel" = 3: all-float32 products).
-static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D) {
-  const bool halves_ok = D <= 8u * XLP_NKB_MAX;
-  return (b->mix_kernel == 3u || !halves_ok) ? 3u : 1u;
-}
+static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D) { return xl_poly_mix_kind_of(b, D); }
 
 // Power-of-two scale of a column's branch spectra for the matrix-core mix: every component of R_b[m] = sum_a r_b[a] e^{..} is at
 // most L = max_b sum_a |r_b[a]| (the same for the delayed taps: a delay permutes the branches); scale = 2^floor(log2(RMAX / L)).
@@ -1173,7 +1187,7 @@ static int xl_batch_plan(xlating_batch *b) {
         ref = (old->rem_ref0 + advanced % D) % D;
         for (uint32_t r : distinct) dmax = std::max(dmax, (ref + D - r) % D);
         const uint32_t A = (T + dmax + D - 1) / D;
-        reuse = A == old->A && xl_poly_pick_m(b, A, m.size()) == old->M && xl_poly_mix_kind(b, D) == old->mix_kind;
+        reuse = A == old->A && xl_poly_pick_m(b, A, m.size(), D) == old->M && xl_poly_mix_kind(b, D) == old->mix_kind;
       }
       if (!reuse) {
         // the shared grid's reference: the member offset that keeps the largest delay of a member smallest
@@ -1186,7 +1200,7 @@ static int xl_batch_plan(xlating_batch *b) {
         ref = best_ref, dmax = best_dmax;
       }
       const uint32_t A = (T + dmax + D - 1) / D;
-      const uint32_t M = xl_poly_pick_m(b, A, m.size());
+      const uint32_t M = xl_poly_pick_m(b, A, m.size(), D);
       const bool fits = A >= 2 && A <= M / 2 && D <= 504;
       // crossover: with the mix on the matrix cores the path costs the same whatever the filter length and little beside the
       // recurrence in small classes (A/B at 8 blocks per call, direct kernel -> polyphase, us per block: 101 taps 37.3 -> 28.2 at

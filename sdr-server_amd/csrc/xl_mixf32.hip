@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void xlp_mix_f32_kernel(const XlpArgs a) {
   const uint32_t sgn = xlmf_a_negate(lane) << 31;
   const uint32_t af = xlmf_a_float(lane);
   // ---- Y: this lane's column of segment s
-  const uint32_t CW = M == 256u ? 16u : 32u, NSUB = XLP_COLS / CW;
+  const uint32_t CW = xlp_tile_columns(M), NSUB = XLP_COLS / CW;
   const uint32_t col = w * 32u + c;
   v2f *__restrict__ Yc = reinterpret_cast<v2f *>(a.Y) + ((((size_t)cg * a.nseg_cap) * NSUB + col / CW) * M + m) * CW + col % CW;
   const size_t ystride = (size_t)NSUB * M * CW;  // v2f per segment
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void xlp_mix_f32_stream_kernel(const XlpArgs a
   const uint32_t loff = xlmf_a_float(lane) * 4u;
   const char *__restrict__ xb = reinterpret_cast<const char *>(a.X) + (size_t)m * (XLP_XS * sizeof(float2));
   const size_t xrow = (size_t)M * (XLP_XS * sizeof(float2));
-  const uint32_t CW = M == 256u ? 16u : 32u, NSUB = XLP_COLS / CW;
+  const uint32_t CW = xlp_tile_columns(M), NSUB = XLP_COLS / CW;
   const uint32_t col = w * 32u + c;
   v2f *__restrict__ Yc = reinterpret_cast<v2f *>(a.Y) + ((((size_t)cg * a.nseg_cap) * NSUB + col / CW) * M + m) * CW + col % CW;
   const size_t ystride = (size_t)NSUB * M * CW;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(XLP_COLS) void xlp_tables_f_kernel(const float2 *__
 
 hipError_t xlp_launch_tables_f(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, uint32_t nlist, uint32_t T, uint32_t D,
                                uint32_t A, uint32_t M, uint32_t nb8, void *Rf, hipStream_t s) {
-  if ((M != 128u && M != 256u) || nlist == 0u || nb8 == 0u || D > 8u * nb8) return hipErrorInvalidValue;
+  if ((M != 64u && M != 128u && M != 256u) || nlist == 0u || nb8 == 0u || D > 8u * nb8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(xlp_tables_f_kernel, dim3(M * 8u * nb8, (nlist + XLP_COLS - 1u) / XLP_COLS), dim3(XLP_COLS), 0, s, rt, delta, colidx,
                      nlist, T, D, A, M, nb8, reinterpret_cast<float *>(Rf));
   return hipGetLastError();

@@ -125,7 +125,7 @@ void xlp_mix_mfma_kernel(const XlpArgs a) {
     }
   };
   // ---- Y image [cg][segment][sub][bin][CW columns] (the inverse workgroups' tiles): this lane's column of segment s
-  const uint32_t CW = M == 256u ? 16u : 32u, NSUB = XLP_COLS / CW;
+  const uint32_t CW = xlp_tile_columns(M), NSUB = XLP_COLS / CW;
   const uint32_t col = w * 32u + c;
   v2f *__restrict__ Yc = reinterpret_cast<v2f *>(a.Y) +
                          ((((size_t)cg * a.nseg_cap) * NSUB + col / CW) * M + m) * CW + col % CW;
@@ -214,7 +214,7 @@ void xlp_mix_mfma_kernel(const XlpArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- launcher
-static bool xlp_valid_m(uint32_t M) { return M == 128u || M == 256u; }
+static bool xlp_valid_m(uint32_t M) { return M == 64u || M == 128u || M == 256u; }
 
 template <int NKB>
 static void xlp_launch_mix_mfma_n(const XlpArgs &a, const dim3 grid, hipStream_t s) {

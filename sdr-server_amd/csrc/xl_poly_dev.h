@@ -13,7 +13,7 @@ XL_DEV v2f xlp_cmul(const v2f a, const v2f b) {
   return (v2f){__builtin_fmaf(-a.y, b.y, a.x * b.x), __builtin_fmaf(a.y, b.x, a.x * b.y)};
 }
 
-// M-point DFT, M = 256 or 128, by M/4 lanes (a wave, or a half-wave: two 128-point transforms per wave): radix-4
+// M-point DFT, M = 256, 128 or 64, by M/4 lanes (a wave, a half-wave, a quarter-wave): radix-4
 // Stockham autosort, passes p = 1, 4, 16 (and 64 for M = 256); lane l < M/4 holds points l + (M/4) r.  M = 128 ends with
 // a radix-2 pass that needs no exchange: after the third scatter a lane's four points are the operands of its two
 // radix-2 butterflies, (l, l + 64) and (l + 32, l + 96).
@@ -105,7 +105,7 @@ XL_DEV void xlp_dft(v2f (&u)[NI][4], v2f *const (&lds)[NI], const XlpTw &tw, con
     const uint32_t k = l & (p - 1u);
 #pragma unroll
     for (int n = 0; n < NI; ++n) xlp_dft_butterfly<SIGN>(u[n], tw, pass);
-    if (pass < 3) {
+    if (pass < NP4 - 1 || M == 128) {  // (no exchange behind the last radix-4 pass, unless a radix-2 pass follows: M = 128)
       const uint32_t jo = ((l - k) << 2) + k;
 #pragma unroll
       for (int n = 0; n < NI; ++n)

@@ -44,6 +44,10 @@
 #define XLP_FWD_GROUP_MIN_WGS 96u  // forward launch, cf32 streams: groups of adjacent branches per workgroup from this many workgroups on
 #define XLP_BSTEP 2u   // the branch count is padded to a multiple of this in the shared-spectrum image (rows D .. Dpad - 1: zeros)
 
+// Columns of one tile of the mixed spectra Y = [cg][segment][sub][bin M][CW columns] (one inverse workgroup's tile, M x CW x 8 bytes =
+// 32 KB contiguous): 16 (M = 256), 32 (M = 128), 64 (M = 64)
+static inline __host__ __device__ uint32_t xlp_tile_columns(uint32_t M) { return M == 256u ? 16u : (M == 64u ? 64u : 32u); }
+
 // One client column of a class: 16 bytes, one load.
 struct XlpCol {
   uint32_t out_off;  // float2 index of the client's row in out (/ XL_PH_STRIDE in the phase table); 0xFFFFFFFF = empty column

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(XLP_COLS) void xlp_tables_h_kernel(const float2 *__
 }
 
 // ------------------------------------------------------------------------------------------- launchers
-static bool xlp_valid_m(uint32_t M) { return M == 128u || M == 256u; }
+static bool xlp_valid_m(uint32_t M) { return M == 64u || M == 128u || M == 256u; }
 
 hipError_t xlp_launch_tables_h(const float2 *rt, const uint32_t *delta, const uint32_t *colidx, const float *scale,
                                uint32_t nlist, uint32_t T, uint32_t D, uint32_t A, uint32_t M, uint32_t nkb, void *Rh,
@@ -446,6 +446,9 @@ hipError_t xlp_launch_forward(const XlpArgs &a, hipStream_t s) {
   if (a.M == 256u) {
     if (grouped) hipLaunchKernelGGL((xlp_forward_kernel<256, 2>), grid, dim3(XLP_SEG * 64u), 0, s, a);
     else hipLaunchKernelGGL((xlp_forward_kernel<256, 1>), grid, dim3(XLP_SEG * 64u), 0, s, a);
+  } else if (a.M == 64u) {
+    if (grouped) hipLaunchKernelGGL((xlp_forward_kernel<64, 4>), grid, dim3(XLP_SEG * 16u), 0, s, a);
+    else hipLaunchKernelGGL((xlp_forward_kernel<64, 1>), grid, dim3(XLP_SEG * 16u), 0, s, a);
   } else {
     if (grouped) hipLaunchKernelGGL((xlp_forward_kernel<128, 4>), grid, dim3(XLP_SEG * 32u), 0, s, a);
     else hipLaunchKernelGGL((xlp_forward_kernel<128, 1>), grid, dim3(XLP_SEG * 32u), 0, s, a);
@@ -469,7 +472,7 @@ hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done)
   // 128-point classes: eight lanes per column, transforms of 16 and 8 points in registers (xl_inv8.hip), the 32 x 4 cut (xl_inv32.hip),
   // or staged in LDS on dense XOR-swizzled rows -- xlp_inverse_pick() says which; 256-point classes: staged in LDS on padded rows.
   // Workgroup = one tile of 32 (16) columns.
-  const uint32_t tiles = a0.nseg * a0.ncg * (a0.M == 256u ? 8u : 4u);
+  const uint32_t tiles = a0.nseg * a0.ncg * (XLP_COLS / xlp_tile_columns(a0.M));
   const uint32_t kind = xlp_inverse_pick(a0.M, a0.inv_reg, tiles);
   const uint32_t work = kind == 6u ? xlp_inverse32_work(tiles) : tiles;
   const XlpArgs a = xlp_checked_skip(a0, work);
@@ -482,7 +485,8 @@ hipError_t xlp_launch_inverse(const XlpArgs &a0, hipStream_t s, hipEvent_t done)
     xlp_inverse8_launch(a, grid, s, done);
     return hipGetLastError();
   }
-  void (*kern)(const XlpArgs) = a.M == 256u ? xlp_inverse_kernel<256, XlpPosPad> : xlp_inverse_kernel<128, XlpPosSwz>;
+  void (*kern)(const XlpArgs) = a.M == 256u ? xlp_inverse_kernel<256, XlpPosPad>
+                                : (a.M == 64u ? xlp_inverse_kernel<64, XlpPosPad> : xlp_inverse_kernel<128, XlpPosSwz>);
   if (done) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, s, nullptr, done, 0, a);
   else hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);
   return hipGetLastError();

@@ -294,9 +294,9 @@ def test_1000_clients_split_group_riders():
 # that the oracle can check every client.
 # The transform length M is 128 for filters of up to 32 taps per branch and 256 beyond; XL_EXP_POLY_M forces either, and
 # the forced-path tests run with both.
-@pytest.fixture(params=[(128, 0, 1), (128, 3, 1), (256, 0, 1), (128, 5, 3), (256, 0, 3), (128, 3, 3), (128, 6, 1), (128, 6, 3)],
+@pytest.fixture(params=[(128, 0, 1), (128, 3, 1), (256, 0, 1), (128, 5, 3), (256, 0, 3), (128, 3, 3), (128, 6, 1), (128, 6, 3), (64, 0, 1), (64, 0, 3)],
                 ids=["M128", "M128-lds-inverse", "M256", "M128-f32-mix", "M256-f32-mix", "M128-lds-inverse-f32-mix", "M128-cut32-inverse",
-                     "M128-cut32-inverse-f32-mix"])
+                     "M128-cut32-inverse-f32-mix", "M64", "M64-f32-mix"])
 def poly_m(request, monkeypatch):
     """Transform length of the forced polyphase plan; at M = 128 the inverse launch's transform in the registers of eight lanes per
     column (option "inverse_kernel" = 5: xlp_inverse8_kernel -- what the default, 0, picks for launches as small as these), cut 32 x 4
