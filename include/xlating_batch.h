@@ -67,7 +67,7 @@ int xlating_batch_create_grouped(uint32_t sampling_freq, int input_format, uint3
 /* Plan options (result-neutral: every setting passes the same parity tests).  Six of them; name / value:
  *   "polyphase"         -1 by the size rule (default: classes of >= 32 clients with >= 2 taps per polyphase branch), 0 never, 1
  *                       whenever the shape allows: which classes take the polyphase overlap-save path in XL_MODE_OPTIMIZED
- *   "polyphase_m"       0 by the size rule, 64, 128, 256: its transform length (the rule: 64 points for classes of 65 .. 112 branches with up
+ *   "polyphase_m"       0 by the size rule, 64, 128, 256: its transform length (the rule: 64 points for classes of more than 64 branches with up
  *                       to 8 taps per branch, else 128 for classes of >= 768 clients with <= 32 taps per branch, else 256; a forced
  *                       length a class's filter does not fit falls back to the next one that does)
  *   "mix_kernel"        polyphase classes: the mix launch (spectra x branch spectra, summed over the branches) runs on the matrix

@@ -933,28 +933,25 @@ fail:
   return xl_errno_of_last_hip_error();
 }
 
-static uint32_t xl_poly_mix_kind_of(const xlating_batch *b, uint32_t D) {  // (see xl_poly_mix_kind below)
-  const bool halves_ok = D <= 8u * XLP_NKB_MAX;
-  return (b->mix_kernel == 3u || !halves_ok) ? 3u : 1u;
-}
-
 // Transform length of a polyphase class: the mix launch streams D x M branch-spectrum values per client and call from HBM,
 // which is what bounds it with many clients and one block per call; M = 128 halves that for ~5-10 % more arithmetic
 // (valid outputs per segment M - A + 1) while the filter is short against the segment.  Measured at D = 42, 505 taps, one
 // block per call: x1.17 at 4096 clients, x1.08 at 2048, x1.015 at 1024, x0.99 at 512 and below.
-// M = 64 (round 6): classes on the WIDE two-half mix (9 .. 14 k-blocks: D = 65 .. 112) with up to 8 taps per branch (57+ of 64 outputs
-// per segment valid).  A wide workgroup holds 104 KB of operands for ONE bin of 128 columns, and half the bins is half the workgroups
+// M = 64 (round 6): classes of more than 64 branches (9+ k-blocks of 8: the wide two-half mix, D = 65 .. 112; the float32 mixes above
+// that or on request) with up to 8 taps per branch (57+ of 64 outputs per segment valid).  A wide workgroup holds 104 KB of operands for ONE bin of 128 columns, and half the bins is half the workgroups
 // and half the operand stream (config 5 at 1024 clients: 512 workgroups = ONE round instead of two): config 5 (cf32, D = 100, 3 taps
 // per branch) 8 blocks per call at 1024 / 2048 / 4096 clients 16.9 / 29.1 / 51.0 -> 16.0 / 26.2 / 47.4 us per block, ONE block per call
 // 48.4 -> 40.8 (4096 clients: 138 -> 94); D = 72 / 100 off cu8 streams with 3 / 5 / 8 taps per branch: ahead or level at 1024 and 4096
 // clients; at 128-768 clients level with 128 and ahead of 256 (which the rule above picked there: 12.0 / 39.4 against 11.9 / 29.1 us
 // per block at 256 clients x 8 / 1 blocks per call).  Narrow classes (D <= 64) LOSE with 64 points (D = 64, 4096 clients: 59.4 -> 65.6):
-// their workgroups hold less and the inverse launch, whose tiles stay 32 KB, gains nothing.  profiles/r06_transform_length_64.txt
+// their workgroups hold less and the inverse launch, whose tiles stay 32 KB, gains nothing.  The float32 mixes gain too (config 5 with
+// mix_kernel = 3: -4 %; D = 128 / 200 on the streamed kernel: -9 / -17 % at 1024 clients, -6 / -11 % at 256); 10-13 taps per branch: level
+// (not taken).  profiles/r06_transform_length_64.txt
 static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t A, size_t members, uint32_t D) {
   if (A > 64) return 256u;
   if (b->poly_m) return A > 32 && b->poly_m == 64u ? 128u : b->poly_m;  // (forced; a class needs A <= M / 2)
   const uint32_t nkb = (D + 7u) / 8u;
-  if (xl_poly_mix_kind_of(b, D) == 1u && nkb > XLP_NKB_4W && A <= 8) return 64u;
+  if (nkb > XLP_NKB_4W && A <= 8) return 64u;
   return A <= 32 && members >= 768 ? 128u : 256u;
 }
 
@@ -962,7 +959,10 @@ static uint32_t xl_poly_pick_m(const xlating_batch *b, uint32_t A, size_t member
 // -- bounded by the input format, or (cf32 streams) scaled per segment by what the forward launch found (PolyClass::d_segmax) -- and
 // holds at most XLP_NKB_MAX k-blocks of 8 branches (D <= 112); the float32 matrix instruction (3) has no such condition: it is what
 // D > 112 takes, and every class on request (option "mix_kernel" = 3: all-float32 products).
-static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D) { return xl_poly_mix_kind_of(b, D); }
+static uint32_t xl_poly_mix_kind(const xlating_batch *b, uint32_t D) {
+  const bool halves_ok = D <= 8u * XLP_NKB_MAX;
+  return (b->mix_kernel == 3u || !halves_ok) ? 3u : 1u;
+}
 
 // Power-of-two scale of a column's branch spectra for the matrix-core mix: every component of R_b[m] = sum_a r_b[a] e^{..} is at
 // most L = max_b sum_a |r_b[a]| (the same for the delayed taps: a delay permutes the branches); scale = 2^floor(log2(RMAX / L)).

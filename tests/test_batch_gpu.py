@@ -1627,6 +1627,7 @@ def test_config5_cf32_10msps_all_clients(nclients):
             if variant == "optimized" and k == 1:  # (block 0: the clients are inside their zero history -- a class of its own)
                 d = eng.describe()
                 assert "polyphase: cls0 D100 T257 cols%d " % nclients in d and ("mix=mf32" if mix == 3 else "mix=mfma") in d, d
+                assert " V62 M64 " in d, d  # (more than 64 branches, 3 taps per branch: 64-point transforms by the size rule)
                 if mix != 3:  # (a plan with a wide two-half class reserves no CUs for the side-stream kernel: xl_batch.cpp)
                     assert "CUs reserved" not in d, d
             got = _engine_outputs(eng, ids)
