@@ -235,7 +235,8 @@ hipError_t xlp_launch_mix(const XlpArgs &a0, hipStream_t s) {
     return hipErrorInvalidValue;
   // (all passes of an 8-block call in one workgroup: the operands are fetched once; A/B at 4096 clients, passes per
   // workgroup 4 / 8 / 16: 42.5 / 38.5 / 34.8 us per block, at 1024 clients 10.3 / 9.3 / 10.0)
-  if (a.mix_pp == 0u) a.mix_pp = 16u;
+  // (64-point classes: twice the segments for the same samples -- 32 passes, so that a call of the same length still is one run)
+  if (a.mix_pp == 0u) a.mix_pp = a.M == 64u ? 32u : 16u;
   const uint32_t runs = (a.mix_passes + a.mix_pp - 1u) / a.mix_pp;
   const dim3 grid(a.M * a.ncg * runs);
   switch (a.nkb) {
