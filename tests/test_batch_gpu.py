@@ -966,10 +966,10 @@ def test_group_of_blocks_polyphase(m, inv, mix, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("m", [128, 256])
+@pytest.mark.parametrize("m", [64, 128, 256])
 @pytest.mark.parametrize("D", [50, 21, 37, 64])
 def test_forward_groups_of_branches_cf32(D, m):
-    """cf32 streams: the forward launch of a big call runs groups of adjacent branches per workgroup (four at M = 128, two at M = 256:
+    """cf32 streams: the forward launch of a big call runs groups of adjacent branches per workgroup (four at M = 64 / 128, two at M = 256:
     one load per group and point, xl_polyphase.hip) -- D = 50 / 21 / 37 leave the last group partial (2 of 4 / 1 of 4, 1 of 2), 64 none; the first call
     reads below the clients' zero line and across history | block, a client joins between two calls (its own zero line inside the next
     call's window), the third call is ragged and short (the one-branch form again).  Calls of 8 blocks, every client per call against
