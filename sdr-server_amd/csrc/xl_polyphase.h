@@ -5,8 +5,8 @@
 //   y[k] = sum_{i<T} r[i] x[kD + i]                      (r = reversed band-pass taps, xlating.c:525-535)
 //        = sum_{b<D} sum_{a<A} r_b[a] x_b[k + a]         r_b[a] = r[D a + b], x_b[n] = x[D n + b], A = ceil(T/D)
 //
-// i.e. D short correlations at the OUTPUT rate.  Over a segment of M branch samples (256, or 128 for big classes of
-// short filters: half the R stream) each correlation is a circular one, exact for the first V = M - A + 1 outputs:
+// i.e. D short correlations at the OUTPUT rate.  Over a segment of M branch samples (256; 128 for big classes of
+// short filters: half the R stream; 64 for classes of many branches with very short branch filters) each correlation is a circular one, exact for the first V = M - A + 1 outputs:
 //
 //   y_seg = IDFT_M( sum_b DFT_M(x_b) * R_b ),            R_b[m] = sum_a r_b[a] e^{+2 pi j a m / M}
 //
@@ -27,7 +27,7 @@
 #include "xl_device.h"
 #include "xl_plan_rules.h"
 
-#define XLP_M_MAX 256u  // transform length M (branch samples per segment): 256 or 128, chosen per class
+#define XLP_M_MAX 256u  // transform length M (branch samples per segment): 256, 128 or 64, chosen per class (xl_batch.cpp: xl_poly_pick_m)
 #define XLP_SEG 16u    // segments per pass of the mix launches: with (re, im) the 32 rows of a matrix instruction (round 5; 14 before: the
                        // packed-FMA mix kernel's register budget -- 16 took 7 % off the two-half mix launch, profiles/r05_mix_f32.txt)
 #define XLP_XS 16u     // row stride (complex) of the shared-spectrum image: the XLP_SEG segments of a pass = 128 bytes
@@ -69,7 +69,7 @@ struct XlpArgs {
   uint32_t zero_below; // samples below read as 0
   uint32_t D, Dpad;    // decimation = number of branches; padded to a multiple of XLP_BSTEP in the images
   uint32_t T, A, V;    // taps, taps per branch of the delayed filters, valid outputs per segment = M - A + 1
-  uint32_t M;          // transform length: 256 or 128
+  uint32_t M;          // transform length: 256, 128 or 64
   uint32_t mix_passes; // (set by xlp_launch_mix) passes of XLP_SEG segments = ceil(nseg / XLP_SEG)
   uint32_t nseg;       // segments of this call = ceil(Kq / V)
   uint32_t nseg_cap;   // segment capacity of the Y image

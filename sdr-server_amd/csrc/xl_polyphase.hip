@@ -12,7 +12,7 @@
 //   xlp_inverse8_kernel (xl_inv8.hip) / xlp_inverse32_kernel (xl_inv32.hip) (128-point classes: small / big launches) /
 //   xlp_inverse_kernel  (256-point classes; 128-point ones on request): per (segment, 32 or 16 columns): Y tile -> M-point inverse DFT
 //                       per column -> scale, NCO rotate (xlating.c:70) with the tabulated float32 phase -> out[k], k < K.
-// M = 256 or 128 per class (xl_polyphase.h).  When the NCO phases of the next call are not tabulated by the side-stream
+// M = 256, 128 or 64 per class (xl_polyphase.h).  When the NCO phases of the next call are not tabulated by the side-stream
 // chain kernel (xl_kernels.hip), the forward and the inverse launch each carry a slice of that recurrence ("NCO role").
 // Rounds 1-4 also shipped a packed-FMA mix kernel, a fused mix + inverse launch, 48-bit mixed spectra and three more inverse
 // kernels: measured, documented (profiles/r03_*, r04_*), and retired in round 5 (tools/experiments/retired/).
