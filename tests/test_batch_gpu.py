@@ -838,7 +838,7 @@ def test_replay_iq_file_end_to_end(fmt, tmp_path):
 
 
 @pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("XL_TEST_FUZZ_SEEDS", "4")))))  # (more seeds: a longer fuzz run)
-@pytest.mark.parametrize("force_poly", [0, 128, 256])
+@pytest.mark.parametrize("force_poly", [0, 64, 128, 256])
 def test_randomised_engine_vs_oracle(seed, force_poly, monkeypatch):
     """Randomised streams: mixed decimations / tap counts (even tap counts too: the reversal quirk), clients joining and
     leaving, block lengths from a few samples to the maximum, native and optimized blocks in any order, with and
